@@ -1,0 +1,519 @@
+/*
+ * fluid_oracle.c -- CPU restatement of flucoma-core's BufNMF hot path (see fluid_oracle.h).
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see header).  Plain C11, no dependencies.
+ *
+ * Reference files followed (relative to /root/reference/include/flucoma/):
+ *   algorithms/public/WindowFuncs.hpp:41-45   Hann
+ *   algorithms/public/STFT.hpp:90-108,61-66   framing, magnitude
+ *   algorithms/util/FFT.hpp:92-108            real FFT convention (plain unnormalised DFT)
+ *   algorithms/util/EigenRandom.hpp:73-110    RNG (mt19937_64, column-major fill)
+ *   algorithms/public/NMF.hpp:91-134,144-183  NMF process / multiplicativeUpdates
+ *   clients/nrt/NMFClient.hpp:233-300         channel loop + write-back
+ */
+#include "fluid_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* window + STFT                                                                         */
+/* ------------------------------------------------------------------------------------ */
+
+void fo_window_hann(int64_t win, double* w)
+{
+  /* alg/WindowFuncs.hpp:43-44: out(i) = 0.5 - 0.5 * cos((pi * 2 * i) / size) */
+  for (int64_t i = 0; i < win; i++) w[i] = 0.5 - 0.5 * cos((M_PI * 2 * (double) i) / (double) win);
+}
+
+int64_t fo_stft_num_frames(int64_t n, int64_t win, int64_t hop)
+{
+  /* alg/STFT.hpp:94,98-99: padded = n + win + hop; nFrames = (padded - win) / hop */
+  (void) win;
+  return (n + hop) / hop;
+}
+
+/* In-place iterative radix-2 DIT complex FFT, forward (e^{-i...}).  tw: n/2 twiddles. */
+static void fft_c2c(double* re, double* im, int64_t n, const double* twr, const double* twi)
+{
+  /* bit reversal */
+  for (int64_t i = 1, j = 0; i < n; i++)
+  {
+    int64_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j)
+    {
+      double t = re[i]; re[i] = re[j]; re[j] = t;
+      t = im[i]; im[i] = im[j]; im[j] = t;
+    }
+  }
+  for (int64_t len = 2; len <= n; len <<= 1)
+  {
+    int64_t half = len >> 1, step = n / len;
+    for (int64_t i = 0; i < n; i += len)
+      for (int64_t k = 0; k < half; k++)
+      {
+        double wr = twr[k * step], wi = twi[k * step];
+        double xr = re[i + k + half], xi = im[i + k + half];
+        double tr = xr * wr - xi * wi, ti = xr * wi + xi * wr;
+        re[i + k + half] = re[i + k] - tr; im[i + k + half] = im[i + k] - ti;
+        re[i + k] += tr; im[i + k] += ti;
+      }
+  }
+}
+
+int64_t fo_stft(const double* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                double* spec, double* mag)
+{
+  const int64_t F = fft / 2 + 1;
+  const int64_t half = win / 2;               /* alg/STFT.hpp:92 */
+  const int64_t padlen = n + win + hop;       /* :94 */
+  const int64_t T = (padlen - win) / hop;     /* :98-99 (std::floor of an integer division) */
+  double* padded = (double*) calloc((size_t) padlen, sizeof(double));
+  double* w = (double*) malloc((size_t) win * sizeof(double));
+  double* re = (double*) malloc((size_t) fft * sizeof(double));
+  double* im = (double*) malloc((size_t) fft * sizeof(double));
+  double* twr = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  double* twi = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  memcpy(padded + half, audio, (size_t) n * sizeof(double)); /* :96-97 */
+  fo_window_hann(win, w);
+  for (int64_t k = 0; k < fft / 2; k++)
+  {
+    twr[k] = cos(-2.0 * M_PI * (double) k / (double) fft);
+    twi[k] = sin(-2.0 * M_PI * (double) k / (double) fft);
+  }
+  for (int64_t t = 0; t < T; t++)
+  {
+    /* :104-105: frame = padded.segment(i*hop, win) * window; util/FFT.hpp:97-98: the FFT library
+     * receives `win` samples and log2(fft): win < fft is zero-padded at the tail. */
+    for (int64_t i = 0; i < win; i++) { re[i] = padded[t * hop + i] * w[i]; im[i] = 0; }
+    for (int64_t i = win; i < fft; i++) { re[i] = 0; im[i] = 0; }
+    fft_c2c(re, im, fft, twr, twi);
+    for (int64_t k = 0; k < F; k++)
+    {
+      double xr = re[k], xi = im[k];
+      /* util/FFT.hpp:99-101: DC and Nyquist bins are purely real */
+      if (k == 0 || k == F - 1) xi = 0;
+      if (spec) { spec[2 * (t * F + k)] = xr; spec[2 * (t * F + k) + 1] = xi; }
+      /* alg/STFT.hpp:64-65: abs() of std::complex<double> == hypot */
+      if (mag) mag[t * F + k] = hypot(xr, xi);
+    }
+  }
+  free(padded); free(w); free(re); free(im); free(twr); free(twi);
+  return T;
+}
+
+int64_t fo_stft_f32(const float* audio, int64_t n, int64_t stride, int64_t win, int64_t fft,
+                    int64_t hop, double* spec, double* mag)
+{
+  /* nrt/NMFClient.hpp:240  tmp <<= source.samps(...)  (element-wise float -> double) */
+  double* tmp = (double*) malloc((size_t) n * sizeof(double));
+  for (int64_t i = 0; i < n; i++) tmp[i] = (double) audio[i * stride];
+  int64_t T = fo_stft(tmp, n, win, fft, hop, spec, mag);
+  free(tmp);
+  return T;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* RNG: std::mt19937_64 + libstdc++ uniform_real_distribution<double>(0,1)              */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct { uint64_t mt[312]; int idx; } mt64_t;
+
+static void mt64_seed(mt64_t* g, uint64_t seed)
+{
+  g->mt[0] = seed;
+  for (int i = 1; i < 312; i++)
+    g->mt[i] = 6364136223846793005ULL * (g->mt[i - 1] ^ (g->mt[i - 1] >> 62)) + (uint64_t) i;
+  g->idx = 312;
+}
+
+static uint64_t mt64_next(mt64_t* g)
+{
+  if (g->idx >= 312)
+  {
+    const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL, A = 0xB5026F5AA96619E9ULL;
+    for (int i = 0; i < 312; i++)
+    {
+      uint64_t x = (g->mt[i] & UM) | (g->mt[(i + 1) % 312] & LM);
+      g->mt[i] = g->mt[(i + 156) % 312] ^ (x >> 1) ^ ((x & 1ULL) ? A : 0ULL);
+    }
+    g->idx = 0;
+  }
+  uint64_t x = g->mt[g->idx++];
+  x ^= (x >> 29) & 0x5555555555555555ULL;
+  x ^= (x << 17) & 0x71D67FFFEDA60000ULL;
+  x ^= (x << 37) & 0xFFF7EEE000000000ULL;
+  x ^= (x >> 43);
+  return x;
+}
+
+static double mt64_uniform01(mt64_t* g)
+{
+  /* libstdc++ generate_canonical<double,53>: one 64-bit draw, double(u64)/2^64, and a result
+   * that rounds to 1.0 is replaced by nextafter(1,0). */
+  double r = (double) mt64_next(g) / 18446744073709551616.0;
+  if (r >= 1.0) r = nextafter(1.0, 0.0);
+  return r;
+}
+
+void fo_rng_uniform01(uint64_t seed, int64_t count, double* out)
+{
+  mt64_t g;
+  mt64_seed(&g, seed);
+  for (int64_t i = 0; i < count; i++) out[i] = mt64_uniform01(&g);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* small dense kernels (column-major, like Eigen::MatrixXd)                              */
+/* ------------------------------------------------------------------------------------ */
+
+/* C(MxN) = A(MxK) * B(KxN); A, C column-major contiguous over rows; B(k,j) = B[k*sbk + j*sbj].
+ * Register-blocked 32x4 micro-kernel, auto-vectorised over rows. */
+static void gemm_nn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                    const double* B, int64_t sbk, int64_t sbj, double* C, int64_t ldc)
+{
+  enum { MB = 32, NB = 4 };
+  for (int64_t j0 = 0; j0 < N; j0 += NB)
+  {
+    int64_t nb = N - j0 < NB ? N - j0 : NB;
+    for (int64_t i0 = 0; i0 < M; i0 += MB)
+    {
+      int64_t mb = M - i0 < MB ? M - i0 : MB;
+      double acc[NB][MB];
+      for (int j = 0; j < NB; j++)
+        for (int i = 0; i < MB; i++) acc[j][i] = 0.0;
+      if (mb == MB && nb == NB)
+      {
+        for (int64_t k = 0; k < Kd; k++)
+        {
+          const double* a = A + i0 + k * lda;
+          double b0 = B[k * sbk + (j0 + 0) * sbj], b1 = B[k * sbk + (j0 + 1) * sbj];
+          double b2 = B[k * sbk + (j0 + 2) * sbj], b3 = B[k * sbk + (j0 + 3) * sbj];
+          for (int i = 0; i < MB; i++)
+          {
+            double av = a[i];
+            acc[0][i] += av * b0; acc[1][i] += av * b1;
+            acc[2][i] += av * b2; acc[3][i] += av * b3;
+          }
+        }
+      }
+      else
+      {
+        for (int64_t k = 0; k < Kd; k++)
+        {
+          const double* a = A + i0 + k * lda;
+          for (int j = 0; j < nb; j++)
+          {
+            double bv = B[k * sbk + (j0 + j) * sbj];
+            for (int i = 0; i < mb; i++) acc[j][i] += a[i] * bv;
+          }
+        }
+      }
+      for (int j = 0; j < nb; j++)
+        for (int i = 0; i < mb; i++) C[i0 + i + (j0 + j) * ldc] = acc[j][i];
+    }
+  }
+}
+
+/* C(MxN) = A^T * B with A (Kd x M) and B (Kd x N) column-major (contraction over rows).
+ * 4x4 blocked dot products, vectorised over the contraction index. */
+static void gemm_tn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc)
+{
+  enum { IB = 4, JB = 4 };
+  for (int64_t j0 = 0; j0 < N; j0 += JB)
+  {
+    int64_t jb = N - j0 < JB ? N - j0 : JB;
+    for (int64_t i0 = 0; i0 < M; i0 += IB)
+    {
+      int64_t ib = M - i0 < IB ? M - i0 : IB;
+      double acc[IB][JB] = {{0}};
+      if (ib == IB && jb == JB)
+      {
+        const double *a0 = A + (i0 + 0) * lda, *a1 = A + (i0 + 1) * lda;
+        const double *a2 = A + (i0 + 2) * lda, *a3 = A + (i0 + 3) * lda;
+        const double *b0 = B + (j0 + 0) * ldb, *b1 = B + (j0 + 1) * ldb;
+        const double *b2 = B + (j0 + 2) * ldb, *b3 = B + (j0 + 3) * ldb;
+        double s00 = 0, s01 = 0, s02 = 0, s03 = 0, s10 = 0, s11 = 0, s12 = 0, s13 = 0;
+        double s20 = 0, s21 = 0, s22 = 0, s23 = 0, s30 = 0, s31 = 0, s32 = 0, s33 = 0;
+        for (int64_t k = 0; k < Kd; k++)
+        {
+          double x0 = a0[k], x1 = a1[k], x2 = a2[k], x3 = a3[k];
+          double y0 = b0[k], y1 = b1[k], y2 = b2[k], y3 = b3[k];
+          s00 += x0 * y0; s01 += x0 * y1; s02 += x0 * y2; s03 += x0 * y3;
+          s10 += x1 * y0; s11 += x1 * y1; s12 += x1 * y2; s13 += x1 * y3;
+          s20 += x2 * y0; s21 += x2 * y1; s22 += x2 * y2; s23 += x2 * y3;
+          s30 += x3 * y0; s31 += x3 * y1; s32 += x3 * y2; s33 += x3 * y3;
+        }
+        acc[0][0] = s00; acc[0][1] = s01; acc[0][2] = s02; acc[0][3] = s03;
+        acc[1][0] = s10; acc[1][1] = s11; acc[1][2] = s12; acc[1][3] = s13;
+        acc[2][0] = s20; acc[2][1] = s21; acc[2][2] = s22; acc[2][3] = s23;
+        acc[3][0] = s30; acc[3][1] = s31; acc[3][2] = s32; acc[3][3] = s33;
+      }
+      else
+      {
+        for (int i = 0; i < ib; i++)
+          for (int j = 0; j < jb; j++)
+          {
+            double s = 0;
+            for (int64_t k = 0; k < Kd; k++) s += A[k + (i0 + i) * lda] * B[k + (j0 + j) * ldb];
+            acc[i][j] = s;
+          }
+      }
+      for (int i = 0; i < ib; i++)
+        for (int j = 0; j < jb; j++) C[i0 + i + (j0 + j) * ldc] = acc[i][j];
+    }
+  }
+}
+
+static void normalize_cols(double* W, int64_t F, int64_t K)
+{
+  /* Eigen VectorwiseOp::normalize(): every column divided by sqrt(sum of squares) */
+  for (int64_t k = 0; k < K; k++)
+  {
+    double s = 0;
+    for (int64_t f = 0; f < F; f++) s += W[f + k * F] * W[f + k * F];
+    double nrm = sqrt(s);
+    for (int64_t f = 0; f < F; f++) W[f + k * F] /= nrm;
+  }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* NMF                                                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+static volatile double fo_sink;
+
+/* alg/NMF.hpp:144-183.  V: FxT, W: FxK, H: KxT, all column-major. Returns 1 if cancelled. */
+static int multiplicative_updates(double* V, double* W, double* H, int64_t F, int64_t T, int64_t K,
+                                  int64_t iters, int updateW, int updateH, int faithful,
+                                  fo_progress_fn progress, void* user)
+{
+  const double eps = FO_EPSILON;
+  double* P = (double*) malloc((size_t) (F * T) * sizeof(double));   /* V1 / V2 / R */
+  double* Rt = (double*) malloc((size_t) (F * T) * sizeof(double));  /* V ./ P       */
+  double* ones = NULL;
+  double* wnum = (double*) malloc((size_t) (F * K) * sizeof(double));
+  double* wden = (double*) malloc((size_t) (F * K) * sizeof(double));
+  double* hnum = (double*) malloc((size_t) (K * T) * sizeof(double));
+  double* hden = (double*) malloc((size_t) (K * T) * sizeof(double));
+  int cancelled = 0;
+  if (faithful)
+  {
+    ones = (double*) malloc((size_t) (F * T) * sizeof(double)); /* :149 */
+    for (int64_t i = 0; i < F * T; i++) ones[i] = 1.0;
+  }
+  /* :150-153 */
+  for (int64_t i = 0; i < K * T; i++) H[i] = H[i] > eps ? H[i] : eps;
+  for (int64_t i = 0; i < F * K; i++) W[i] = W[i] > eps ? W[i] : eps;
+  normalize_cols(W, F, K);
+  for (int64_t k = 0; k < K; k++)
+  {
+    double s = 0;
+    for (int64_t t = 0; t < T; t++) s += H[k + t * K] * H[k + t * K];
+    double nrm = sqrt(s);
+    for (int64_t t = 0; t < T; t++) H[k + t * K] /= nrm;
+  }
+  for (int64_t it = 0; it < iters; it++)
+  {
+    if (updateW)
+    {
+      /* :158 V1 = (W*H).max(eps) */
+      gemm_nn(F, T, K, W, F, H, 1, K, P, F);
+      for (int64_t i = 0; i < F * T; i++) { double p = P[i] > eps ? P[i] : eps; Rt[i] = V[i] / p; }
+      /* :159 wnum = (V/V1) * H^T : B(t,k) = H[k + t*K] */
+      gemm_nn(F, K, T, Rt, F, H, K, 1, wnum, F);
+      /* :160 wden = ones * H^T */
+      if (faithful) gemm_nn(F, K, T, ones, F, H, K, 1, wden, F);
+      else
+        for (int64_t k = 0; k < K; k++)
+        {
+          double s = 0;
+          for (int64_t t = 0; t < T; t++) s += H[k + t * K];
+          for (int64_t f = 0; f < F; f++) wden[f + k * F] = s;
+        }
+      /* :161 W = W * wnum / wden.max(eps) */
+      double mx = -INFINITY;
+      for (int64_t i = 0; i < F * K; i++)
+      {
+        double d = wden[i] > eps ? wden[i] : eps;
+        W[i] = (W[i] * wnum[i]) / d;
+        if (W[i] > mx) mx = W[i];
+      }
+      /* :162 */
+      if (mx > eps) normalize_cols(W, F, K);
+    }
+    /* :165 V2 = (W*H).max(eps) */
+    gemm_nn(F, T, K, W, F, H, 1, K, P, F);
+    if (updateH)
+    {
+      for (int64_t i = 0; i < F * T; i++) { double p = P[i] > eps ? P[i] : eps; Rt[i] = V[i] / p; }
+      /* :168 hnum = W^T * (V/V2) */
+      gemm_tn(K, T, F, W, F, Rt, F, hnum, K);
+      /* :169 hden = W^T * ones */
+      if (faithful) gemm_tn(K, T, F, W, F, ones, F, hden, K);
+      else
+        for (int64_t k = 0; k < K; k++)
+        {
+          double s = 0;
+          for (int64_t f = 0; f < F; f++) s += W[f + k * F];
+          for (int64_t t = 0; t < T; t++) hden[k + t * K] = s;
+        }
+      /* :170 */
+      for (int64_t i = 0; i < K * T; i++)
+      {
+        double d = hden[i] > eps ? hden[i] : eps;
+        H[i] = (H[i] * hnum[i]) / d;
+      }
+    }
+    if (faithful)
+    {
+      /* :173-174 R = W*H; R = R.cwiseMax(eps)  (dead: only fed a commented-out divergence) */
+      gemm_nn(F, T, K, W, F, H, 1, K, P, F);
+      double s = 0;
+      for (int64_t i = 0; i < F * T; i++) { P[i] = P[i] > eps ? P[i] : eps; }
+      s = P[0] + P[F * T - 1];
+      fo_sink = s;
+    }
+    /* :175-176 */
+    if (progress && !progress(it + 1, user)) { cancelled = 1; break; }
+  }
+  /* :182 V = W*H (not reached when a callback cancelled: early return) */
+  if (!cancelled) gemm_nn(F, T, K, W, F, H, 1, K, V, F);
+  free(P); free(Rt); free(ones); free(wnum); free(wden); free(hnum); free(hden);
+  return cancelled;
+}
+
+int fo_nmf_process(const double* X, int64_t T, int64_t F, int64_t K, int64_t iters,
+                   int updateW, int updateH, int64_t seed, const double* W0,
+                   const double* H0, double* W1, double* H1, double* V1, int faithful,
+                   fo_progress_fn progress, void* user)
+{
+  double* W = (double*) malloc((size_t) (F * K) * sizeof(double)); /* F x K col-major */
+  double* H = (double*) malloc((size_t) (K * T) * sizeof(double)); /* K x T col-major */
+  double* V = (double*) malloc((size_t) (F * T) * sizeof(double)); /* F x T col-major */
+  /* alg/NMF.hpp:102-112: random W is filled in Eigen's column-major linear order; a seeded W0
+   * (K x F row-major) transposed is the very same memory. */
+  if (W0) memcpy(W, W0, (size_t) (F * K) * sizeof(double));
+  else fo_rng_uniform01((uint64_t) seed, F * K, W);
+  /* :113-124: H0 is T x K row-major == K x T column-major. A *fresh* generator from the same
+   * seed is used (both EigenRandom calls construct their own RandomGenerator). */
+  if (H0) memcpy(H, H0, (size_t) (K * T) * sizeof(double));
+  else fo_rng_uniform01((uint64_t) seed, K * T, H);
+  /* :125 V = X^T : T x F row-major is F x T column-major */
+  memcpy(V, X, (size_t) (F * T) * sizeof(double));
+  int cancelled = multiplicative_updates(V, W, H, F, T, K, iters, updateW, updateH, faithful,
+                                         progress, user);
+  /* :127-133 outputs: W1 = W^T (K x F), H1 = H^T (T x K), V1 = V^T (T x F): same bytes */
+  memcpy(W1, W, (size_t) (F * K) * sizeof(double));
+  memcpy(H1, H, (size_t) (K * T) * sizeof(double));
+  if (V1) memcpy(V1, V, (size_t) (F * T) * sizeof(double));
+  free(W); free(H); free(V);
+  return cancelled;
+}
+
+void fo_bufnmf_writeback(const double* W1, const double* H1, int64_t T, int64_t F, int64_t K,
+                         float* bases_out, float* acts_out)
+{
+  /* nrt/NMFClient.hpp:281-282 */
+  if (bases_out)
+    for (int64_t i = 0; i < K * F; i++) bases_out[i] = (float) W1[i];
+  if (acts_out)
+  {
+    /* :289-291 */
+    double mx = H1[0];
+    for (int64_t i = 1; i < T * K; i++) if (H1[i] > mx) mx = H1[i];
+    double scale = 1. / mx;
+    /* :295-298: double -> float converting copy, then x *= float(scale) in float */
+    for (int64_t k = 0; k < K; k++)
+      for (int64_t t = 0; t < T; t++)
+      {
+        float x = (float) H1[t * K + k];
+        x *= (float) scale;
+        acts_out[k * T + t] = x;
+      }
+  }
+}
+
+int64_t fo_bufnmf_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                          int64_t K, int64_t iters, int64_t seed, int faithful,
+                          float* bases_out, float* acts_out, double* mag_out)
+{
+  const int64_t F = fft / 2 + 1;
+  const int64_t T = fo_stft_num_frames(n, win, hop);
+  double* mag = (double*) malloc((size_t) (T * F) * sizeof(double));
+  double* W1 = (double*) malloc((size_t) (K * F) * sizeof(double));
+  double* H1 = (double*) malloc((size_t) (T * K) * sizeof(double));
+  fo_stft_f32(audio, n, 1, win, fft, hop, NULL, mag);
+  if (mag_out) memcpy(mag_out, mag, (size_t) (T * F) * sizeof(double));
+  fo_nmf_process(mag, T, F, K, iters, 1, 1, seed, NULL, NULL, W1, H1, NULL, faithful, NULL, NULL);
+  fo_bufnmf_writeback(W1, H1, T, F, K, bases_out, acts_out);
+  free(mag); free(W1); free(H1);
+  return T;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* resynthesis                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+void fo_resynth_component(const double* spec, const double* W1, const double* H1,
+                          const double* V1, int64_t T, int64_t F, int64_t K, int64_t k,
+                          int64_t win, int64_t fft, int64_t hop, int64_t n, double* out)
+{
+  const double eps = FO_EPSILON;
+  /* alg/STFT.hpp:181-184 */
+  const int64_t outsz = win + (T - 1) * hop + win + hop;
+  double* acc = (double*) calloc((size_t) outsz, sizeof(double));
+  double* nrm = (double*) calloc((size_t) outsz, sizeof(double));
+  double* w = (double*) malloc((size_t) win * sizeof(double));
+  double* re = (double*) malloc((size_t) fft * sizeof(double));
+  double* im = (double*) malloc((size_t) fft * sizeof(double));
+  double* twr = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  double* twi = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  const double scale = 1 / (double) fft; /* :157 */
+  fo_window_hann(win, w);
+  for (int64_t j = 0; j < fft / 2; j++)
+  {
+    twr[j] = cos(-2.0 * M_PI * (double) j / (double) fft);
+    twi[j] = sin(-2.0 * M_PI * (double) j / (double) fft);
+  }
+  for (int64_t t = 0; t < T; t++)
+  {
+    /* alg/NMF.hpp:33-42 estimate = W1[k][:] * H1[:][k]; alg/RatioMask.hpp:39-41,52-56:
+     * out = mixture * min(1, est^1 * (1/max(V1,eps))^1) */
+    for (int64_t f = 0; f < F; f++)
+    {
+      double est = H1[t * K + k] * W1[k * F + f];
+      double mult = 1 / (V1[t * F + f] > eps ? V1[t * F + f] : eps);
+      double m = est * mult;
+      if (m > 1.0) m = 1.0;
+      double yr = spec[2 * (t * F + f)] * m, yi = spec[2 * (t * F + f) + 1] * m;
+      /* util/FFT.hpp:155-160: imag of DC is replaced by the Nyquist real (packed format), so
+       * the imaginary parts of DC and Nyquist never reach the inverse transform. */
+      if (f == 0 || f == F - 1) yi = 0;
+      /* Hermitian extension; inverse = conj(FFT(conj(Y))) */
+      re[f] = yr; im[f] = -yi;
+      if (f > 0 && f < F - 1) { re[fft - f] = yr; im[fft - f] = yi; }
+    }
+    fft_c2c(re, im, fft, twr, twi);
+    /* alg/STFT.hpp:190-194 */
+    for (int64_t i = 0; i < win; i++)
+    {
+      acc[t * hop + i] += re[i] * scale * w[i];
+      nrm[t * hop + i] += w[i] * w[i];
+    }
+  }
+  /* :196-197 */
+  for (int64_t i = 0; i < n; i++)
+  {
+    double d = nrm[win / 2 + i] > eps ? nrm[win / 2 + i] : eps;
+    out[i] = acc[win / 2 + i] / d;
+  }
+  free(acc); free(nrm); free(w); free(re); free(im); free(twr); free(twi);
+}

@@ -1,0 +1,93 @@
+/*
+ * fluid_oracle.h -- CPU restatement ("oracle") of flucoma-core's BufNMF hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call it, and
+ * there only as the checker / the timed CPU baseline, never as the thing shipped.
+ *
+ * PARITY UNPINNED: the reference (flucoma-core, C++17 header-only) cannot be compiled in
+ * this image -- every header on the path needs Eigen 3.4.0, HISSTools_Library@f3292ad and
+ * foonathan/memory, all network FetchContent dependencies (reference CMakeLists.txt:54-123)
+ * that are absent -- and its own test-suite holds no known-answer vectors for STFT spectra
+ * or NMF factors (tests/algorithms/public/TestNMF.cpp:11-46 only checks same-seed
+ * repeatability).  What *is* pinned: the RNG stream (libstdc++ <random>, checked in
+ * tests/test_oracle.py against std::mt19937_64 + uniform_real_distribution compiled here),
+ * the Hann formula (tests/clients/common/TestBufferedProcess.cpp:42-44), frame counts
+ * (include/flucoma/clients/nrt/NMFClient.hpp:111-112), and agreement to <=1e-12 with an
+ * independent numpy restatement (oracle/oracle_np.py) whose outputs are committed as
+ * tests/golden fixtures.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/include/flucoma/).
+ */
+#ifndef FLUID_ORACLE_H
+#define FLUID_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* util/AlgorithmUtils.hpp:19  epsilon = std::numeric_limits<double>::epsilon() */
+#define FO_EPSILON 2.220446049250313e-16
+
+/* alg/WindowFuncs.hpp:41-45  (kHann, periodic): w[i] = 0.5 - 0.5*cos(2*pi*i/size) */
+void fo_window_hann(int64_t win, double* w);
+
+/* alg/STFT.hpp:98-99 and nrt/NMFClient.hpp:111-112: T = (N + hop) / hop (integer division) */
+int64_t fo_stft_num_frames(int64_t n, int64_t win, int64_t hop);
+
+/* alg/STFT.hpp:90-108 + util/FFT.hpp:92-108 + alg/STFT.hpp:61-66.
+ * audio: n doubles.  spec (may be NULL): T*F interleaved (re,im).  mag (may be NULL): T*F.
+ * Row-major T x F, F = fft/2+1.  Returns T. */
+int64_t fo_stft(const double* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                double* spec, double* mag);
+
+/* float -> double converting copy then fo_stft (nrt/NMFClient.hpp:240-242); stride in floats */
+int64_t fo_stft_f32(const float* audio, int64_t n, int64_t stride, int64_t win, int64_t fft,
+                    int64_t hop, double* spec, double* mag);
+
+/* util/EigenRandom.hpp:73-101 with libstdc++'s uniform_real_distribution<double>(0,1) over
+ * std::mt19937_64{seed}: out[i] = double(g())/2^64 (clamped below 1). */
+void fo_rng_uniform01(uint64_t seed, int64_t count, double* out);
+
+typedef int (*fo_progress_fn)(int64_t iteration, void* user); /* return 0 => cancel */
+
+/* alg/NMF.hpp:91-134 (process) + :144-183 (multiplicativeUpdates).
+ * X: T x F row-major (ldx = F).  W0: K x F or NULL.  H0: T x K or NULL.
+ * Outputs W1: K x F, H1: T x K, V1: T x F (may be NULL).
+ * faithful != 0 executes all seven GEMMs of alg/NMF.hpp:158-173 per iteration (incl. the two
+ * "ones" GEMMs and the dead R = W*H) -- this is what the CPU baseline times; faithful == 0
+ * replaces the "ones" GEMMs by sums and drops R (same maths, summation order in den differs).
+ * Returns 0, or 1 if a progress callback cancelled (outputs are then still written from the
+ * current W,H like the reference's early return leaves V untouched: V1 = X^T copy). */
+int fo_nmf_process(const double* X, int64_t T, int64_t F, int64_t K, int64_t iters,
+                   int updateW, int updateH, int64_t seed, const double* W0,
+                   const double* H0, double* W1, double* H1, double* V1, int faithful,
+                   fo_progress_fn progress, void* user);
+
+/* nrt/NMFClient.hpp:277-300 write-back of one channel.
+ * bases_out: K x F floats (channel-major: row k = bases channel k).
+ * acts_out : K x T floats (row k = activations channel k): float(H1[t][k]) * float(1/max(H1)). */
+void fo_bufnmf_writeback(const double* W1, const double* H1, int64_t T, int64_t F, int64_t K,
+                         float* bases_out, float* acts_out);
+
+/* One channel of nrt/NMFClient.hpp:233-300 end to end (random init, both factors updated).
+ * Returns T.  mag_out (T*F) may be NULL. */
+int64_t fo_bufnmf_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                          int64_t K, int64_t iters, int64_t seed, int faithful,
+                          float* bases_out, float* acts_out, double* mag_out);
+
+/* ---- "next" rows: resynthesis ------------------------------------------ */
+/* alg/NMF.hpp:33-42 + alg/RatioMask.hpp:33-57 + alg/STFT.hpp:178-199 for component k.
+ * spec: T*F interleaved complex; W1 KxF; H1 TxK; V1 TxF (= W*H estimate);
+ * out: n doubles (already trimmed by win/2). */
+void fo_resynth_component(const double* spec, const double* W1, const double* H1,
+                          const double* V1, int64_t T, int64_t F, int64_t K, int64_t k,
+                          int64_t win, int64_t fft, int64_t hop, int64_t n, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

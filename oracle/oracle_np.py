@@ -1,0 +1,206 @@
+"""Independent numpy restatement of flucoma-core's BufNMF hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/fluid_oracle.h).  PARITY UNPINNED by the reference's own
+tests; this file exists so that two independently written restatements (this one: numpy
+pocketfft + BLAS matmul; fluid_oracle.c: hand-rolled radix-2 FFT + blocked loops) must agree
+to <=1e-12 before either is trusted, and to mint the fixtures under tests/golden/
+(tools/make_golden.py).
+
+Reference files followed (relative to /root/reference/include/flucoma/):
+  algorithms/public/WindowFuncs.hpp:41-45, algorithms/public/STFT.hpp:90-108,61-66,
+  algorithms/util/FFT.hpp:92-108, algorithms/util/EigenRandom.hpp:73-110,
+  algorithms/public/NMF.hpp:91-134,144-183, clients/nrt/NMFClient.hpp:233-300.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+EPS = np.finfo(np.float64).eps  # util/AlgorithmUtils.hpp:19
+
+
+# --------------------------------------------------------------------------------------
+# RNG: std::mt19937_64 + libstdc++ uniform_real_distribution<double>(0, 1)
+# --------------------------------------------------------------------------------------
+class MT19937_64:
+    """std::mt19937_64 (vectorised twist)."""
+
+    NN, MM = 312, 156
+    A = np.uint64(0xB5026F5AA96619E9)
+    UM = np.uint64(0xFFFFFFFF80000000)
+    LM = np.uint64(0x7FFFFFFF)
+
+    def __init__(self, seed: int):
+        mt = np.zeros(self.NN, dtype=np.uint64)
+        x = int(seed) & 0xFFFFFFFFFFFFFFFF
+        mt[0] = x
+        for i in range(1, self.NN):
+            x = (6364136223846793005 * (x ^ (x >> 62)) + i) & 0xFFFFFFFFFFFFFFFF
+            mt[i] = x
+        self.mt = mt
+        self.idx = self.NN
+
+    def _twist(self):
+        mt, NN, MM = self.mt, self.NN, self.MM
+
+        def mix(up, lo, far):
+            x = (up & self.UM) | (lo & self.LM)
+            return far ^ (x >> np.uint64(1)) ^ np.where(x & np.uint64(1), self.A, np.uint64(0))
+
+        # i in [0, NN-MM): uses old mt[i+1], old mt[i+MM]
+        mt[: NN - MM] = mix(mt[: NN - MM], mt[1 : NN - MM + 1], mt[MM:NN])
+        # i in [NN-MM, NN-1): uses old mt[i+1], NEW mt[i+MM-NN]
+        mt[NN - MM : NN - 1] = mix(mt[NN - MM : NN - 1], mt[NN - MM + 1 : NN], mt[: MM - 1])
+        # i = NN-1: uses NEW mt[0], NEW mt[MM-1]
+        mt[NN - 1 : NN] = mix(mt[NN - 1 : NN], mt[0:1], mt[MM - 1 : MM])
+        self.idx = 0
+
+    def raw(self, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.uint64)
+        done = 0
+        while done < count:
+            if self.idx >= self.NN:
+                self._twist()
+            take = min(count - done, self.NN - self.idx)
+            out[done : done + take] = self.mt[self.idx : self.idx + take]
+            self.idx += take
+            done += take
+        x = out
+        x = x ^ ((x >> np.uint64(29)) & np.uint64(0x5555555555555555))
+        x = x ^ ((x << np.uint64(17)) & np.uint64(0x71D67FFFEDA60000))
+        x = x ^ ((x << np.uint64(37)) & np.uint64(0xFFF7EEE000000000))
+        x = x ^ (x >> np.uint64(43))
+        return x
+
+
+def rng_uniform01(seed: int, count: int) -> np.ndarray:
+    """libstdc++ generate_canonical<double,53> over mt19937_64: double(u64) / 2**64."""
+    u = MT19937_64(seed).raw(count)
+    r = u.astype(np.float64) / 18446744073709551616.0  # u64 -> f64 is round-to-nearest
+    r[r >= 1.0] = np.nextafter(1.0, 0.0)
+    return r
+
+
+# --------------------------------------------------------------------------------------
+# STFT
+# --------------------------------------------------------------------------------------
+def hann(win: int) -> np.ndarray:
+    i = np.arange(win, dtype=np.float64)
+    return 0.5 - 0.5 * np.cos((np.pi * 2 * i) / win)
+
+
+def stft_num_frames(n: int, win: int, hop: int) -> int:
+    return (n + hop) // hop
+
+
+def stft(audio: np.ndarray, win: int, fft: int, hop: int):
+    """Returns (spec complex128 [T,F], mag float64 [T,F])."""
+    audio = np.asarray(audio, dtype=np.float64)
+    n = audio.shape[0]
+    padded = np.zeros(n + win + hop)
+    padded[win // 2 : win // 2 + n] = audio
+    T = (padded.shape[0] - win) // hop
+    w = hann(win)
+    idx = np.arange(T)[:, None] * hop + np.arange(win)[None, :]
+    frames = padded[idx] * w[None, :]
+    spec = np.fft.rfft(frames, n=fft, axis=1)  # zero-pads the tail when win < fft
+    spec[:, 0] = spec[:, 0].real
+    spec[:, -1] = spec[:, -1].real
+    return spec, np.abs(spec)
+
+
+# --------------------------------------------------------------------------------------
+# NMF
+# --------------------------------------------------------------------------------------
+def nmf_process(X, K, iters, updateW=True, updateH=True, seed=42, W0=None, H0=None,
+                progress=None):
+    """X: [T,F].  Returns W1 [K,F], H1 [T,K], V1 [T,F] (alg/NMF.hpp:91-134)."""
+    X = np.asarray(X, dtype=np.float64)
+    T, F = X.shape
+    if W0 is None:
+        W = rng_uniform01(seed, F * K).reshape(K, F).T.copy()  # column-major F x K fill
+    else:
+        W = np.asarray(W0, dtype=np.float64).T.copy()
+    if H0 is None:
+        H = rng_uniform01(seed, K * T).reshape(T, K).T.copy()  # column-major K x T fill
+    else:
+        H = np.asarray(H0, dtype=np.float64).T.copy()
+    V = X.T.copy()
+    H = np.maximum(H, EPS)
+    W = np.maximum(W, EPS)
+    W = W / np.sqrt((W * W).sum(axis=0, keepdims=True))
+    H = H / np.sqrt((H * H).sum(axis=1, keepdims=True))
+    cancelled = False
+    for it in range(iters):
+        if updateW:
+            V1 = np.maximum(W @ H, EPS)
+            wnum = (V / V1) @ H.T
+            wden = H.sum(axis=1)[None, :]
+            W = W * wnum / np.maximum(wden, EPS)
+            if W.max() > EPS:
+                W = W / np.sqrt((W * W).sum(axis=0, keepdims=True))
+        V2 = np.maximum(W @ H, EPS)
+        if updateH:
+            hnum = W.T @ (V / V2)
+            hden = W.sum(axis=0)[:, None]
+            H = H * hnum / np.maximum(hden, EPS)
+        if progress is not None and not progress(it + 1):
+            cancelled = True
+            break
+    Vout = V if cancelled else W @ H
+    return W.T.copy(), H.T.copy(), Vout.T.copy()
+
+
+def bufnmf_writeback(W1, H1):
+    """nrt/NMFClient.hpp:277-300: bases [K,F] f32; activations [K,T] f32 (float multiply)."""
+    bases = W1.astype(np.float32)
+    scale = 1.0 / H1.max()
+    acts = H1.T.astype(np.float32) * np.float32(scale)
+    return bases, acts.astype(np.float32)
+
+
+def bufnmf_channel(audio_f32, win, fft, hop, K, iters, seed):
+    audio = np.asarray(audio_f32, dtype=np.float32).astype(np.float64)
+    _, mag = stft(audio, win, fft, hop)
+    W1, H1, V1 = nmf_process(mag, K, iters, True, True, seed)
+    bases, acts = bufnmf_writeback(W1, H1)
+    return bases, acts, mag, W1, H1, V1
+
+
+# --------------------------------------------------------------------------------------
+# resynthesis
+# --------------------------------------------------------------------------------------
+def resynth_component(spec, W1, H1, V1, k, win, fft, hop, n):
+    T, F = spec.shape
+    est = np.outer(H1[:, k], W1[k, :])
+    mask = np.minimum(est * (1.0 / np.maximum(V1, EPS)), 1.0)
+    Y = spec * mask
+    frames = np.fft.irfft(Y, n=fft, axis=1)[:, :win]  # = unnormalised inverse * (1/fft)
+    w = hann(win)
+    outsz = win + (T - 1) * hop + win + hop
+    acc = np.zeros(outsz)
+    nrm = np.zeros(outsz)
+    for t in range(T):
+        acc[t * hop : t * hop + win] += frames[t] * w
+        nrm[t * hop : t * hop + win] += w * w
+    out = acc / np.maximum(nrm, EPS)
+    return out[win // 2 : win // 2 + n]
+
+
+# --------------------------------------------------------------------------------------
+# synthetic audio (SURVEY 8 d): decaying sinusoid "notes" + -40 dB noise, float32
+# --------------------------------------------------------------------------------------
+def synth_audio(n: int, seed: int, sr: float = 44100.0, notes: int = 8) -> np.ndarray:
+    rs = np.random.RandomState(seed)
+    t = np.arange(n, dtype=np.float64) / sr
+    x = np.zeros(n)
+    dur = n / sr
+    for _ in range(notes):
+        onset = rs.uniform(0, 0.8 * dur)
+        f = np.exp(rs.uniform(np.log(100.0), np.log(8000.0)))
+        decay = rs.uniform(2.0, 12.0)
+        amp = rs.uniform(0.2, 1.0)
+        tt = np.maximum(t - onset, 0.0)
+        x += np.where(t >= onset, amp * np.exp(-decay * tt) * np.sin(2 * np.pi * f * tt), 0.0)
+    x += 0.01 * rs.standard_normal(n)
+    x /= max(1.0, np.abs(x).max())
+    return x.astype(np.float32)
