@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""bench.py -- BufNMF hot path (STFT -> magnitude -> KL-NMF -> write-back) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric "rank-32 fft2048", config 4's per-GPU shard): every rank holds
+128 independent 10 s mono 44.1 kHz synthetic buffers (441 000 samples each), STFT win/fft 2048,
+hop 512 (T = 862 frames, F = 1025 bins), NMF rank 32, 200 iterations, NMF seed 42.  One "step" =
+one full pass of the hot path over the rank's 128 buffers with the audio already resident in
+HBM: batched STFT+magnitude, 200 multiplicative-update iterations, float write-back of bases
+and activations, and (N > 1) the RCCL all-gather of the dictionaries/activations.  Weak scaling:
+per-GPU work is fixed, buffers shard across ranks with no data-path collective.
+
+value = NMF buffer-iterations per second over the whole job
+      = ranks * 128 buffers * 200 iterations / (max-over-ranks time of one step).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+import numpy as np  # noqa: E402
+
+# MI355X peaks used for the roofline fractions.  HBM: /opt/skills/guides/MI355X_MICROARCH.md
+# (8.0 TB/s spec).  FP64 matrix: AMD datasheet 78.6 TFLOP/s (the guide has no f64 row); the
+# v_mfma_f64_16x16x4_f64 issue rate this implies (64 cycles/SIMD at 2.4 GHz) is confirmed by
+# tools/mfma_f64_probe (profiles/).
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+WORKLOAD = dict(buffers_per_gpu=128, seconds=10.0, sr=44100, win=2048, fft=2048, hop=512, rank=32,
+                iters=200, seed=42)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--buffers", type=int, default=WORKLOAD["buffers_per_gpu"],
+                    help="buffers per GPU (default: the BASELINE config-4 shard, 128)")
+    ap.add_argument("--iters", type=int, default=WORKLOAD["iters"])
+    ap.add_argument("--rank", type=int, default=WORKLOAD["rank"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget")
+    return ap.parse_args()
+
+
+def cpu_baseline(audio_one, wl, budget_s):
+    """The oracle's faithful mode (all seven GEMMs of alg/NMF.hpp:158-173 per iteration) on ONE
+    buffer of the same workload, one core -- what one BufNMF job costs the reference."""
+    import oracle_c
+    import oracle_np
+    o = oracle_c.get("native")
+    n = audio_one.shape[0]
+    t0 = time.perf_counter()
+    _, mag = o.stft_f32(audio_one, wl["win"], wl["fft"], wl["hop"])
+    t_stft = time.perf_counter() - t0
+    T, F = mag.shape
+    # probe 3 iterations, then size the sample to the budget
+    t0 = time.perf_counter()
+    o.nmf_process(mag, wl["rank"], 3, True, True, wl["seed"], faithful=True)
+    per_iter = (time.perf_counter() - t0) / 3
+    iters = int(max(3, min(wl["iters"], budget_s / max(per_iter, 1e-9))))
+    t0 = time.perf_counter()
+    o.nmf_process(mag, wl["rank"], iters, True, True, wl["seed"], faithful=True)
+    t_nmf = time.perf_counter() - t0
+    executed_flop = 14.0 * F * T * wl["rank"] * iters
+    cpu_model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {
+        "value": iters / t_nmf, "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": f"1 buffer ({n} samples, T={T}, F={F}), rank {wl['rank']}, {iters} of {wl['iters']} "
+                  f"iterations, oracle faithful mode (7 GEMMs/iter like alg/NMF.hpp), gcc -O3 -march=native",
+        "stft_frames_per_s": T / t_stft,
+        "executed_gflops": executed_flop / t_nmf / 1e9,
+        "bufnmf_wall_s_200iter_est": t_stft + t_nmf / iters * wl["iters"],
+        "cpu_model": cpu_model, "host_cores_available": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse()
+    wl = dict(WORKLOAD)
+    wl["buffers_per_gpu"], wl["iters"], wl["rank"] = args.buffers, args.iters, args.rank
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs a torch.distributed.run launch with "
+                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
+            sys.exit(2)
+
+    # torch first: it owns the HIP runtime the process shares; our library is loaded afterwards
+    import torch
+    import torch.distributed as dist
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import fluhip
+    import oracle_np
+    ctx = fluhip.Context(local)
+    name, arch, cus = ctx.device_info()
+
+    B, n = wl["buffers_per_gpu"], int(wl["seconds"] * wl["sr"])
+    K, iters = wl["rank"], wl["iters"]
+    # synthetic corpus: buffer b of rank r uses audio seed 1000 + r*B + b
+    audio = np.stack([oracle_np.synth_audio(n, 1000 + rank * B + b) for b in range(B)])
+    corpus = fluhip.Corpus(ctx, B, n, wl["win"], wl["fft"], wl["hop"], K)
+    T, F = corpus.T, corpus.F
+    audio_dev = torch.from_numpy(audio).cuda()           # resident in HBM before the timed region
+    corpus.set_audio_dev(audio_dev.data_ptr())
+    bases = torch.empty((B, K, F), dtype=torch.float32, device="cuda")
+    acts = torch.empty((B, K, T), dtype=torch.float32, device="cuda")
+    if world > 1:
+        bases_all = torch.empty((world * B, K, F), dtype=torch.float32, device="cuda")
+        acts_all = torch.empty((world * B, K, T), dtype=torch.float32, device="cuda")
+
+    def step():
+        corpus.stft()
+        corpus.nmf(iters, seed=wl["seed"])
+        corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
+        ctx.synchronize()
+        if world > 1:  # the one collective of the path: final dictionary/activation gather
+            dist.all_gather_into_tensor(bases_all, bases)
+            dist.all_gather_into_tensor(acts_all, acts)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.prof_enable(True)
+    ctx.prof_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    n_upd, ms_upd = ctx.prof_read(1)
+    n_stft, ms_stft = ctx.prof_read(0)
+    ctx.prof_enable(False)
+
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed_max = float(tmax.item())
+
+    # sanity on the result of the last step (not timed)
+    a_host = acts.cpu().numpy()
+    finite = bool(np.isfinite(a_host).all())
+
+    if rank == 0:
+        ms_per_step = elapsed_max / args.steps * 1e3
+        value = world * B * iters * args.steps / elapsed_max
+        # dominant kernel: nmf_update (one launch = one factor update of all B buffers)
+        flop_per_launch = 4.0 * F * T * K * B
+        bytes_per_launch = (F * T * 8.0 + 2.0 * (F * K + K * T) * 8.0) * B
+        avg_ms = ms_upd / max(n_upd, 1)
+        ach_tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        stft_ms = ms_stft / max(n_stft, 1)
+        stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
+        out = {
+            "metric": "NMF iterations/sec (buffer-iterations over the whole BufNMF job: STFT + 200-iter "
+                      "KL-NMF + write-back), rank-32 fft2048",
+            "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4 shard: {B} x 10 s mono 44.1 kHz buffers per GPU, "
+                                   f"fft 2048 / hop 512, rank {K}, {iters} iterations, seed 42",
+                       "buffers_per_gpu": B, "samples": n, "frames": T, "bins": F, "rank": K,
+                       "iterations": iters, "parallelism": f"shard{world}" if world > 1 else "single"},
+            "stft_frames_per_s": (T * B) / (stft_ms * 1e-3) if stft_ms > 0 else None,
+            "nmf_iterations_per_s_kernel_only": B / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
+            "roofline": {"bound": "mfma", "kernel": "nmf_update_kernel<2,2,2>", "achieved": ach_tflops,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
+                         "traffic": None, "launches": int(n_upd), "avg_launch_ms": avg_ms,
+                         "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
+                         "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": ach_gbs / PEAK_HBM_GBS}},
+            "roofline_stft": {"bound": "hbm", "kernel": "stft_r2c_mag_kernel", "avg_launch_ms": stft_ms,
+                              "achieved": stft_bytes / (stft_ms * 1e-3) / 1e9 if stft_ms > 0 else None,
+                              "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": (stft_bytes / (stft_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if stft_ms > 0 else None},
+            "device": {"name": name, "arch": arch, "compute_units": cus,
+                       "corpus_device_bytes": corpus.device_bytes()},
+            "result_finite": finite,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(audio[0], wl, args.cpu_seconds)
+            gpu_job_s = elapsed_max / args.steps / B   # per-buffer share of one step
+            out["cpu_baseline"]["gpu_speedup_per_buffer_job"] = (
+                out["cpu_baseline"]["bufnmf_wall_s_200iter_est"] * (iters / WORKLOAD["iters"]) / gpu_job_s)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    corpus.close()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,934 @@
+// api.hip -- the C ABI of libflucoma_hip.so (include/flucoma_hip.h) over the gfx950 kernels.
+//
+// Host-side control flow mirrors the reference call sites it replaces:
+//   algorithm::STFT::process / magnitude   include/flucoma/algorithms/public/STFT.hpp:90-108,61-66
+//   algorithm::NMF::process                include/flucoma/algorithms/public/NMF.hpp:91-134
+//   NMF::multiplicativeUpdates             include/flucoma/algorithms/public/NMF.hpp:144-183
+//   bufnmf::NMFClient::process write-back  include/flucoma/clients/nrt/NMFClient.hpp:277-300
+// There is no CPU fallback anywhere in this file: every compute path launches HIP kernels and
+// fails with FLUHIP_ERROR when the device is unusable.
+#include "../../include/flucoma_hip.h"
+#include "fluhip_kernels.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <optional>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace fluhip;
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+struct ProfRec
+{
+  int cls;
+  hipEvent_t start, stop;
+};
+
+struct fluhip_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<std::pair<int, int>, double*> windows; // (win, type) -> device table
+  std::map<int, double*> twiddles;                // fft -> device table
+  bool prof = false;
+  std::vector<ProfRec> profRecs;
+  std::vector<hipEvent_t> eventPool;
+  hipDeviceProp_t props;
+};
+
+static int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERROR)
+{
+  if (ctx) ctx->err = msg;
+  return status;
+}
+
+#define HIPCHK(ctx, expr)                                                                        \
+  do                                                                                             \
+  {                                                                                              \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess)                                                                       \
+      return fail(ctx, std::string("HIP error: ") + hipGetErrorString(e__) + " in " #expr);      \
+  } while (0)
+
+struct DevBuf
+{
+  void* p = nullptr;
+  size_t bytes = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release()
+  {
+    if (p) (void) hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  hipError_t alloc(size_t n, bool zero, hipStream_t s)
+  {
+    release();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) { p = nullptr; return e; }
+    bytes = n;
+    if (zero) e = hipMemsetAsync(p, 0, n, s);
+    return e;
+  }
+  template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+static hipEvent_t take_event(fluhip_ctx* ctx)
+{
+  if (!ctx->eventPool.empty())
+  {
+    hipEvent_t e = ctx->eventPool.back();
+    ctx->eventPool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void) hipEventCreate(&e);
+  return e;
+}
+
+struct ProfScope
+{
+  fluhip_ctx* ctx;
+  ProfRec rec;
+  bool on;
+  ProfScope(fluhip_ctx* c, int cls) : ctx(c), on(c->prof)
+  {
+    if (!on) return;
+    rec.cls = cls;
+    rec.start = take_event(ctx);
+    rec.stop = take_event(ctx);
+    (void) hipEventRecord(rec.start, ctx->stream);
+  }
+  ~ProfScope()
+  {
+    if (!on) return;
+    (void) hipEventRecord(rec.stop, ctx->stream);
+    ctx->profRecs.push_back(rec);
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// tables: window (alg/WindowFuncs.hpp:38-72) and FFT twiddles, computed on the host in f64
+// ---------------------------------------------------------------------------------------
+static bool make_window(int type, int64_t size, std::vector<double>& out)
+{
+  const double pi = M_PI; // util/AlgorithmUtils.hpp:21
+  out.resize((size_t) size);
+  switch (type)
+  {
+  case FLUHIP_WINDOW_HANN: // alg/WindowFuncs.hpp:41-45
+    for (int64_t i = 0; i < size; i++) out[(size_t) i] = 0.5 - 0.5 * std::cos((pi * 2 * i) / size);
+    return true;
+  case FLUHIP_WINDOW_HANND: // :46-51
+  {
+    double norm = pi / size;
+    for (int64_t i = 0; i < size; i++) out[(size_t) i] = norm * std::sin((2 * pi * i) / size);
+    return true;
+  }
+  case FLUHIP_WINDOW_HAMMING: // :52-56
+    for (int64_t i = 0; i < size; i++) out[(size_t) i] = 0.54 - 0.46 * std::cos((pi * 2 * i) / size);
+    return true;
+  case FLUHIP_WINDOW_BLACKMANHARRIS: // :57-65 (all three cosines share one argument, as written there)
+    for (int64_t i = 0; i < size; i++)
+      out[(size_t) i] = 0.35875 - 0.48829 * std::cos((pi * 2 * i) / size) +
+                        0.14128 * std::cos((pi * 2 * i) / size) +
+                        0.01168 * std::cos((pi * 2 * i) / size);
+    return true;
+  case FLUHIP_WINDOW_GAUSSIAN: // :66-72 (requires odd size; sigma = size / 3 in integer arithmetic)
+  {
+    if (size % 2 == 0) return false;
+    double sigma = (double) (size / 3);
+    int64_t h = (size - 1) / 2;
+    for (int64_t i = -h; i <= h; i++) out[(size_t) (i + h)] = std::exp(-i * i / (2 * sigma * sigma));
+    return true;
+  }
+  default: return false;
+  }
+}
+
+static int get_window(fluhip_ctx* ctx, int64_t win, int type, const double** out)
+{
+  auto key = std::make_pair((int) win, type);
+  auto it = ctx->windows.find(key);
+  if (it == ctx->windows.end())
+  {
+    std::vector<double> w;
+    if (!make_window(type, win, w)) return fail(ctx, "unsupported window type / size");
+    double* d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d, (size_t) win * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(d, w.data(), (size_t) win * sizeof(double), hipMemcpyHostToDevice));
+    it = ctx->windows.emplace(key, d).first;
+  }
+  *out = it->second;
+  return FLUHIP_OK;
+}
+
+static int get_twiddle(fluhip_ctx* ctx, int64_t fft, const double** out)
+{
+  auto it = ctx->twiddles.find((int) fft);
+  if (it == ctx->twiddles.end())
+  {
+    const size_t nc = (size_t) fft / 2;
+    std::vector<double> t(2 * nc);
+    for (size_t j = 0; j < nc; j++)
+    {
+      const double ang = -2.0 * M_PI * (double) j / (double) fft;
+      t[2 * j] = std::cos(ang);
+      t[2 * j + 1] = std::sin(ang);
+    }
+    double* d = nullptr;
+    HIPCHK(ctx, hipMalloc(&d, std::max<size_t>(16, t.size() * sizeof(double))));
+    HIPCHK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    it = ctx->twiddles.emplace((int) fft, d).first;
+  }
+  *out = it->second;
+  return FLUHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// corpus
+// ---------------------------------------------------------------------------------------
+struct fluhip_corpus
+{
+  fluhip_ctx* ctx = nullptr;
+  int64_t B = 0, n = 0, win = 0, fft = 0, hop = 0, K = 0;
+  int64_t T = 0, F = 0, Tp = 0, Fp = 0, Kp = 0;
+  int windowType = FLUHIP_WINDOW_HANN;
+  bool keepSpec = false;
+  const float* audioDev = nullptr; // borrowed or owned (audioOwn)
+  DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax;
+  int nsplitW = 1, nsplitH = 1;
+  bool haveMag = false, haveFactors = false;
+  int64_t device_bytes() const
+  {
+    return (int64_t) (audioOwn.bytes + mag.bytes + magT.bytes + Wf.bytes + H1.bytes + spec.bytes +
+                      part.bytes + dpart.bytes + stage.bytes + hmax.bytes);
+  }
+};
+
+static int choose_split(int64_t B, int64_t nCW, int64_t nRt)
+{
+  // enough workgroups to fill 256 CUs twice over; only single/few-buffer problems ever split
+  const int64_t have = B * nCW;
+  if (have >= 384) return 1;
+  int64_t s = (512 + have - 1) / have;
+  s = std::min<int64_t>(s, 64);
+  s = std::min<int64_t>(s, std::max<int64_t>(1, nRt / 2));
+  return (int) std::max<int64_t>(1, s);
+}
+
+static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  c->T = (c->n + c->hop) / c->hop; // alg/STFT.hpp:98-99; nrt/NMFClient.hpp:111-112
+  c->F = c->fft / 2 + 1;
+  c->Tp = round_up(c->T, 32);
+  c->Fp = round_up(c->F, 32);
+  c->Kp = round_up(c->K, 16);
+  const size_t B = (size_t) c->B;
+  HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
+  HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
+  HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
+  const int cpw = nmf_update_cols_per_wave((int) c->Kp);
+  c->nsplitW = choose_split(c->B, (c->F + 4 * cpw - 1) / (4 * cpw), (c->T + 15) / 16);
+  c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
+  const int ns = std::max(c->nsplitW, c->nsplitH);
+  if (ns > 1)
+  {
+    const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
+    HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
+    HIPCHK(ctx, c->dpart.alloc(B * ns * c->Kp * sizeof(double), true, s));
+  }
+  return FLUHIP_OK;
+}
+
+static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t K)
+{
+  if (n <= 0) return fail(ctx, "not enough frames");
+  if (win < 1 || hop < 1) return fail(ctx, "window and hop sizes must be positive");
+  if (fft < 4 || (fft & (fft - 1)) || fft < win)
+    return fail(ctx, "fft size must be a power of two >= window size");
+  if (!stft_supported(win, fft))
+    return fail(ctx, "fft sizes above 8192 are not supported by the gfx950 STFT kernel");
+  if (K < 1) return fail(ctx, "rank must be >= 1");
+  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
+  if ((n + hop) / hop > 2000000000LL / 16) return fail(ctx, "too many frames");
+  return FLUHIP_OK;
+}
+
+static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride)
+{
+  fluhip_ctx* ctx = c->ctx;
+  const double *wtab = nullptr, *ttab = nullptr;
+  int rc = get_window(ctx, c->win, c->windowType, &wtab);
+  if (rc) return rc;
+  rc = get_twiddle(ctx, c->fft, &ttab);
+  if (rc) return rc;
+  if (c->keepSpec && !c->spec.p)
+    HIPCHK(ctx, c->spec.alloc((size_t) c->B * c->T * c->F * 2 * sizeof(double), false, ctx->stream));
+  StftArgs a;
+  a.audio = a32; a.audio64 = a64; a.n = c->n; a.audioStride = audioStride;
+  a.win = (int) c->win; a.fft = (int) c->fft; a.hop = (int) c->hop;
+  a.T = (int) c->T; a.F = (int) c->F; a.B = (int) c->B;
+  a.window = wtab; a.twiddle = ttab;
+  a.mag = c->mag.as<double>(); a.magStride = c->Tp * c->Fp; a.ldMag = c->Fp;
+  a.spec = c->keepSpec ? c->spec.as<double>() : nullptr; a.specStride = c->T * c->F * 2;
+  {
+    ProfScope p(ctx, 0);
+    launch_stft(a, ctx->stream);
+  }
+  // second copy of V with the frame index contiguous, for the H update
+  launch_transpose(c->mag.as<double>(), c->Fp, c->Tp * c->Fp, c->magT.as<double>(), c->Tp,
+                   c->Fp * c->Tp, (int) c->T, (int) c->F, (int) c->B, ctx->stream);
+  HIPCHK(ctx, hipGetLastError());
+  c->haveMag = true;
+  return FLUHIP_OK;
+}
+
+// util/EigenRandom.hpp:73-101: std::mt19937_64 g{seed ? *seed : rd()} +
+// std::uniform_real_distribution<double>{0, 1}; one draw per coefficient in Eigen's column-major
+// linear order.  libstdc++'s <random> is used verbatim, exactly as the reference does.
+static void draw_uniform(int64_t seed, size_t count, std::vector<double>& out)
+{
+  std::random_device rd;
+  std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
+  std::uniform_real_distribution<double> d{0.0, 1.0};
+  out.resize(count);
+  for (size_t i = 0; i < count; i++) out[i] = d(g);
+}
+
+struct FactorInit
+{
+  // device sources already in the padded layout are marked by null here
+  const double* W0host = nullptr; // [B or 1][K][F] f64
+  const double* H0host = nullptr; // [B or 1][T][K] f64
+  const float* W0f32 = nullptr;   // [B][K][F] f32 channel-major seeds
+  const float* H0f32 = nullptr;   // [B][K][T] f32 channel-major seeds
+  bool sharedW = false, sharedH = false;
+};
+
+static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds,
+                               const FactorInit& fi)
+{
+  fluhip_ctx* ctx = c->ctx;
+  hipStream_t s = ctx->stream;
+  const size_t FK = (size_t) c->F * c->K, TK = (size_t) c->T * c->K;
+  const int B = (int) c->B;
+  // --- W ---
+  if (fi.W0f32)
+  {
+    HIPCHK(ctx, c->stage.alloc((size_t) B * FK * sizeof(float), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, fi.W0f32, (size_t) B * FK * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_scatter_factor_f32(c->stage.as<float>(), (int64_t) FK, c->Wf.as<double>(), c->Fp * c->Kp,
+                              (int) c->F, (int) c->K, (int) c->Kp, B, s);
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  else
+  {
+    std::vector<double> host;
+    const double* src = fi.W0host;
+    int nsrc = fi.W0host ? (fi.sharedW ? 1 : B) : 1;
+    if (!src)
+    {
+      if (seeds)
+      {
+        nsrc = B;
+        host.resize((size_t) B * FK);
+        std::vector<double> tmp;
+        std::map<int64_t, int> seen;
+        for (int b = 0; b < B; b++)
+        {
+          auto it = seeds[b] >= 0 ? seen.find(seeds[b]) : seen.end();
+          if (it != seen.end())
+            std::memcpy(&host[(size_t) b * FK], &host[(size_t) it->second * FK], FK * sizeof(double));
+          else
+          {
+            draw_uniform(seeds[b], FK, tmp);
+            std::memcpy(&host[(size_t) b * FK], tmp.data(), FK * sizeof(double));
+            if (seeds[b] >= 0) seen[seeds[b]] = b;
+          }
+        }
+      }
+      else
+        draw_uniform(seed, FK, host); // alg/NMF.hpp:104-105
+      src = host.data();
+    }
+    HIPCHK(ctx, c->stage.alloc((size_t) nsrc * FK * sizeof(double), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, src, (size_t) nsrc * FK * sizeof(double), hipMemcpyHostToDevice, s));
+    // K x F row-major source (random: column-major F x K fill; seeded: W0 transposed, :102-112)
+    launch_scatter_factor(c->stage.as<double>(), nsrc == 1 ? 0 : (int64_t) FK, c->Wf.as<double>(),
+                          c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, s);
+    HIPCHK(ctx, hipStreamSynchronize(s)); // host vector goes out of scope
+  }
+  // --- H ---
+  if (fi.H0f32)
+  {
+    HIPCHK(ctx, c->stage.alloc((size_t) B * TK * sizeof(float), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, fi.H0f32, (size_t) B * TK * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_scatter_factor_f32(c->stage.as<float>(), (int64_t) TK, c->H1.as<double>(), c->Tp * c->Kp,
+                              (int) c->T, (int) c->K, (int) c->Kp, B, s);
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  else
+  {
+    std::vector<double> host;
+    const double* src = fi.H0host;
+    int nsrc = fi.H0host ? (fi.sharedH ? 1 : B) : 1;
+    if (!src)
+    {
+      if (seeds)
+      {
+        nsrc = B;
+        host.resize((size_t) B * TK);
+        std::vector<double> tmp;
+        std::map<int64_t, int> seen;
+        for (int b = 0; b < B; b++)
+        {
+          auto it = seeds[b] >= 0 ? seen.find(seeds[b]) : seen.end();
+          if (it != seen.end())
+            std::memcpy(&host[(size_t) b * TK], &host[(size_t) it->second * TK], TK * sizeof(double));
+          else
+          {
+            draw_uniform(seeds[b], TK, tmp);
+            std::memcpy(&host[(size_t) b * TK], tmp.data(), TK * sizeof(double));
+            if (seeds[b] >= 0) seen[seeds[b]] = b;
+          }
+        }
+      }
+      else
+        draw_uniform(seed, TK, host); // alg/NMF.hpp:116-117 (a fresh generator from the same seed)
+      src = host.data();
+    }
+    HIPCHK(ctx, c->stage.alloc((size_t) nsrc * TK * sizeof(double), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, src, (size_t) nsrc * TK * sizeof(double), hipMemcpyHostToDevice, s));
+    // T x K row-major source (random: column-major K x T fill; seeded: H0 transposed, :113-124)
+    launch_scatter_factor(c->stage.as<double>(), nsrc == 1 ? 0 : (int64_t) TK, c->H1.as<double>(),
+                          c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, false, s);
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  // alg/NMF.hpp:150-153: clamp both to eps, normalise columns of W and rows of H (= columns of H1)
+  launch_colnorm(c->H1.as<double>(), c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, true, false, s);
+  launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, false, s);
+  HIPCHK(ctx, hipGetLastError());
+  c->haveFactors = true;
+  return FLUHIP_OK;
+}
+
+static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
+{
+  fluhip_ctx* ctx = c->ctx;
+  hipStream_t s = ctx->stream;
+  const int B = (int) c->B;
+  if (updateW)
+  {
+    // alg/NMF.hpp:158-161
+    UpdateArgs a;
+    a.V = c->mag.as<double>(); a.ldv = c->Fp; a.strideV = c->Tp * c->Fp;
+    a.Mv = c->H1.as<double>(); a.strideM = c->Tp * c->Kp;
+    a.S = c->Wf.as<double>(); a.strideS = c->Fp * c->Kp;
+    a.R = (int) c->T; a.C = (int) c->F; a.B = B; a.Kp = (int) c->Kp;
+    a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
+    a.Cp = std::max(c->Fp, c->Tp);
+    {
+      ProfScope p(ctx, 1);
+      launch_nmf_update(a, s);
+    }
+    // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
+    launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true, s);
+  }
+  if (updateH)
+  {
+    // alg/NMF.hpp:165-170 (V2 is formed from the already updated W)
+    UpdateArgs a;
+    a.V = c->magT.as<double>(); a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
+    a.Mv = c->Wf.as<double>(); a.strideM = c->Fp * c->Kp;
+    a.S = c->H1.as<double>(); a.strideS = c->Tp * c->Kp;
+    a.R = (int) c->F; a.C = (int) c->T; a.B = B; a.Kp = (int) c->Kp;
+    a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
+    a.Cp = std::max(c->Fp, c->Tp);
+    ProfScope p(ctx, 1);
+    launch_nmf_update(a, s);
+  }
+}
+
+// alg/NMF.hpp:154-181 loop + :175-176 callbacks.  Iterations are enqueued back to back; when a
+// progress callback is present the stream is drained every `chunk` iterations and the callback
+// is invoked once per completed iteration, in order, on the calling thread.
+static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
+                          fluhip_progress_fn progress, void* user)
+{
+  fluhip_ctx* ctx = c->ctx;
+  if (!progress)
+  {
+    for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH);
+    HIPCHK(ctx, hipGetLastError());
+    return FLUHIP_OK;
+  }
+  int64_t done = 0, chunk = 1;
+  while (done < iters)
+  {
+    const int64_t nthis = std::min(chunk, iters - done);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int64_t i = 0; i < nthis; i++) enqueue_iteration(c, updateW, updateH);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    for (int64_t i = 0; i < nthis; i++)
+      if (!progress(done + i + 1, user)) return fail(ctx, "cancelled", FLUHIP_CANCELLED);
+    done += nthis;
+    // aim for ~4 ms between drains so the cancellation latency stays small
+    if (ms < 2.0 && chunk < 64) chunk *= 2;
+    else if (ms > 8.0 && chunk > 1) chunk /= 2;
+  }
+  return FLUHIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int fluhip_abi_version(void) { return FLUHIP_ABI_VERSION; }
+
+int fluhip_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int fluhip_ctx_create(int device, fluhip_ctx** out)
+{
+  if (!out) return FLUHIP_ERROR;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FLUHIP_ERROR;
+  std::unique_ptr<fluhip_ctx> ctx(new fluhip_ctx);
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) return FLUHIP_ERROR;
+  if (hipGetDeviceProperties(&ctx->props, device) != hipSuccess) return FLUHIP_ERROR;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return FLUHIP_ERROR;
+  *out = ctx.release();
+  return FLUHIP_OK;
+}
+
+void fluhip_ctx_destroy(fluhip_ctx* ctx)
+{
+  if (!ctx) return;
+  (void) hipSetDevice(ctx->device);
+  if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->windows) (void) hipFree(kv.second);
+  for (auto& kv : ctx->twiddles) (void) hipFree(kv.second);
+  for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
+  for (auto e : ctx->eventPool) (void) hipEventDestroy(e);
+  if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* fluhip_last_error(const fluhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char* arch,
+                           int arch_len, int* compute_units)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (name && name_len > 0) { std::snprintf(name, (size_t) name_len, "%s", ctx->props.name); }
+  if (arch && arch_len > 0) { std::snprintf(arch, (size_t) arch_len, "%s", ctx->props.gcnArchName); }
+  if (compute_units) *compute_units = ctx->props.multiProcessorCount;
+  return FLUHIP_OK;
+}
+
+void* fluhip_ctx_stream(const fluhip_ctx* ctx) { return ctx ? (void*) ctx->stream : nullptr; }
+
+int fluhip_ctx_synchronize(fluhip_ctx* ctx)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
+int fluhip_fft_params(int64_t win, int64_t hop, int64_t fft, int64_t* win_out, int64_t* hop_out,
+                      int64_t* fft_out, int64_t* bins_out)
+{
+  // clients/common/ParameterTypes.hpp:295-312
+  if (win < 4) return FLUHIP_ERROR;
+  int64_t h = hop > 0 ? hop : win >> 1;
+  int64_t f = fft;
+  if (f < 0)
+  {
+    f = 1;
+    while (f < win) f <<= 1; // nextPow2(win, up)
+  }
+  if ((f & (f - 1)) || f < win) return FLUHIP_ERROR;
+  if (win_out) *win_out = win;
+  if (hop_out) *hop_out = h;
+  if (fft_out) *fft_out = f;
+  if (bins_out) *bins_out = (f >> 1) + 1;
+  return FLUHIP_OK;
+}
+
+int64_t fluhip_stft_num_frames(int64_t n, int64_t win, int64_t hop)
+{
+  (void) win;
+  return hop > 0 ? (n + hop) / hop : 0;
+}
+
+// ---- corpus ---------------------------------------------------------------------------
+int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
+                         int64_t hop, int64_t K, fluhip_corpus** out)
+{
+  if (!ctx || !out) return FLUHIP_ERROR;
+  *out = nullptr;
+  if (count < 1) return fail(ctx, "corpus must hold at least one buffer");
+  int rc = check_shape(ctx, n, win, fft, hop, K);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<fluhip_corpus> c(new fluhip_corpus);
+  c->ctx = ctx; c->B = count; c->n = n; c->win = win; c->fft = fft; c->hop = hop; c->K = K;
+  rc = corpus_alloc(ctx, c.get());
+  if (rc) return rc;
+  *out = c.release();
+  return FLUHIP_OK;
+}
+
+void fluhip_corpus_destroy(fluhip_corpus* c)
+{
+  if (!c) return;
+  (void) hipSetDevice(c->ctx->device);
+  (void) hipStreamSynchronize(c->ctx->stream);
+  delete c;
+}
+
+int64_t fluhip_corpus_frames(const fluhip_corpus* c) { return c ? c->T : 0; }
+int64_t fluhip_corpus_bins(const fluhip_corpus* c) { return c ? c->F : 0; }
+int64_t fluhip_corpus_device_bytes(const fluhip_corpus* c) { return c ? c->device_bytes() : 0; }
+
+int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio)
+{
+  if (!c || !audio) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t) c->B * c->n * sizeof(float);
+  if (c->audioOwn.bytes < bytes) HIPCHK(ctx, c->audioOwn.alloc(bytes, false, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(c->audioOwn.p, audio, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  c->audioDev = c->audioOwn.as<float>();
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_set_audio_dev(fluhip_corpus* c, const float* audio_dev)
+{
+  if (!c || !audio_dev) return FLUHIP_ERROR;
+  c->audioDev = audio_dev;
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_stft(fluhip_corpus* c)
+{
+  if (!c) return FLUHIP_ERROR;
+  if (!c->audioDev) return fail(c->ctx, "corpus has no audio");
+  HIPCHK(c->ctx, hipSetDevice(c->ctx->device));
+  return corpus_stft(c, c->audioDev, nullptr, c->n);
+}
+
+int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
+                      const int64_t* seeds, fluhip_progress_fn progress, void* user)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  if (!c->haveMag) return fail(ctx, "corpus has no spectrogram: call fluhip_corpus_stft first");
+  if (iters < 0) return fail(ctx, "negative iteration count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  FactorInit fi;
+  int rc = corpus_init_factors(c, seed, seeds, fi);
+  if (rc) return rc;
+  return corpus_iterate(c, iters, update_w != 0, update_h != 0, progress, user);
+}
+
+int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  if (!c->haveFactors) return fail(ctx, "corpus has no factors: call fluhip_corpus_nmf first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (bases_dev) // clients/nrt/NMFClient.hpp:277-283
+    launch_gather_w_f32(c->Wf.as<double>(), c->Fp * c->Kp, bases_dev, c->K * c->F, (int) c->F,
+                        (int) c->K, (int) c->Kp, (int) c->B, s);
+  if (acts_dev) // :286-300
+    launch_acts_f32(c->H1.as<double>(), c->Tp * c->Kp, acts_dev, c->K * c->T, (int) c->T, (int) c->K,
+                    (int) c->Kp, (int) c->B, c->hmax.as<double>(), s);
+  HIPCHK(ctx, hipGetLastError());
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf db, da;
+  const size_t nb = (size_t) c->B * c->K * c->F * sizeof(float), na = (size_t) c->B * c->K * c->T * sizeof(float);
+  if (bases) HIPCHK(ctx, db.alloc(nb, false, ctx->stream));
+  if (acts) HIPCHK(ctx, da.alloc(na, false, ctx->stream));
+  int rc = fluhip_corpus_writeback_dev(c, bases ? db.as<float>() : nullptr, acts ? da.as<float>() : nullptr);
+  if (rc) return rc;
+  if (bases) HIPCHK(ctx, hipMemcpyAsync(bases, db.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+  if (acts) HIPCHK(ctx, hipMemcpyAsync(acts, da.p, na, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  if (mag)
+  {
+    if (!c->haveMag) return fail(ctx, "corpus has no spectrogram");
+    for (int64_t b = 0; b < c->B; b++)
+      HIPCHK(ctx, hipMemcpy2DAsync(mag + b * c->T * c->F, (size_t) c->F * sizeof(double),
+                                   c->mag.as<double>() + b * c->Tp * c->Fp, (size_t) c->Fp * sizeof(double),
+                                   (size_t) c->F * sizeof(double), (size_t) c->T, hipMemcpyDeviceToHost, s));
+  }
+  DevBuf dw, dh;
+  if (W1 || H1)
+    if (!c->haveFactors) return fail(ctx, "corpus has no factors");
+  if (W1)
+  {
+    const size_t bytes = (size_t) c->B * c->K * c->F * sizeof(double);
+    HIPCHK(ctx, dw.alloc(bytes, false, s));
+    launch_gather_w_f64(c->Wf.as<double>(), c->Fp * c->Kp, dw.as<double>(), c->K * c->F, (int) c->F,
+                        (int) c->K, (int) c->Kp, (int) c->B, s);
+    HIPCHK(ctx, hipMemcpyAsync(W1, dw.p, bytes, hipMemcpyDeviceToHost, s));
+  }
+  if (H1)
+  {
+    const size_t bytes = (size_t) c->B * c->T * c->K * sizeof(double);
+    HIPCHK(ctx, dh.alloc(bytes, false, s));
+    launch_gather_h_f64(c->H1.as<double>(), c->Tp * c->Kp, dh.as<double>(), c->T * c->K, (int) c->T,
+                        (int) c->K, (int) c->Kp, (int) c->B, s);
+    HIPCHK(ctx, hipMemcpyAsync(H1, dh.p, bytes, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return FLUHIP_OK;
+}
+
+// ---- algorithm-level single-buffer entry points -----------------------------------------
+static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int64_t n, int64_t stride,
+                       int64_t win, int64_t fft, int64_t hop, int window_type, double* spec,
+                       double* mag, int64_t* frames_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!a32 && !a64) return fail(ctx, "null audio");
+  if (stride < 1) return fail(ctx, "stride must be >= 1");
+  int rc = check_shape(ctx, n, win, fft, hop, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = 1;
+  c.windowType = window_type;
+  c.keepSpec = spec != nullptr;
+  rc = corpus_alloc(ctx, &c);
+  if (rc) return rc;
+  // strided host view -> contiguous device copy (clients/nrt/NMFClient.hpp:240 `tmp <<= samps(...)`)
+  DevBuf in;
+  const size_t esz = a32 ? sizeof(float) : sizeof(double);
+  HIPCHK(ctx, in.alloc((size_t) n * esz, false, ctx->stream));
+  HIPCHK(ctx, hipMemcpy2DAsync(in.p, esz, a32 ? (const void*) a32 : (const void*) a64, (size_t) stride * esz,
+                               esz, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+  rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n);
+  if (rc) return rc;
+  if (frames_out) *frames_out = c.T;
+  if (mag)
+    HIPCHK(ctx, hipMemcpy2DAsync(mag, (size_t) c.F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
+                                 (size_t) c.F * sizeof(double), (size_t) c.T, hipMemcpyDeviceToHost, ctx->stream));
+  if (spec)
+    HIPCHK(ctx, hipMemcpyAsync(spec, c.spec.p, (size_t) c.T * c.F * 2 * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
+int fluhip_stft_f64(fluhip_ctx* ctx, const double* audio, int64_t n, int64_t stride, int64_t win,
+                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
+                    int64_t* frames_out)
+{
+  return stft_common(ctx, nullptr, audio, n, stride, win, fft, hop, window_type, spec, mag, frames_out);
+}
+
+int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
+                    int64_t* frames_out)
+{
+  return stft_common(ctx, audio, nullptr, n, stride, win, fft, hop, window_type, spec, mag, frames_out);
+}
+
+int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                           int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                           const double* W0, const double* H0, double* W1, double* H1,
+                           double* V1, fluhip_progress_fn progress, void* user)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
+  if (K < 1) return fail(ctx, "rank must be >= 1");
+  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
+  if (iters < 0) return fail(ctx, "negative iteration count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.K = K;
+  // shape the corpus directly from the matrix extents (no audio behind it)
+  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
+  c.T = T; c.F = F;
+  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = round_up(K, 16);
+  {
+    HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
+    HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
+    HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
+    HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
+    HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
+    const int cpw = nmf_update_cols_per_wave((int) c.Kp);
+    c.nsplitW = choose_split(1, (F + 4 * cpw - 1) / (4 * cpw), (T + 15) / 16);
+    c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
+    const int ns = std::max(c.nsplitW, c.nsplitH);
+    if (ns > 1)
+    {
+      const size_t Cp = (size_t) std::max(c.Fp, c.Tp);
+      HIPCHK(ctx, c.part.alloc((size_t) ns * Cp * c.Kp * sizeof(double), true, s));
+      HIPCHK(ctx, c.dpart.alloc((size_t) ns * c.Kp * sizeof(double), true, s));
+    }
+  }
+  // alg/NMF.hpp:125  V = X^T (same bytes as the T x F row-major view)
+  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
+                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
+  launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T,
+                   (int) F, 1, s);
+  c.haveMag = true;
+  FactorInit fi;
+  fi.W0host = W0; fi.H0host = H0; fi.sharedW = fi.sharedH = true;
+  int rc = corpus_init_factors(&c, seed, nullptr, fi);
+  if (rc) return rc;
+  rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user);
+  if (rc != FLUHIP_OK && rc != FLUHIP_CANCELLED) return rc;
+  const bool cancelled = rc == FLUHIP_CANCELLED;
+  // alg/NMF.hpp:127-133 outputs; :182 V = W*H only when the loop ran to completion
+  DevBuf dw, dh, dv;
+  if (W1)
+  {
+    HIPCHK(ctx, dw.alloc((size_t) K * F * sizeof(double), false, s));
+    launch_gather_w_f64(c.Wf.as<double>(), 0, dw.as<double>(), 0, (int) F, (int) K, (int) c.Kp, 1, s);
+    HIPCHK(ctx, hipMemcpyAsync(W1, dw.p, (size_t) K * F * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (H1)
+  {
+    HIPCHK(ctx, dh.alloc((size_t) T * K * sizeof(double), false, s));
+    launch_gather_h_f64(c.H1.as<double>(), 0, dh.as<double>(), 0, (int) T, (int) K, (int) c.Kp, 1, s);
+    HIPCHK(ctx, hipMemcpyAsync(H1, dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (V1 && !cancelled)
+  {
+    HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
+    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F,
+                (int) c.Kp, 1, s);
+    HIPCHK(ctx, hipMemcpyAsync(V1, dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return cancelled ? FLUHIP_CANCELLED : FLUHIP_OK;
+}
+
+int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride,
+                              int64_t win, int64_t fft, int64_t hop, int64_t K, int64_t iters,
+                              int update_w, int update_h, int64_t seed, const float* bases_seed,
+                              const float* acts_seed, float* bases_out, float* acts_out,
+                              float* resynth_out, fluhip_progress_fn progress, void* user)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!audio) return fail(ctx, "null audio");
+  if (stride < 1) return fail(ctx, "stride must be >= 1");
+  if (resynth_out) return fail(ctx, "resynthesis is not implemented in this build");
+  int rc = check_shape(ctx, n, win, fft, hop, K);
+  if (rc) return rc;
+  if (iters < 0) return fail(ctx, "negative iteration count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = K;
+  rc = corpus_alloc(ctx, &c);
+  if (rc) return rc;
+  DevBuf in;
+  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
+  HIPCHK(ctx, hipMemcpy2DAsync(in.p, sizeof(float), audio, (size_t) stride * sizeof(float), sizeof(float),
+                               (size_t) n, hipMemcpyHostToDevice, s));
+  rc = corpus_stft(&c, in.as<float>(), nullptr, n); // nrt/NMFClient.hpp:240-242
+  if (rc) return rc;
+  FactorInit fi;
+  fi.W0f32 = bases_seed; // :246-258 seeds gathered channel by channel
+  fi.H0f32 = acts_seed;
+  rc = corpus_init_factors(&c, seed, nullptr, fi);
+  if (rc) return rc;
+  rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user); // :268-271
+  if (rc) return rc;                                                             // :273-274
+  rc = fluhip_corpus_writeback_host(&c, bases_out, acts_out);                    // :277-300
+  return rc;
+}
+
+// ---- profiling ------------------------------------------------------------------------
+int fluhip_prof_enable(fluhip_ctx* ctx, int on)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  ctx->prof = on != 0;
+  return FLUHIP_OK;
+}
+
+int fluhip_prof_reset(fluhip_ctx* ctx)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& r : ctx->profRecs)
+  {
+    ctx->eventPool.push_back(r.start);
+    ctx->eventPool.push_back(r.stop);
+  }
+  ctx->profRecs.clear();
+  return FLUHIP_OK;
+}
+
+int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int64_t n = 0;
+  double tot = 0.0;
+  for (auto& r : ctx->profRecs)
+  {
+    if (r.cls != kernel_class) continue;
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, r.start, r.stop));
+    tot += ms;
+    n++;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = tot;
+  return FLUHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,126 @@
+// fluhip_kernels.h -- internal launch interface between the C-ABI layer (api.hip) and the
+// gfx950 kernels (kernels_stft.hip, kernels_nmf.hip).  Not installed; not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fluhip {
+
+constexpr double kEpsilon = 2.220446049250313e-16; // util/AlgorithmUtils.hpp:19
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------------------
+// HBM layout of one corpus (B equal-shape buffers); everything f64 unless noted.
+//   audio  f32 [B][N]
+//   mag    [B][Tp][Fp]   row = frame t, f contiguous      ("V col-major F x T" of alg/NMF.hpp:125)
+//   magT   [B][Fp][Tp]   row = bin f,  t contiguous       (second copy, so both factor updates
+//                                                          stream V with lanes along the
+//                                                          contiguous axis)
+//   Wf     [B][Fp][Kp]   row = bin f,  k contiguous       (W of alg/NMF.hpp, F x K)
+//   H1     [B][Tp][Kp]   row = frame t, k contiguous      (H^T; == output H1 of NMF::process)
+// Tp = round_up(T, 32), Fp = round_up(F, 32), Kp = round_up(K, 16); all padding is zero and
+// stays zero (zero rows/cols contribute exactly 0 to every contraction).
+// ---------------------------------------------------------------------------------------
+
+struct StftArgs
+{
+  const float* audio;   // [B][n]  (or nullptr when audio64 is used)
+  const double* audio64; // [B][n] f64 input variant
+  int64_t n;            // samples per buffer
+  int64_t audioStride;  // elements between buffers
+  int win, fft, hop;
+  int T, F;             // frames per buffer, bins
+  int B;
+  const double* window; // [win]
+  const double* twiddle; // [fft/2] interleaved (cos, sin) of e^{-2 pi i j / fft}
+  double* mag;          // [B][Tp][Fp] or nullptr
+  int64_t magStride;    // per buffer
+  int64_t ldMag;        // Fp
+  double* spec;         // [B][T][F] interleaved complex, or nullptr
+  int64_t specStride;
+};
+
+void launch_stft(const StftArgs& a, hipStream_t s);
+// true when the in-LDS kernel supports this fft size
+bool stft_supported(int64_t win, int64_t fft);
+
+// out[b][c][r] = in[b][r][c]; in [R][ldin], out [C][ldout] (valid R x C)
+void launch_transpose(const double* in, int64_t ldin, int64_t strideIn, double* out,
+                      int64_t ldout, int64_t strideOut, int R, int C, int B, hipStream_t s);
+
+struct UpdateArgs
+{
+  const double* V;  // [B][*][ldv] rows = contraction index r, cols = c (contiguous)
+  int64_t ldv, strideV;
+  const double* Mv; // moving factor   [B][>=round_up(R,16)][Kp]
+  int64_t strideM;
+  double* S;        // stationary factor [B][>=round_up(C,32)][Kp], updated in place
+  int64_t strideS;
+  int R, C, B;
+  int Kp;
+  // split-R mode (single large buffer): partial numerators / denominators
+  int nsplit;
+  double* part;     // [B][nsplit][Cp][Kp]
+  double* dpart;    // [B][nsplit][Kp]
+  int64_t Cp;
+};
+
+// S[c][k] <- S[c][k] * (sum_r (V[r][c] / max(sum_j Mv[r][j] S[c][j], eps)) * Mv[r][k])
+//                    / max(sum_r Mv[r][k], eps)
+// alg/NMF.hpp:158-161 with (V, Mv, S) = (mag, H1, Wf) and :165-170 with (magT, Wf, H1).
+void launch_nmf_update(const UpdateArgs& a, hipStream_t s);
+int nmf_update_cols_per_wave(int Kp);
+
+// per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
+// divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).
+void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
+                    bool checkMax, hipStream_t s);
+
+// dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
+void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,
+                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s);
+// f32 seed variant: src[b][k][rows] floats (BufferAdaptor channel-major)
+void launch_scatter_factor_f32(const float* src, int64_t strideSrc, double* dst,
+                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s);
+
+// W1[b][k][f] = Wf[b][f][k]  (f64 and f32 flavours; f32 == clients/nrt/NMFClient.hpp:281-282)
+void launch_gather_w_f64(const double* Wf, int64_t strideW, double* W1, int64_t strideOut, int F,
+                         int K, int Kp, int B, hipStream_t s);
+void launch_gather_w_f32(const double* Wf, int64_t strideW, float* bases, int64_t strideOut,
+                         int F, int K, int Kp, int B, hipStream_t s);
+// H1out[b][t][k] = H1[b][t][k] without the Kp padding
+void launch_gather_h_f64(const double* H1, int64_t strideH, double* out, int64_t strideOut, int T,
+                         int K, int Kp, int B, hipStream_t s);
+// acts[b][k][t] = float(H1[t][k]) * float(1 / max H1)   (clients/nrt/NMFClient.hpp:289-298)
+void launch_acts_f32(const double* H1, int64_t strideH, float* acts, int64_t strideOut, int T,
+                     int K, int Kp, int B, double* scratchMax, hipStream_t s);
+// Vhat[b][t][f] = sum_k Wf[f][k] H1[t][k]   (alg/NMF.hpp:182)
+void launch_vhat(const double* Wf, int64_t strideW, const double* H1, int64_t strideH,
+                 double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp, int B,
+                 hipStream_t s);
+// dst[b][t][f] (ld) = src[b][t*ldsrc + f] : strided host-layout copy into the padded layout
+void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
+                     int64_t lddst, int64_t strideDst, int rows, int cols, int B, hipStream_t s);
+
+// resynthesis: masked inverse STFT of component k with overlap-add
+struct ResynthArgs
+{
+  const double* spec;   // [T][F] interleaved complex
+  const double* Wf;     // [Fp][Kp]
+  const double* H1;     // [Tp][Kp]
+  const double* Vhat;   // [T][ldV]
+  int64_t ldV;
+  int Kp, k;
+  int win, fft, hop, T, F;
+  const double* window;
+  const double* twiddle;
+  double* frames;       // scratch [T][win] windowed, scaled inverse frames
+  double* out;          // [n] f64 overlap-added, normalised, trimmed
+  float* out32;         // [n] or nullptr
+  int64_t n;
+};
+void launch_resynth(const ResynthArgs& a, hipStream_t s);
+
+} // namespace fluhip

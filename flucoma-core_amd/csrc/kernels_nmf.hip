@@ -1,0 +1,543 @@
+// kernels_nmf.hip -- gfx950 kernels for the KL-divergence NMF multiplicative updates of
+// flucoma-core's algorithm::NMF (include/flucoma/algorithms/public/NMF.hpp:144-183).
+//
+// One kernel serves both factor updates.  With V the magnitude spectrogram, the W update
+// (NMF.hpp:158-161) and the H update (:165-170) are the same contraction with the roles of the
+// factors swapped:
+//
+//   S[c][k] <- S[c][k] * ( sum_r  V[r][c] / max(Q[r][c], eps) * Mv[r][k] ) / max(sum_r Mv[r][k], eps)
+//   Q[r][c]  = sum_j Mv[r][j] * S[c][j]
+//
+//   W update: r = frame t, c = bin f,   V = mag  [T][F], Mv = H1 [T][K], S = Wf [F][K]
+//   H update: r = bin f,   c = frame t, V = magT [F][T], Mv = Wf [F][K], S = H1 [T][K]
+//
+// The F x T product W*H and the ratio V/(W*H) are never written to memory: each wavefront
+// owns a strip of 16*CB columns c, walks the contraction index r in tiles of 16, forms the
+// 16x16 tile of Q on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), divides in registers,
+// and feeds the quotient tile straight back into the matrix cores as the A operand of the
+// second contraction -- the C/D register layout of the first MFMA (row = (lane>>4)+4i,
+// col = lane&15) *is* the A layout of the second (row = lane&15, k = lane>>4) once the tile
+// is read as "rows = c, k = r", so no cross-lane shuffle or LDS transpose is needed.
+//
+// Algorithmic cost per 16 x 16 tile: K/4 + K/4 MFMAs of 2048 flop = 4*256*K flop, i.e.
+// 8*F*T*K flop per full iteration, V streamed exactly twice per iteration (once per update).
+#include "fluhip_kernels.h"
+
+namespace fluhip {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct UpdKArgs
+{
+  const double* V;
+  int64_t ldv, strideV;
+  const double* Mv;
+  int64_t strideM;
+  double* S;
+  int64_t strideS;
+  int R, C, B;
+  int nCW;       // workgroups per buffer along c
+  int nRt;       // r tiles
+  int nsplit;
+  int tilesPerSplit;
+  double* part;
+  double* dpart;
+  int64_t Cp;
+  int xcdMap;
+};
+
+template <int N>
+__device__ __forceinline__ void load_row(double (&dst)[N], const double* p)
+{
+  if constexpr (N % 2 == 0)
+  {
+#pragma unroll
+    for (int j = 0; j < N; j += 2)
+    {
+      d2 t = *reinterpret_cast<const d2*>(p + j);
+      dst[j] = t[0];
+      dst[j + 1] = t[1];
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < N; j++) dst[j] = p[j];
+  }
+}
+
+// NB = Kp/16, CB = 16-column blocks per wavefront.
+template <int NB, int CB, int MINW>
+__global__ __launch_bounds__(256, MINW) void nmf_update_kernel(UpdKArgs a)
+{
+  constexpr int KP = 16 * NB; // padded rank
+  constexpr int KQ = 4 * NB;  // rank elements per lane group for the Q contraction
+
+  int id = blockIdx.x;
+  int buf, cw, split;
+  if (a.xcdMap)
+  {
+    // blocks are dispatched round-robin over the 8 XCDs: keep every workgroup of one buffer
+    // on one XCD so its factor matrices stay in that XCD's L2 (speed only, never correctness)
+    int xcd = id & 7, slot = id >> 3;
+    split = slot % a.nsplit;
+    slot /= a.nsplit;
+    cw = slot % a.nCW;
+    buf = xcd + 8 * (slot / a.nCW);
+  }
+  else
+  {
+    split = id % a.nsplit;
+    cw = (id / a.nsplit) % a.nCW;
+    buf = id / (a.nsplit * a.nCW);
+  }
+  if (buf >= a.B) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int c0 = (cw * 4 + wave) * 16 * CB;
+  if (c0 >= a.C) return;
+
+  const double* __restrict__ V = a.V + (int64_t) buf * a.strideV;
+  const double* __restrict__ Mv = a.Mv + (int64_t) buf * a.strideM;
+  double* S = a.S + (int64_t) buf * a.strideS;
+
+  // stationary operand: B[kk = g][n = c] of the Q MFMAs, rank index j*? -> g*KQ + j
+  double sb[CB][KQ];
+#pragma unroll
+  for (int cb = 0; cb < CB; cb++) load_row<KQ>(sb[cb], S + (int64_t) (c0 + CB * c + cb) * KP + g * KQ);
+
+  d4 acc[CB][NB];
+  double dsum[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+  {
+    dsum[nb] = 0.0;
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) acc[cb][nb] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+
+  const int rt0 = split * a.tilesPerSplit;
+  const int rt1 = min(rt0 + a.tilesPerSplit, a.nRt);
+
+  for (int rt = rt0; rt < rt1; ++rt)
+  {
+    const int r0 = rt * 16;
+    // moving operand, two register distributions of the same 16 x KP tile of Mv
+    double ma[KQ];        // A of the Q MFMAs:   Mv[r0 + c][g*KQ + j]
+    double mb[4][NB];     // B of the out MFMAs: Mv[r0 + g + 4i][c*NB + nb]
+    double v[4][CB];      // V[r0 + g + 4i][c0 + CB*c + cb]
+    load_row<KQ>(ma, Mv + (int64_t) (r0 + c) * KP + g * KQ);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      load_row<NB>(mb[i], Mv + (int64_t) (r0 + g + 4 * i) * KP + c * NB);
+      load_row<CB>(v[i], V + (int64_t) (r0 + g + 4 * i) * a.ldv + c0 + CB * c);
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+    {
+      d4 q = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < KQ; j++) q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[j], sb[cb][j], q, 0, 0, 0);
+      // q[i] = Q[r0 + g + 4i][col c of block cb]
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+      {
+        const double ratio = v[i][cb] / fmax(q[i], kEpsilon);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+          acc[cb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ratio, mb[i][nb], acc[cb][nb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) dsum[nb] += (mb[0][nb] + mb[1][nb]) + (mb[2][nb] + mb[3][nb]);
+  }
+
+  // denominators: column sums of Mv; lane (g,c) holds the partial over rows == g (mod 4)
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++)
+  {
+    double d = dsum[nb];
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    dsum[nb] = d;
+  }
+
+  // acc[cb][nb][q] = out[col index m = g + 4q of block cb][k = c*NB + nb]
+  if (a.nsplit == 1)
+  {
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        const int col = c0 + CB * (g + 4 * q) + cb;
+        if (col < a.C)
+        {
+          double* sp = S + (int64_t) col * KP + c * NB;
+          double sold[NB];
+          load_row<NB>(sold, sp);
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            sp[nb] = (sold[nb] * acc[cb][nb][q]) / fmax(dsum[nb], kEpsilon);
+        }
+      }
+  }
+  else
+  {
+    double* part = a.part + ((int64_t) buf * a.nsplit + split) * a.Cp * KP;
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        const int col = c0 + CB * (g + 4 * q) + cb;
+        double* pp = part + (int64_t) col * KP + c * NB;
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++) pp[nb] = acc[cb][nb][q];
+      }
+    if (c0 == 0 && g == 0)
+    {
+      double* dp = a.dpart + ((int64_t) buf * a.nsplit + split) * KP + c * NB;
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) dp[nb] = dsum[nb];
+    }
+  }
+}
+
+// split-R epilogue: fixed-order reduction of the partials, then the multiplicative step
+__global__ void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
+                                           const double* dpart, int C, int Kp, int64_t Cp,
+                                           int nsplit)
+{
+  const int buf = blockIdx.y;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) C * Kp) return;
+  const int k = (int) (idx % Kp);
+  double num = 0.0, den = 0.0;
+  for (int s = 0; s < nsplit; s++)
+  {
+    num += part[((int64_t) buf * nsplit + s) * Cp * Kp + idx];
+    den += dpart[((int64_t) buf * nsplit + s) * Kp + k];
+  }
+  double* sp = S + (int64_t) buf * strideS + idx;
+  *sp = (*sp * num) / fmax(den, kEpsilon);
+}
+
+template <int NB, int CB, int MINW>
+static void launch_update_t(const UpdateArgs& a, hipStream_t s)
+{
+  UpdKArgs k;
+  k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
+  k.Mv = a.Mv; k.strideM = a.strideM;
+  k.S = a.S; k.strideS = a.strideS;
+  k.R = a.R; k.C = a.C; k.B = a.B;
+  k.nCW = (a.C + 64 * CB - 1) / (64 * CB);
+  k.nRt = (a.R + 15) / 16;
+  k.nsplit = a.nsplit < 1 ? 1 : a.nsplit;
+  k.tilesPerSplit = (k.nRt + k.nsplit - 1) / k.nsplit;
+  k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
+  k.xcdMap = a.B >= 8 ? 1 : 0;
+  const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
+  const unsigned grid = (unsigned) (bufs * k.nCW * k.nsplit);
+  hipLaunchKernelGGL((nmf_update_kernel<NB, CB, MINW>), dim3(grid), dim3(256), 0, s, k);
+  if (k.nsplit > 1)
+  {
+    const int64_t total = (int64_t) a.C * a.Kp;
+    dim3 g((unsigned) ((total + 255) / 256), (unsigned) a.B);
+    hipLaunchKernelGGL(nmf_update_finalize_kernel, g, dim3(256), 0, s, a.S, a.strideS, a.part,
+                       a.dpart, a.C, a.Kp, a.Cp, k.nsplit);
+  }
+}
+
+int nmf_update_cols_per_wave(int Kp) { return Kp <= 64 ? 32 : 16; }
+
+void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
+{
+  switch (a.Kp / 16)
+  {
+  case 1: launch_update_t<1, 2, 2>(a, s); break;
+  case 2: launch_update_t<2, 2, 2>(a, s); break;
+  case 3: launch_update_t<3, 2, 1>(a, s); break;
+  case 4: launch_update_t<4, 2, 1>(a, s); break;
+  case 5: launch_update_t<5, 1, 1>(a, s); break;
+  case 6: launch_update_t<6, 1, 1>(a, s); break;
+  case 7: launch_update_t<7, 1, 1>(a, s); break;
+  case 8: launch_update_t<8, 1, 1>(a, s); break;
+  default: break; // api.hip rejects Kp > 128 before getting here
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// column L2 normalisation (Eigen colwise().normalize(): x / sqrt(sum x^2), alg/NMF.hpp:152-153,162)
+// one workgroup per buffer; thread (rg, k) owns rows rg, rg+nrg, ... of column k
+// ---------------------------------------------------------------------------------------
+__global__ void colnorm_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
+                               int checkMax)
+{
+  extern __shared__ double sh[]; // [nrg][Kp] sums, then [nrg][Kp] maxima
+  double* S = Sbase + (int64_t) blockIdx.x * strideS;
+  const int nrg = blockDim.x / Kp;
+  const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  double ss = 0.0, mx = -INFINITY;
+  if (k < K)
+    for (int r = rg; r < C; r += nrg)
+    {
+      double x = S[(int64_t) r * Kp + k];
+      if (clampEps)
+      {
+        x = fmax(x, kEpsilon);
+        S[(int64_t) r * Kp + k] = x;
+      }
+      ss += x * x;
+      mx = fmax(mx, x);
+    }
+  sh[rg * Kp + k] = ss;
+  sh[(nrg + rg) * Kp + k] = mx;
+  __syncthreads();
+  // fixed-order combine (every thread recomputes its column's total identically)
+  double tot = 0.0;
+  for (int j = 0; j < nrg; j++) tot += sh[j * Kp + k];
+  double gmax = -INFINITY;
+  if (checkMax)
+    for (int j = 0; j < nrg * Kp; j++) gmax = fmax(gmax, sh[nrg * Kp + j]);
+  if (k < K && (!checkMax || gmax > kEpsilon))
+  {
+    const double nrm = sqrt(tot);
+    for (int r = rg; r < C; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
+  }
+}
+
+void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
+                    bool checkMax, hipStream_t s)
+{
+  int nrg = 1024 / Kp;
+  if (nrg < 1) nrg = 1;
+  const int threads = nrg * Kp;
+  const size_t shmem = (size_t) 2 * nrg * Kp * sizeof(double);
+  hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned) B), dim3((unsigned) threads), shmem, s, S,
+                     strideS, C, K, Kp, clampEps ? 1 : 0, checkMax ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// layout plumbing (all tiny next to the updates)
+// ---------------------------------------------------------------------------------------
+__global__ void scatter_factor_kernel(const double* src, int64_t strideSrc, double* dst,
+                                      int64_t strideDst, int rows, int K, int Kp, int kMajor)
+{
+  const int b = blockIdx.y;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) rows * K) return;
+  int row, k;
+  if (kMajor) { k = (int) (idx / rows); row = (int) (idx % rows); }
+  else { row = (int) (idx / K); k = (int) (idx % K); }
+  dst[(int64_t) b * strideDst + (int64_t) row * Kp + k] = src[(int64_t) b * strideSrc + idx];
+}
+
+void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,
+                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s)
+{
+  const int64_t total = (int64_t) rows * K;
+  dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
+  hipLaunchKernelGGL(scatter_factor_kernel, g, dim3(256), 0, s, src, strideSrc, dst, strideDst,
+                     rows, K, Kp, srcIsKMajor ? 1 : 0);
+}
+
+__global__ void scatter_factor_f32_kernel(const float* src, int64_t strideSrc, double* dst,
+                                          int64_t strideDst, int rows, int K, int Kp)
+{
+  const int b = blockIdx.y;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) rows * K) return;
+  const int k = (int) (idx / rows), row = (int) (idx % rows);
+  dst[(int64_t) b * strideDst + (int64_t) row * Kp + k] = (double) src[(int64_t) b * strideSrc + idx];
+}
+
+void launch_scatter_factor_f32(const float* src, int64_t strideSrc, double* dst,
+                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s)
+{
+  const int64_t total = (int64_t) rows * K;
+  dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
+  hipLaunchKernelGGL(scatter_factor_f32_kernel, g, dim3(256), 0, s, src, strideSrc, dst,
+                     strideDst, rows, K, Kp);
+}
+
+template <typename OutT>
+__global__ void gather_w_kernel(const double* Wf, int64_t strideW, OutT* out, int64_t strideOut,
+                                int F, int K, int Kp)
+{
+  // 32 x 32 tile transpose through LDS so both sides are coalesced
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z;
+  const int f0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int f = f0 + j, k = k0 + tx;
+    tile[j][tx] = (f < F && k < K) ? Wf[(int64_t) b * strideW + (int64_t) f * Kp + k] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int k = k0 + j, f = f0 + tx;
+    if (k < K && f < F) out[(int64_t) b * strideOut + (int64_t) k * F + f] = (OutT) tile[tx][j];
+  }
+}
+
+void launch_gather_w_f64(const double* Wf, int64_t strideW, double* W1, int64_t strideOut, int F,
+                         int K, int Kp, int B, hipStream_t s)
+{
+  dim3 g((unsigned) ((F + 31) / 32), (unsigned) ((K + 31) / 32), (unsigned) B);
+  hipLaunchKernelGGL(gather_w_kernel<double>, g, dim3(256), 0, s, Wf, strideW, W1, strideOut, F, K, Kp);
+}
+
+void launch_gather_w_f32(const double* Wf, int64_t strideW, float* bases, int64_t strideOut,
+                         int F, int K, int Kp, int B, hipStream_t s)
+{
+  dim3 g((unsigned) ((F + 31) / 32), (unsigned) ((K + 31) / 32), (unsigned) B);
+  hipLaunchKernelGGL(gather_w_kernel<float>, g, dim3(256), 0, s, Wf, strideW, bases, strideOut, F, K, Kp);
+}
+
+__global__ void gather_h_kernel(const double* H1, int64_t strideH, double* out, int64_t strideOut,
+                                int T, int K, int Kp)
+{
+  const int b = blockIdx.y;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) T * K) return;
+  const int t = (int) (idx / K), k = (int) (idx % K);
+  out[(int64_t) b * strideOut + idx] = H1[(int64_t) b * strideH + (int64_t) t * Kp + k];
+}
+
+void launch_gather_h_f64(const double* H1, int64_t strideH, double* out, int64_t strideOut, int T,
+                         int K, int Kp, int B, hipStream_t s)
+{
+  const int64_t total = (int64_t) T * K;
+  dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
+  hipLaunchKernelGGL(gather_h_kernel, g, dim3(256), 0, s, H1, strideH, out, strideOut, T, K, Kp);
+}
+
+// max over the valid T x K block of H1, one workgroup per buffer
+__global__ void hmax_kernel(const double* H1, int64_t strideH, int T, int K, int Kp, double* out)
+{
+  __shared__ double sh[256];
+  const double* H = H1 + (int64_t) blockIdx.x * strideH;
+  double mx = -INFINITY;
+  for (int64_t idx = threadIdx.x; idx < (int64_t) T * K; idx += blockDim.x)
+  {
+    const int t = (int) (idx / K), k = (int) (idx % K);
+    mx = fmax(mx, H[(int64_t) t * Kp + k]);
+  }
+  sh[threadIdx.x] = mx;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1)
+  {
+    if ((int) threadIdx.x < st) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + st]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+__global__ void acts_kernel(const double* H1, int64_t strideH, float* acts, int64_t strideOut,
+                            int T, int K, int Kp, const double* hmax)
+{
+  // acts[k][t] = float(H1[t][k]) * float(1/max): tile transpose for coalescing on both sides
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float scale = (float) (1. / hmax[b]); // clients/nrt/NMFClient.hpp:291,298
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int t = t0 + j, k = k0 + tx;
+    tile[j][tx] = (t < T && k < K) ? H1[(int64_t) b * strideH + (int64_t) t * Kp + k] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int k = k0 + j, t = t0 + tx;
+    if (k < K && t < T)
+    {
+      float x = (float) tile[tx][j];
+      x *= scale;
+      acts[(int64_t) b * strideOut + (int64_t) k * T + t] = x;
+    }
+  }
+}
+
+void launch_acts_f32(const double* H1, int64_t strideH, float* acts, int64_t strideOut, int T,
+                     int K, int Kp, int B, double* scratchMax, hipStream_t s)
+{
+  hipLaunchKernelGGL(hmax_kernel, dim3((unsigned) B), dim3(256), 0, s, H1, strideH, T, K, Kp, scratchMax);
+  dim3 g((unsigned) ((T + 31) / 32), (unsigned) ((K + 31) / 32), (unsigned) B);
+  hipLaunchKernelGGL(acts_kernel, g, dim3(256), 0, s, H1, strideH, acts, strideOut, T, K, Kp, scratchMax);
+}
+
+__global__ void vhat_kernel(const double* Wf, int64_t strideW, const double* H1, int64_t strideH,
+                            double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp)
+{
+  const int b = blockIdx.z;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int t = blockIdx.y;
+  if (f >= F) return;
+  const double* w = Wf + (int64_t) b * strideW + (int64_t) f * Kp;
+  const double* h = H1 + (int64_t) b * strideH + (int64_t) t * Kp;
+  double s = 0.0;
+  for (int k = 0; k < Kp; k++) s += w[k] * h[k];
+  Vhat[(int64_t) b * strideV + (int64_t) t * ldV + f] = s;
+}
+
+void launch_vhat(const double* Wf, int64_t strideW, const double* H1, int64_t strideH,
+                 double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp, int B,
+                 hipStream_t s)
+{
+  dim3 g((unsigned) ((F + 255) / 256), (unsigned) T, (unsigned) B);
+  hipLaunchKernelGGL(vhat_kernel, g, dim3(256), 0, s, Wf, strideW, H1, strideH, Vhat, ldV, strideV, T, F, Kp);
+}
+
+__global__ void pad_copy_kernel(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
+                                int64_t lddst, int64_t strideDst, int rows, int cols)
+{
+  const int b = blockIdx.z;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (c >= cols) return;
+  dst[(int64_t) b * strideDst + (int64_t) r * lddst + c] = src[(int64_t) b * strideSrc + (int64_t) r * ldsrc + c];
+}
+
+void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
+                     int64_t lddst, int64_t strideDst, int rows, int cols, int B, hipStream_t s)
+{
+  dim3 g((unsigned) ((cols + 255) / 256), (unsigned) rows, (unsigned) B);
+  hipLaunchKernelGGL(pad_copy_kernel, g, dim3(256), 0, s, src, ldsrc, strideSrc, dst, lddst, strideDst, rows, cols);
+}
+
+__global__ void transpose_kernel(const double* in, int64_t ldin, int64_t strideIn, double* out,
+                                 int64_t ldout, int64_t strideOut, int R, int C)
+{
+  __shared__ double tile[32][33];
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int r = r0 + j, c = c0 + tx;
+    tile[j][tx] = (r < R && c < C) ? in[(int64_t) b * strideIn + (int64_t) r * ldin + c] : 0.0;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int c = c0 + j, r = r0 + tx;
+    if (c < C && r < R) out[(int64_t) b * strideOut + (int64_t) c * ldout + r] = tile[tx][j];
+  }
+}
+
+void launch_transpose(const double* in, int64_t ldin, int64_t strideIn, double* out,
+                      int64_t ldout, int64_t strideOut, int R, int C, int B, hipStream_t s)
+{
+  dim3 g((unsigned) ((C + 31) / 32), (unsigned) ((R + 31) / 32), (unsigned) B);
+  hipLaunchKernelGGL(transpose_kernel, g, dim3(256), 0, s, in, ldin, strideIn, out, ldout, strideOut, R, C);
+}
+
+} // namespace fluhip

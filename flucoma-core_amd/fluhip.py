@@ -1,0 +1,272 @@
+"""ctypes binding of libflucoma_hip.so (include/flucoma_hip.h) for the Python-side tests and
+bench.py.  The product is the shared library and the C++ client headers; this module is a thin
+caller that mirrors the C ABI one to one and FAILS LOUDLY when the library is missing -- there
+is no numpy / torch fallback anywhere.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libflucoma_hip.so")
+
+OK, WARNING, ERROR, CANCELLED = 0, 1, 2, 3
+
+_i64 = ctypes.c_int64
+_dp = ctypes.POINTER(ctypes.c_double)
+_fp = ctypes.POINTER(ctypes.c_float)
+_ip = ctypes.POINTER(ctypes.c_int64)
+_vp = ctypes.c_void_p
+PROGRESS_FN = ctypes.CFUNCTYPE(ctypes.c_int, _i64, ctypes.c_void_p)
+
+EXPORTS = [
+    "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
+    "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
+    "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
+    "fluhip_nmf_process_f64", "fluhip_bufnmf_channel_f32", "fluhip_corpus_create",
+    "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
+    "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
+    "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
+    "fluhip_corpus_writeback_host", "fluhip_corpus_read_f64", "fluhip_prof_enable",
+    "fluhip_prof_reset", "fluhip_prof_read",
+]
+
+
+class FluhipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"fluhip status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} is missing: build it with `python flucoma-core_amd/build.py` "
+            "(there is no fallback implementation)")
+    L = ctypes.CDLL(path)
+    L.fluhip_abi_version.restype = ctypes.c_int
+    L.fluhip_device_count.restype = ctypes.c_int
+    L.fluhip_ctx_create.argtypes = [ctypes.c_int, ctypes.POINTER(_vp)]
+    L.fluhip_ctx_destroy.argtypes = [_vp]
+    L.fluhip_ctx_destroy.restype = None
+    L.fluhip_last_error.argtypes = [_vp]
+    L.fluhip_last_error.restype = ctypes.c_char_p
+    L.fluhip_ctx_device_info.argtypes = [_vp, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p,
+                                         ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+    L.fluhip_ctx_stream.argtypes = [_vp]
+    L.fluhip_ctx_stream.restype = _vp
+    L.fluhip_ctx_synchronize.argtypes = [_vp]
+    L.fluhip_fft_params.argtypes = [_i64, _i64, _i64, _ip, _ip, _ip, _ip]
+    L.fluhip_stft_num_frames.argtypes = [_i64, _i64, _i64]
+    L.fluhip_stft_num_frames.restype = _i64
+    L.fluhip_stft_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _dp, _dp, _ip]
+    L.fluhip_stft_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _dp, _dp, _ip]
+    L.fluhip_nmf_process_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
+                                         ctypes.c_int, _i64, _dp, _dp, _dp, _dp, _dp, PROGRESS_FN, _vp]
+    L.fluhip_bufnmf_channel_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                                            ctypes.c_int, ctypes.c_int, _i64, _fp, _fp, _fp, _fp,
+                                            _fp, PROGRESS_FN, _vp]
+    L.fluhip_corpus_create.argtypes = [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
+    L.fluhip_corpus_destroy.argtypes = [_vp]
+    L.fluhip_corpus_destroy.restype = None
+    for f in ("fluhip_corpus_frames", "fluhip_corpus_bins", "fluhip_corpus_device_bytes"):
+        getattr(L, f).argtypes = [_vp]
+        getattr(L, f).restype = _i64
+    L.fluhip_corpus_set_audio_host.argtypes = [_vp, _fp]
+    L.fluhip_corpus_set_audio_dev.argtypes = [_vp, _vp]
+    L.fluhip_corpus_stft.argtypes = [_vp]
+    L.fluhip_corpus_nmf.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_int, _i64, _ip, PROGRESS_FN, _vp]
+    L.fluhip_corpus_writeback_dev.argtypes = [_vp, _vp, _vp]
+    L.fluhip_corpus_writeback_host.argtypes = [_vp, _fp, _fp]
+    L.fluhip_corpus_read_f64.argtypes = [_vp, _dp, _dp, _dp]
+    L.fluhip_prof_enable.argtypes = [_vp, ctypes.c_int]
+    L.fluhip_prof_reset.argtypes = [_vp]
+    L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
+    return L
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _f(a):
+    return a.ctypes.data_as(_fp) if a is not None else None
+
+
+def _cb(progress):
+    if progress is None:
+        return PROGRESS_FN()
+    return PROGRESS_FN(lambda it, _u: 1 if progress(int(it)) else 0)
+
+
+class Context:
+    """fluhip_ctx: one device, one stream."""
+
+    def __init__(self, device: int = 0, lib: ctypes.CDLL | None = None):
+        self.lib = lib or load_library()
+        h = _vp()
+        rc = self.lib.fluhip_ctx_create(device, ctypes.byref(h))
+        if rc != OK:
+            raise FluhipError(rc, f"cannot create context on device {device} "
+                                  f"({self.lib.fluhip_device_count()} HIP devices visible)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.fluhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=(OK,)):
+        if rc not in allow:
+            raise FluhipError(rc, self.lib.fluhip_last_error(self.h).decode())
+        return rc
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(256)
+        arch = ctypes.create_string_buffer(256)
+        cus = ctypes.c_int(0)
+        self._check(self.lib.fluhip_ctx_device_info(self.h, name, 256, arch, 256, ctypes.byref(cus)))
+        return name.value.decode(), arch.value.decode(), cus.value
+
+    def synchronize(self):
+        self._check(self.lib.fluhip_ctx_synchronize(self.h))
+
+    # ---- algorithm::STFT ----------------------------------------------------------------
+    def stft(self, audio, win, fft, hop, window_type=0, want_spec=True, want_mag=True, stride=1):
+        audio = np.ascontiguousarray(audio)
+        n = (audio.shape[0] + stride - 1) // stride
+        T = (n + hop) // hop
+        F = fft // 2 + 1
+        spec = np.empty((T, F, 2)) if want_spec else None
+        mag = np.empty((T, F)) if want_mag else None
+        Tout = _i64(0)
+        if audio.dtype == np.float32:
+            rc = self.lib.fluhip_stft_f32(self.h, _f(audio), n, stride, win, fft, hop, window_type,
+                                          _d(spec), _d(mag), ctypes.byref(Tout))
+        else:
+            audio = audio.astype(np.float64, copy=False)
+            rc = self.lib.fluhip_stft_f64(self.h, _d(audio), n, stride, win, fft, hop, window_type,
+                                          _d(spec), _d(mag), ctypes.byref(Tout))
+        self._check(rc)
+        assert Tout.value == T
+        cs = spec[..., 0] + 1j * spec[..., 1] if want_spec else None
+        return cs, mag
+
+    # ---- algorithm::NMF -----------------------------------------------------------------
+    def nmf_process(self, X, K, iters, updateW=True, updateH=True, seed=42, W0=None, H0=None,
+                    progress=None, want_v=True):
+        X = np.asarray(X, dtype=np.float64)
+        assert X.ndim == 2 and X.strides[1] == 8
+        T, F = X.shape
+        ldx = X.strides[0] // 8
+        W0c = None if W0 is None else np.ascontiguousarray(W0, dtype=np.float64)
+        H0c = None if H0 is None else np.ascontiguousarray(H0, dtype=np.float64)
+        W1, H1 = np.empty((K, F)), np.empty((T, K))
+        V1 = np.empty((T, F)) if want_v else None
+        cb = _cb(progress)
+        rc = self.lib.fluhip_nmf_process_f64(self.h, X.ctypes.data_as(_dp), T, F, ldx, K, iters,
+                                             int(updateW), int(updateH), seed, _d(W0c), _d(H0c),
+                                             _d(W1), _d(H1), _d(V1), cb, None)
+        self._check(rc, allow=(OK, CANCELLED))
+        return W1, H1, V1, rc
+
+    # ---- one BufNMF channel -------------------------------------------------------------
+    def bufnmf_channel(self, audio, win, fft, hop, K, iters, seed, updateW=True, updateH=True,
+                       bases_seed=None, acts_seed=None, progress=None, stride=1):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = (audio.shape[0] + stride - 1) // stride
+        T, F = (n + hop) // hop, fft // 2 + 1
+        bases = np.empty((K, F), dtype=np.float32)
+        acts = np.empty((K, T), dtype=np.float32)
+        bs = None if bases_seed is None else np.ascontiguousarray(bases_seed, dtype=np.float32)
+        as_ = None if acts_seed is None else np.ascontiguousarray(acts_seed, dtype=np.float32)
+        cb = _cb(progress)
+        rc = self.lib.fluhip_bufnmf_channel_f32(self.h, _f(audio), n, stride, win, fft, hop, K, iters,
+                                                int(updateW), int(updateH), seed, _f(bs), _f(as_),
+                                                _f(bases), _f(acts), None, cb, None)
+        self._check(rc, allow=(OK, CANCELLED))
+        return bases, acts, rc
+
+    # ---- profiling ----------------------------------------------------------------------
+    def prof_enable(self, on=True):
+        self._check(self.lib.fluhip_prof_enable(self.h, int(on)))
+
+    def prof_reset(self):
+        self._check(self.lib.fluhip_prof_reset(self.h))
+
+    def prof_read(self, cls):
+        n, ms = _i64(0), ctypes.c_double(0)
+        self._check(self.lib.fluhip_prof_read(self.h, cls, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+
+class Corpus:
+    """fluhip_corpus: `count` equal-shape mono buffers resident in HBM."""
+
+    def __init__(self, ctx: Context, count, n, win, fft, hop, K):
+        self.ctx = ctx
+        self.count, self.n, self.win, self.fft, self.hop, self.K = count, n, win, fft, hop, K
+        h = _vp()
+        ctx._check(ctx.lib.fluhip_corpus_create(ctx.h, count, n, win, fft, hop, K, ctypes.byref(h)))
+        self.h = h
+        self.T = int(ctx.lib.fluhip_corpus_frames(h))
+        self.F = int(ctx.lib.fluhip_corpus_bins(h))
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.fluhip_corpus_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def device_bytes(self):
+        return int(self.ctx.lib.fluhip_corpus_device_bytes(self.h))
+
+    def set_audio(self, audio):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        assert audio.shape == (self.count, self.n)
+        self.ctx._check(self.ctx.lib.fluhip_corpus_set_audio_host(self.h, _f(audio)))
+
+    def set_audio_dev(self, dev_ptr: int):
+        self.ctx._check(self.ctx.lib.fluhip_corpus_set_audio_dev(self.h, _vp(dev_ptr)))
+
+    def stft(self):
+        self.ctx._check(self.ctx.lib.fluhip_corpus_stft(self.h))
+
+    def nmf(self, iters, seed=42, updateW=True, updateH=True, seeds=None, progress=None):
+        sarr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)
+        sp = sarr.ctypes.data_as(_ip) if sarr is not None else None
+        cb = _cb(progress)
+        rc = self.ctx.lib.fluhip_corpus_nmf(self.h, iters, int(updateW), int(updateH), seed, sp, cb, None)
+        return self.ctx._check(rc, allow=(OK, CANCELLED))
+
+    def writeback_dev(self, bases_ptr: int | None, acts_ptr: int | None):
+        self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_dev(
+            self.h, _vp(bases_ptr) if bases_ptr else None, _vp(acts_ptr) if acts_ptr else None))
+
+    def writeback(self):
+        bases = np.empty((self.count, self.K, self.F), dtype=np.float32)
+        acts = np.empty((self.count, self.K, self.T), dtype=np.float32)
+        self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_host(self.h, _f(bases), _f(acts)))
+        return bases, acts
+
+    def read_f64(self, mag=True, factors=True):
+        m = np.empty((self.count, self.T, self.F)) if mag else None
+        W1 = np.empty((self.count, self.K, self.F)) if factors else None
+        H1 = np.empty((self.count, self.T, self.K)) if factors else None
+        self.ctx._check(self.ctx.lib.fluhip_corpus_read_f64(self.h, _d(m), _d(W1), _d(H1)))
+        return m, W1, H1

@@ -1,0 +1,161 @@
+/*
+ * flucoma_hip.h -- C ABI of libflucoma_hip.so: the MI355X (gfx950) implementation of
+ * flucoma-core's buffered spectral-decomposition hot path (STFT -> magnitude -> KL-NMF).
+ *
+ * This is the drop-in boundary.  Every entry point replaces a reference interface that is
+ * cited next to it (paths relative to <flucoma-core>/include/flucoma/).  Plain pointers and
+ * sizes only: no C++ types, no torch types, no exceptions cross this boundary.
+ *
+ * Conventions
+ *   - status codes map 1:1 onto client::Result::Status (clients/common/Result.hpp:24);
+ *     the message of the last non-OK result is read with fluhip_last_error().
+ *   - "host" pointers are ordinary CPU memory; "dev" pointers are HIP device memory on the
+ *     context's device.  Nothing is retained after a call returns except inside handles.
+ *   - all matrices are dense row-major with the layouts of the reference's FluidTensorViews:
+ *       spectrogram / magnitude  T x F       (F = fft/2 + 1, T = (N + hop) / hop)
+ *       W1 (bases)               K x F
+ *       H1 (activations)         T x K
+ *   - the library is re-entrant; a context may be used by one thread at a time (the reference
+ *     runs one job per std::thread: clients/common/FluidNRTClientWrapper.hpp:1048).
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute entry point
+ *     returns FLUHIP_ERROR.
+ */
+#ifndef FLUCOMA_HIP_H
+#define FLUCOMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLUHIP_ABI_VERSION 1
+
+/* clients/common/Result.hpp:24  enum class Status { kOk, kWarning, kError, kCancelled } */
+enum fluhip_status
+{
+  FLUHIP_OK = 0,
+  FLUHIP_WARNING = 1,
+  FLUHIP_ERROR = 2,
+  FLUHIP_CANCELLED = 3
+};
+
+/* algorithms/public/WindowFuncs.hpp:26-32  enum class WindowTypes */
+enum fluhip_window
+{
+  FLUHIP_WINDOW_HANN = 0,
+  FLUHIP_WINDOW_HANND = 1,
+  FLUHIP_WINDOW_HAMMING = 2,
+  FLUHIP_WINDOW_BLACKMANHARRIS = 3,
+  FLUHIP_WINDOW_GAUSSIAN = 4
+};
+
+typedef struct fluhip_ctx    fluhip_ctx;    /* one device + one HIP stream + scratch arena */
+typedef struct fluhip_corpus fluhip_corpus; /* a device-resident batch of equal-shape buffers */
+
+/* algorithms/public/NMF.hpp:31 ProgressCallback = std::function<bool(index)>; invoked on the
+ * calling thread with iteration = 1..iters in order; returning 0 cancels (NMF.hpp:175-176). */
+typedef int (*fluhip_progress_fn)(int64_t iteration, void* user);
+
+/* ---- library / context ------------------------------------------------------------- */
+int         fluhip_abi_version(void);
+int         fluhip_device_count(void);                    /* 0 when no HIP device is visible */
+int         fluhip_ctx_create(int device, fluhip_ctx** out);
+void        fluhip_ctx_destroy(fluhip_ctx* ctx);
+const char* fluhip_last_error(const fluhip_ctx* ctx);     /* never NULL */
+/* device name / gcnArchName into caller buffers (for bench reports) */
+int         fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char* arch,
+                                   int arch_len, int* compute_units);
+/* raw HIP stream (hipStream_t) the context launches on -- for event timing by the caller */
+void*       fluhip_ctx_stream(const fluhip_ctx* ctx);
+int         fluhip_ctx_synchronize(fluhip_ctx* ctx);
+
+/* ---- parameter arithmetic (integer, bit-exact) --------------------------------------- */
+/* clients/common/ParameterTypes.hpp:295-312 FFTParams::fftSize/hopSize/frameSize.
+ * in: win, hop (<=0: win/2), fft (<0: nextPow2(win)).  Returns FLUHIP_ERROR when fft is not a
+ * power of two >= win or win < 4 (the reference clamps these at set time: :371-393). */
+int fluhip_fft_params(int64_t win, int64_t hop, int64_t fft, int64_t* win_out, int64_t* hop_out,
+                      int64_t* fft_out, int64_t* bins_out);
+/* algorithms/public/STFT.hpp:98-99, clients/nrt/NMFClient.hpp:111-112: (n + hop) / hop */
+int64_t fluhip_stft_num_frames(int64_t n, int64_t win, int64_t hop);
+
+/* ---- algorithm::STFT ------------------------------------------------------------------ */
+/* Replaces STFT::STFT(win, fft, hop, windowType) + STFT::process(audio, spectrogram) +
+ * STFT::magnitude(spectrogram, magnitude)  (algorithms/public/STFT.hpp:36-47, 90-108, 61-66).
+ * audio: n host doubles with element stride `stride`.  spec (may be NULL): T*F interleaved
+ * (re,im) doubles == std::complex<double>[T][F].  mag (may be NULL): T*F doubles. */
+int fluhip_stft_f64(fluhip_ctx* ctx, const double* audio, int64_t n, int64_t stride, int64_t win,
+                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
+                    int64_t* frames_out);
+/* same with the float->double conversion of clients/nrt/NMFClient.hpp:240 folded in */
+int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
+                    int64_t* frames_out);
+
+/* ---- algorithm::NMF ------------------------------------------------------------------- */
+/* Replaces NMF::process(X, W1, H1, V1, rank, nIterations, updateW, updateH, randomSeed, W0, H0)
+ * + NMF::addProgressCallback  (algorithms/public/NMF.hpp:91-139, 144-183).
+ * X: T x F with row stride ldx (doubles).  W0: K x F or NULL ("0x0 view").  H0: T x K or NULL.
+ * W1: K x F, H1: T x K, V1: T x F or NULL.  seed < 0 => std::random_device like the reference.
+ * On cancellation returns FLUHIP_CANCELLED; W1/H1 then hold the factors of the last completed
+ * iteration batch and V1 is left unwritten. */
+int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                           int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                           const double* W0, const double* H0, double* W1, double* H1,
+                           double* V1, fluhip_progress_fn progress, void* user);
+
+/* ---- client::bufnmf::NMFClient::process, one channel ---------------------------------- */
+/* Replaces the body of the channel loop, clients/nrt/NMFClient.hpp:240-300 (STFT -> magnitude
+ * -> NMF -> float write-back with H/max(H)), without a host round trip in between.
+ * audio: n host floats, element stride `stride`.
+ * bases_seed: K x F floats or NULL (basesMode Seed/Fixed);  acts_seed: K x T floats or NULL
+ * (channel-major like BufferAdaptor::samps(channel)).
+ * bases_out: K x F floats or NULL;  acts_out: K x T floats or NULL (already scaled by
+ * float(1/max H) in float arithmetic, :297-298);  resynth_out: K x n floats or NULL
+ * (resynthMode 1, :302-334). */
+int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride,
+                              int64_t win, int64_t fft, int64_t hop, int64_t K, int64_t iters,
+                              int update_w, int update_h, int64_t seed, const float* bases_seed,
+                              const float* acts_seed, float* bases_out, float* acts_out,
+                              float* resynth_out, fluhip_progress_fn progress, void* user);
+
+/* ---- corpus: many independent equal-shape buffers, resident in HBM --------------------- */
+/* The data-parallel form of the same path (BASELINE config 4): `count` mono buffers of n
+ * samples each; every buffer is an independent BufNMF job (clients/nrt/NMFClient.hpp:233 loop
+ * body; no cross-buffer state).  Lifetime: create -> set_audio -> stft -> nmf -> read-back. */
+int  fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
+                          int64_t hop, int64_t K, fluhip_corpus** out);
+void fluhip_corpus_destroy(fluhip_corpus* c);
+int64_t fluhip_corpus_frames(const fluhip_corpus* c);   /* T */
+int64_t fluhip_corpus_bins(const fluhip_corpus* c);     /* F */
+int64_t fluhip_corpus_device_bytes(const fluhip_corpus* c);
+/* audio: count x n floats, host (synchronous copy) or device pointer */
+int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio);
+int fluhip_corpus_set_audio_dev(fluhip_corpus* c, const float* audio_dev);
+/* K1: batched window + real FFT + magnitude for every frame of every buffer */
+int fluhip_corpus_stft(fluhip_corpus* c);
+/* NMF on every buffer; seeds: `count` seeds or NULL (then `seed` for all, like one ParameterSet
+ * shared by all jobs).  Asynchronous on the context stream unless a progress callback is
+ * given (progress is then reported per iteration across the whole batch). */
+int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
+                      const int64_t* seeds, fluhip_progress_fn progress, void* user);
+/* write-back (clients/nrt/NMFClient.hpp:277-300) into device or host float arrays:
+ * bases: count x K x F, acts: count x K x T.  Either may be NULL. */
+int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev);
+int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts);
+/* raw f64 results for parity tests: mag count x T x F, W1 count x K x F, H1 count x T x K */
+int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1);
+
+/* ---- live kernel timing (HIP events on the context stream) ----------------------------- */
+/* When enabled, every launch of the two dominant kernel classes is bracketed by hipEvents on
+ * the stream it is launched on.  Classes: 0 = stft_r2c_mag, 1 = nmf_update (both factor
+ * updates share one kernel).  fluhip_prof_read synchronises and returns the launch count and
+ * the summed duration since the last reset. */
+int fluhip_prof_enable(fluhip_ctx* ctx, int on);
+int fluhip_prof_reset(fluhip_ctx* ctx);
+int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUCOMA_HIP_H */

@@ -204,3 +204,31 @@ def synth_audio(n: int, seed: int, sr: float = 44100.0, notes: int = 8) -> np.nd
     x += 0.01 * rs.standard_normal(n)
     x /= max(1.0, np.abs(x).max())
     return x.astype(np.float32)
+
+
+def drum_like(n, seed=7):
+    """c1-shaped stand-in for Resources/AudioFiles/Nicol-LoopE-M.wav (which is not redistributable):
+    three kinds of decaying hits (low thump, mid noise burst, high tick) on a loop grid."""
+    rs = np.random.RandomState(seed)
+    sr = 44100.0
+    x = np.zeros(n)
+    step = int(sr * 0.125)
+    pos = 0
+    i = 0
+    while pos < n:
+        kind = [0, 2, 1, 2, 0, 0, 1, 2][i % 8]
+        L = min(n - pos, int(sr * 0.25))
+        tt = np.arange(L) / sr
+        if kind == 0:
+            hit = np.exp(-18 * tt) * np.sin(2 * np.pi * (55 + 60 * np.exp(-30 * tt)) * tt)
+        elif kind == 1:
+            hit = 0.6 * np.exp(-25 * tt) * rs.standard_normal(L) + 0.3 * np.exp(-20 * tt) * np.sin(2 * np.pi * 190 * tt)
+        else:
+            hit = 0.35 * np.exp(-60 * tt) * rs.standard_normal(L)
+        x[pos:pos + L] += hit
+        pos += step
+        i += 1
+    x += 0.002 * rs.standard_normal(n)
+    x /= np.abs(x).max() * 1.05
+    # 16-bit quantisation like the WAV it stands in for
+    return (np.round(x * 32767.0) / 32768.0).astype(np.float32)

@@ -1,0 +1,68 @@
+"""pytest configuration: markers and import paths.
+
+`-m "not gpu"` : oracle vs golden vectors, host logic, ABI load/export checks (no GPU calls).
+`-m gpu`       : parity tests proper -- the HIP path, called through the C ABI, against the
+                 oracle and the committed fixtures.
+"""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_c
+    return oracle_c.get("native")
+
+
+@pytest.fixture(scope="session")
+def onp():
+    import oracle_np
+    return oracle_np
+
+
+@pytest.fixture(scope="session")
+def fluhip_lib_path():
+    """Path of the in-tree shared library; builds it when missing (hipcc cross-compiles)."""
+    spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    if not os.path.exists(mod.LIB):
+        mod.build()
+    return mod.LIB
+
+
+@pytest.fixture(scope="session")
+def ctx(fluhip_lib_path):
+    """A fluhip context on device 0.  GPU tests must not silently pass without one."""
+    import fluhip
+    lib = fluhip.load_library(fluhip_lib_path)
+    assert lib.fluhip_device_count() > 0, "no HIP device visible: gpu tests need a real MI355X"
+    c = fluhip.Context(0, lib)
+    name, arch, cus = c.device_info()
+    assert arch.startswith("gfx950"), f"expected gfx950, got {arch} ({name})"
+    yield c
+    c.close()
+
+
+def rel_err(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))

@@ -1,0 +1,345 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/flucoma_hip.h), against
+the CPU oracle on the same seeded inputs and against the committed golden fixtures.
+
+Bars (BASELINE.json north_star): frame indexing bit-exact; spectrogram <= 1e-12 relative (f64
+vs f64); W, H within 1e-5 relative -- the f64 kernels are expected to sit many orders below
+that, which the *_tight assertions record.
+"""
+import numpy as np
+import pytest
+
+from helpers import TOL_FACTORS, TOL_FACTORS_TIGHT, TOL_STFT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+# ---------------------------------------------------------------------------------------
+# K1: STFT
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wfh", [(1024, 1024, 512), (2048, 2048, 512), (512, 1024, 256)])
+def test_stft_golden(ctx, golden, wfh):
+    win, fft, hop = wfh
+    sig = golden["g2_signal"]
+    spec, mag = ctx.stft(sig, win, fft, hop)
+    key = f"g2_{win}_{fft}_{hop}"
+    assert spec.shape[0] == int(golden[key + "_T"][0])          # frame count: exact
+    rows = golden[key + "_rows"]
+    scale = np.abs(golden[key + "_spec"]).max()
+    assert np.abs(spec[rows] - golden[key + "_spec"]).max() / scale < TOL_STFT
+    assert np.abs(mag[rows] - golden[key + "_mag"]).max() / scale < TOL_STFT
+    assert abs(mag.sum() - golden[key + "_magsum"][0]) / golden[key + "_magsum"][0] < TOL_STFT
+    assert np.all(spec[:, 0].imag == 0) and np.all(spec[:, -1].imag == 0)  # util/FFT.hpp:99-101
+
+
+@pytest.mark.parametrize("n,win,fft,hop", [
+    (44100, 1024, 1024, 512), (44100, 2048, 2048, 512), (30000, 4096, 4096, 1024),
+    (10000, 1000, 1024, 250),   # non power-of-two window, zero-padded tail
+    (5000, 64, 64, 16), (777, 16, 16, 4), (100, 8, 8, 2), (50, 4, 4, 1),
+    (1, 1024, 1024, 512),       # a single sample: T = 1
+    (511, 1024, 1024, 512), (512, 1024, 1024, 512), (513, 1024, 1024, 512),  # ragged around one hop
+    (20000, 8192, 8192, 2048),  # largest in-LDS size (twiddles from global memory)
+    (3000, 256, 512, 64), (3000, 32, 2048, 8),
+])
+def test_stft_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
+    x = onp.synth_audio(n, 1000 + n % 17)
+    spec, mag = ctx.stft(x, win, fft, hop)
+    rspec, rmag = oracle.stft_f32(x, win, fft, hop)
+    assert spec.shape == rspec.shape == ((n + hop) // hop, fft // 2 + 1)
+    scale = max(np.abs(rspec).max(), 1e-30)
+    assert np.abs(spec - rspec).max() / scale < TOL_STFT
+    assert np.abs(mag - rmag).max() / scale < TOL_STFT
+
+
+def test_stft_f64_input_and_stride(ctx, oracle):
+    rs = np.random.RandomState(4)
+    x = rs.standard_normal(9000)
+    spec, mag = ctx.stft(x, 512, 512, 128)
+    rspec, rmag = oracle.stft(x, 512, 512, 128)
+    assert rel_err(spec, rspec) < TOL_STFT and rel_err(mag, rmag) < TOL_STFT
+    # strided view (BufferAdaptor::samps of an interleaved 2-channel buffer: cc/BufferAdaptor.hpp:61-66)
+    inter = np.zeros(18000, dtype=np.float32)
+    inter[0::2] = x.astype(np.float32)
+    inter[1::2] = 99.0
+    spec2, mag2 = ctx.stft(inter, 512, 512, 128, stride=2)
+    rspec2, rmag2 = oracle.stft_f32(x.astype(np.float32), 512, 512, 128)
+    assert rel_err(mag2, rmag2) < TOL_STFT
+
+
+def test_stft_linearity_and_shift(ctx, onp):
+    """size-independent properties at a BASELINE shape (fft 2048 / hop 512)"""
+    n, win, fft, hop = 441000, 2048, 2048, 512
+    a = onp.synth_audio(n, 1).astype(np.float64)
+    b = onp.synth_audio(n, 2).astype(np.float64)
+    sa, _ = ctx.stft(a, win, fft, hop)
+    sb, _ = ctx.stft(b, win, fft, hop)
+    sab, _ = ctx.stft(2.0 * a - 3.0 * b, win, fft, hop)
+    assert sa.shape == (862, 1025)
+    assert rel_err(sab, 2.0 * sa - 3.0 * sb) < 1e-11
+    # shifting the input by one hop shifts the frames by one
+    sh, _ = ctx.stft(np.concatenate([np.zeros(hop), a])[:n], win, fft, hop)
+    assert rel_err(sh[3:-3], sa[2:-4]) < 1e-11
+    # Parseval per frame on an interior frame: sum |x w|^2 = (|X0|^2 + 2 sum |Xk|^2 + |XN|^2)/fft
+    w = onp.hann(win)
+    t = 400
+    fr = a[t * hop - win // 2: t * hop - win // 2 + win] * w
+    e = (np.abs(sa[t, 0]) ** 2 + 2 * (np.abs(sa[t, 1:-1]) ** 2).sum() + np.abs(sa[t, -1]) ** 2) / fft
+    assert abs(e - (fr * fr).sum()) / (fr * fr).sum() < 1e-12
+
+
+def test_stft_rejects_bad_shapes(ctx):
+    import fluhip
+    x = np.zeros(1000, dtype=np.float32)
+    with pytest.raises(fluhip.FluhipError):
+        ctx.stft(x, 1024, 1000, 512)      # fft not a power of two
+    with pytest.raises(fluhip.FluhipError):
+        ctx.stft(x, 2048, 1024, 512)      # fft < win
+    with pytest.raises(fluhip.FluhipError):
+        ctx.stft(x, 1024, 32768, 512)     # beyond the in-LDS kernel
+
+
+# ---------------------------------------------------------------------------------------
+# NMF
+# ---------------------------------------------------------------------------------------
+def test_nmf_repeatable_with_seed(ctx):
+    """tests/algorithms/public/TestNMF.cpp:11-46 verbatim, through the C ABI"""
+    X = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9.0]])
+    a = ctx.nmf_process(X, 2, 1, True, True, 42)
+    b = ctx.nmf_process(X, 2, 1, True, True, 42)
+    c = ctx.nmf_process(X, 2, 1, True, True, 5063)
+    d = ctx.nmf_process(X, 2, 1, True, True, 5063)
+    for i in range(3):
+        assert np.array_equal(a[i], b[i]) and np.array_equal(c[i], d[i])
+        assert not np.array_equal(a[i], c[i])
+        assert np.isfinite(a[i]).all()
+
+
+@pytest.mark.parametrize("seed", [42, 5063])
+@pytest.mark.parametrize("iters", [1, 50])
+def test_nmf_tiny_golden(ctx, golden, seed, iters):
+    W1, H1, V1, rc = ctx.nmf_process(golden["g4_X"], 2, iters, True, True, seed)
+    assert rc == 0
+    assert rel_err(W1, golden[f"g4_s{seed}_i{iters}_W"]) < TOL_FACTORS_TIGHT
+    assert rel_err(H1, golden[f"g4_s{seed}_i{iters}_H"]) < TOL_FACTORS_TIGHT
+    assert rel_err(V1, golden[f"g4_s{seed}_i{iters}_V"]) < TOL_FACTORS_TIGHT
+
+
+@pytest.mark.parametrize("mode", ["u11", "u10", "u01", "u00", "seeded"])
+def test_nmf_g5_golden(ctx, golden, mode):
+    X, W0, H0 = golden["g5_X"], golden["g5_W0"], golden["g5_H0"]
+    if mode == "seeded":
+        uw, uh, iters, w0, h0 = True, True, 200, W0, H0
+    else:
+        uw, uh = mode[1] == "1", mode[2] == "1"
+        iters = 200 if (uw or uh) else 0
+        w0, h0 = (None if uw else W0), (None if uh else H0)
+    W1, H1, V1, rc = ctx.nmf_process(X, 4, iters, uw, uh, 42, w0, h0)
+    assert rc == 0
+    for got, name in ((W1, "W"), (H1, "H"), (V1, "V")):
+        e = rel_err(got, golden[f"g5_{mode}_{name}"])
+        assert e < TOL_FACTORS, (mode, name, e)
+        assert e < TOL_FACTORS_TIGHT, (mode, name, e)
+
+
+@pytest.mark.parametrize("T,F,K,iters", [
+    (87, 513, 3, 50),      # c1-like rank (padded to 16 inside)
+    (200, 1025, 16, 30),   # c2 bins / rank
+    (173, 1025, 32, 30),   # c4 bins / rank
+    (97, 257, 48, 10), (64, 129, 64, 10), (50, 100, 100, 5), (40, 65, 128, 5),
+    (33, 17, 1, 20), (16, 16, 16, 5), (17, 33, 5, 5), (1, 9, 2, 3), (9, 1, 2, 3),
+])
+def test_nmf_vs_oracle(ctx, oracle, T, F, K, iters):
+    rs = np.random.RandomState(T * 7 + F)
+    X = np.abs(rs.standard_normal((T, 3)) @ rs.standard_normal((3, F))) + 0.01 * rs.uniform(0, 1, (T, F))
+    W1, H1, V1, rc = ctx.nmf_process(X, K, iters, True, True, 42)
+    rW, rH, rV, _ = oracle.nmf_process(X, K, iters, True, True, 42)
+    assert rc == 0
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT
+    assert rel_err(H1, rH) < TOL_FACTORS_TIGHT
+    assert rel_err(V1, rV) < TOL_FACTORS_TIGHT
+    # column L2 norms of W are 1 after the last update (alg/NMF.hpp:162)
+    assert np.allclose(np.sqrt((W1 * W1).sum(axis=1)), 1.0, atol=1e-12)
+
+
+def test_nmf_strided_input(ctx, oracle):
+    rs = np.random.RandomState(3)
+    big = np.abs(rs.standard_normal((40, 80)))
+    X = big[:, :33]  # ldx = 80
+    W1, H1, V1, _ = ctx.nmf_process(X, 4, 10, True, True, 7)
+    rW, rH, rV, _ = oracle.nmf_process(np.ascontiguousarray(X), 4, 10, True, True, 7)
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
+
+
+def test_nmf_zero_columns_and_rows(ctx, oracle):
+    """silent frames / empty bins: V has exact zeros (clamps at eps keep everything finite)"""
+    rs = np.random.RandomState(8)
+    X = np.abs(rs.standard_normal((48, 40)))
+    X[5] = 0
+    X[:, 7] = 0
+    X[40:] = 0
+    W1, H1, V1, _ = ctx.nmf_process(X, 3, 40, True, True, 42)
+    rW, rH, rV, _ = oracle.nmf_process(X, 3, 40, True, True, 42)
+    assert np.isfinite(W1).all() and np.isfinite(H1).all()
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
+
+
+def test_nmf_progress_and_cancel(ctx):
+    import fluhip
+    X = np.abs(np.random.RandomState(1).standard_normal((64, 33)))
+    calls = []
+    W1, H1, V1, rc = ctx.nmf_process(X, 4, 25, True, True, 1, progress=lambda it: calls.append(it) or True)
+    assert rc == fluhip.OK and calls == list(range(1, 26))      # alg/NMF.hpp:175: cb(i + 1), every iteration
+    calls2 = []
+
+    def cancel_at_5(it):
+        calls2.append(it)
+        return it < 5
+
+    W1, H1, V1, rc = ctx.nmf_process(X, 4, 25, True, True, 1, progress=cancel_at_5)
+    assert rc == fluhip.CANCELLED and calls2 == [1, 2, 3, 4, 5]  # stops at once (:176)
+
+
+def test_nmf_single_buffer_large_uses_split_path(ctx, oracle):
+    """a single c2-shaped buffer (few column strips) exercises the split-R partial-sum path"""
+    rs = np.random.RandomState(21)
+    T, F, K = 700, 1025, 16
+    X = np.abs(rs.standard_normal((T, 5)) @ rs.standard_normal((5, F))) + 0.001
+    W1, H1, V1, _ = ctx.nmf_process(X, K, 20, True, True, 42, want_v=False)
+    rW, rH, rV, _ = oracle.nmf_process(X, K, 20, True, True, 42)
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
+    # run-to-run reproducibility (fixed-order reductions): TestNMF.cpp:31-39
+    W2, H2, _, _ = ctx.nmf_process(X, K, 20, True, True, 42, want_v=False)
+    assert np.array_equal(W1, W2) and np.array_equal(H1, H2)
+
+
+# ---------------------------------------------------------------------------------------
+# BufNMF channel + corpus
+# ---------------------------------------------------------------------------------------
+def test_bufnmf_channel_vs_oracle(ctx, oracle, onp):
+    x = onp.synth_audio(44100, 1001)
+    bases, acts, rc = ctx.bufnmf_channel(x, 1024, 1024, 512, 5, 50, 42)
+    rb, ra = oracle.bufnmf_channel(x, 1024, 1024, 512, 5, 50, 42)
+    assert rc == 0 and bases.shape == (5, 513) and acts.shape == (5, 87)
+    assert rel_err(bases, rb) < TOL_FACTORS and rel_err(acts, ra) < TOL_FACTORS
+    assert rel_err(bases, rb) < 1e-6 and rel_err(acts, ra) < 1e-6   # f32 outputs: 1 ulp-ish
+    assert acts.max() == pytest.approx(1.0, abs=1e-6)                # H / max(H): nrt/NMFClient.hpp:289-298
+
+
+def test_bufnmf_c1_shape_golden(ctx, onp, golden):
+    """BASELINE config 1 shape end to end against the committed fixture"""
+    import hashlib
+    x = onp.drum_like(453932)
+    sha = np.frombuffer(hashlib.sha256(x.tobytes()).digest(), dtype=np.uint8)
+    if not np.array_equal(sha, golden["g6_input_sha256"]):
+        pytest.skip("numpy RandomState stream differs from the one the fixture was minted with")
+    bases, acts, rc = ctx.bufnmf_channel(x, 1024, 1024, 512, 3, 50, 42)
+    assert bases.shape == (3, 513) and acts.shape == (3, 887)
+    pb, pa = golden["g6_probe_bases_idx"], golden["g6_probe_acts_idx"]
+    assert np.allclose(bases[pb[:, 0], pb[:, 1]], golden["g6_probe_bases"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(acts[pa[:, 0], pa[:, 1]], golden["g6_probe_acts"], rtol=1e-5, atol=1e-7)
+    sums = golden["g6_sums"]
+    assert abs(bases.astype(np.float64).sum() - sums[0]) / sums[0] < 1e-6
+    assert abs(acts.astype(np.float64).sum() - sums[1]) / sums[1] < 1e-6
+
+
+def test_bufnmf_seeded_and_fixed_bases(ctx, oracle, onp):
+    """basesMode Seed / Fixed (nrt/NMFClient.hpp:246-258, 268-271)"""
+    x = onp.synth_audio(22050, 1002)
+    win, fft, hop, K = 512, 512, 128, 4
+    _, mag = oracle.stft_f32(x, win, fft, hop)
+    rs = np.random.RandomState(0)
+    seedW = rs.uniform(0.05, 1.0, (K, fft // 2 + 1)).astype(np.float32)
+    # Fixed bases: only H updates
+    bases, acts, rc = ctx.bufnmf_channel(x, win, fft, hop, K, 30, 42, updateW=False, bases_seed=seedW)
+    rW, rH, _, _ = oracle.nmf_process(mag, K, 30, False, True, 42, W0=seedW.astype(np.float64))
+    rb, ra = oracle.bufnmf_writeback(rW, rH)
+    assert rel_err(acts, ra) < 1e-6 and rel_err(bases, rb) < 1e-6
+    # Seeded bases: both update
+    bases, acts, rc = ctx.bufnmf_channel(x, win, fft, hop, K, 30, 42, bases_seed=seedW)
+    rW, rH, _, _ = oracle.nmf_process(mag, K, 30, True, True, 42, W0=seedW.astype(np.float64))
+    rb, ra = oracle.bufnmf_writeback(rW, rH)
+    assert rel_err(acts, ra) < 1e-6 and rel_err(bases, rb) < 1e-6
+
+
+def test_corpus_matches_per_buffer_oracle(ctx, oracle, onp):
+    """the batched (corpus) form against independent per-buffer oracle runs, c4's fft/rank"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 12, 22050, 2048, 2048, 512, 32, 25
+    audio = np.stack([onp.synth_audio(n, 1000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    assert (c.T, c.F) == ((n + hop) // hop, 1025)
+    c.set_audio(audio)
+    c.stft()
+    c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    bases, acts = c.writeback()
+    for b in (0, 5, 11):
+        _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
+        assert rel_err(mag[b], rmag) < TOL_STFT
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6
+    c.close()
+
+
+def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
+    """sharding property: a buffer's result does not depend on which batch (or rank) holds it"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 9, 11025, 1024, 1024, 256, 16, 15
+    audio = np.stack([onp.synth_audio(n, 2000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    _, W_all, H_all = c.read_f64()
+    c.close()
+    perm = np.array([4, 0, 8])
+    c2 = fluhip.Corpus(ctx, 3, n, win, fft, hop, K)
+    c2.set_audio(audio[perm]); c2.stft(); c2.nmf(iters, seed=42)
+    _, W_sub, H_sub = c2.read_f64()
+    c2.close()
+    assert np.array_equal(W_sub, W_all[perm]) and np.array_equal(H_sub, H_all[perm])
+
+
+def test_corpus_per_buffer_seeds(ctx, oracle, onp):
+    import fluhip
+    B, n, win, fft, hop, K, iters = 3, 8000, 512, 512, 128, 4, 10
+    audio = np.stack([onp.synth_audio(n, 3000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.set_audio(audio); c.stft(); c.nmf(iters, seeds=[42, 5063, 42])
+    mag, W1, H1 = c.read_f64()
+    for b, seed in enumerate((42, 5063, 42)):
+        rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, True, True, seed)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
+    c.close()
+
+
+def test_corpus_c4_shape_properties(ctx, onp):
+    """BASELINE config 4 shape at full per-buffer size (10 s, fft 2048, rank 32, 200 iterations),
+    checked through size-independent properties: unit-norm dictionary columns, non-negativity,
+    activations' max exactly 1 after write-back, monotone KL divergence between 50 and 200
+    iterations, bit-identical repeat."""
+    import fluhip
+    B, n, win, fft, hop, K = 8, 441000, 2048, 2048, 512, 32
+    audio = np.stack([onp.synth_audio(n, 1000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    assert (c.T, c.F) == (862, 1025)
+    c.set_audio(audio); c.stft()
+
+    def kl(V, W1, H1):
+        P = np.maximum(H1 @ W1, 1e-300)
+        Vs = np.maximum(V, 1e-300)
+        return float((V * np.log(Vs / P) - V + P).sum())
+
+    c.nmf(50, seed=42)
+    mag, W50, H50 = c.read_f64()
+    c.nmf(200, seed=42)
+    _, W200, H200 = c.read_f64()
+    bases, acts = c.writeback()
+    c.nmf(200, seed=42)
+    _, W200b, H200b = c.read_f64()
+    c.close()
+    assert np.array_equal(W200, W200b) and np.array_equal(H200, H200b)
+    assert (W200 >= 0).all() and (H200 >= 0).all() and np.isfinite(W200).all() and np.isfinite(H200).all()
+    assert np.allclose(np.sqrt((W200 * W200).sum(axis=2)), 1.0, atol=1e-12)
+    assert np.allclose(acts.reshape(B, -1).max(axis=1), 1.0, atol=1e-6)
+    for b in range(B):
+        assert kl(mag[b], W200[b], H200[b]) <= kl(mag[b], W50[b], H50[b]) * (1 + 1e-9)

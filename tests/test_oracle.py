@@ -1,0 +1,230 @@
+"""CPU tests: the C oracle against the committed golden vectors (minted by the independent numpy
+restatement) and against the pins the reference's own tests provide for this path.
+
+Reference tests mirrored here:
+  tests/algorithms/public/TestNMF.cpp:11-46          same seed => identical output, other seed differs
+  tests/algorithms/util/TestEigenRandom.cpp:92-114   seed repeatability, range
+  tests/clients/common/TestBufferedProcess.cpp:42-44 Hann formula 0.5 - 0.5 cos(2 pi i / N), COLA
+"""
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+RNG_CPP = r"""
+#include <random>
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+  unsigned long seed = strtoul(argv[1], 0, 10); int n = atoi(argv[2]);
+  std::mt19937_64 g{seed}; std::uniform_real_distribution<double> d{0.0, 1.0};
+  for (int i = 0; i < n; i++) printf("%.17g\n", d(g));
+}
+"""
+
+
+def test_rng_matches_libstdcxx(oracle, onp):
+    """util/EigenRandom.hpp:73-101 uses libstdc++'s <random> verbatim: compile it and compare."""
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "r.cpp"), os.path.join(td, "r")
+        open(src, "w").write(RNG_CPP)
+        subprocess.run(["g++", "-O1", "-o", exe, src], check=True)
+        for seed in (0, 42, 5063, 2**31 + 7):
+            out = subprocess.run([exe, str(seed), "1000"], check=True, capture_output=True, text=True).stdout
+            ref = np.array([float(x) for x in out.split()])
+            assert np.array_equal(oracle.rng_uniform01(seed, 1000), ref)
+            assert np.array_equal(onp.rng_uniform01(seed, 1000), ref)
+
+
+def test_rng_golden(oracle, golden):
+    for seed in (42, 5063):
+        r = oracle.rng_uniform01(seed, 16)
+        assert np.array_equal(r, golden[f"g3_rng{seed}"])
+        assert (r >= 0).all() and (r < 1).all()
+    # SURVEY 8 a6 known values
+    assert oracle.rng_uniform01(42, 1)[0] == 0.75515553295453897
+    assert oracle.rng_uniform01(5063, 1)[0] == 0.05300292112151906
+
+
+def test_hann_window(oracle, golden):
+    for win in (1024, 2048, 4096):
+        w = oracle.hann(win)
+        assert np.array_equal(w[:8], golden[f"g1_hann{win}_head"])
+        assert np.array_equal(w[-8:], golden[f"g1_hann{win}_tail"])
+        assert abs(w.sum() - golden[f"g1_hann{win}_sum"][0]) < 1e-9
+    # TestBufferedProcess.cpp:42-44 + COLA of the periodic Hann at overlap 2
+    N = 1024
+    w = oracle.hann(N)
+    i = np.arange(N)
+    assert np.allclose(w, 0.5 - 0.5 * np.cos(2 * np.pi * i / N), atol=1e-15)
+    assert np.allclose(w[: N // 2] + w[N // 2:], 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n,win,hop", [(453932, 1024, 512), (2646000, 2048, 512), (441000, 2048, 512),
+                                       (88200, 1024, 512), (1, 1024, 512), (511, 1024, 512), (512, 1024, 512)])
+def test_frame_count(oracle, n, win, hop):
+    """nrt/NMFClient.hpp:111-112 / alg/STFT.hpp:98-99 -- integer arithmetic, exact."""
+    assert oracle.num_frames(n, win, hop) == (n + hop) // hop == n // hop + 1
+
+
+def test_frame_counts_of_baseline_configs(oracle):
+    assert oracle.num_frames(453932, 1024, 512) == 887
+    assert oracle.num_frames(2646000, 2048, 512) == 5168
+    assert oracle.num_frames(26460000, 4096, 1024) == 25840
+    assert oracle.num_frames(441000, 2048, 512) == 862
+
+
+@pytest.mark.parametrize("wfh", [(1024, 1024, 512), (2048, 2048, 512), (512, 1024, 256)])
+def test_stft_golden(oracle, golden, wfh):
+    win, fft, hop = wfh
+    sig = golden["g2_signal"]
+    spec, mag = oracle.stft_f32(sig, win, fft, hop)
+    key = f"g2_{win}_{fft}_{hop}"
+    assert spec.shape[0] == int(golden[key + "_T"][0])
+    rows = golden[key + "_rows"]
+    scale = np.abs(golden[key + "_spec"]).max()
+    assert np.abs(spec[rows] - golden[key + "_spec"]).max() / scale < 1e-12
+    assert np.abs(mag[rows] - golden[key + "_mag"]).max() / scale < 1e-12
+    assert abs(mag.sum() - golden[key + "_magsum"][0]) / golden[key + "_magsum"][0] < 1e-12
+    # DC and Nyquist purely real (util/FFT.hpp:99-101)
+    assert np.all(spec[:, 0].imag == 0) and np.all(spec[:, -1].imag == 0)
+
+
+def test_stft_against_naive_dft(oracle):
+    """the hand-rolled FFT against a long-double direct DFT on one frame"""
+    rs = np.random.RandomState(0)
+    x = rs.standard_normal(300)
+    win, fft, hop = 64, 128, 16
+    spec, mag = oracle.stft(x, win, fft, hop)
+    t = 7
+    padded = np.zeros(len(x) + win + hop, dtype=np.longdouble)
+    padded[win // 2: win // 2 + len(x)] = x
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win) / win)).astype(np.longdouble)
+    fr = np.zeros(fft, dtype=np.longdouble)
+    fr[:win] = padded[t * hop: t * hop + win] * w
+    k = np.arange(fft // 2 + 1)[:, None].astype(np.longdouble)
+    nn = np.arange(fft)[None, :].astype(np.longdouble)
+    ang = -2 * np.pi * k * nn / fft
+    re = (fr[None, :] * np.cos(ang)).sum(axis=1)
+    im = (fr[None, :] * np.sin(ang)).sum(axis=1)
+    assert np.abs(spec[t].real - re.astype(np.float64)).max() < 1e-13
+    assert np.abs(spec[t].imag[1:-1] - im.astype(np.float64)[1:-1]).max() < 1e-13
+
+
+def test_nmf_repeatable_with_seed(oracle):
+    """tests/algorithms/public/TestNMF.cpp:11-46"""
+    X = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9.0]])
+    a = oracle.nmf_process(X, 2, 1, True, True, 42)
+    b = oracle.nmf_process(X, 2, 1, True, True, 42)
+    c = oracle.nmf_process(X, 2, 1, True, True, 5063)
+    d = oracle.nmf_process(X, 2, 1, True, True, 5063)
+    for i in range(3):
+        assert np.array_equal(a[i], b[i]) and np.array_equal(c[i], d[i])
+        assert not np.array_equal(a[i], c[i])
+        assert np.isfinite(a[i]).all()
+
+
+@pytest.mark.parametrize("seed", [42, 5063])
+@pytest.mark.parametrize("iters", [1, 50])
+def test_nmf_tiny_golden(oracle, golden, seed, iters):
+    W1, H1, V1, rc = oracle.nmf_process(golden["g4_X"], 2, iters, True, True, seed)
+    assert rc == 0
+    assert rel_err(W1, golden[f"g4_s{seed}_i{iters}_W"]) < 1e-12
+    assert rel_err(H1, golden[f"g4_s{seed}_i{iters}_H"]) < 1e-12
+    assert rel_err(V1, golden[f"g4_s{seed}_i{iters}_V"]) < 1e-12
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+@pytest.mark.parametrize("mode", ["u11", "u10", "u01", "u00", "seeded"])
+def test_nmf_g5_golden(oracle, golden, mode, faithful):
+    X, W0, H0 = golden["g5_X"], golden["g5_W0"], golden["g5_H0"]
+    if mode == "seeded":
+        uw, uh, iters, w0, h0 = True, True, 200, W0, H0
+    else:
+        uw, uh = mode[1] == "1", mode[2] == "1"
+        iters = 200 if (uw or uh) else 0
+        w0, h0 = (None if uw else W0), (None if uh else H0)
+    W1, H1, V1, rc = oracle.nmf_process(X, 4, iters, uw, uh, 42, w0, h0, faithful=faithful)
+    assert rc == 0
+    assert rel_err(W1, golden[f"g5_{mode}_W"]) < 1e-11
+    assert rel_err(H1, golden[f"g5_{mode}_H"]) < 1e-11
+    assert rel_err(V1, golden[f"g5_{mode}_V"]) < 1e-11
+
+
+def test_nmf_cancel(oracle):
+    X = np.abs(np.random.RandomState(1).standard_normal((20, 9)))
+    calls = []
+
+    def cb(it):
+        calls.append(it)
+        return it < 3
+
+    W1, H1, V1, rc = oracle.nmf_process(X, 2, 10, True, True, 1, progress=cb)
+    assert rc == 1 and calls == [1, 2, 3]
+    assert np.array_equal(V1, X)  # alg/NMF.hpp:175-176: early return leaves V untouched
+
+
+def test_writeback(oracle, onp):
+    rs = np.random.RandomState(2)
+    W1, H1 = rs.uniform(0, 1, (3, 17)), rs.uniform(0, 2, (29, 3))
+    b, a = oracle.bufnmf_writeback(W1, H1)
+    b2, a2 = onp.bufnmf_writeback(W1, H1)
+    assert np.array_equal(b, b2) and np.array_equal(a, a2)
+    assert a.max() == pytest.approx(1.0, abs=1e-6)
+
+
+def test_c1_shape_end_to_end_golden(oracle, onp, golden):
+    """BASELINE config 1 shape (453932 samples, rank 3, 1024/512, 50 iterations) on the
+    synthetic drum-like stand-in for Nicol-LoopE-M.wav."""
+    x = onp.drum_like(453932)
+    sha = np.frombuffer(hashlib.sha256(x.tobytes()).digest(), dtype=np.uint8)
+    if not np.array_equal(sha, golden["g6_input_sha256"]):
+        pytest.skip("numpy RandomState stream differs from the one the fixture was minted with")
+    bases, acts, mag = oracle.bufnmf_channel(x, 1024, 1024, 512, 3, 50, 42, want_mag=True)
+    assert mag.shape == tuple(golden["g6_TF"])
+    pb, pa = golden["g6_probe_bases_idx"], golden["g6_probe_acts_idx"]
+    assert np.allclose(bases[pb[:, 0], pb[:, 1]], golden["g6_probe_bases"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(acts[pa[:, 0], pa[:, 1]], golden["g6_probe_acts"], rtol=1e-5, atol=1e-7)
+    sums = golden["g6_sums"]
+    assert abs(mag.sum() - sums[2]) / sums[2] < 1e-12
+    assert abs(bases.astype(np.float64).sum() - sums[0]) / sums[0] < 1e-6
+
+
+def test_resynth_oracles_agree(oracle, onp):
+    x = onp.synth_audio(6000, 5)
+    win, fft, hop, K = 256, 256, 64, 3
+    spec, mag = onp.stft(x.astype(np.float64), win, fft, hop)
+    W1, H1, V1 = onp.nmf_process(mag, K, 20, True, True, 42)
+    tot = np.zeros(len(x))
+    for k in range(K):
+        a = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, len(x))
+        b = onp.resynth_component(spec, W1, H1, V1, k, win, fft, hop, len(x))
+        assert np.abs(a - b).max() < 1e-12
+        tot += a
+    # the masks sum to ~1 so the components add back up to (almost) the input
+    assert np.abs(tot - x).max() < 0.05
+
+
+def test_reference_wav_c1_when_available(oracle, onp):
+    """Plumbing config c1 on the real bundled WAV; only where /root/reference exists (never on
+    the GPU box)."""
+    path = "/root/reference/Resources/AudioFiles/Nicol-LoopE-M.wav"
+    if not os.path.exists(path):
+        pytest.skip("reference resources not present")
+    import wave
+    with wave.open(path, "rb") as w:
+        assert w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getframerate() == 44100
+        n = w.getnframes()
+        pcm = np.frombuffer(w.readframes(n), dtype="<i2")
+    assert n == 453932
+    x = (pcm.astype(np.float32) / 32768.0)
+    bases, acts, mag = oracle.bufnmf_channel(x, 1024, 1024, 512, 3, 50, 42, want_mag=True)
+    b2, a2, m2, *_ = onp.bufnmf_channel(x, 1024, 1024, 512, 3, 50, 42)
+    assert mag.shape == (887, 513)
+    assert rel_err(mag, m2) < 1e-12
+    assert rel_err(bases, b2) < 1e-6 and rel_err(acts, a2) < 1e-6
