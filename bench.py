@@ -118,31 +118,32 @@ def main():
 
     import fluhip
     import oracle_np
+    import sharding
     ctx = fluhip.Context(local)
     name, arch, cus = ctx.device_info()
 
     B, n = wl["buffers_per_gpu"], int(wl["seconds"] * wl["sr"])
     K, iters = wl["rank"], wl["iters"]
-    # synthetic corpus: buffer b of rank r uses audio seed 1000 + r*B + b
-    audio = np.stack([oracle_np.synth_audio(n, 1000 + rank * B + b) for b in range(B)])
+    # synthetic corpus of world*B buffers, contiguous-block sharded; global buffer g uses audio
+    # seed 1000 + g
+    g_begin, g_end = sharding.shard_range(world * B, world, rank)
+    audio = np.stack([oracle_np.synth_audio(n, 1000 + g) for g in range(g_begin, g_end)])
     corpus = fluhip.Corpus(ctx, B, n, wl["win"], wl["fft"], wl["hop"], K)
     T, F = corpus.T, corpus.F
     audio_dev = torch.from_numpy(audio).cuda()           # resident in HBM before the timed region
     corpus.set_audio_dev(audio_dev.data_ptr())
     bases = torch.empty((B, K, F), dtype=torch.float32, device="cuda")
     acts = torch.empty((B, K, T), dtype=torch.float32, device="cuda")
-    if world > 1:
-        bases_all = torch.empty((world * B, K, F), dtype=torch.float32, device="cuda")
-        acts_all = torch.empty((world * B, K, T), dtype=torch.float32, device="cuda")
+    gathered = {}
 
     def step():
         corpus.stft()
         corpus.nmf(iters, seed=wl["seed"])
         corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
         ctx.synchronize()
-        if world > 1:  # the one collective of the path: final dictionary/activation gather
-            dist.all_gather_into_tensor(bases_all, bases)
-            dist.all_gather_into_tensor(acts_all, acts)
+        if world > 1:  # the one collective of the path: final dictionary/activation gather (RCCL)
+            gathered["bases"] = sharding.gather_results(bases, dist, world)
+            gathered["acts"] = sharding.gather_results(acts, dist, world)
 
     def fence():
         if world > 1:

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -211,15 +212,36 @@ struct fluhip_corpus
   int windowType = FLUHIP_WINDOW_HANN;
   bool keepSpec = false;
   const float* audioDev = nullptr; // borrowed or owned (audioOwn)
-  DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax;
+  DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
   int nsplitW = 1, nsplitH = 1;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
     return (int64_t) (audioOwn.bytes + mag.bytes + magT.bytes + Wf.bytes + H1.bytes + spec.bytes +
-                      part.bytes + dpart.bytes + stage.bytes + hmax.bytes);
+                      part.bytes + dpart.bytes + stage.bytes + hmax.bytes + normScratch.bytes);
   }
 };
+
+// which MFMA form the factor update uses: 4 = v_mfma_f64_4x4x4_4b (default), 16 = 16x16x4 (A/B)
+static int update_variant(int Kp)
+{
+  static const int forced = [] {
+    const char* e = std::getenv("FLUHIP_NMF_KERNEL");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced == 16) return 16;
+  return nmf_update4_supported(Kp) ? 4 : 16;
+}
+
+static int choose_split4(int64_t B, int C, int R, int Kp)
+{
+  const int64_t waves = B * nmf_update4_waves_per_buffer(C, Kp, (int) B);
+  if (waves >= 768) return 1;
+  int64_t s = (1024 + waves - 1) / waves;
+  s = std::min<int64_t>(s, 64);
+  s = std::min<int64_t>(s, std::max<int64_t>(1, ((R + 3) / 4) / 8));
+  return (int) std::max<int64_t>(1, s);
+}
 
 static int choose_split(int64_t B, int64_t nCW, int64_t nRt)
 {
@@ -246,9 +268,17 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
-  const int cpw = nmf_update_cols_per_wave((int) c->Kp);
-  c->nsplitW = choose_split(c->B, (c->F + 4 * cpw - 1) / (4 * cpw), (c->T + 15) / 16);
-  c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
+  if (update_variant((int) c->Kp) == 4)
+  {
+    c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
+    c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
+  }
+  else
+  {
+    const int cpw = nmf_update_cols_per_wave((int) c->Kp);
+    c->nsplitW = choose_split(c->B, (c->F + 4 * cpw - 1) / (4 * cpw), (c->T + 15) / 16);
+    c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
+  }
   const int ns = std::max(c->nsplitW, c->nsplitH);
   if (ns > 1)
   {
@@ -424,8 +454,15 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     HIPCHK(ctx, hipStreamSynchronize(s));
   }
   // alg/NMF.hpp:150-153: clamp both to eps, normalise columns of W and rows of H (= columns of H1)
-  launch_colnorm(c->H1.as<double>(), c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, true, false, s);
-  launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, false, s);
+  if (!c->normScratch.p)
+  {
+    const size_t nd = (size_t) colnorm_scratch_doubles((int) std::max(c->T, c->F), (int) c->Kp, B);
+    HIPCHK(ctx, c->normScratch.alloc(nd * sizeof(double), false, s));
+  }
+  launch_colnorm(c->H1.as<double>(), c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, true, false,
+                 c->normScratch.as<double>(), s);
+  launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, false,
+                 c->normScratch.as<double>(), s);
   HIPCHK(ctx, hipGetLastError());
   c->haveFactors = true;
   return FLUHIP_OK;
@@ -448,10 +485,12 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.Cp = std::max(c->Fp, c->Tp);
     {
       ProfScope p(ctx, 1);
-      launch_nmf_update(a, s);
+      if (update_variant(a.Kp) == 4) launch_nmf_update4(a, s);
+      else launch_nmf_update(a, s);
     }
     // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
-    launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true, s);
+    launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
+                   c->normScratch.as<double>(), s);
   }
   if (updateH)
   {
@@ -464,7 +503,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp);
     ProfScope p(ctx, 1);
-    launch_nmf_update(a, s);
+    if (update_variant(a.Kp) == 4) launch_nmf_update4(a, s);
+    else launch_nmf_update(a, s);
   }
 }
 
@@ -805,9 +845,17 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
     HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
-    const int cpw = nmf_update_cols_per_wave((int) c.Kp);
-    c.nsplitW = choose_split(1, (F + 4 * cpw - 1) / (4 * cpw), (T + 15) / 16);
-    c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
+    if (update_variant((int) c.Kp) == 4)
+    {
+      c.nsplitW = choose_split4(1, (int) F, (int) T, (int) c.Kp);
+      c.nsplitH = choose_split4(1, (int) T, (int) F, (int) c.Kp);
+    }
+    else
+    {
+      const int cpw = nmf_update_cols_per_wave((int) c.Kp);
+      c.nsplitW = choose_split(1, (F + 4 * cpw - 1) / (4 * cpw), (T + 15) / 16);
+      c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
+    }
     const int ns = std::max(c.nsplitW, c.nsplitH);
     if (ns > 1)
     {

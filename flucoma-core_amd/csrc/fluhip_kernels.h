@@ -70,13 +70,17 @@ struct UpdateArgs
 // S[c][k] <- S[c][k] * (sum_r (V[r][c] / max(sum_j Mv[r][j] S[c][j], eps)) * Mv[r][k])
 //                    / max(sum_r Mv[r][k], eps)
 // alg/NMF.hpp:158-161 with (V, Mv, S) = (mag, H1, Wf) and :165-170 with (magT, Wf, H1).
-void launch_nmf_update(const UpdateArgs& a, hipStream_t s);
+void launch_nmf_update(const UpdateArgs& a, hipStream_t s);      // v_mfma_f64_16x16x4 form (A/B)
 int nmf_update_cols_per_wave(int Kp);
+void launch_nmf_update4(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b form
+bool nmf_update4_supported(int Kp);
+int nmf_update4_waves_per_buffer(int C, int Kp, int B);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
 // divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, hipStream_t s);
+                    bool checkMax, double* scratch, hipStream_t s);
+int colnorm_scratch_doubles(int C, int Kp, int B);
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,

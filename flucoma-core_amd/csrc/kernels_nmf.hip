@@ -226,6 +226,15 @@ __global__ void nmf_update_finalize_kernel(double* S, int64_t strideS, const dou
   *sp = (*sp * num) / fmax(den, kEpsilon);
 }
 
+void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
+                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s)
+{
+  const int64_t total = (int64_t) C * Kp;
+  dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
+  hipLaunchKernelGGL(nmf_update_finalize_kernel, g, dim3(256), 0, s, S, strideS, part, dpart, C, Kp,
+                     Cp, nsplit);
+}
+
 template <int NB, int CB, int MINW>
 static void launch_update_t(const UpdateArgs& a, hipStream_t s)
 {
@@ -244,12 +253,7 @@ static void launch_update_t(const UpdateArgs& a, hipStream_t s)
   const unsigned grid = (unsigned) (bufs * k.nCW * k.nsplit);
   hipLaunchKernelGGL((nmf_update_kernel<NB, CB, MINW>), dim3(grid), dim3(256), 0, s, k);
   if (k.nsplit > 1)
-  {
-    const int64_t total = (int64_t) a.C * a.Kp;
-    dim3 g((unsigned) ((total + 255) / 256), (unsigned) a.B);
-    hipLaunchKernelGGL(nmf_update_finalize_kernel, g, dim3(256), 0, s, a.S, a.strideS, a.part,
-                       a.dpart, a.C, a.Kp, a.Cp, k.nsplit);
-  }
+    launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s);
 }
 
 int nmf_update_cols_per_wave(int Kp) { return Kp <= 64 ? 32 : 16; }
@@ -272,18 +276,24 @@ void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
 
 // ---------------------------------------------------------------------------------------
 // column L2 normalisation (Eigen colwise().normalize(): x / sqrt(sum x^2), alg/NMF.hpp:152-153,162)
-// one workgroup per buffer; thread (rg, k) owns rows rg, rg+nrg, ... of column k
+// two small launches over (row chunk, buffer): per-chunk partial sums of squares and maxima,
+// then a fixed-order combine + scale.  Deterministic: no atomics, the same summation tree on
+// every run and for every buffer.
 // ---------------------------------------------------------------------------------------
-__global__ void colnorm_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
-                               int checkMax)
+constexpr int kNormRows = 64; // rows per chunk
+
+__global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
+                                double* part, int nch)
 {
-  extern __shared__ double sh[]; // [nrg][Kp] sums, then [nrg][Kp] maxima
-  double* S = Sbase + (int64_t) blockIdx.x * strideS;
+  extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
   double ss = 0.0, mx = -INFINITY;
   if (k < K)
-    for (int r = rg; r < C; r += nrg)
+    for (int r = rbeg + rg; r < rend; r += nrg)
     {
       double x = S[(int64_t) r * Kp + k];
       if (clampEps)
@@ -297,28 +307,67 @@ __global__ void colnorm_kernel(double* Sbase, int64_t strideS, int C, int K, int
   sh[rg * Kp + k] = ss;
   sh[(nrg + rg) * Kp + k] = mx;
   __syncthreads();
-  // fixed-order combine (every thread recomputes its column's total identically)
-  double tot = 0.0;
-  for (int j = 0; j < nrg; j++) tot += sh[j * Kp + k];
-  double gmax = -INFINITY;
-  if (checkMax)
-    for (int j = 0; j < nrg * Kp; j++) gmax = fmax(gmax, sh[nrg * Kp + j]);
-  if (k < K && (!checkMax || gmax > kEpsilon))
+  if (rg == 0)
   {
-    const double nrm = sqrt(tot);
-    for (int r = rg; r < C; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
+    double tot = 0.0, m = -INFINITY;
+    for (int j = 0; j < nrg; j++)
+    {
+      tot += sh[j * Kp + k];
+      m = fmax(m, sh[(nrg + j) * Kp + k]);
+    }
+    double* p = part + ((int64_t) b * nch + chunk) * 2 * Kp;
+    p[k] = tot;
+    p[Kp + k] = m;
   }
 }
 
-void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, hipStream_t s)
+__global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int checkMax,
+                                const double* part, int nch)
 {
-  int nrg = 1024 / Kp;
+  extern __shared__ double sh[]; // [Kp] totals, [Kp] maxima
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  double* S = Sbase + (int64_t) b * strideS;
+  const int nrg = blockDim.x / Kp;
+  const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  if (rg == 0)
+  {
+    double tot = 0.0, m = -INFINITY;
+    const double* p = part + (int64_t) b * nch * 2 * Kp;
+    for (int j = 0; j < nch; j++)
+    {
+      tot += p[(int64_t) j * 2 * Kp + k];
+      m = fmax(m, p[(int64_t) j * 2 * Kp + Kp + k]);
+    }
+    sh[k] = tot;
+    sh[Kp + k] = (k < K) ? m : -INFINITY;
+  }
+  __syncthreads();
+  if (checkMax)
+  {
+    double gmax = -INFINITY;
+    for (int j = 0; j < Kp; j++) gmax = fmax(gmax, sh[Kp + j]);
+    if (!(gmax > kEpsilon)) return; // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
+  }
+  if (k >= K) return;
+  const double nrm = sqrt(sh[k]);
+  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
+  for (int r = rbeg + rg; r < rend; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
+}
+
+int colnorm_scratch_doubles(int C, int Kp, int B) { return ((C + kNormRows - 1) / kNormRows) * 2 * Kp * B; }
+
+void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
+                    bool checkMax, double* scratch, hipStream_t s)
+{
+  int nrg = 256 / Kp;
   if (nrg < 1) nrg = 1;
   const int threads = nrg * Kp;
-  const size_t shmem = (size_t) 2 * nrg * Kp * sizeof(double);
-  hipLaunchKernelGGL(colnorm_kernel, dim3((unsigned) B), dim3((unsigned) threads), shmem, s, S,
-                     strideS, C, K, Kp, clampEps ? 1 : 0, checkMax ? 1 : 0);
+  const int nch = (C + kNormRows - 1) / kNormRows;
+  dim3 grid((unsigned) nch, (unsigned) B);
+  hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
+                     strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) 2 * Kp * sizeof(double), s, S,
+                     strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,0 +1,212 @@
+// BufferAdaptor.hpp -- the host-buffer contract of the BufNMF drop-in.
+//
+//   client::BufferAdaptor (+ ReadAccess / Access)  include/flucoma/clients/common/BufferAdaptor.hpp:18-208
+//   client::MemoryBufferAdaptor                    include/flucoma/clients/common/MemoryBufferAdaptor.hpp:21-140
+//   client::bufferRangeCheck                       include/flucoma/clients/common/BufferAdaptor.hpp:175-208
+//
+// The virtual set, the RAII access objects and the range-check messages are those of the
+// reference, so a host wrapper's existing BufferAdaptor subclasses port by changing the base
+// class.  Element type is float, a buffer is frames x channels, views may be strided.
+#pragma once
+
+#include "Types.hpp"
+
+#include <memory>
+#include <ostream>
+#include <vector>
+
+namespace fluhip {
+
+class BufferAdaptor
+{
+public:
+  class ReadAccess
+  {
+  public:
+    explicit ReadAccess(const BufferAdaptor* a) : mAdaptor(a && a->acquire() ? a : nullptr) {}
+    ~ReadAccess()
+    {
+      if (mAdaptor) mAdaptor->release();
+    }
+    ReadAccess(const ReadAccess&) = delete;
+    ReadAccess& operator=(const ReadAccess&) = delete;
+    ReadAccess(ReadAccess&& o) noexcept : mAdaptor(o.mAdaptor) { o.mAdaptor = nullptr; }
+
+    bool valid() const { return mAdaptor ? mAdaptor->valid() : false; }
+    bool exists() const { return mAdaptor ? mAdaptor->exists() : false; }
+    MatrixView<const float> allFrames() const { return mAdaptor->allFrames(); }
+    VectorView<const float> samps(index channel) const { return mAdaptor->samps(channel); }
+    VectorView<const float> samps(index offset, index nframes, index chan) const
+    {
+      return mAdaptor->samps(offset, nframes, chan);
+    }
+    index  numFrames() const { return mAdaptor ? mAdaptor->numFrames() : 0; }
+    index  numChans() const { return mAdaptor ? mAdaptor->numChans() : 0; }
+    double sampleRate() const { return mAdaptor ? mAdaptor->sampleRate() : 0; }
+
+  protected:
+    const BufferAdaptor* mAdaptor;
+  };
+
+  class Access : public ReadAccess
+  {
+  public:
+    explicit Access(BufferAdaptor* a) : ReadAccess(a), mMutable(a) {}
+    ~Access()
+    {
+      if (mMutable) mMutable->refresh(); // cc/BufferAdaptor.hpp:87-90
+    }
+    MatrixView<float> allFrames() { return mMutable->allFrames(); }
+    VectorView<float> samps(index channel) { return mMutable->samps(channel); }
+    VectorView<float> samps(index offset, index nframes, index chan) { return mMutable->samps(offset, nframes, chan); }
+    Result            resize(index frames, index channels, double sampleRate)
+    {
+      return mMutable ? mMutable->resize(frames, channels, sampleRate)
+                      : Result{Result::Status::kError, "Trying to resize null buffer"};
+    }
+    void refresh()
+    {
+      if (mMutable) mMutable->refresh();
+    }
+
+  private:
+    BufferAdaptor* mMutable;
+  };
+
+  BufferAdaptor() = default;
+  virtual ~BufferAdaptor() = default;
+
+  virtual std::string asString() const = 0;
+
+private:
+  friend class ReadAccess;
+  friend class Access;
+  // cc/BufferAdaptor.hpp:144-166
+  virtual bool                    acquire() const = 0;
+  virtual void                    release() const = 0;
+  virtual bool                    valid() const = 0;
+  virtual bool                    exists() const = 0;
+  virtual Result                  resize(index frames, index channels, double sampleRate) = 0;
+  virtual VectorView<float>       samps(index channel) = 0;
+  virtual VectorView<float>       samps(index offset, index nframes, index chanoffset) = 0;
+  virtual VectorView<const float> samps(index channel) const = 0;
+  virtual VectorView<const float> samps(index offset, index nframes, index chanoffset) const = 0;
+  virtual MatrixView<float>       allFrames() = 0;
+  virtual MatrixView<const float> allFrames() const = 0;
+  virtual index                   numFrames() const = 0;
+  virtual index                   numChans() const = 0;
+  virtual double                  sampleRate() const = 0;
+  virtual void                    refresh() {}
+};
+
+inline std::ostream& operator<<(std::ostream& os, const BufferAdaptor* b) { return os << b->asString(); }
+
+// cc/BufferAdaptor.hpp:175-208 -- same order of checks, same messages, resolves -1 counts in place
+inline Result bufferRangeCheck(const BufferAdaptor* b, index startFrame, index& nFrames, index startChan,
+                               index& nChans)
+{
+  using S = Result::Status;
+  if (!b) return {S::kError, "Input buffer not set"};
+  BufferAdaptor::ReadAccess in(b);
+  if (!in.exists()) return {S::kError, "Input buffer ", b, " not found."};
+  if (!in.valid()) return {S::kError, "Input buffer ", b, " invalid (possibly zero-size?)"};
+  if (startFrame >= in.numFrames() || startFrame < 0)
+    return {S::kError, "Input buffer ", b, " invalid start frame ", startFrame};
+  if (startChan >= in.numChans() || startChan < 0)
+    return {S::kError, "Input buffer ", b, " invalid start channel ", startChan};
+  nFrames = nFrames < 0 ? in.numFrames() - startFrame : nFrames;
+  if (nFrames <= 0 || nFrames > in.numFrames() - startFrame)
+    return {S::kError, "Input buffer ", b, ": not enough frames"};
+  nChans = nChans < 0 ? in.numChans() - startChan : nChans;
+  if (nChans <= 0 || nChans > in.numChans() - startChan)
+    return {S::kError, "Input buffer ", b, ": not enough channels"};
+  return {S::kOk, ""};
+}
+
+// In-memory buffer, frames-major like the reference's (frame f, channel c at data[f * chans + c]),
+// so samps(channel) is a strided view (cc/MemoryBufferAdaptor.hpp:24-26, 96-115).
+class MemoryBufferAdaptor : public BufferAdaptor
+{
+public:
+  MemoryBufferAdaptor(index chans, index frames, double sampleRate = 44100)
+      : mData(static_cast<size_t>(frames * chans), 0.f), mFrames(frames), mChans(chans), mSampleRate(sampleRate)
+  {}
+  // deep copy of any adaptor: the thread-isolation step of cc/FluidNRTClientWrapper.hpp:1045-1046
+  explicit MemoryBufferAdaptor(const std::shared_ptr<BufferAdaptor>& other) { copyFrom(other.get()); mOrigin = other; }
+  explicit MemoryBufferAdaptor(const std::shared_ptr<const BufferAdaptor>& other) { copyFrom(other.get()); }
+
+  // cc/MemoryBufferAdaptor.hpp:51-67
+  void copyToOrigin(Result& r)
+  {
+    if (!mWrite || !mOrigin) return;
+    BufferAdaptor::Access dst(mOrigin.get());
+    if (!dst.exists()) return;
+    if (numChans() != dst.numChans() || numFrames() != dst.numFrames())
+      r = dst.resize(numFrames(), numChans(), mSampleRate);
+    if (r.ok() && dst.valid())
+      for (index c = 0; c < numChans(); ++c)
+      {
+        auto d = dst.samps(c);
+        VectorView<float>(d.ptr, numFrames(), d.stride) <<= VectorView<const float>(samps(c));
+      }
+  }
+
+  std::string asString() const override { return ""; }
+  float*      raw() { return mData.data(); }
+  const float* raw() const { return mData.data(); }
+
+private:
+  void copyFrom(const BufferAdaptor* other)
+  {
+    BufferAdaptor::ReadAccess src(other);
+    mExists = src.exists();
+    mValid = src.valid();
+    mSampleRate = src.sampleRate();
+    mWrite = false;
+    if (mValid)
+    {
+      mFrames = src.numFrames();
+      mChans = src.numChans();
+      mData.assign(static_cast<size_t>(mFrames * mChans), 0.f);
+      for (index c = 0; c < mChans; ++c) samps(c) <<= src.samps(0, mFrames, c);
+    }
+  }
+
+  bool   acquire() const override { return true; }
+  void   release() const override {}
+  bool   valid() const override { return mValid; }
+  bool   exists() const override { return mExists; }
+  Result resize(index frames, index channels, double sampleRate) override
+  {
+    mWrite = true;
+    mSampleRate = sampleRate;
+    mFrames = frames;
+    mChans = channels;
+    mData.assign(static_cast<size_t>(frames * channels), 0.f);
+    return {};
+  }
+  VectorView<float>       samps(index c) override { return {mData.data() + c, mFrames, mChans}; }
+  VectorView<float>       samps(index off, index n, index c) override { return {mData.data() + off * mChans + c, n, mChans}; }
+  VectorView<const float> samps(index c) const override { return {mData.data() + c, mFrames, mChans}; }
+  VectorView<const float> samps(index off, index n, index c) const override
+  {
+    return {mData.data() + off * mChans + c, n, mChans};
+  }
+  MatrixView<float>       allFrames() override { return MatrixView<float>(mData.data(), mFrames, mChans).transpose(); }
+  MatrixView<const float> allFrames() const override
+  {
+    return MatrixView<const float>(mData.data(), mFrames, mChans).transpose();
+  }
+  index  numFrames() const override { return mFrames; }
+  index  numChans() const override { return mChans; }
+  double sampleRate() const override { return mSampleRate; }
+  void   refresh() override { mWrite = true; }
+
+  std::shared_ptr<BufferAdaptor> mOrigin;
+  std::vector<float>             mData;
+  index                          mFrames{0}, mChans{0};
+  double                         mSampleRate{44100};
+  bool                           mValid{true}, mExists{true}, mWrite{false};
+};
+
+} // namespace fluhip

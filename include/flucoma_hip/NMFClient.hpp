@@ -1,0 +1,253 @@
+// NMFClient.hpp -- BufNMF client over the MI355X C ABI (include/flucoma_hip.h).
+//
+// Mirrors client::bufnmf::NMFClient, include/flucoma/clients/nrt/NMFClient.hpp:36-343:
+//   parameter table   :36-71     -> NMFParams (plain struct, same names / defaults / constraints)
+//   process<T>()      :96-337    -> same order of checks, same Result codes and messages, same
+//                                   output buffer shapes and sample rates; the per-channel body
+//                                   (:240-300: STFT -> magnitude -> NMF -> float write-back) is one
+//                                   call into libflucoma_hip.so instead of algorithm::STFT / NMF.
+// There is no CPU path: if the library cannot create a context on the requested device the job
+// returns kError.
+#pragma once
+
+#include "../flucoma_hip.h"
+#include "BufferAdaptor.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+#include <vector>
+
+namespace fluhip {
+namespace bufnmf {
+
+// nrt/NMFClient.hpp:36-52
+enum NMFParamIndex {
+  kSource, kOffset, kNumFrames, kStartChan, kNumChans, kResynth, kResynthMode, kFilters, kFiltersUpdate,
+  kEnvelopes, kEnvelopesUpdate, kRank, kIterations, kRandomSeed, kFFT
+};
+
+// nrt/NMFClient.hpp:54-71 (names, defaults and constraints of defineParameters(...))
+struct NMFParams
+{
+  std::shared_ptr<const BufferAdaptor> source;            // "source"
+  index                                startFrame{0};     // Min(0)
+  index                                numFrames{-1};
+  index                                startChan{0};      // Min(0)
+  index                                numChans{-1};
+  std::shared_ptr<BufferAdaptor>       resynth;           // "resynth"
+  index                                resynthMode{0};    // 0..1
+  std::shared_ptr<BufferAdaptor>       bases;             // "bases"
+  index                                basesMode{0};      // None, Seed, Fixed
+  std::shared_ptr<BufferAdaptor>       activations;       // "activations"
+  index                                actMode{0};        // None, Seed, Fixed
+  index                                components{1};     // Min(1)
+  index                                iterations{100};   // Min(1)
+  index                                seed{-1};
+  FFTParams                            fftSettings{1024, -1, -1};
+
+  // the clamping the reference's constraints apply when a value is set
+  void constrain()
+  {
+    startFrame = std::max<index>(0, startFrame);
+    startChan = std::max<index>(0, startChan);
+    resynthMode = std::min<index>(1, std::max<index>(0, resynthMode));
+    basesMode = std::min<index>(2, std::max<index>(0, basesMode));
+    actMode = std::min<index>(2, std::max<index>(0, actMode));
+    components = std::max<index>(1, components);
+    iterations = std::max<index>(1, iterations);
+    // cc/ParameterTypes.hpp:371-393: win >= 4, fft a power of two >= nextPow2(win)
+    fftSettings.win = std::max<index>(4, fftSettings.win);
+    if (fftSettings.fft >= 0)
+    {
+      index p = 1;
+      while (p < std::max(fftSettings.fft, fftSettings.win)) p <<= 1;
+      fftSettings.fft = p;
+    }
+  }
+};
+
+class NMFClient
+{
+public:
+  using ParamSetViewType = NMFParams;
+
+  NMFClient(NMFParams& p, FluidContext&) : mParams(&p) {}
+  ~NMFClient()
+  {
+    if (mCtx) fluhip_ctx_destroy(mCtx);
+  }
+  NMFClient(const NMFClient&) = delete;
+  NMFClient& operator=(const NMFClient&) = delete;
+
+  void setParams(NMFParams& p) { mParams = &p; }
+
+  template <typename T>
+  Result process(FluidContext& c)
+  {
+    using S = Result::Status;
+    const NMFParams& P = *mParams;
+    index            nFrames = P.numFrames;
+    index            nChannels = P.numChans;
+    Result           rangeCheck = bufferRangeCheck(P.source.get(), P.startFrame, nFrames, P.startChan, nChannels);
+    if (!rangeCheck.ok()) return rangeCheck;
+
+    BufferAdaptor::ReadAccess source(P.source.get());
+    const double              sampleRate = source.sampleRate();
+    const FFTParams           fftParams = P.fftSettings;
+    const index               hop = fftParams.hopSize();
+    const index               nWindows = (nFrames + hop) / hop; // :111-112
+    const index               nBins = fftParams.frameSize();
+    const index               rank = P.components;
+
+    bool       hasFilters = false;
+    const bool seedFilters = P.basesMode > 0;
+    const bool fixFilters = P.basesMode == 2;
+    const bool shouldResynth = P.resynthMode != 0;
+
+    if (P.bases)
+    {
+      BufferAdaptor::Access buf(P.bases.get());
+      if (!buf.exists()) return {S::kError, "Bases Buffer Supplied But Invalid"};
+      if (P.basesMode > 0 && (!buf.valid() || buf.numFrames() != nBins || buf.numChans() != rank * nChannels))
+        return {S::kError, "Supplied bases buffer for seeding must be [(FFTSize / 2) + "
+                           "1] frames long, and have [rank] * [channels] channels"};
+      hasFilters = true;
+    }
+    else if (P.basesMode > 0)
+      return {S::kError, "Bases Mode set to Seed or Fix , but no Bases Buffer supplied"};
+
+    bool       hasEnvelopes = false;
+    const bool seedEnvelopes = P.actMode > 0;
+    const bool fixEnvelopes = P.actMode == 2;
+    const bool needsAnalysis = !(fixEnvelopes && fixFilters);
+
+    if (!needsAnalysis && !shouldResynth)
+      return {S::kWarning, "Bases and Activations buffers both fixed, but resynthesis disabled: no work to do"};
+
+    if (P.activations)
+    {
+      BufferAdaptor::Access buf(P.activations.get());
+      if (!buf.exists()) return {S::kError, "Activations Buffer Supplied But Invalid"};
+      if (P.actMode > 0 &&
+          (!buf.valid() || buf.numFrames() != (nFrames / hop) + 1 || buf.numChans() != rank * nChannels))
+        return {S::kError, "Supplied activations buffer for seeding must be [(num samples / hop "
+                           "size)  + 1] frames long, and have [rank] * [channels] channels"};
+      hasEnvelopes = true;
+    }
+    else if (P.actMode > 0)
+      return {S::kError, "Activations Mode set to Seed or Fix , but no Activations Buffer supplied"};
+
+    bool hasResynth = false;
+    if (shouldResynth)
+    {
+      if (!P.resynth) return {S::kError, "Resynthesis requested but no buffer supplied"};
+      BufferAdaptor::Access buf(P.resynth.get());
+      if (!buf.exists()) return {S::kError, "Resynthesis Buffer Supplied But Invalid"};
+      hasResynth = true;
+      Result r = buf.resize(nFrames, nChannels * rank, sampleRate);
+      if (!r.ok()) return r;
+    }
+    if (hasFilters && P.basesMode == 0)
+    {
+      Result r = BufferAdaptor::Access(P.bases.get()).resize(nBins, nChannels * rank, sampleRate / fftParams.fftSize());
+      if (!r.ok()) return r;
+    }
+    if (hasEnvelopes && P.actMode == 0)
+    {
+      Result r = BufferAdaptor::Access(P.activations.get()).resize((nFrames / hop) + 1, nChannels * rank, sampleRate / hop);
+      if (!r.ok()) return r;
+    }
+
+    // device context (one per client, like the per-client algorithm objects of the reference)
+    if (!mCtx || mDevice != c.device())
+    {
+      if (mCtx) fluhip_ctx_destroy(mCtx);
+      mCtx = nullptr;
+      if (fluhip_ctx_create(c.device(), &mCtx) != FLUHIP_OK)
+        return {S::kError, "BufNMF: no usable MI355X device ", c.device(), " (libflucoma_hip has no CPU fallback)"};
+      mDevice = c.device();
+    }
+
+    std::vector<float> mono(static_cast<size_t>(nFrames));
+    std::vector<float> seedW, seedH, outW, outH, outR;
+    if (seedFilters) seedW.resize(static_cast<size_t>(rank * nBins));
+    if (seedEnvelopes) seedH.resize(static_cast<size_t>(rank * nWindows));
+    if (hasFilters && !fixFilters) outW.resize(static_cast<size_t>(rank * nBins));
+    if (hasEnvelopes && !fixEnvelopes) outH.resize(static_cast<size_t>(rank * nWindows));
+    if (shouldResynth && hasResynth) outR.resize(static_cast<size_t>(rank * nFrames));
+
+    const double progressTotal =
+        static_cast<double>((needsAnalysis ? P.iterations : 0) + ((shouldResynth && hasResynth) ? 3 * rank : 0)); // :229-230
+
+    struct Prog
+    {
+      FluidContext* c;
+      int           count;
+      double        total;
+    };
+
+    for (index i = 0; i < nChannels; ++i)
+    {
+      if (c.task() && !c.task()->iterationUpdate(static_cast<double>(i), static_cast<double>(nChannels)))
+        return {S::kCancelled, ""};
+      // :240  tmp <<= source.samps(offset, nFrames, startChan + i)   (float stays float: the
+      //        float -> double conversion happens on the device)
+      VectorView<float>(mono.data(), nFrames) <<= source.samps(P.startFrame, nFrames, P.startChan + i);
+      // :246-258 seeds, gathered channel by channel
+      for (index j = 0; j < rank; ++j)
+      {
+        if (seedFilters)
+          VectorView<float>(seedW.data() + j * nBins, nBins) <<=
+              VectorView<const float>(BufferAdaptor::Access(P.bases.get()).samps(i * rank + j));
+        if (seedEnvelopes)
+          VectorView<float>(seedH.data() + j * nWindows, nWindows) <<=
+              VectorView<const float>(BufferAdaptor::Access(P.activations.get()).samps(i * rank + j));
+      }
+      Prog prog{&c, 0, progressTotal};
+      auto cb = [](int64_t, void* u) -> int { // :261-267
+        auto* p = static_cast<Prog*>(u);
+        return p->c->task() ? (p->c->task()->processUpdate(static_cast<double>(++p->count), p->total) ? 1 : 0) : 1;
+      };
+      const int rc = fluhip_bufnmf_channel_f32(
+          mCtx, mono.data(), nFrames, 1, fftParams.winSize(), fftParams.fftSize(), hop, rank,
+          needsAnalysis ? P.iterations : 0, !fixFilters, !fixEnvelopes, P.seed, seedFilters ? seedW.data() : nullptr,
+          seedEnvelopes ? seedH.data() : nullptr, outW.empty() ? nullptr : outW.data(),
+          outH.empty() ? nullptr : outH.data(), outR.empty() ? nullptr : outR.data(), cb, &prog); // :268-271
+      if (rc == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""}; // :273-274
+      if (rc != FLUHIP_OK) return {S::kError, "BufNMF: ", fluhip_last_error(mCtx)};
+
+      if (hasFilters && !fixFilters) // :277-283
+      {
+        BufferAdaptor::Access filters(P.bases.get());
+        for (index j = 0; j < rank; ++j)
+          filters.samps(i * rank + j) <<= VectorView<const float>(outW.data() + j * nBins, nBins);
+      }
+      if (hasEnvelopes && !fixEnvelopes) // :286-300 (scaling by 1/max(H) already applied on the device)
+      {
+        BufferAdaptor::Access envelopes(P.activations.get());
+        for (index j = 0; j < rank; ++j)
+          envelopes.samps(i * rank + j) <<= VectorView<const float>(outH.data() + j * nWindows, nWindows);
+      }
+      if (shouldResynth && hasResynth) // :302-334
+      {
+        BufferAdaptor::Access resynth(P.resynth.get());
+        for (index j = 0; j < rank; ++j)
+        {
+          resynth.samps(i * rank + j) <<= VectorView<const float>(outR.data() + j * nFrames, nFrames);
+          for (int step = 0; step < 3; ++step)
+            if (c.task() && !c.task()->processUpdate(++prog.count, progressTotal)) return {S::kCancelled, ""};
+        }
+      }
+    }
+    return {S::kOk, ""};
+  }
+
+private:
+  NMFParams*  mParams;
+  fluhip_ctx* mCtx{nullptr};
+  int         mDevice{-1};
+};
+
+} // namespace bufnmf
+} // namespace fluhip

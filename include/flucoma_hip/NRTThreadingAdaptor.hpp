@@ -1,0 +1,187 @@
+// NRTThreadingAdaptor.hpp -- job layer of the BufNMF drop-in.
+//
+// Mirrors client::NRTThreadingAdaptor + ThreadedTask,
+// include/flucoma/clients/common/FluidNRTClientWrapper.hpp:788-1132: a queue of parameter sets,
+// synchronous execution on the caller thread or one std::thread per job, deep copies of every
+// buffer parameter before the worker starts (:1045-1046) and copy-back to the host's buffers from
+// the thread that polls checkProgress (:1089-1100), progress and cancellation through FluidTask.
+#pragma once
+
+#include "NMFClient.hpp"
+
+#include <deque>
+#include <functional>
+#include <future>
+#include <thread>
+
+namespace fluhip {
+
+enum ProcessState { kNoProcess, kProcessing, kDone, kDoneStillProcessing }; // cc/FluidBaseClient.hpp:32
+
+class NRTThreadedNMFClient
+{
+public:
+  using Client = bufnmf::NMFClient;
+  using ParamSetType = bufnmf::NMFParams;
+
+  explicit NRTThreadedNMFClient(ParamSetType& p, FluidContext c = {}) : mHostParams(p), mContext(c) {}
+  ~NRTThreadedNMFClient()
+  {
+    mQueue.clear();
+    if (mTask)
+    {
+      mTask->cancel();
+      mTask->join();
+    }
+  }
+
+  void   setParams(ParamSetType& p) { mHostParams = p; }
+  Result enqueue(ParamSetType& p, std::function<void()> callback = {})
+  {
+    if (mTask && (mSynchronous || !mQueueEnabled)) return {Result::Status::kError, "already processing"};
+    mQueue.push_back({p, std::move(callback)});
+    return {};
+  }
+
+  Result process()
+  {
+    if (mTask && (mSynchronous || !mQueueEnabled)) return {Result::Status::kError, "already processing"};
+    if (mTask) return {};
+    if (mQueue.empty()) return {Result::Status::kWarning, "Process() called on empty queue"};
+    if (mSynchronous) mSynchronousDone = false;
+    mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext.device(), mSynchronous);
+    mQueue.pop_front();
+    Result result;
+    if (mSynchronous)
+    {
+      result = mTask->result();
+      mTask.reset();
+      mSynchronousDone = true;
+    }
+    return result;
+  }
+
+  ProcessState checkProgress(Result& result)
+  {
+    if (!mTask) return kNoProcess;
+    ProcessState state = mTask->checkProgress(result);
+    if (state == kDone)
+    {
+      if (!mQueue.empty())
+      {
+        mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext.device(), false);
+        mQueue.pop_front();
+        state = kDoneStillProcessing;
+      }
+      else
+        mTask.reset();
+    }
+    return state;
+  }
+
+  bool   synchronous() const { return mSynchronous; }
+  void   setSynchronous(bool s) { mSynchronous = s; }
+  void   setQueueEnabled(bool q) { mQueueEnabled = q; }
+  double progress() { return mTask ? mTask->progress() : 0.0; }
+  void   cancel()
+  {
+    mQueue.clear();
+    if (mTask) mTask->cancel();
+  }
+  bool done() const { return mTask ? mTask->done() : (mSynchronous && mSynchronousDone); }
+  ProcessState state() const { return mTask ? mTask->state() : kNoProcess; }
+
+private:
+  struct NRTJob
+  {
+    ParamSetType          params;
+    std::function<void()> callback;
+  };
+
+  class ThreadedTask
+  {
+  public:
+    ThreadedTask(NRTJob& job, int device, bool synchronous) : mJob(job), mContext(mTaskState, device)
+    {
+      mState = kProcessing;
+      if (synchronous)
+      {
+        mClient = std::make_unique<Client>(mJob.params, mContext);
+        mResult = mClient->process<float>(mContext);
+        mState = kDone;
+        mDetached = true;
+        return;
+      }
+      // deep copies: the worker only ever touches MemoryBufferAdaptors
+      ParamSetType& P = mJob.params;
+      if (P.source) { mSourceCopy = std::make_shared<MemoryBufferAdaptor>(P.source); P.source = mSourceCopy; }
+      auto isolate = [](std::shared_ptr<BufferAdaptor>& b, std::shared_ptr<MemoryBufferAdaptor>& keep) {
+        if (b) { keep = std::make_shared<MemoryBufferAdaptor>(b); b = keep; }
+      };
+      isolate(P.resynth, mResynthCopy);
+      isolate(P.bases, mBasesCopy);
+      isolate(P.activations, mActsCopy);
+      mClient = std::make_unique<Client>(mJob.params, mContext);
+      mFuture = mPromise.get_future();
+      mThread = std::thread([this] {
+        Result r = mClient->process<float>(mContext);
+        mState = kDone;
+        mPromise.set_value(r);
+        if (mJob.callback) mJob.callback();
+      });
+    }
+    ~ThreadedTask() { join(); }
+
+    Result result() const { return mResult; }
+    double progress() { return mTaskState.progress(); }
+    void   cancel() { mTaskState.cancel(); }
+    bool   done() const { return mState == kDone || mState == kDoneStillProcessing; }
+    ProcessState state() const { return mState; }
+    void   join()
+    {
+      if (mThread.joinable()) mThread.join();
+    }
+
+    ProcessState checkProgress(Result& result)
+    {
+      if (mDetached) { result = mResult; return kDone; }
+      if (mState != kDone) return kProcessing;
+      if (mFuture.valid())
+      {
+        mResult = mFuture.get();
+        join();
+        if (mResult.ok() || mResult.status() == Result::Status::kWarning)
+        {
+          // copy-back happens on the polling (host) thread, like :1089-1100
+          for (auto* b : {&mResynthCopy, &mBasesCopy, &mActsCopy})
+            if (*b) (*b)->copyToOrigin(mResult);
+        }
+      }
+      result = mResult;
+      return kDone;
+    }
+
+  private:
+    NRTJob                               mJob;
+    FluidTask                            mTaskState;
+    FluidContext                         mContext;
+    std::unique_ptr<Client>              mClient;
+    std::shared_ptr<MemoryBufferAdaptor> mSourceCopy, mResynthCopy, mBasesCopy, mActsCopy;
+    std::promise<Result>                 mPromise;
+    std::future<Result>                  mFuture;
+    std::thread                          mThread;
+    Result                               mResult;
+    std::atomic<ProcessState>            mState{kNoProcess};
+    bool                                 mDetached{false};
+  };
+
+  ParamSetType                  mHostParams;
+  FluidContext                  mContext;
+  std::deque<NRTJob>            mQueue;
+  std::unique_ptr<ThreadedTask> mTask;
+  bool                          mSynchronous{false};
+  bool                          mQueueEnabled{false};
+  bool                          mSynchronousDone{false};
+};
+
+} // namespace fluhip

@@ -1,0 +1,220 @@
+// client_driver.cpp -- exercises the host-side BufNMF client (include/flucoma_hip/*.hpp) the way a
+// host wrapper would: MemoryBufferAdaptor buffers, NMFParams, NRTThreadedNMFClient sync/async,
+// progress polling and cancellation.  Driven by tests/test_client.py, which checks the outputs
+// against the oracle.
+//
+//   client_driver errors
+//   client_driver run <in.f32> <frames> <chans> <win> <hop> <fft> <rank> <iters> <seed>
+//                     <basesMode> <actMode> <async> <startFrame> <numFrames> <startChan> <numChans>
+//                     <outprefix> [<bases_seed.f32> <acts_seed.f32>]
+//   client_driver cancel <frames>
+#include "../../include/flucoma_hip/NRTThreadingAdaptor.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <thread>
+
+using fluhip::BufferAdaptor; using fluhip::FFTParams; using fluhip::FluidContext; using fluhip::MemoryBufferAdaptor;
+using fluhip::NRTThreadedNMFClient; using fluhip::ProcessState; using fluhip::Result; using fluhip::kProcessing;
+namespace bufnmf = fluhip::bufnmf;
+using idx = fluhip::index; // (::index is a POSIX function)
+
+static std::vector<float> readFile(const char* path)
+{
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) { std::fprintf(stderr, "cannot read %s\n", path); std::exit(3); }
+  size_t bytes = (size_t) f.tellg();
+  f.seekg(0);
+  std::vector<float> v(bytes / sizeof(float));
+  f.read(reinterpret_cast<char*>(v.data()), (std::streamsize) bytes);
+  return v;
+}
+
+static void writeBuffer(const std::string& path, const std::shared_ptr<MemoryBufferAdaptor>& b)
+{
+  BufferAdaptor::ReadAccess a(b.get());
+  std::ofstream f(path, std::ios::binary);
+  int64_t hdr[2] = {a.numFrames(), a.numChans()};
+  double  sr = a.sampleRate();
+  f.write(reinterpret_cast<const char*>(hdr), sizeof(hdr));
+  f.write(reinterpret_cast<const char*>(&sr), sizeof(sr));
+  for (idx c = 0; c < a.numChans(); ++c) // channel-major dump
+  {
+    auto v = a.samps(c);
+    for (idx i = 0; i < v.size(); ++i) { float x = v(i); f.write(reinterpret_cast<const char*>(&x), 4); }
+  }
+}
+
+static void report(const char* tag, const Result& r)
+{
+  std::printf("%s|%d|%s\n", tag, (int) r.status(), r.message().c_str());
+}
+
+static std::shared_ptr<MemoryBufferAdaptor> makeBuffer(idx chans, idx frames, const float* interleaved = nullptr)
+{
+  auto b = std::make_shared<MemoryBufferAdaptor>(chans, frames, 44100.0);
+  if (interleaved) std::memcpy(b->raw(), interleaved, sizeof(float) * (size_t) (chans * frames));
+  return b;
+}
+
+static int runErrors()
+{
+  // every validation branch of nrt/NMFClient.hpp:100-185 that needs no device
+  FluidContext          ctx;
+  bufnmf::NMFParams     p;
+  bufnmf::NMFClient     client(p, ctx);
+  report("no_source", client.process<float>(ctx));
+  auto src = makeBuffer(2, 4096);
+  p.source = src;
+  p.startFrame = 5000;
+  report("bad_start_frame", client.process<float>(ctx));
+  p.startFrame = 0;
+  p.startChan = 2;
+  report("bad_start_chan", client.process<float>(ctx));
+  p.startChan = 0;
+  p.numFrames = 5000;
+  report("too_many_frames", client.process<float>(ctx));
+  p.numFrames = -1;
+  p.numChans = 3;
+  report("too_many_chans", client.process<float>(ctx));
+  p.numChans = -1;
+  p.basesMode = 1;
+  report("seed_no_bases", client.process<float>(ctx));
+  p.bases = makeBuffer(1, 10);
+  report("seed_bad_bases_shape", client.process<float>(ctx));
+  p.basesMode = 0;
+  p.bases.reset();
+  p.actMode = 2;
+  report("fix_no_acts", client.process<float>(ctx));
+  p.activations = makeBuffer(1, 10);
+  report("fix_bad_acts_shape", client.process<float>(ctx));
+  // both fixed, no resynthesis -> warning, no work
+  p.components = 2;
+  p.bases = makeBuffer(2 * 2, 513);
+  p.activations = makeBuffer(2 * 2, 4096 / 512 + 1);
+  p.basesMode = 2;
+  p.actMode = 2;
+  report("both_fixed", client.process<float>(ctx));
+  p.basesMode = 0;
+  p.actMode = 0;
+  p.resynthMode = 1;
+  report("resynth_no_buffer", client.process<float>(ctx));
+  // threading adaptor bookkeeping
+  bufnmf::NMFParams    q;
+  NRTThreadedNMFClient adaptor(q);
+  report("empty_queue", adaptor.process());
+  return 0;
+}
+
+int main(int argc, char** argv)
+{
+  if (argc < 2) return 2;
+  const std::string mode = argv[1];
+  if (mode == "errors") return runErrors();
+
+  if (mode == "cancel")
+  {
+    const idx frames = std::atol(argv[2]);
+    std::vector<float> x((size_t) frames);
+    for (idx i = 0; i < frames; ++i) x[(size_t) i] = 0.5f * std::sin(0.05f * i) + 0.25f * std::sin(0.31f * i);
+    bufnmf::NMFParams p;
+    p.source = makeBuffer(1, frames, x.data());
+    p.bases = makeBuffer(1, 1);
+    p.activations = makeBuffer(1, 1);
+    p.components = 16;
+    p.iterations = 100000; // far more than can finish before the cancel lands
+    p.seed = 42;
+    p.fftSettings = FFTParams(2048, 512, 2048);
+    NRTThreadedNMFClient adaptor(p);
+    adaptor.enqueue(p);
+    report("process", adaptor.process());
+    Result r;
+    double lastProgress = 0;
+    for (int i = 0; i < 50 && adaptor.progress() <= 0.0; ++i) std::this_thread::sleep_for(std::chrono::milliseconds(20));
+    lastProgress = adaptor.progress();
+    adaptor.cancel();
+    ProcessState st = kProcessing;
+    for (int i = 0; i < 2000 && st == kProcessing; ++i)
+    {
+      st = adaptor.checkProgress(r);
+      std::this_thread::sleep_for(std::chrono::milliseconds(5));
+    }
+    std::printf("progress_before_cancel|%d|%g\n", lastProgress > 0.0 && lastProgress < 1.0 ? 1 : 0, lastProgress);
+    report("cancelled", r);
+    return 0;
+  }
+
+  if (mode == "run")
+  {
+    if (argc < 19) return 2;
+    auto        in = readFile(argv[2]);
+    const idx frames = std::atol(argv[3]), chans = std::atol(argv[4]);
+    bufnmf::NMFParams p;
+    p.source = makeBuffer(chans, frames, in.data());
+    p.fftSettings = FFTParams(std::atol(argv[5]), std::atol(argv[6]), std::atol(argv[7]));
+    p.components = std::atol(argv[8]);
+    p.iterations = std::atol(argv[9]);
+    p.seed = std::atol(argv[10]);
+    p.basesMode = std::atol(argv[11]);
+    p.actMode = std::atol(argv[12]);
+    const bool async = std::atoi(argv[13]) != 0;
+    p.startFrame = std::atol(argv[14]);
+    p.numFrames = std::atol(argv[15]);
+    p.startChan = std::atol(argv[16]);
+    p.numChans = std::atol(argv[17]);
+    const std::string prefix = argv[18];
+    p.constrain();
+    idx nCh = p.numChans < 0 ? chans - p.startChan : p.numChans;
+    idx nFr = p.numFrames < 0 ? frames - p.startFrame : p.numFrames;
+    auto  bases = makeBuffer(1, 1);
+    auto  acts = makeBuffer(1, 1);
+    if (argc >= 21)
+    {
+      auto        sb = readFile(argv[19]);
+      auto        sa = readFile(argv[20]);
+      const idx F = p.fftSettings.frameSize(), T = nFr / p.fftSettings.hopSize() + 1, KC = p.components * nCh;
+      bases = makeBuffer(KC, F);
+      acts = makeBuffer(KC, T);
+      // seed files are channel-major [KC][frames]
+      for (idx c = 0; c < KC; ++c)
+      {
+        for (idx f = 0; f < F; ++f) bases->raw()[f * KC + c] = sb[(size_t) (c * F + f)];
+        for (idx t = 0; t < T; ++t) acts->raw()[t * KC + c] = sa[(size_t) (c * T + t)];
+      }
+    }
+    p.bases = bases;
+    p.activations = acts;
+    Result r;
+    if (!async)
+    {
+      NRTThreadedNMFClient adaptor(p);
+      adaptor.setSynchronous(true);
+      adaptor.enqueue(p);
+      r = adaptor.process();
+    }
+    else
+    {
+      NRTThreadedNMFClient adaptor(p);
+      adaptor.enqueue(p);
+      report("process", adaptor.process());
+      ProcessState st = kProcessing;
+      double       maxProgress = 0;
+      while (st == kProcessing)
+      {
+        maxProgress = std::max(maxProgress, adaptor.progress());
+        st = adaptor.checkProgress(r);
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      std::printf("max_progress|%d|%g\n", maxProgress <= 1.0 ? 1 : 0, maxProgress);
+    }
+    report("result", r);
+    writeBuffer(prefix + "_bases.bin", bases);
+    writeBuffer(prefix + "_acts.bin", acts);
+    return 0;
+  }
+  return 2;
+}

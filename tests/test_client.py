@@ -1,0 +1,129 @@
+"""The C++17 host-side client (include/flucoma_hip/*.hpp: BufferAdaptor, NMFClient,
+NRTThreadedNMFClient) driven through tests/cpp/client_driver.cpp.
+
+CPU part: parameter validation, Result codes and the exact user-visible messages of
+include/flucoma/clients/nrt/NMFClient.hpp:100-185 and clients/common/BufferAdaptor.hpp:175-208.
+GPU part: sync / async jobs on MemoryBufferAdaptors against the oracle, offsets and multichannel
+layout (nrt/NMFClient.hpp:233, 277-300), seeding, progress, cancellation.
+"""
+import importlib.util
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def driver(fluhip_lib_path):
+    spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_host_tests()
+
+
+def run(driver, *args):
+    out = subprocess.run([driver, *map(str, args)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    res = {}
+    for line in out.stdout.splitlines():
+        tag, status, msg = line.split("|", 2)
+        res[tag] = (int(status), msg)
+    return res
+
+
+def read_buffer(path):
+    raw = open(path, "rb").read()
+    frames, chans = struct.unpack("<qq", raw[:16])
+    sr, = struct.unpack("<d", raw[16:24])
+    data = np.frombuffer(raw[24:], dtype=np.float32).reshape(chans, frames)
+    return data, sr
+
+
+OK, WARNING, ERROR, CANCELLED = 0, 1, 2, 3
+
+
+def test_validation_messages(driver):
+    r = run(driver, "errors")
+    assert r["no_source"] == (ERROR, "Input buffer not set")
+    assert r["bad_start_frame"] == (ERROR, "Input buffer  invalid start frame 5000")
+    assert r["bad_start_chan"] == (ERROR, "Input buffer  invalid start channel 2")
+    assert r["too_many_frames"] == (ERROR, "Input buffer : not enough frames")
+    assert r["too_many_chans"] == (ERROR, "Input buffer : not enough channels")
+    assert r["seed_no_bases"] == (ERROR, "Bases Mode set to Seed or Fix , but no Bases Buffer supplied")
+    assert r["seed_bad_bases_shape"] == (
+        ERROR, "Supplied bases buffer for seeding must be [(FFTSize / 2) + 1] frames long, and have [rank] * [channels] channels")
+    assert r["fix_no_acts"] == (ERROR, "Activations Mode set to Seed or Fix , but no Activations Buffer supplied")
+    assert r["fix_bad_acts_shape"] == (
+        ERROR, "Supplied activations buffer for seeding must be [(num samples / hop size)  + 1] frames long, and have [rank] * [channels] channels")
+    assert r["both_fixed"] == (
+        WARNING, "Bases and Activations buffers both fixed, but resynthesis disabled: no work to do")
+    assert r["resynth_no_buffer"] == (ERROR, "Resynthesis requested but no buffer supplied")
+    assert r["empty_queue"] == (WARNING, "Process() called on empty queue")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+def test_client_stereo_with_offsets(driver, oracle, onp, tmp_path, use_async, ctx):
+    frames, chans = 30000, 3
+    audio = np.stack([onp.synth_audio(frames, 500 + c) for c in range(chans)], axis=1)  # frames x chans
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    win, hop, fft, K, iters, seed = 1024, 256, 1024, 4, 30, 42
+    start_frame, num_frames, start_chan, num_chans = 1000, 20000, 1, 2
+    prefix = str(tmp_path / "out")
+    r = run(driver, "run", inp, frames, chans, win, hop, fft, K, iters, seed, 0, 0, use_async, start_frame,
+            num_frames, start_chan, num_chans, prefix)
+    assert r["result"] == (OK, "")
+    if use_async:
+        assert r["process"][0] == OK and r["max_progress"][0] == 1
+    bases, sr_b = read_buffer(prefix + "_bases.bin")
+    acts, sr_a = read_buffer(prefix + "_acts.bin")
+    F, T = fft // 2 + 1, num_frames // hop + 1
+    assert bases.shape == (K * num_chans, F) and acts.shape == (K * num_chans, T)     # :188-211
+    assert sr_b == pytest.approx(44100.0 / fft) and sr_a == pytest.approx(44100.0 / hop)  # :199-209
+    for i in range(num_chans):
+        x = audio[start_frame:start_frame + num_frames, start_chan + i]
+        rb, ra = oracle.bufnmf_channel(np.ascontiguousarray(x), win, fft, hop, K, iters, seed)
+        assert rel_err(bases[i * K:(i + 1) * K], rb) < 1e-6    # channel i*K + j holds component j (:281,:295)
+        assert rel_err(acts[i * K:(i + 1) * K], ra) < 1e-6
+
+
+@pytest.mark.gpu
+def test_client_seeded_bases_fixed_activations(driver, oracle, onp, tmp_path, ctx):
+    frames = 16384
+    audio = onp.synth_audio(frames, 77)
+    inp = tmp_path / "in.f32"
+    audio.tofile(inp)
+    win, hop, fft, K, iters = 512, 128, 512, 3, 25
+    F, T = fft // 2 + 1, frames // hop + 1
+    rs = np.random.RandomState(1)
+    seedW = rs.uniform(0.05, 1, (K, F)).astype(np.float32)
+    seedH = rs.uniform(0.05, 1, (K, T)).astype(np.float32)
+    seedW.tofile(tmp_path / "sw.f32")
+    seedH.tofile(tmp_path / "sh.f32")
+    prefix = str(tmp_path / "out")
+    # basesMode = Seed (1), actMode = Fixed (2): W updates from the seed, H stays
+    r = run(driver, "run", inp, frames, 1, win, hop, fft, K, iters, 42, 1, 2, 0, 0, -1, 0, -1, prefix,
+            tmp_path / "sw.f32", tmp_path / "sh.f32")
+    assert r["result"] == (OK, "")
+    bases, _ = read_buffer(prefix + "_bases.bin")
+    acts, _ = read_buffer(prefix + "_acts.bin")
+    _, mag = oracle.stft_f32(audio, win, fft, hop)
+    rW, rH, _, _ = oracle.nmf_process(mag, K, iters, True, False, 42, W0=seedW.astype(np.float64),
+                                      H0=seedH.T.astype(np.float64))
+    assert rel_err(bases, rW.astype(np.float32)) < 1e-6
+    assert np.array_equal(acts, seedH)            # fixed activations are not written back (:286)
+
+
+@pytest.mark.gpu
+def test_client_cancel(driver, ctx):
+    r = run(driver, "cancel", 441000)
+    assert r["process"][0] == OK
+    assert r["progress_before_cancel"][0] == 1     # progress was moving and below 1
+    assert r["cancelled"] == (CANCELLED, "")       # :273-274
