@@ -40,7 +40,7 @@ struct fluhip_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  std::map<std::pair<int, int>, double*> windows; // (win, type) -> device table
+  std::map<std::pair<int, int>, double*> windows; // (win | fft << 16, type) -> device table
   std::map<int, double*> twiddles;                // fft -> device table
   bool prof = false;
   std::vector<ProfRec> profRecs;
@@ -162,17 +162,20 @@ static bool make_window(int type, int64_t size, std::vector<double>& out)
   }
 }
 
-static int get_window(fluhip_ctx* ctx, int64_t win, int type, const double** out)
+// device table of `fft` doubles: the window followed by zeros (a frame shorter than the transform
+// is zero-padded at its tail, util/FFT.hpp:97-98)
+static int get_window(fluhip_ctx* ctx, int64_t win, int64_t fft, int type, const double** out)
 {
-  auto key = std::make_pair((int) win, type);
+  auto key = std::make_pair((int) win + (int) (fft << 16), type);
   auto it = ctx->windows.find(key);
   if (it == ctx->windows.end())
   {
     std::vector<double> w;
     if (!make_window(type, win, w)) return fail(ctx, "unsupported window type / size");
+    w.resize((size_t) std::max(win, fft), 0.0);
     double* d = nullptr;
-    HIPCHK(ctx, hipMalloc(&d, (size_t) win * sizeof(double)));
-    HIPCHK(ctx, hipMemcpy(d, w.data(), (size_t) win * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMalloc(&d, w.size() * sizeof(double)));
+    HIPCHK(ctx, hipMemcpy(d, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
     it = ctx->windows.emplace(key, d).first;
   }
   *out = it->second;
@@ -222,7 +225,10 @@ struct fluhip_corpus
   }
 };
 
-// which MFMA form the factor update uses: 4 = v_mfma_f64_4x4x4_4b (default), 16 = 16x16x4 (A/B)
+// which factor-update kernel runs (FLUHIP_NMF_KERNEL forces one for A/B runs):
+//   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (default, Kp 16/32)
+//   4 = v_mfma_f64_4x4x4_4b, register-staged operands (Kp 64)
+//  16 = v_mfma_f64_16x16x4 (Kp 128, and the first version kept for comparison)
 static int update_variant(int Kp)
 {
   static const int forced = [] {
@@ -230,6 +236,8 @@ static int update_variant(int Kp)
     return e ? std::atoi(e) : 0;
   }();
   if (forced == 16) return 16;
+  if (forced == 4 && nmf_update4_supported(Kp)) return 4;
+  if (nmf_update5_supported(Kp)) return 5;
   return nmf_update4_supported(Kp) ? 4 : 16;
 }
 
@@ -268,7 +276,7 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
-  if (update_variant((int) c->Kp) == 4)
+  if (update_variant((int) c->Kp) != 16)
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
     c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
@@ -307,7 +315,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
 {
   fluhip_ctx* ctx = c->ctx;
   const double *wtab = nullptr, *ttab = nullptr;
-  int rc = get_window(ctx, c->win, c->windowType, &wtab);
+  int rc = get_window(ctx, c->win, c->fft, c->windowType, &wtab);
   if (rc) return rc;
   rc = get_twiddle(ctx, c->fft, &ttab);
   if (rc) return rc;
@@ -485,7 +493,9 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.Cp = std::max(c->Fp, c->Tp);
     {
       ProfScope p(ctx, 1);
-      if (update_variant(a.Kp) == 4) launch_nmf_update4(a, s);
+      const int uv = update_variant(a.Kp);
+      if (uv == 5) launch_nmf_update5(a, s);
+      else if (uv == 4) launch_nmf_update4(a, s);
       else launch_nmf_update(a, s);
     }
     // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
@@ -503,7 +513,9 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp);
     ProfScope p(ctx, 1);
-    if (update_variant(a.Kp) == 4) launch_nmf_update4(a, s);
+    const int uv = update_variant(a.Kp);
+    if (uv == 5) launch_nmf_update5(a, s);
+    else if (uv == 4) launch_nmf_update4(a, s);
     else launch_nmf_update(a, s);
   }
 }
@@ -845,7 +857,7 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
     HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
-    if (update_variant((int) c.Kp) == 4)
+    if (update_variant((int) c.Kp) != 16)
     {
       c.nsplitW = choose_split4(1, (int) F, (int) T, (int) c.Kp);
       c.nsplitH = choose_split4(1, (int) T, (int) F, (int) c.Kp);

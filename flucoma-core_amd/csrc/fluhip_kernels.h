@@ -75,6 +75,8 @@ int nmf_update_cols_per_wave(int Kp);
 void launch_nmf_update4(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b form
 bool nmf_update4_supported(int Kp);
 int nmf_update4_waves_per_buffer(int C, int Kp, int B);
+void launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // + LDS-DMA operand streaming
+bool nmf_update5_supported(int Kp);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
 // divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).

@@ -379,11 +379,7 @@ static void launch4_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         switch (var)
         {
         case 0: launch4_t<M, NG, 0>(a, w, s); break;
-        case 1: launch4_t<M, NG, 1>(a, w, s); break;
-        case 2: launch4_t<M, NG, 2>(a, w, s); break;
-        case 4: launch4_t<M, NG, 4>(a, w, s); break;
-        case 8: launch4_t<M, NG, 8>(a, w, s); break;
-        case 24: launch4_t<M, NG, 24>(a, w, s); break;
+        case 24: launch4_t<M, NG, 24>(a, w, s); break; // no operand loads at all: compute-side floor
         default: launch4_t<M, NG, (M * NG <= 56 ? 1 : 0)>(a, w, s); break;
         }
       }

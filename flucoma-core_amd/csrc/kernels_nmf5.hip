@@ -1,0 +1,431 @@
+// kernels_nmf5.hip -- NMF factor update, v_mfma_f64_4x4x4_4b_f64 + LDS-DMA operand streaming.
+//
+// Same mathematics and register tiling as kernels_nmf4.hip (see there for the derivation and the
+// measured lane map).  What changes is how operands reach the wavefront: both streamed operands --
+// the 4-row slab of V under the wavefront's column strip and the 4 x Kp slab of the moving factor
+// -- are copied HBM/L2 -> LDS by `global_load_lds_dwordx4` (no VGPRs, asynchronous, counted on
+// vmcnt) into a private per-wavefront ring of NS stages, NS-1 steps ahead of their use, and read
+// back with ds_read just before the MFMAs that consume them.  That removes the two VGPR prefetch
+// sets of the register-staged kernel (room for the stage-wise quotient at 9 groups) and makes the
+// prefetch depth a matter of LDS, not registers.  Rings are private to a wavefront, so there are
+// no workgroup barriers: ordering is the issuing wavefront's own counted `s_waitcnt vmcnt(N)`.
+//
+// LDS images
+//   V stage : [4 rows][NG*16 doubles], linear copy of the strip          (ds_read_b64, conflict free)
+//   Mv stage: [4 rows][Kp doubles], 16-byte chunks of row r rotated by r  (pos = (c + r) mod Kp/2)
+//             so that the two register distributions the MFMAs need -- (row x, chunks of y) and
+//             (row y, chunks of x) -- both hit distinct banks within a ds_read_b128 lane group.
+//             The rotation is applied on the per-lane *source* address; the LDS destination of an
+//             LDS-DMA is always base + lane*16.
+#include "fluhip_kernels.h"
+
+#include <cstdlib>
+
+namespace fluhip {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+struct Upd5Args
+{
+  const double* V;
+  int64_t ldv, strideV;
+  const double* Mv;
+  int64_t strideM;
+  double* S;
+  int64_t strideS;
+  int R, C, B;
+  int nGroups, wavesPerBuf, wgPerBuf, nSteps, nsplit, stepsPerSplit;
+  double* part;
+  double* dpart;
+  int64_t Cp;
+  int xcdMap;
+};
+
+#define FLUHIP_GLDS(src, dst)                                                                     \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (src),          \
+                                   (__attribute__((address_space(3))) void*) (dst), 16, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
+{
+#pragma unroll
+  for (int j = 0; j < N; j += 2)
+  {
+    d2 t = *reinterpret_cast<const d2*>(p + j);
+    dst[j] = t[0];
+    dst[j + 1] = t[1];
+  }
+}
+
+template <int M, int NG, int NS, int WPS>
+__global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
+{
+  constexpr int KP = 4 * M;
+  constexpr int SPR = KP / 2;                      // 16-byte chunks per Mv row
+  constexpr int NJV = (32 * NG + 63) / 64;         // DMA instructions per V stage
+  constexpr int NJM = (4 * SPR + 63) / 64;         // DMA instructions per Mv stage
+  constexpr int VSTAGE = NJV * 1024;               // bytes
+  constexpr int MSTAGE = NJM * 1024;
+  constexpr int WAVE_LDS = NS * (VSTAGE + MSTAGE);
+  constexpr int IPS = NJV + NJM;                   // vmcnt events per stage
+
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  int id = blockIdx.x;
+  int buf, wg, split;
+  if (a.xcdMap)
+  {
+    const int xcd = id & 7;
+    int slot = id >> 3;
+    split = slot % a.nsplit;
+    slot /= a.nsplit;
+    wg = slot % a.wgPerBuf;
+    buf = xcd + 8 * (slot / a.wgPerBuf);
+  }
+  else
+  {
+    split = id % a.nsplit;
+    wg = (id / a.nsplit) % a.wgPerBuf;
+    buf = id / (a.nsplit * a.wgPerBuf);
+  }
+  if (buf >= a.B) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int WPB = 4 * WPS; // wavefronts per workgroup
+  const int strip = wg * WPB + wave;
+  if (strip >= a.wavesPerBuf) return;
+  // Column groups are dealt out as evenly as possible.  With two wavefronts per SIMD (WPS == 2)
+  // wavefronts w and w+4 of a workgroup share a SIMD, so the "one extra group" strips are spread
+  // over distinct SIMD pairs first: the per-SIMD load stays within one group of the mean.
+  const int base = a.nGroups / a.wavesPerBuf, rem = a.nGroups % a.wavesPerBuf;
+  int g0 = 0, ng = 0;
+  {
+    const int nPairs = (a.wavesPerBuf + WPS - 1) / WPS;
+    int acc0 = 0;
+    for (int st = 0; st <= strip; st++)
+    {
+      const int wgi = st / WPB, w = st % WPB;
+      const int pair = wgi * 4 + (w & 3), member = w >> 2;
+      // extras e = pair + nPairs * member  (e < rem)
+      const int extra = (pair + nPairs * member) < rem ? 1 : 0;
+      const int cnt = base + extra;
+      if (st == strip) { g0 = acc0; ng = cnt; }
+      acc0 += cnt;
+    }
+  }
+  if (ng <= 0) return;
+
+  const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
+  const double* __restrict__ V = a.V + (int64_t) buf * a.strideV;
+  const double* __restrict__ Mv = a.Mv + (int64_t) buf * a.strideM;
+  double* S = a.S + (int64_t) buf * a.strideS;
+
+  char* vring = lds + wave * WAVE_LDS;
+  char* mring = vring + NS * VSTAGE;
+
+  // ---- per-lane DMA source offsets (fixed for the whole pass) ---------------------------------
+  // V stage chunk i = 64 j + lane: row = i / (8 NG), 16-byte column chunk cc = i % (8 NG); chunks of
+  // groups this strip does not own (tail strips) and the slack of the last instruction re-read
+  // valid data of the strip instead of running off the row.
+  int64_t voffs[NJV];
+#pragma unroll
+  for (int j = 0; j < NJV; j++)
+  {
+    int i = 64 * j + lane;
+    int row = i / (8 * NG), cc = i % (8 * NG);
+    if (row > 3) { row = 3; }
+    cc = min(cc, 8 * ng - 1);
+    voffs[j] = (int64_t) row * a.ldv + (int64_t) g0 * 16 + cc * 2;
+  }
+  int moffs[NJM];
+#pragma unroll
+  for (int j = 0; j < NJM; j++)
+  {
+    int p = 64 * j + lane;
+    int row = p / SPR, pos = p % SPR;
+    if (row > 3) row = 3;
+    const int c = (pos - row + SPR) % SPR; // slot pos of row `row` holds chunk c
+    moffs[j] = row * KP + c * 2;
+  }
+
+  const int s0 = split * a.stepsPerSplit;
+  const int s1 = min(s0 + a.stepsPerSplit, a.nSteps);
+  const int sLast = s1 - 1;
+
+  auto issue_stage = [&](int st) {
+    const int sc = min(st, sLast); // past the end: harmless re-read of the last step
+    const int slot = st % NS;
+    const double* vsrc = V + (int64_t) sc * 4 * a.ldv;
+    const double* msrc = Mv + (int64_t) sc * 4 * KP;
+#pragma unroll
+    for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + slot * VSTAGE + j * 1024);
+#pragma unroll
+    for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
+  };
+
+  // ---- stationary operand + accumulators ------------------------------------------------------
+  double sb[NG][M];
+  double acc[NG][M];
+#pragma unroll
+  for (int g = 0; g < NG; g++)
+  {
+#pragma unroll
+    for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
+    if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KP + M * y);
+  }
+  double dsum[M];
+#pragma unroll
+  for (int m = 0; m < M; m++) dsum[m] = 0.0;
+
+  // ---- LDS read addresses (bytes within a stage) ------------------------------------------------
+  // ma: row x, chunks M/2*y .. ; mb: row y, chunks M/2*x .. ; chunk c of row r sits at slot (c + r) % SPR
+  int maOff[M / 2], mbOff[M / 2];
+#pragma unroll
+  for (int j = 0; j < M / 2; j++)
+  {
+    maOff[j] = x * (KP * 8) + (((M / 2) * y + j + x) % SPR) * 16;
+    mbOff[j] = y * (KP * 8) + (((M / 2) * x + j + y) % SPR) * 16;
+  }
+  const int vOff = y * (NG * 128) + (4 * blk + x) * 8;
+
+  auto read_ma = [&](int st, double (&ma)[M]) {
+    const char* mp = mring + (st % NS) * MSTAGE;
+#pragma unroll
+    for (int j = 0; j < M / 2; j++)
+    {
+      d2 t = *reinterpret_cast<const d2*>(mp + maOff[j]);
+      ma[2 * j] = t[0];
+      ma[2 * j + 1] = t[1];
+    }
+  };
+  auto read_mbv = [&](int st, double (&mb)[M], double (&v)[NG]) {
+    const char* mp = mring + (st % NS) * MSTAGE;
+#pragma unroll
+    for (int j = 0; j < M / 2; j++)
+    {
+      d2 t = *reinterpret_cast<const d2*>(mp + mbOff[j]);
+      mb[2 * j] = t[0];
+      mb[2 * j + 1] = t[1];
+    }
+    const char* vp = vring + (st % NS) * VSTAGE + vOff;
+#pragma unroll
+    for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vp + g * 128);
+  };
+
+  auto q_phase = [&](const double (&ma)[M], double (&q)[NG]) {
+#pragma unroll
+    for (int g = 0; g < NG; g++) q[g] = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int g = 0; g < NG; g++) q[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], q[g], 0, 0, 0);
+  };
+  // V / max(Q, eps), stage by stage across the NG independent quotients:
+  // v_rcp_f64 (~24 bits) -> one Newton step -> quotient -> residual correction (error ~2^-96)
+  auto ratio_phase = [&](const double (&v)[NG], const double (&q)[NG], double (&ratio)[NG]) {
+    double d[NG], yv[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) d[g] = q[g] > kEpsilon ? q[g] : kEpsilon;
+#pragma unroll
+    for (int g = 0; g < NG; g++) yv[g] = __builtin_amdgcn_rcp(d[g]);
+#pragma unroll
+    for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(-d[g], yv[g], 1.0);
+#pragma unroll
+    for (int g = 0; g < NG; g++) yv[g] = __builtin_fma(yv[g], ratio[g], yv[g]);
+#pragma unroll
+    for (int g = 0; g < NG; g++) ratio[g] = v[g] * yv[g];
+#pragma unroll
+    for (int g = 0; g < NG; g++) d[g] = __builtin_fma(-d[g], ratio[g], v[g]);
+#pragma unroll
+    for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(d[g], yv[g], ratio[g]);
+  };
+  auto out_phase = [&](const double (&ratio)[NG], const double (&mb)[M]) {
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+      for (int m = 0; m < M; m++) acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ratio[g], mb[m], acc[g][m], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < M; m++) dsum[m] += mb[m];
+  };
+
+  // ---- pipeline -------------------------------------------------------------------------------
+  // stages s0 .. s0+NS-1 in flight; iteration s consumes stage s (mb, v) and stage s+1 (ma), then
+  // refills the slot of stage s with stage s+NS.  Completion is in issue order, so "stage s+1 has
+  // landed" == at most (NS-2) stages outstanding.
+  if (s0 < s1)
+  {
+#pragma unroll
+    for (int t = 0; t < NS; t++) issue_stage(s0 + t);
+    double ma[M], mb[M], v[NG], qA[NG], qB[NG], ratio[NG];
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * IPS) : "memory");
+    read_ma(s0, ma);
+    q_phase(ma, qA);
+    for (int s = s0; s < s1; s += 2)
+    {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+      read_ma(s + 1, ma);
+      read_mbv(s, mb, v);
+      ratio_phase(v, qA, ratio);
+      q_phase(ma, qB);
+      out_phase(ratio, mb);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every ds_read of stage s has returned
+      issue_stage(s + NS);
+      if (s + 1 < s1)
+      {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+        read_ma(s + 2, ma);
+        read_mbv(s + 1, mb, v);
+        ratio_phase(v, qB, ratio);
+        q_phase(ma, qA);
+        out_phase(ratio, mb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_stage(s + 1 + NS);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the run-ahead DMAs before the LDS is released
+  }
+
+#pragma unroll
+  for (int m = 0; m < M; m++)
+  {
+    double d = dsum[m];
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    dsum[m] = d;
+  }
+
+  if (a.nsplit == 1)
+  {
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+    {
+      if (g < ng)
+      {
+        const int col = (g0 + g) * 16 + 4 * blk + y;
+        if (col < a.C)
+        {
+          double* sp = S + (int64_t) col * KP + M * x;
+          double sold[M];
+          load_vec5<M>(sold, sp);
+#pragma unroll
+          for (int m = 0; m < M; m++) sp[m] = (sold[m] * acc[g][m]) / fmax(dsum[m], kEpsilon);
+        }
+      }
+    }
+  }
+  else
+  {
+    double* part = a.part + ((int64_t) buf * a.nsplit + split) * a.Cp * KP;
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+    {
+      if (g < ng)
+      {
+        const int col = (g0 + g) * 16 + 4 * blk + y;
+        double* pp = part + (int64_t) col * KP + M * x;
+#pragma unroll
+        for (int m = 0; m < M; m++) pp[m] = acc[g][m];
+      }
+    }
+    if (strip == 0 && blk == 0 && y == 0)
+    {
+      double* dp = a.dpart + ((int64_t) buf * a.nsplit + split) * KP + M * x;
+#pragma unroll
+      for (int m = 0; m < M; m++) dp[m] = dsum[m];
+    }
+  }
+}
+
+void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
+                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
+
+template <int M, int NG, int NS, int WPS>
+static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
+{
+  Upd5Args k;
+  k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
+  k.Mv = a.Mv; k.strideM = a.strideM;
+  k.S = a.S; k.strideS = a.strideS;
+  k.R = a.R; k.C = a.C; k.B = a.B;
+  k.nGroups = (a.C + 15) / 16;
+  k.wavesPerBuf = wavesPerBuf;
+  k.wgPerBuf = (wavesPerBuf + 4 * WPS - 1) / (4 * WPS);
+  k.nSteps = (a.R + 3) / 4;
+  k.nsplit = a.nsplit < 1 ? 1 : a.nsplit;
+  k.stepsPerSplit = (k.nSteps + k.nsplit - 1) / k.nsplit;
+  k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
+  k.xcdMap = a.B >= 8 ? 1 : 0;
+  const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
+  const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
+  constexpr int KP = 4 * M, SPR = KP / 2;
+  constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
+  constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
+  static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS>;
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int) shmem);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
+  if (k.nsplit > 1)
+    launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s);
+}
+
+int nmf_update4_waves_per_buffer(int C, int Kp, int B);
+
+// ring depth bounded by the 160 KiB of LDS: 4*WPS wavefronts x NS x (V + Mv stage)
+template <int M, int NG, int WPS>
+constexpr int ring_depth()
+{
+  constexpr int NJ = (32 * NG + 63) / 64 + (4 * (2 * M) + 63) / 64;
+  constexpr int fit = 160 / (4 * WPS * NJ);
+  return fit >= 6 ? 6 : (fit < 3 ? 3 : fit);
+}
+
+template <int M, int NG, int WPS>
+static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
+{
+  if constexpr (NG == 1) launch5_t<M, 1, ring_depth<M, 1, WPS>(), WPS>(a, w, s);
+  else
+  {
+    if (ng >= NG)
+    {
+      constexpr int NS = ring_depth<M, NG, WPS>();
+      launch5_t<M, NG, NS, WPS>(a, w, s);
+    }
+    else launch5_ng<M, NG - 1, WPS>(a, w, ng, s);
+  }
+}
+
+bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32; }
+
+// strips per buffer for WPS wavefronts per SIMD: WPS x the one-wave plan, as long as every strip
+// keeps at least one group
+void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
+{
+  // two wavefronts per SIMD measured no faster than one (profiles/r01/update_kernel_notes.md)
+  static const int wps = [] { const char* e = std::getenv("FLUHIP_K5_WPS"); return e ? std::atoi(e) : 1; }();
+  const int G = (a.C + 15) / 16;
+  int w = nmf_update4_waves_per_buffer(a.C, a.Kp, a.B);
+  const bool two = wps == 2 && 2 * w <= G && (G + 2 * w - 1) / (2 * w) <= 4;
+  if (two) w *= 2;
+  const int ng = (G + w - 1) / w;
+  if (two)
+  {
+    switch (a.Kp / 4)
+    {
+    case 4: launch5_ng<4, 4, 2>(a, w, ng, s); break;
+    case 8: launch5_ng<8, 4, 2>(a, w, ng, s); break;
+    default: break;
+    }
+  }
+  else
+  {
+    switch (a.Kp / 4)
+    {
+    case 4: launch5_ng<4, 9, 1>(a, w, ng, s); break;
+    case 8: launch5_ng<8, 9, 1>(a, w, ng, s); break;
+    default: break;
+    }
+  }
+}
+
+} // namespace fluhip
