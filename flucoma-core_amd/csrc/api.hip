@@ -924,7 +924,6 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
   if (!ctx) return FLUHIP_ERROR;
   if (!audio) return fail(ctx, "null audio");
   if (stride < 1) return fail(ctx, "stride must be >= 1");
-  if (resynth_out) return fail(ctx, "resynthesis is not implemented in this build");
   int rc = check_shape(ctx, n, win, fft, hop, K);
   if (rc) return rc;
   if (iters < 0) return fail(ctx, "negative iteration count");
@@ -932,6 +931,7 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
   hipStream_t s = ctx->stream;
   fluhip_corpus c;
   c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = K;
+  c.keepSpec = resynth_out != nullptr; // the complex spectrogram is only needed for resynthesis
   rc = corpus_alloc(ctx, &c);
   if (rc) return rc;
   DevBuf in;
@@ -948,7 +948,37 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
   rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user); // :268-271
   if (rc) return rc;                                                             // :273-274
   rc = fluhip_corpus_writeback_host(&c, bases_out, acts_out);                    // :277-300
-  return rc;
+  if (rc) return rc;
+  if (resynth_out) // :302-334  estimate -> ratio mask -> ISTFT per component
+  {
+    const double *wtab = nullptr, *ttab = nullptr;
+    rc = get_window(ctx, win, fft, c.windowType, &wtab);
+    if (rc) return rc;
+    rc = get_twiddle(ctx, fft, &ttab);
+    if (rc) return rc;
+    DevBuf vhat, frames, out32;
+    HIPCHK(ctx, vhat.alloc((size_t) c.T * c.F * sizeof(double), false, s));
+    HIPCHK(ctx, frames.alloc((size_t) c.T * win * sizeof(double), false, s));
+    HIPCHK(ctx, out32.alloc((size_t) K * n * sizeof(float), false, s));
+    // mask.init(outputMags): outputMags = V1 = (W*H)^T of NMF::process (NMF.hpp:182, NMFClient.hpp:305-306)
+    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, vhat.as<double>(), c.F, 0, (int) c.T, (int) c.F,
+                (int) c.Kp, 1, s);
+    ResynthArgs ra;
+    ra.spec = c.spec.as<double>(); ra.Wf = c.Wf.as<double>(); ra.H1 = c.H1.as<double>();
+    ra.Vhat = vhat.as<double>(); ra.ldV = c.F; ra.Kp = (int) c.Kp;
+    ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) c.T; ra.F = (int) c.F;
+    ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = n;
+    for (int64_t k = 0; k < K; k++)
+    {
+      ra.k = (int) k;
+      ra.out32 = out32.as<float>() + k * n;
+      launch_resynth(ra, s);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(resynth_out, out32.p, (size_t) K * n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  return FLUHIP_OK;
 }
 
 // ---- profiling ------------------------------------------------------------------------

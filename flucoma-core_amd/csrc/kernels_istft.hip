@@ -1,0 +1,169 @@
+// kernels_istft.hip -- resynthesis of one NMF component:
+//   algorithm::NMF::estimate      include/flucoma/algorithms/public/NMF.hpp:33-42      est[t][f] = H1[t][k] W1[k][f]
+//   algorithm::RatioMask::process include/flucoma/algorithms/public/RatioMask.hpp:33-57  Y = X * min(est * (1/max(Vhat,eps)), 1)
+//   algorithm::ISTFT::process     include/flucoma/algorithms/public/STFT.hpp:178-199     inverse real FFT, * 1/fft, * window,
+//                                                                           overlap-add, / max(sum w^2, eps), trim win/2
+//   driver                        include/flucoma/clients/nrt/NMFClient.hpp:302-334
+//
+// Kernel R1 (one workgroup per frame): masked spectrum -> C2R through an n = fft/2 point complex
+// FFT in LDS (Z[k] = E[k] + i O[k] with E, O the spectra of the even / odd samples; inverse taken
+// as conj(FFT(conj Z)) / n with the forward Stockham passes of the STFT kernel) -> first `win`
+// samples * window -> frames[t][win].
+// Kernel R2 (one thread per output sample): gathers the <= ceil(win/hop) overlapping frames in
+// increasing frame order -- the same summation order as the reference's sequential overlap-add,
+// so the result does not depend on scheduling -- and divides by the window-power normaliser.
+#include "fluhip_kernels.h"
+
+namespace fluhip {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ d2 cmul_i(d2 a, d2 b)
+{
+  return d2{a[0] * b[0] - a[1] * b[1], a[0] * b[1] + a[1] * b[0]};
+}
+
+__device__ __forceinline__ d2 twid_i(const d2* tw, int m, int half)
+{
+  if (m >= half)
+  {
+    d2 t = tw[m - half];
+    return d2{-t[0], -t[1]};
+  }
+  return tw[m];
+}
+
+__global__ __launch_bounds__(256) void resynth_frames_kernel(ResynthArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int nc = a.fft / 2;
+  d2* bufA = reinterpret_cast<d2*>(lds);
+  d2* bufB = bufA + nc;
+  const d2* tw = reinterpret_cast<const d2*>(a.twiddle); // e^{-2 pi i m / fft}, m < fft/2 (global, L1/L2 resident)
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int t = blockIdx.x;
+  const double* spec = a.spec + (int64_t) t * a.F * 2;
+  const double* vhat = a.Vhat + (int64_t) t * a.ldV;
+  const double hk = a.H1[(int64_t) t * a.Kp + a.k];
+
+  auto masked = [&](int f) -> d2 {
+    const double est = hk * a.Wf[(int64_t) f * a.Kp + a.k];   // NMF.hpp:41
+    const double mult = 1.0 / fmax(vhat[f], kEpsilon);          // RatioMask.hpp:39-41
+    const double m = fmin(est * mult, 1.0);                     // RatioMask.hpp:52-56 (exponent 1)
+    d2 x = reinterpret_cast<const d2*>(spec)[f];
+    x = d2{x[0] * m, x[1] * m};
+    if (f == 0 || f == nc) x[1] = 0.0;                          // util/FFT.hpp:155-160 packed DC / Nyquist
+    return x;
+  };
+
+  // ---- Z[k] = E[k] + i O[k], stored conjugated for the forward transform ----------------------
+  for (int k = tid; k < nc; k += nt)
+  {
+    const d2 X = masked(k), Xn = masked(nc - k);
+    const d2 Xc = d2{Xn[0], -Xn[1]};
+    const d2 E = d2{0.5 * (X[0] + Xc[0]), 0.5 * (X[1] + Xc[1])};
+    d2 D = d2{0.5 * (X[0] - Xc[0]), 0.5 * (X[1] - Xc[1])};
+    const d2 w = tw[k];                       // e^{-2 pi i k / fft}; we need its conjugate e^{+...}
+    const d2 O = cmul_i(D, d2{w[0], -w[1]});
+    const d2 Z = d2{E[0] - O[1], E[1] + O[0]}; // E + i O
+    bufA[k] = d2{Z[0], -Z[1]};                // conj
+  }
+  __syncthreads();
+  d2* src = bufA;
+  d2* dst = bufB;
+  for (int Ns = 1; Ns < nc;)
+  {
+    if (nc / Ns >= 4)
+    {
+      const int q = nc >> 2;
+      const int tstep = a.fft / (Ns * 4);
+      for (int j = tid; j < q; j += nt)
+      {
+        const int k = j & (Ns - 1);
+        d2 v0 = src[j], v1 = src[j + q], v2 = src[j + 2 * q], v3 = src[j + 3 * q];
+        if (k)
+        {
+          const int m1 = k * tstep;
+          v1 = cmul_i(v1, twid_i(tw, m1, nc));
+          v2 = cmul_i(v2, twid_i(tw, 2 * m1, nc));
+          v3 = cmul_i(v3, twid_i(tw, 3 * m1, nc));
+        }
+        const d2 t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3;
+        const d2 d13 = v1 - v3;
+        const d2 t3 = d2{d13[1], -d13[0]};
+        const int o = ((j - k) << 2) + k;
+        dst[o] = t0 + t2;
+        dst[o + Ns] = t1 + t3;
+        dst[o + 2 * Ns] = t0 - t2;
+        dst[o + 3 * Ns] = t1 - t3;
+      }
+      Ns <<= 2;
+    }
+    else
+    {
+      const int h = nc >> 1;
+      const int tstep = a.fft / (Ns * 2);
+      for (int j = tid; j < h; j += nt)
+      {
+        const int k = j & (Ns - 1);
+        d2 v0 = src[j], v1 = src[j + h];
+        if (k) v1 = cmul_i(v1, twid_i(tw, k * tstep, nc));
+        const int o = ((j - k) << 1) + k;
+        dst[o] = v0 + v1;
+        dst[o + Ns] = v0 - v1;
+      }
+      Ns <<= 1;
+    }
+    __syncthreads();
+    d2* tmp = src; src = dst; dst = tmp;
+  }
+  // z[m] = conj(src[m]) / nc ; x[2m] = Re z, x[2m+1] = Im z ; keep the first `win` samples
+  // (alg/STFT.hpp:191), scale by 1/fft is already contained in the normalised inverse
+  // (unnormalised C2R = fft * x, times mScale = 1/fft), then * window (:193)
+  double* fr = a.frames + (int64_t) t * a.win;
+  const double inv = 1.0 / (double) nc;
+  for (int m = tid; m < nc; m += nt)
+  {
+    const d2 z = src[m];
+    const int i0 = 2 * m, i1 = 2 * m + 1;
+    if (i0 < a.win) fr[i0] = (z[0] * inv) * a.window[i0];
+    if (i1 < a.win) fr[i1] = (-z[1] * inv) * a.window[i1];
+  }
+}
+
+__global__ void resynth_ola_kernel(ResynthArgs a)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int64_t p = i + a.win / 2; // position in the padded output (alg/STFT.hpp:197)
+  // frames t with t*hop <= p < t*hop + win
+  int64_t tlo = (p - a.win + a.hop) / a.hop; // ceil((p - win + 1) / hop) for p - win + 1 > 0
+  if (p - a.win + 1 <= 0) tlo = 0;
+  int64_t thi = p / a.hop;
+  if (thi > a.T - 1) thi = a.T - 1;
+  double acc = 0.0, nrm = 0.0;
+  for (int64_t t = tlo; t <= thi; t++)
+  {
+    const int64_t off = p - t * a.hop;
+    const double w = a.window[off];
+    acc += a.frames[t * a.win + off];
+    nrm += w * w;
+  }
+  const double y = acc / fmax(nrm, kEpsilon); // :196
+  if (a.out) a.out[i] = y;
+  if (a.out32) a.out32[i] = (float) y;
+}
+
+void launch_resynth(const ResynthArgs& a, hipStream_t s)
+{
+  const size_t shmem = (size_t) a.fft * 2 * sizeof(double); // two complex buffers of fft/2 points
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(resynth_frames_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  int threads = a.fft / 8;
+  if (threads < 64) threads = 64;
+  if (threads > 256) threads = 256;
+  hipLaunchKernelGGL(resynth_frames_kernel, dim3((unsigned) a.T), dim3((unsigned) threads), shmem, s, a);
+  hipLaunchKernelGGL(resynth_ola_kernel, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+} // namespace fluhip

@@ -182,7 +182,7 @@ class Context:
 
     # ---- one BufNMF channel -------------------------------------------------------------
     def bufnmf_channel(self, audio, win, fft, hop, K, iters, seed, updateW=True, updateH=True,
-                       bases_seed=None, acts_seed=None, progress=None, stride=1):
+                       bases_seed=None, acts_seed=None, progress=None, stride=1, resynth=False):
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         n = (audio.shape[0] + stride - 1) // stride
         T, F = (n + hop) // hop, fft // 2 + 1
@@ -191,10 +191,13 @@ class Context:
         bs = None if bases_seed is None else np.ascontiguousarray(bases_seed, dtype=np.float32)
         as_ = None if acts_seed is None else np.ascontiguousarray(acts_seed, dtype=np.float32)
         cb = _cb(progress)
+        res = np.empty((K, n), dtype=np.float32) if resynth else None
         rc = self.lib.fluhip_bufnmf_channel_f32(self.h, _f(audio), n, stride, win, fft, hop, K, iters,
                                                 int(updateW), int(updateH), seed, _f(bs), _f(as_),
-                                                _f(bases), _f(acts), None, cb, None)
+                                                _f(bases), _f(acts), _f(res), cb, None)
         self._check(rc, allow=(OK, CANCELLED))
+        if resynth:
+            return bases, acts, res, rc
         return bases, acts, rc
 
     # ---- profiling ----------------------------------------------------------------------

@@ -343,3 +343,25 @@ def test_corpus_c4_shape_properties(ctx, onp):
     assert np.allclose(acts.reshape(B, -1).max(axis=1), 1.0, atol=1e-6)
     for b in range(B):
         assert kl(mag[b], W200[b], H200[b]) <= kl(mag[b], W50[b], H50[b]) * (1 + 1e-9)
+
+
+# ---------------------------------------------------------------------------------------
+# resynthesis: NMF::estimate -> RatioMask -> ISTFT, nrt/NMFClient.hpp:302-334
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,win,fft,hop,K", [(20000, 1024, 1024, 256, 3), (9000, 512, 1024, 128, 2),
+                                             (44100, 2048, 2048, 512, 4), (5000, 64, 64, 16, 2)])
+def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
+    x = onp.synth_audio(n, 4242)
+    iters = 30
+    bases, acts, res, rc = ctx.bufnmf_channel(x, win, fft, hop, K, iters, 42, resynth=True)
+    assert rc == 0 and res.shape == (K, n)
+    spec, mag = oracle.stft_f32(x, win, fft, hop)
+    W1, H1, V1, _ = oracle.nmf_process(mag, K, iters, True, True, 42)
+    total = np.zeros(n)
+    for k in range(K):
+        ref = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, n)
+        scale = max(np.abs(ref).max(), 1e-12)
+        assert np.abs(res[k] - ref).max() / scale < 1e-5      # float output of an f64 pipeline
+        total += res[k]
+    # soft masks sum to ~1: the components add back up to the input (away from the edges)
+    assert np.abs(total[win:-win] - x[win:-win]).max() < 0.02

@@ -1,0 +1,48 @@
+"""Timing of the other BASELINE configs (c1, c2, c3) through the C ABI: these are parity-test shapes,
+not bench.py lines, but their per-iteration cost shows how the single-buffer (split-R) path behaves.
+    python tools/bench_configs.py [c1 c2 c3]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import fluhip  # noqa: E402
+import oracle_np  # noqa: E402
+
+CONFIGS = {
+    "c1": dict(n=453932, win=1024, fft=1024, hop=512, K=3, iters=50),
+    "c2": dict(n=2646000, win=2048, fft=2048, hop=512, K=16, iters=200),
+    "c3": dict(n=26460000, win=4096, fft=4096, hop=1024, K=128, iters=20),  # 1 channel, 20 of 500 iterations
+    "c4x1": dict(n=441000, win=2048, fft=2048, hop=512, K=32, iters=200),
+}
+
+
+def main():
+    names = sys.argv[1:] or ["c1", "c2", "c4x1"]
+    ctx = fluhip.Context(0)
+    for name in names:
+        c = CONFIGS[name]
+        # tile a 10 s synthetic clip to the requested length (content is irrelevant for timing)
+        base = oracle_np.synth_audio(min(c["n"], 441000), 1000)
+        x = np.tile(base, c["n"] // len(base) + 1)[:c["n"]].copy()
+        cor = fluhip.Corpus(ctx, 1, c["n"], c["win"], c["fft"], c["hop"], c["K"])
+        cor.set_audio(x[None, :])
+        cor.stft(); ctx.synchronize()
+        t0 = time.perf_counter(); cor.stft(); ctx.synchronize(); t_stft = time.perf_counter() - t0
+        cor.nmf(2, seed=42); ctx.synchronize()
+        t0 = time.perf_counter(); cor.nmf(c["iters"], seed=42); ctx.synchronize(); t_nmf = time.perf_counter() - t0
+        T, F, K = cor.T, cor.F, c["K"]
+        flop = 8.0 * F * T * K * c["iters"]
+        print(f"{name}: T={T} F={F} K={K}  stft {t_stft*1e3:.2f} ms ({T/t_stft/1e6:.2f} Mframes/s)  "
+              f"nmf {c['iters']} it {t_nmf*1e3:.1f} ms = {t_nmf/c['iters']*1e6:.1f} us/it "
+              f"({flop/t_nmf/1e12:.1f} TF algorithmic, incl. init)  device {cor.device_bytes()/1e6:.0f} MB")
+        cor.close()
+
+
+if __name__ == "__main__":
+    main()
