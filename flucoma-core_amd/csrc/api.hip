@@ -243,12 +243,14 @@ static int update_variant(int Kp)
 
 static int choose_split4(int64_t B, int C, int R, int Kp)
 {
+  static const int forceS = [] { const char* e = std::getenv("FLUHIP_PLAN_SPLIT"); return e ? std::atoi(e) : 0; }();
+  const int64_t nSteps = (R + 3) / 4;
+  const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(64, nSteps / 12)); // >= 12 steps per wavefront
+  if (forceS > 0) return (int) std::min<int64_t>(forceS, std::max<int64_t>(1, nSteps / 2));
   const int64_t waves = B * nmf_update4_waves_per_buffer(C, Kp, (int) B);
   if (waves >= 768) return 1;
   int64_t s = (1024 + waves - 1) / waves;
-  s = std::min<int64_t>(s, 64);
-  s = std::min<int64_t>(s, std::max<int64_t>(1, ((R + 3) / 4) / 8));
-  return (int) std::max<int64_t>(1, s);
+  return (int) std::max<int64_t>(1, std::min(s, smax));
 }
 
 static int choose_split(int64_t B, int64_t nCW, int64_t nRt)

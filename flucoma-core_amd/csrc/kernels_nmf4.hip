@@ -346,20 +346,22 @@ int nmf_update4_waves_per_buffer(int C, int Kp, int B)
 {
   const int M = Kp / 4, G = (C + 15) / 16, ngmax = max_groups(M);
   const int wmin = (G + ngmax - 1) / ngmax;
+  static const int forceW = [] { const char* e = std::getenv("FLUHIP_PLAN_W"); return e ? std::atoi(e) : 0; }();
+  if (forceW > 0) return forceW < wmin ? wmin : (forceW > G ? G : forceW);
   int w = wmin;
   const int simds = 1024;
-  if ((int64_t) B * w < simds)
-  {
-    // not enough strips for one round: narrower strips, up to one group each
-    w = (simds + B - 1) / B;
-    if (w > G) w = G;
-    if (w < wmin) w = wmin;
-  }
-  else
+  if ((int64_t) B * w >= simds)
   {
     // round the strip count up so that B*w is a multiple of the SIMD count when that is cheap
     for (int cand = wmin; cand <= wmin + 2 && cand <= G; cand++)
       if (((int64_t) B * cand) % simds == 0) { w = cand; break; }
+  }
+  else
+  {
+    // few buffers: keep strips wide (operand reuse) and let the contraction split fill the chip;
+    // only when even 32 splits cannot reach one wavefront per SIMD are the strips narrowed
+    const int64_t need = (simds + (int64_t) B * 32 - 1) / ((int64_t) B * 32);
+    if (need > w) w = (int) (need > G ? G : need);
   }
   return w;
 }
