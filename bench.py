@@ -183,6 +183,15 @@ def main():
         avg_ms = ms_upd / max(n_upd, 1)
         ach_tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
+        # gfx950 rocprofv3 correction + WRITE_SIZE); only quoted for the workload they were taken on
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_update_kernel.json")))
+            if (B, K, T, F) == (128, 32, 862, 1025):
+                traffic = pmc["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         stft_ms = ms_stft / max(n_stft, 1)
         stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
         out = {
@@ -197,9 +206,9 @@ def main():
                        "iterations": iters, "parallelism": f"shard{world}" if world > 1 else "single"},
             "stft_frames_per_s": (T * B) / (stft_ms * 1e-3) if stft_ms > 0 else None,
             "nmf_iterations_per_s_kernel_only": B / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
-            "roofline": {"bound": "mfma", "kernel": "nmf_update_kernel<2,2,2>", "achieved": ach_tflops,
+            "roofline": {"bound": "mfma", "kernel": "nmf_update5_kernel (v_mfma_f64_4x4x4_4b + LDS-DMA)", "achieved": ach_tflops,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": None, "launches": int(n_upd), "avg_launch_ms": avg_ms,
+                         "traffic": traffic, "launches": int(n_upd), "avg_launch_ms": avg_ms,
                          "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": ach_gbs / PEAK_HBM_GBS}},

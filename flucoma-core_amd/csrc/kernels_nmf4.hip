@@ -24,6 +24,7 @@
 // loaded once per step (in the two register distributions above) and reused by every group.
 #include "fluhip_kernels.h"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace fluhip {
@@ -358,10 +359,14 @@ int nmf_update4_waves_per_buffer(int C, int Kp, int B)
   }
   else
   {
-    // few buffers: keep strips wide (operand reuse) and let the contraction split fill the chip;
-    // only when even 32 splits cannot reach one wavefront per SIMD are the strips narrowed
-    const int64_t need = (simds + (int64_t) B * 32 - 1) / ((int64_t) B * 32);
-    if (need > w) w = (int) (need > G ? G : need);
+    const int64_t wfill = (simds + B - 1) / B; // strips per buffer that give every SIMD a wavefront
+    if (wfill <= G / 3 || wfill <= wmin)
+      w = (int) std::max<int64_t>(wmin, wfill);  // fill the chip by narrowing strips (>= 3 groups each)
+    else
+      w = std::max(wmin, G / 3);                 // few buffers: ~3 groups per strip, the contraction
+                                                 // split (nsplit) supplies the rest of the parallelism
+    if (w > G) w = G;
+    if (w < 1) w = 1;
   }
   return w;
 }
