@@ -330,6 +330,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
   a.window = wtab; a.twiddle = ttab;
   a.mag = c->mag.as<double>(); a.magStride = c->Tp * c->Fp; a.ldMag = c->Fp;
   a.spec = c->keepSpec ? c->spec.as<double>() : nullptr; a.specStride = c->T * c->F * 2;
+  a.frameOffset = 0;
   {
     ProfScope p(ctx, 0);
     launch_stft(a, ctx->stream);
@@ -981,6 +982,128 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
     HIPCHK(ctx, hipStreamSynchronize(s));
   }
   return FLUHIP_OK;
+}
+
+// ---- feature pipeline -------------------------------------------------------
+static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64_t count, int64_t n, int64_t win,
+                           int64_t fft, int64_t hop, int64_t nBands, int64_t nCoefs, int64_t startCoeff,
+                           double minFreq, double maxFreq, double sampleRate, int normalize, int scaleDb,
+                           float* out, int64_t* frames_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!audio || !out) return fail(ctx, "null buffer");
+  if (count < 1) return fail(ctx, "need at least one buffer");
+  int rc = check_shape(ctx, n, win, fft, hop, 1);
+  if (rc) return rc;
+  if (nBands < 2 || nBands > fft / 2 + 1) return fail(ctx, "numBands must be in [2, fft/2 + 1]");
+  if (!(maxFreq > minFreq)) return fail(ctx, "maxFreq must be above minFreq");
+  if (mfcc && (nCoefs < 2 || nCoefs > nBands || startCoeff < 0 || startCoeff > 1))
+    return fail(ctx, "numCoeffs must be in [2, numBands] and startCoeff in [0, 1]");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t F = fft / 2 + 1;
+  // StreamingControl bookkeeping (cc/FluidNRTClientWrapper.hpp:564-579, 642-644)
+  const int64_t latencyHops = win / hop;
+  const int64_t T = 1 + (n + win) / hop - latencyHops;
+  const int64_t frameOffset = latencyHops * hop - win;
+  if (T < 1) return fail(ctx, "not enough frames");
+  if (frames_out) *frames_out = T;
+  const int64_t Tp = round_up(T, 32), Fp = round_up(F, 32);
+  const int64_t bandsPad = round_up(nBands, 64);
+  // mel filter bank (alg/MelBands.hpp:53-73), bin-major and zero padded; f64 on the host like the reference
+  std::vector<double> filtT((size_t) F * bandsPad, 0.0);
+  {
+    auto hz2mel = [](double x) { return 1127.01048 * std::log(x / 700.0 + 1.0); };
+    const int64_t nc = nBands + 2;
+    std::vector<double> centres((size_t) nc);
+    const double mlo = hz2mel(minFreq), mhi = hz2mel(maxFreq);
+    for (int64_t i = 0; i < nc; i++)
+      centres[(size_t) i] = 700.0 * (std::exp((mlo + (double) i * (mhi - mlo) / (double) (nc - 1)) / 1127.01048) - 1.0);
+    for (int64_t b = 0; b < nBands; b++)
+    {
+      const double d0 = std::fabs(centres[(size_t) b] - centres[(size_t) b + 1]);
+      const double d1 = std::fabs(centres[(size_t) b + 1] - centres[(size_t) b + 2]);
+      for (int64_t f = 0; f < F; f++)
+      {
+        const double hz = (double) f * (sampleRate / 2.0) / (double) (F - 1);
+        const double lower = -(centres[(size_t) b] - hz) / d0, upper = (centres[(size_t) b + 2] - hz) / d1;
+        filtT[(size_t) (f * bandsPad + b)] = std::max(0.0, std::min(lower, upper));
+      }
+    }
+  }
+  const int64_t nDct = mfcc ? std::min(nCoefs + startCoeff, nBands) : 0; // rt/MFCCClient.hpp:104-105
+  std::vector<double> dct((size_t) std::max<int64_t>(1, nDct * nBands));
+  for (int64_t i = 0; i < nDct; i++) // alg/DCT.hpp:53-61
+  {
+    const double scale = i == 0 ? 1.0 / std::sqrt((double) nBands) : std::sqrt(2.0 / (double) nBands);
+    for (int64_t j = 0; j < nBands; j++)
+      dct[(size_t) (i * nBands + j)] = std::cos((M_PI / (double) nBands) * (double) i * (0.5 + (double) j)) * scale;
+  }
+  const int64_t nOut = mfcc ? nCoefs : nBands;
+  const double *wtab = nullptr, *ttab = nullptr;
+  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
+  if (rc) return rc;
+  rc = get_twiddle(ctx, fft, &ttab);
+  if (rc) return rc;
+  DevBuf dFilt, dDct, dAudio, dMag, dOut;
+  HIPCHK(ctx, dFilt.alloc(filtT.size() * sizeof(double), false, s));
+  HIPCHK(ctx, dDct.alloc(dct.size() * sizeof(double), false, s));
+  HIPCHK(ctx, hipMemcpyAsync(dFilt.p, filtT.data(), filtT.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(dDct.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  // buffers are processed in chunks that keep the magnitude scratch around 2 GiB
+  const int64_t perBuf = Tp * Fp * (int64_t) sizeof(double);
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(count, (2LL << 30) / perBuf));
+  HIPCHK(ctx, dAudio.alloc((size_t) chunk * n * sizeof(float), false, s));
+  HIPCHK(ctx, dMag.alloc((size_t) chunk * perBuf, true, s));
+  HIPCHK(ctx, dOut.alloc((size_t) chunk * nOut * T * sizeof(float), false, s));
+  for (int64_t b0 = 0; b0 < count; b0 += chunk)
+  {
+    const int64_t nb = std::min(chunk, count - b0);
+    HIPCHK(ctx, hipMemcpyAsync(dAudio.p, audio + b0 * n, (size_t) nb * n * sizeof(float), hipMemcpyHostToDevice, s));
+    StftArgs sa;
+    sa.audio = dAudio.as<float>(); sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
+    sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = (int) nb;
+    sa.window = wtab; sa.twiddle = ttab;
+    sa.mag = dMag.as<double>(); sa.magStride = Tp * Fp; sa.ldMag = Fp;
+    sa.spec = nullptr; sa.specStride = 0; sa.frameOffset = (int) frameOffset;
+    {
+      ProfScope p(ctx, 0);
+      launch_stft(sa, s);
+    }
+    FeatArgs fa;
+    fa.mag = dMag.as<double>(); fa.magStride = Tp * Fp; fa.ldMag = Fp;
+    fa.T = (int) T; fa.F = (int) F; fa.B = (int) nb; fa.win = (int) win;
+    fa.filtT = dFilt.as<double>(); fa.nBands = (int) nBands; fa.bandsPad = (int) bandsPad;
+    // rt/MFCCClient.hpp:123-124 (false, false, true); rt/MelBandsClient.hpp:106-108 (normalize, false, scale == dB)
+    fa.magNorm = mfcc ? 0 : (normalize ? 1 : 0); fa.usePower = 0; fa.logOutput = mfcc ? 1 : (scaleDb ? 1 : 0);
+    fa.dct = mfcc ? dDct.as<double>() : nullptr; fa.nDct = (int) nDct; fa.startCoeff = (int) startCoeff;
+    fa.nOut = (int) nOut; fa.out = dOut.as<float>();
+    {
+      ProfScope p(ctx, 2);
+      launch_features(fa, s);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out + b0 * nOut * T, dOut.p, (size_t) nb * nOut * T * sizeof(float),
+                               hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  return FLUHIP_OK;
+}
+
+int fluhip_bufmelbands_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
+                           int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
+                           double sample_rate, int normalize, int scale_db, float* out, int64_t* frames_out)
+{
+  return features_common(ctx, false, audio, count, n, win, fft, hop, n_bands, 0, 0, min_freq, max_freq,
+                         sample_rate, normalize, scale_db, out, frames_out);
+}
+
+int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                       int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
+                       double max_freq, double sample_rate, float* out, int64_t* frames_out)
+{
+  return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
+                         max_freq, sample_rate, 0, 0, out, frames_out);
 }
 
 // ---- profiling ------------------------------------------------------------------------

@@ -40,6 +40,8 @@ struct StftArgs
   int64_t ldMag;        // Fp
   double* spec;         // [B][T][F] interleaved complex, or nullptr
   int64_t specStride;
+  int frameOffset;      // extra sample offset of frame 0 (0 for STFT::process; the buffered feature
+                        // clients start (win/hop)*hop - win earlier when hop does not divide win)
 };
 
 void launch_stft(const StftArgs& a, hipStream_t s);
@@ -109,6 +111,22 @@ void launch_vhat(const double* Wf, int64_t strideW, const double* H1, int64_t st
 // dst[b][t][f] (ld) = src[b][t*ldsrc + f] : strided host-layout copy into the padded layout
 void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
                      int64_t lddst, int64_t strideDst, int rows, int cols, int B, hipStream_t s);
+
+// MelBands / MFCC over magnitudes
+struct FeatArgs
+{
+  const double* mag;    // [B][*][ldMag]
+  int64_t magStride, ldMag;
+  int T, F, B, win;
+  const double* filtT;  // [F][bandsPad], bin-major mel filter bank, zero padded
+  int nBands, bandsPad;
+  int magNorm, usePower, logOutput;
+  const double* dct;    // [nDct][nBands] or nullptr (MelBands output)
+  int nDct, startCoeff;
+  int nOut;             // features per frame written (nBands, or nCoefs)
+  float* out;           // [B][nOut][T]
+};
+void launch_features(const FeatArgs& a, hipStream_t s);
 
 // resynthesis: masked inverse STFT of component k with overlap-add
 struct ResynthArgs

@@ -39,6 +39,7 @@ struct StftKArgs
   double* spec;
   int64_t specStride;
   int winInLds, twInLds;
+  int frameOffset;
   int64_t totalFrames;
 };
 
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void stft_r2c_mag_kernel(StftKArgs a)
   for (int64_t frame = blockIdx.x; frame < a.totalFrames; frame += gridDim.x)
   {
     const int b = (int) (frame / a.T), t = (int) (frame % a.T);
-    const int64_t s0 = (int64_t) t * a.hop - halfWin; // first sample of the frame
+    const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset; // first sample of the frame
     // ---- 1. gather + window (alg/STFT.hpp:94-97,104-105; clients/nrt/NMFClient.hpp:240) ----
     for (int m = tid; m < nc; m += nt)
     {
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
   // raw samples of one frame, two per point; out-of-range samples read as zero
   auto gather = [&](int64_t frame, float2 (&raw)[PPL]) {
     const int b = (int) (frame / a.T), t = (int) (frame % a.T);
-    const int64_t s0 = (int64_t) t * a.hop - halfWin;
+    const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset;
     const float* src = a.audio + (int64_t) b * a.audioStride;
     const int64_t last = a.n - 1;
 #pragma unroll
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
   };
   auto gather64 = [&](int64_t frame, d2 (&pts)[PPL]) {
     const int b = (int) (frame / a.T), t = (int) (frame % a.T);
-    const int64_t s0 = (int64_t) t * a.hop - halfWin;
+    const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset;
     const double* src = a.audio64 + (int64_t) b * a.audioStride;
     const int64_t last = a.n - 1;
 #pragma unroll
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
     {
       // straight into the pass-1 registers.  All loads are unconditional (clamped address, value
       // selected afterwards) so the whole frame's samples are in flight together.
-      const int64_t s0 = (int64_t) t * a.hop - halfWin;
+      const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset;
       const float* src = a.audio + (int64_t) b * a.audioStride;
       const bool inside = s0 >= 0 && s0 + 2 * N <= a.n;                      // wave-uniform
       const bool aligned = inside && ((reinterpret_cast<uintptr_t>(src + s0) & 7) == 0);
@@ -498,6 +499,7 @@ void launch_stft(const StftArgs& a, hipStream_t s)
   k.window = a.window; k.twiddle = a.twiddle;
   k.mag = a.mag; k.magStride = a.magStride; k.ldMag = a.ldMag;
   k.spec = a.spec; k.specStride = a.specStride;
+  k.frameOffset = a.frameOffset;
   k.totalFrames = (int64_t) a.B * a.T;
   k.twInLds = 1; k.winInLds = 0;
   {

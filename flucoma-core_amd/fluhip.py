@@ -26,7 +26,8 @@ EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
-    "fluhip_nmf_process_f64", "fluhip_bufnmf_channel_f32", "fluhip_corpus_create",
+    "fluhip_nmf_process_f64", "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
+    "fluhip_corpus_create",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
@@ -70,6 +71,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_bufnmf_channel_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                             ctypes.c_int, ctypes.c_int, _i64, _fp, _fp, _fp, _fp,
                                             _fp, PROGRESS_FN, _vp]
+    _dbl = ctypes.c_double
+    L.fluhip_bufmelbands_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                         ctypes.c_int, ctypes.c_int, _fp, _ip]
+    L.fluhip_bufmfcc_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                     _fp, _ip]
     L.fluhip_corpus_create.argtypes = [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
     L.fluhip_corpus_destroy.argtypes = [_vp]
     L.fluhip_corpus_destroy.restype = None
@@ -199,6 +205,35 @@ class Context:
         if resynth:
             return bases, acts, res, rc
         return bases, acts, rc
+
+    # ---- feature pipeline -----------------------------------------------------------------
+    @staticmethod
+    def feature_frames(n, win, hop):
+        return 1 + (n + win) // hop - win // hop
+
+    def bufmfcc(self, audio, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0,
+                sr=44100.0):
+        audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        count, n = audio.shape
+        T = self.feature_frames(n, win, hop)
+        out = np.empty((count, n_coefs, T), dtype=np.float32)
+        Tr = _i64(0)
+        self._check(self.lib.fluhip_bufmfcc_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, n_coefs,
+                                                start_coeff, lo, hi, sr, _f(out), ctypes.byref(Tr)))
+        assert Tr.value == T
+        return out
+
+    def bufmelbands(self, audio, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0, normalize=True,
+                    scale_db=False):
+        audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        count, n = audio.shape
+        T = self.feature_frames(n, win, hop)
+        out = np.empty((count, n_bands, T), dtype=np.float32)
+        Tr = _i64(0)
+        self._check(self.lib.fluhip_bufmelbands_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr,
+                                                    int(normalize), int(scale_db), _f(out), ctypes.byref(Tr)))
+        assert Tr.value == T
+        return out
 
     # ---- profiling ----------------------------------------------------------------------
     def prof_enable(self, on=True):

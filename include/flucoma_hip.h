@@ -119,6 +119,22 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
                               const float* acts_seed, float* bases_out, float* acts_out,
                               float* resynth_out, fluhip_progress_fn progress, void* user);
 
+/* ---- feature pipeline: BufMelBands / BufMFCC (BASELINE config 5) ------------------------------ */
+/* Replaces, for `count` equal-length mono buffers at once, the offline-wrapped real-time clients
+ *   NRTThreadedMelBandsClient  clients/rt/MelBandsClient.hpp:77-119  (MelBands::processFrame, alg/MelBands.hpp:79-97)
+ *   NRTThreadedMFCCClient      clients/rt/MFCCClient.hpp:86-131      (+ DCT::processFrame, alg/DCT.hpp:65-75)
+ * as driven by StreamingControl with the default padding (clients/common/FluidNRTClientWrapper.hpp:551-660):
+ * T = 1 + (n + win)/hop - win/hop frames, frame k starting at sample (win/hop)*hop - win - win/2 + k*hop
+ * (for hop | win: [k*hop - win/2, k*hop + win/2), T = n/hop + 1).
+ * audio: count x n host floats.  out: count x nFeatures x T host floats, feature-major per buffer like
+ * BufferAdaptor::samps(feature).  window: Hann (the clients pass no window type). */
+int fluhip_bufmelbands_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
+                           int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
+                           double sample_rate, int normalize, int scale_db, float* out, int64_t* frames_out);
+int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                       int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
+                       double max_freq, double sample_rate, float* out, int64_t* frames_out);
+
 /* ---- corpus: many independent equal-shape buffers, resident in HBM --------------------- */
 /* The data-parallel form of the same path (BASELINE config 4): `count` mono buffers of n
  * samples each; every buffer is an independent BufNMF job (clients/nrt/NMFClient.hpp:233 loop

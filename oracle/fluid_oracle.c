@@ -517,3 +517,185 @@ void fo_resynth_component(const double* spec, const double* W1, const double* H1
   }
   free(acc); free(nrm); free(w); free(re); free(im); free(twr); free(twi);
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* MelBands / DCT / MFCC                                                   */
+/* ------------------------------------------------------------------------------------ */
+
+static double hz2mel(double x) { return 1127.01048 * log(x / 700.0 + 1.0); } /* alg/MelBands.hpp:37-40 */
+
+void fo_mel_filters(double lo, double hi, int64_t nBands, int64_t nBins, double sampleRate, double* filt)
+{
+  /* alg/MelBands.hpp:53-73 */
+  const int64_t nc = nBands + 2;
+  double* centres = (double*) malloc((size_t) nc * sizeof(double));
+  const double mlo = hz2mel(lo), mhi = hz2mel(hi);
+  for (int64_t i = 0; i < nc; i++)
+  {
+    const double m = mlo + (double) i * (mhi - mlo) / (double) (nc - 1); /* LinSpaced */
+    centres[i] = 700.0 * (exp(m / 1127.01048) - 1.0);
+  }
+  for (int64_t b = 0; b < nBands; b++)
+  {
+    const double d0 = fabs(centres[b] - centres[b + 1]), d1 = fabs(centres[b + 1] - centres[b + 2]);
+    for (int64_t f = 0; f < nBins; f++)
+    {
+      const double hz = (double) f * (sampleRate / 2.0) / (double) (nBins - 1); /* LinSpaced(nBins, 0, sr/2) */
+      const double lower = -(centres[b] - hz) / d0;
+      const double upper = (centres[b + 2] - hz) / d1;
+      double v = lower < upper ? lower : upper;
+      filt[b * nBins + f] = v > 0 ? v : 0;
+    }
+  }
+  free(centres);
+}
+
+void fo_dct_table(int64_t nIn, int64_t nOut, double* table)
+{
+  /* alg/DCT.hpp:53-61 */
+  for (int64_t i = 0; i < nOut; i++)
+  {
+    const double scale = i == 0 ? 1.0 / sqrt((double) nIn) : sqrt(2.0 / (double) nIn);
+    for (int64_t j = 0; j < nIn; j++)
+    {
+      const double x = 0.5 + (double) j * ((double) nIn - 1.0) / (double) (nIn > 1 ? nIn - 1 : 1); /* LinSpaced(n, .5, n-.5) */
+      table[i * nIn + j] = cos((M_PI / (double) nIn) * (double) i * x) * scale;
+    }
+  }
+}
+
+void fo_melbands(const double* mag, int64_t T, int64_t F, const double* filt, int64_t nBands, int64_t win,
+                 int magNorm, int usePower, int logOutput, double* out)
+{
+  const double eps = FO_EPSILON;
+  const double scale1 = 1.0 / ((double) win / 4.0);                 /* alg/MelBands.hpp:49 */
+  const int64_t fftSize = 2 * (F - 1);
+  const double scale2 = 1.0 / (2.0 * (double) fftSize / (double) win); /* :52 */
+  double* frame = (double*) malloc((size_t) F * sizeof(double));
+  for (int64_t t = 0; t < T; t++)
+  {
+    double energy = 0;
+    for (int64_t f = 0; f < F; f++)
+    {
+      double x = mag[t * F + f];
+      if (magNorm) x = x * scale1;   /* :86 */
+      energy += x;
+      frame[f] = x;
+    }
+    energy *= scale2;                /* :87 */
+    if (usePower)
+      for (int64_t f = 0; f < F; f++) frame[f] = frame[f] * frame[f];
+    double sum = 0;
+    for (int64_t b = 0; b < nBands; b++)
+    {
+      double s = 0;
+      for (int64_t f = 0; f < F; f++) s += filt[b * F + f] * frame[f]; /* :90-91 */
+      out[t * nBands + b] = s;
+      sum += s;
+    }
+    if (magNorm)
+    {
+      const double d = sum > eps ? sum : eps; /* :93 */
+      for (int64_t b = 0; b < nBands; b++) out[t * nBands + b] = out[t * nBands + b] * energy / d;
+    }
+    if (logOutput)
+      for (int64_t b = 0; b < nBands; b++)
+      {
+        const double v = out[t * nBands + b] > eps ? out[t * nBands + b] : eps;
+        out[t * nBands + b] = 20 * log10(v); /* :95 */
+      }
+  }
+  free(frame);
+}
+
+/* StreamingControl framing (cc/FluidNRTClientWrapper.hpp:564-579, 642-644; cc/FluidSource.hpp:68-90):
+ * padded = [win/2 zeros][audio][...], analysis frame j sees padded[j*hop - win, j*hop), the first
+ * win/hop frames are dropped.  Kept frame k starts at audio sample start0 + k*hop. */
+static int64_t feature_frames(int64_t n, int64_t win, int64_t hop, int64_t* start0)
+{
+  const int64_t nAnalysis = 1 + (n + win) / hop;
+  const int64_t latencyHops = win / hop;
+  *start0 = latencyHops * hop - win - win / 2;
+  return nAnalysis - latencyHops;
+}
+
+static void framed_magnitude(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t T,
+                             int64_t start0, double* mag)
+{
+  /* same window/FFT/magnitude as fo_stft (STFT::processFrame + magnitude), different bookkeeping */
+  const int64_t F = fft / 2 + 1;
+  double* w = (double*) malloc((size_t) win * sizeof(double));
+  double* re = (double*) malloc((size_t) fft * sizeof(double));
+  double* im = (double*) malloc((size_t) fft * sizeof(double));
+  double* twr = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  double* twi = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  fo_window_hann(win, w);
+  for (int64_t k = 0; k < fft / 2; k++)
+  {
+    twr[k] = cos(-2.0 * M_PI * (double) k / (double) fft);
+    twi[k] = sin(-2.0 * M_PI * (double) k / (double) fft);
+  }
+  for (int64_t t = 0; t < T; t++)
+  {
+    for (int64_t i = 0; i < fft; i++)
+    {
+      const int64_t p = start0 + t * hop + i;
+      re[i] = (i < win && p >= 0 && p < n) ? (double) audio[p] * w[i] : 0.0;
+      im[i] = 0;
+    }
+    fft_c2c(re, im, fft, twr, twi);
+    for (int64_t k = 0; k < F; k++)
+    {
+      const double xi = (k == 0 || k == F - 1) ? 0 : im[k];
+      mag[t * F + k] = hypot(re[k], xi);
+    }
+  }
+  free(w); free(re); free(im); free(twr); free(twi);
+}
+
+int64_t fo_bufmelbands_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                               int64_t nBands, double minFreq, double maxFreq, double sampleRate,
+                               int normalize, int scaleDb, float* out)
+{
+  int64_t start0;
+  const int64_t F = fft / 2 + 1, T = feature_frames(n, win, hop, &start0);
+  double* mag = (double*) malloc((size_t) (T * F) * sizeof(double));
+  double* filt = (double*) malloc((size_t) (nBands * F) * sizeof(double));
+  double* bands = (double*) malloc((size_t) (T * nBands) * sizeof(double));
+  framed_magnitude(audio, n, win, fft, hop, T, start0, mag);
+  fo_mel_filters(minFreq, maxFreq, nBands, F, sampleRate, filt);
+  /* rt/MelBandsClient.hpp:106-108: magNorm = normalize, usePower = false, logOutput = (scale == dB) */
+  fo_melbands(mag, T, F, filt, nBands, win, normalize, 0, scaleDb, bands);
+  for (int64_t b = 0; b < nBands; b++)
+    for (int64_t t = 0; t < T; t++) out[b * T + t] = (float) bands[t * nBands + b];
+  free(mag); free(filt); free(bands);
+  return T;
+}
+
+int64_t fo_bufmfcc_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t nBands,
+                           int64_t nCoefs, int64_t startCoeff, double minFreq, double maxFreq,
+                           double sampleRate, float* out)
+{
+  int64_t start0;
+  const int64_t F = fft / 2 + 1, T = feature_frames(n, win, hop, &start0);
+  /* rt/MFCCClient.hpp:104-105: DCT(nBands -> min(nCoefs + startCoeff, nBands)) */
+  const int64_t nOut = nCoefs + startCoeff < nBands ? nCoefs + startCoeff : nBands;
+  double* mag = (double*) malloc((size_t) (T * F) * sizeof(double));
+  double* filt = (double*) malloc((size_t) (nBands * F) * sizeof(double));
+  double* bands = (double*) malloc((size_t) (T * nBands) * sizeof(double));
+  double* dct = (double*) malloc((size_t) (nOut * nBands) * sizeof(double));
+  framed_magnitude(audio, n, win, fft, hop, T, start0, mag);
+  fo_mel_filters(minFreq, maxFreq, nBands, F, sampleRate, filt);
+  fo_dct_table(nBands, nOut, dct);
+  fo_melbands(mag, T, F, filt, nBands, win, 0, 0, 1, bands); /* :123-124: magNorm false, power false, log true */
+  for (int64_t t = 0; t < T; t++)
+    for (int64_t i = 0; i < nCoefs; i++)
+    {
+      double s = 0;
+      if (startCoeff + i < nOut)
+        for (int64_t b = 0; b < nBands; b++) s += dct[(startCoeff + i) * nBands + b] * bands[t * nBands + b]; /* alg/DCT.hpp:73-75 */
+      out[i * T + t] = (float) s; /* :129 output = coefficients[startCoeff : startCoeff + nCoefs] */
+    }
+  free(mag); free(filt); free(bands); free(dct);
+  return T;
+}

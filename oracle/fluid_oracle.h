@@ -87,6 +87,29 @@ void fo_resynth_component(const double* spec, const double* W1, const double* H1
                           const double* V1, int64_t T, int64_t F, int64_t K, int64_t k,
                           int64_t win, int64_t fft, int64_t hop, int64_t n, double* out);
 
+/* ---- "next" rows: MelBands / MFCC feature pipeline --------------------------- */
+/* alg/MelBands.hpp:41-77 init(): triangular filters on linear-Hz FFT bins between mel-spaced
+ * centres.  filt: nBands x nBins row-major. */
+void fo_mel_filters(double lo, double hi, int64_t nBands, int64_t nBins, double sampleRate, double* filt);
+/* alg/DCT.hpp:36-63 init(): orthonormal DCT-II table, nOut x nIn row-major. */
+void fo_dct_table(int64_t nIn, int64_t nOut, double* table);
+/* alg/MelBands.hpp:79-97 processFrame() over every row of mag (T x F, modified like the reference
+ * modifies its input when magNorm is set): out T x nBands. */
+void fo_melbands(const double* mag, int64_t T, int64_t F, const double* filt, int64_t nBands, int64_t win,
+                 int magNorm, int usePower, int logOutput, double* out);
+/* BufMFCC on one channel with the default padding mode (rt/MFCCClient.hpp:86-131 driven by
+ * StreamingControl, cc/FluidNRTClientWrapper.hpp:551-660): kept frame k starts at audio sample
+ * (win/hop)*hop - win - win/2 + k*hop; T = 1 + (n + win)/hop - win/hop.  For hop | win that is the
+ * framing of fo_stft: [k*hop - win/2, k*hop + win/2), T = n/hop + 1.
+ * out: nCoefs x T floats (channel-major like BufferAdaptor::samps(i)).  Returns T. */
+int64_t fo_bufmfcc_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t nBands,
+                           int64_t nCoefs, int64_t startCoeff, double minFreq, double maxFreq,
+                           double sampleRate, float* out);
+/* BufMelBands on one channel (rt/MelBandsClient.hpp:77-119): out nBands x T floats. */
+int64_t fo_bufmelbands_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                               int64_t nBands, double minFreq, double maxFreq, double sampleRate,
+                               int normalize, int scaleDb, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,14 @@ class Oracle:
         L.fo_bufnmf_channel.restype = _i64
         L.fo_resynth_component.argtypes = [_dp, _dp, _dp, _dp, _i64, _i64, _i64, _i64, _i64,
                                            _i64, _i64, _i64, _dp]
+        _dbl = ctypes.c_double
+        L.fo_mel_filters.argtypes = [_dbl, _dbl, _i64, _i64, _dbl, _dp]
+        L.fo_dct_table.argtypes = [_i64, _i64, _dp]
+        L.fo_bufmfcc_channel.argtypes = [_fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl, _fp]
+        L.fo_bufmfcc_channel.restype = _i64
+        L.fo_bufmelbands_channel.argtypes = [_fp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                             ctypes.c_int, ctypes.c_int, _fp]
+        L.fo_bufmelbands_channel.restype = _i64
 
     # ---- wrappers returning numpy arrays ------------------------------------------------
     def hann(self, win):
@@ -169,6 +177,41 @@ class Oracle:
                                       _d(np.ascontiguousarray(H1)),
                                       _d(np.ascontiguousarray(V1)), T, F, K, k, win, fft, hop, n,
                                       _d(out))
+        return out
+
+
+    def _feature_T(self, n, win, hop):
+        return 1 + (n + win) // hop - win // hop
+
+    def mel_filters(self, lo, hi, n_bands, n_bins, sr):
+        f = np.empty((n_bands, n_bins))
+        self.lib.fo_mel_filters(lo, hi, n_bands, n_bins, sr, _d(f))
+        return f
+
+    def dct_table(self, n_in, n_out):
+        t = np.empty((n_out, n_in))
+        self.lib.fo_dct_table(n_in, n_out, _d(t))
+        return t
+
+    def bufmfcc_channel(self, audio, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0,
+                        hi=20000.0, sr=44100.0):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = audio.shape[0]
+        T = self._feature_T(n, win, hop)
+        out = np.empty((n_coefs, T), dtype=np.float32)
+        Tr = self.lib.fo_bufmfcc_channel(_f(audio), n, win, fft, hop, n_bands, n_coefs, start_coeff, lo, hi, sr, _f(out))
+        assert Tr == T
+        return out
+
+    def bufmelbands_channel(self, audio, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0,
+                            normalize=True, scale_db=False):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = audio.shape[0]
+        T = self._feature_T(n, win, hop)
+        out = np.empty((n_bands, T), dtype=np.float32)
+        Tr = self.lib.fo_bufmelbands_channel(_f(audio), n, win, fft, hop, n_bands, lo, hi, sr, int(normalize),
+                                             int(scale_db), _f(out))
+        assert Tr == T
         return out
 
 

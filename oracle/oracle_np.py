@@ -232,3 +232,81 @@ def drum_like(n, seed=7):
     x /= np.abs(x).max() * 1.05
     # 16-bit quantisation like the WAV it stands in for
     return (np.round(x * 32767.0) / 32768.0).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# MelBands / DCT / MFCC: alg/MelBands.hpp:36-97, alg/DCT.hpp:36-75,
+# rt/MFCCClient.hpp:86-131, rt/MelBandsClient.hpp:77-119, StreamingControl framing
+# (cc/FluidNRTClientWrapper.hpp:551-660)
+# --------------------------------------------------------------------------------------
+def feature_frames(n: int, win: int, hop: int):
+    """(T, first-sample offset of frame 0) of the buffered feature clients with default padding:
+    nAnalysisFrames = 1 + (n + 2 win - win) // hop, minus win // hop latency frames; analysis frame j
+    sees padded[j hop - win, j hop), audio sits at padded[win // 2 :]."""
+    n_analysis = 1 + (n + win) // hop
+    latency_hops = win // hop
+    T = n_analysis - latency_hops
+    start0 = latency_hops * hop - win - win // 2
+    return T, start0
+
+
+def framed_magnitude(audio, win, fft, hop):
+    audio = np.asarray(audio, dtype=np.float64)
+    n = audio.shape[0]
+    T, start0 = feature_frames(n, win, hop)
+    w = hann(win)
+    idx = start0 + np.arange(T)[:, None] * hop + np.arange(win)[None, :]
+    ok = (idx >= 0) & (idx < n)
+    frames = np.where(ok, audio[np.clip(idx, 0, n - 1)], 0.0) * w[None, :]
+    return np.abs(np.fft.rfft(frames, n=fft, axis=1))
+
+
+def mel_filters(lo, hi, n_bands, n_bins, sr):
+    mel = lambda x: 1127.01048 * np.log(x / 700.0 + 1.0)
+    centres = 700.0 * (np.exp(np.linspace(mel(lo), mel(hi), n_bands + 2) / 1127.01048) - 1.0)
+    hz = np.linspace(0.0, sr / 2.0, n_bins)
+    d = np.abs(centres[:-1] - centres[1:])
+    lower = (hz[None, :] - centres[:n_bands, None]) / d[:n_bands, None]
+    upper = (centres[2:, None] - hz[None, :]) / d[1:, None]
+    return np.maximum(0.0, np.minimum(lower, upper))
+
+
+def dct_table(n_in, n_out):
+    i = np.arange(n_out)[:, None]
+    j = np.linspace(0.5, n_in - 0.5, n_in)[None, :]
+    scale = np.where(i == 0, 1.0 / np.sqrt(n_in), np.sqrt(2.0 / n_in))
+    return np.cos((np.pi / n_in) * i * j) * scale
+
+
+def melbands(mag, filt, win, mag_norm, use_power, log_output):
+    F = mag.shape[1]
+    frame = mag * (1.0 / (win / 4.0)) if mag_norm else mag
+    energy = frame.sum(axis=1) * (1.0 / (2.0 * (2 * (F - 1)) / win))
+    if use_power:
+        frame = frame * frame
+    out = frame @ filt.T
+    if mag_norm:
+        out = out * energy[:, None] / np.maximum(EPS, out.sum(axis=1))[:, None]
+    if log_output:
+        out = 20.0 * np.log10(np.maximum(out, EPS))
+    return out
+
+
+def bufmelbands_channel(audio_f32, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0,
+                        normalize=True, scale_db=False):
+    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop)
+    filt = mel_filters(lo, hi, n_bands, fft // 2 + 1, sr)
+    return melbands(mag, filt, win, normalize, False, scale_db).T.astype(np.float32)
+
+
+def bufmfcc_channel(audio_f32, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0,
+                    sr=44100.0):
+    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop)
+    filt = mel_filters(lo, hi, n_bands, fft // 2 + 1, sr)
+    bands = melbands(mag, filt, win, False, False, True)
+    n_out = min(n_coefs + start_coeff, n_bands)
+    coefs = bands @ dct_table(n_bands, n_out).T
+    out = np.zeros((mag.shape[0], n_coefs))
+    take = max(0, min(n_coefs, n_out - start_coeff))
+    out[:, :take] = coefs[:, start_coeff:start_coeff + take]
+    return out.T.astype(np.float32)

@@ -365,3 +365,50 @@ def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
         total += res[k]
     # soft masks sum to ~1: the components add back up to the input (away from the edges)
     assert np.abs(total[win:-win] - x[win:-win]).max() < 0.02
+
+
+# ---------------------------------------------------------------------------------------
+# feature pipeline (BASELINE config 5): BufMelBands / BufMFCC
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,win,fft,hop", [(88200, 1024, 1024, 512),   # config 5 slice: 173 frames
+                                           (30000, 1024, 2048, 256), (20000, 2048, 2048, 512),
+                                           (12345, 1000, 1024, 300),    # hop does not divide win
+                                           (5000, 256, 256, 64)])
+def test_bufmfcc_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
+    audio = np.stack([onp.synth_audio(n, 7000 + b) for b in range(3)])
+    got = ctx.bufmfcc(audio, win, fft, hop)
+    assert got.shape == (3, 13, 1 + (n + win) // hop - win // hop)
+    if (n, win, hop) == (88200, 1024, 512):
+        assert got.shape[2] == 173
+    for b in range(3):
+        ref = oracle.bufmfcc_channel(audio[b], win, fft, hop)
+        # dB-scaled cepstra of magnitude O(100): absolute agreement far below audible resolution
+        assert np.abs(got[b] - ref).max() < 2e-3, np.abs(got[b] - ref).max()
+        assert np.abs(got[b] - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_bufmfcc_options(ctx, oracle, onp):
+    x = onp.synth_audio(40000, 99)
+    for (nb, nc, sc) in ((40, 13, 1), (20, 20, 0), (64, 5, 0), (100, 13, 1)):
+        got = ctx.bufmfcc(x, 1024, 1024, 512, n_bands=nb, n_coefs=nc, start_coeff=sc, lo=50.0, hi=12000.0)[0]
+        ref = oracle.bufmfcc_channel(x, 1024, 1024, 512, n_bands=nb, n_coefs=nc, start_coeff=sc, lo=50.0, hi=12000.0)
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("normalize,scale_db", [(True, False), (False, False), (False, True), (True, True)])
+def test_bufmelbands_vs_oracle(ctx, oracle, onp, normalize, scale_db):
+    audio = np.stack([onp.synth_audio(30000, 8000 + b) for b in range(2)])
+    got = ctx.bufmelbands(audio, 1024, 1024, 512, normalize=normalize, scale_db=scale_db)
+    for b in range(2):
+        ref = oracle.bufmelbands_channel(audio[b], 1024, 1024, 512, normalize=normalize, scale_db=scale_db)
+        if scale_db:
+            assert np.abs(got[b] - ref).max() < 2e-3
+        else:
+            assert np.abs(got[b] - ref).max() / np.abs(ref).max() < 1e-5
+
+
+def test_bufmfcc_batch_matches_single(ctx, onp):
+    audio = np.stack([onp.synth_audio(22050, 9000 + b) for b in range(5)])
+    batch = ctx.bufmfcc(audio, 1024, 1024, 512)
+    for b in (0, 3, 4):
+        assert np.array_equal(batch[b], ctx.bufmfcc(audio[b], 1024, 1024, 512)[0])
