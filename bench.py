@@ -74,6 +74,15 @@ def cpu_baseline(audio_one, wl, budget_s):
     t0 = time.perf_counter()
     o.nmf_process(mag, wl["rank"], iters, True, True, wl["seed"], faithful=True)
     t_nmf = time.perf_counter() - t0
+    # the reference's shipped Linux default is -msse4 (script/flucoma_simdcmd.cmake:20-22): short probe
+    sse4_rate = None
+    try:
+        o4 = oracle_c.get("sse4")
+        t0 = time.perf_counter()
+        o4.nmf_process(mag, wl["rank"], 3, True, True, wl["seed"], faithful=True)
+        sse4_rate = 3 / (time.perf_counter() - t0)
+    except Exception:
+        pass
     executed_flop = 14.0 * F * T * wl["rank"] * iters
     cpu_model = "unknown"
     try:
@@ -88,6 +97,7 @@ def cpu_baseline(audio_one, wl, budget_s):
         "sample": f"1 buffer ({n} samples, T={T}, F={F}), rank {wl['rank']}, {iters} of {wl['iters']} "
                   f"iterations, oracle faithful mode (7 GEMMs/iter like alg/NMF.hpp), gcc -O3 -march=native",
         "stft_frames_per_s": T / t_stft,
+        "value_sse4_build": sse4_rate,
         "executed_gflops": executed_flop / t_nmf / 1e9,
         "bufnmf_wall_s_200iter_est": t_stft + t_nmf / iters * wl["iters"],
         "cpu_model": cpu_model, "host_cores_available": os.cpu_count(),
@@ -111,10 +121,21 @@ def main():
     import torch
     import torch.distributed as dist
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # FLUHIP_BENCH_BACKEND=gloo is a debugging aid: it lets the N > 1 control flow run on a box with
+    # fewer GPUs than ranks (ranks share devices, the gather goes through host memory).  The driver's
+    # runs use the default: one rank per GPU, RCCL.
+    backend = os.environ.get("FLUHIP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "gloo":
+        local = local % ndev
+    assert local < ndev, f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPUs visible"
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import fluhip
     import oracle_np
@@ -142,8 +163,9 @@ def main():
         corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
         ctx.synchronize()
         if world > 1:  # the one collective of the path: final dictionary/activation gather (RCCL)
-            gathered["bases"] = sharding.gather_results(bases, dist, world)
-            gathered["acts"] = sharding.gather_results(acts, dist, world)
+            src_b, src_a = (bases, acts) if backend == "nccl" else (bases.cpu(), acts.cpu())
+            gathered["bases"] = sharding.gather_results(src_b, dist, world)
+            gathered["acts"] = sharding.gather_results(src_a, dist, world)
 
     def fence():
         if world > 1:
@@ -165,7 +187,7 @@ def main():
     n_stft, ms_stft = ctx.prof_read(0)
     ctx.prof_enable(False)
 
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
@@ -195,8 +217,8 @@ def main():
         stft_ms = ms_stft / max(n_stft, 1)
         stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
         out = {
-            "metric": "NMF iterations/sec (buffer-iterations over the whole BufNMF job: STFT + 200-iter "
-                      "KL-NMF + write-back), rank-32 fft2048",
+            "metric": f"NMF iterations/sec (buffer-iterations over the whole BufNMF job: STFT + {iters}-iter "
+                      f"KL-NMF + write-back), rank-{K} fft{wl['fft']}",
             "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -23,7 +23,7 @@ CONFIGS = {
 
 
 def main():
-    names = sys.argv[1:] or ["c1", "c2", "c4x1"]
+    names = [a for a in sys.argv[1:] if a != "c5"] or ([] if "c5" in sys.argv[1:] else ["c1", "c2", "c4x1"])
     ctx = fluhip.Context(0)
     for name in names:
         c = CONFIGS[name]
@@ -46,3 +46,26 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def config5():
+    """BASELINE config 5: STFT -> MelBands(40) -> MFCC(13) over 8192 x 2 s slices (host buffers in/out)."""
+    import oracle_c
+    ctx = fluhip.Context(0)
+    count, n = 8192, 88200
+    base = np.stack([oracle_np.synth_audio(n, 1000 + b) for b in range(64)])
+    audio = np.tile(base, (count // 64, 1))
+    ctx.bufmfcc(audio[:64], 1024, 1024, 512)
+    t0 = time.perf_counter(); out = ctx.bufmfcc(audio, 1024, 1024, 512); dt = time.perf_counter() - t0
+    frames = out.shape[0] * out.shape[2]
+    o = oracle_c.get("native")
+    t0 = time.perf_counter()
+    for b in range(8):
+        o.bufmfcc_channel(audio[b], 1024, 1024, 512)
+    cpu = (time.perf_counter() - t0) / 8
+    print(f"c5: {count} slices x {out.shape[2]} frames: {dt*1e3:.1f} ms incl. PCIe ({frames/dt/1e6:.1f} Mframes/s); "
+          f"CPU oracle {cpu*1e3:.2f} ms per slice ({out.shape[2]/cpu/1e3:.1f} kframes/s, 1 core) -> {cpu*count/dt:.0f}x")
+
+
+if __name__ == "__main__" and "c5" in sys.argv[1:]:
+    config5()
