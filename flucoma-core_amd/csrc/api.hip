@@ -650,6 +650,7 @@ int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win,
   if (!ctx || !out) return FLUHIP_ERROR;
   *out = nullptr;
   if (count < 1) return fail(ctx, "corpus must hold at least one buffer");
+  if (count > 65535) return fail(ctx, "a corpus holds at most 65535 buffers (split larger corpora into several)");
   int rc = check_shape(ctx, n, win, fft, hop, K);
   if (rc) return rc;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -971,6 +972,7 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
     ra.Vhat = vhat.as<double>(); ra.ldV = c.F; ra.Kp = (int) c.Kp;
     ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) c.T; ra.F = (int) c.F;
     ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = n;
+    ra.trim = win / 2;
     for (int64_t k = 0; k < K; k++)
     {
       ra.k = (int) k;
@@ -981,6 +983,103 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
     HIPCHK(ctx, hipMemcpyAsync(resynth_out, out32.p, (size_t) K * n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
   }
+  return FLUHIP_OK;
+}
+
+// ---- BufSTFT ------------------------------------------------------------------
+static int64_t bufstft_padding(int64_t win, int64_t hop, int mode)
+{
+  return mode == 0 ? 0 : (mode == 1 ? win >> 1 : win - hop); // cc/ParameterTypes.hpp:315-323
+}
+
+int fluhip_bufstft_forward_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                               int64_t fft, int64_t hop, int padding_mode, float* mag, float* phase,
+                               int64_t* hops_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!audio) return fail(ctx, "No input buffer supplied");
+  if (!mag && !phase) return fail(ctx, "Neither magnitude nor phase buffer supplied");
+  if (padding_mode < 0 || padding_mode > 2) return fail(ctx, "padding mode must be 0, 1 or 2");
+  if (stride < 1) return fail(ctx, "stride must be >= 1");
+  int rc = check_shape(ctx, n, win, fft, hop, 1);
+  if (rc) return rc;
+  if (fft / 2 + 1 >= 65536) // nrt/BufSTFTClient.hpp:135-138
+    return fail(ctx, "Can produce up to 65536 channels. Split your data up and try again");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t F = fft / 2 + 1, pad = bufstft_padding(win, hop, padding_mode);
+  int64_t padded = n + 2 * pad;                                      // :121-124
+  if (padding_mode == 2) padded = ((padded + hop - 1) / hop) * hop;   // :125-127
+  if (padded < win) return fail(ctx, "not enough frames");
+  const int64_t T = 1 + (padded - win) / hop;                         // :129-130
+  if (hops_out) *hops_out = T;
+  const double *wtab = nullptr, *ttab = nullptr;
+  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
+  if (rc) return rc;
+  rc = get_twiddle(ctx, fft, &ttab);
+  if (rc) return rc;
+  DevBuf in, spec, dm, dp;
+  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
+  HIPCHK(ctx, hipMemcpy2DAsync(in.p, sizeof(float), audio, (size_t) stride * sizeof(float), sizeof(float),
+                               (size_t) n, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, spec.alloc((size_t) T * F * 2 * sizeof(double), false, s));
+  if (mag) HIPCHK(ctx, dm.alloc((size_t) T * F * sizeof(float), false, s));
+  if (phase) HIPCHK(ctx, dp.alloc((size_t) T * F * sizeof(float), false, s));
+  StftArgs sa;
+  sa.audio = in.as<float>(); sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
+  sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = 1;
+  sa.window = wtab; sa.twiddle = ttab; sa.mag = nullptr; sa.magStride = 0; sa.ldMag = 0;
+  sa.spec = spec.as<double>(); sa.specStride = 0;
+  sa.frameOffset = (int) (win / 2 - pad); // frame i starts at sample i*hop - padding (:151-162)
+  launch_stft(sa, s);
+  launch_spec_to_magphase(spec.as<double>(), (int) T, (int) F, mag ? dm.as<float>() : nullptr,
+                          phase ? dp.as<float>() : nullptr, s);
+  HIPCHK(ctx, hipGetLastError());
+  if (mag) HIPCHK(ctx, hipMemcpyAsync(mag, dm.p, (size_t) T * F * sizeof(float), hipMemcpyDeviceToHost, s));
+  if (phase) HIPCHK(ctx, hipMemcpyAsync(phase, dp.p, (size_t) T * F * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return FLUHIP_OK;
+}
+
+int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* phase, int64_t hops, int64_t win,
+                               int64_t fft, int64_t hop, int padding_mode, float* out, int64_t* n_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!mag || !phase) return fail(ctx, "Need both magnutude and phase buffers for inverse transform");
+  if (padding_mode < 0 || padding_mode > 2) return fail(ctx, "padding mode must be 0, 1 or 2");
+  if (hops < 1) return fail(ctx, "not enough frames");
+  int rc = check_shape(ctx, 1, win, fft, hop, 1);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const int64_t F = fft / 2 + 1, T = hops, pad = bufstft_padding(win, hop, padding_mode);
+  const int64_t paddedOut = (T - 1) * hop + win; // nrt/BufSTFTClient.hpp:233
+  const int64_t finalOut = paddedOut - pad;      // :234
+  if (n_out) *n_out = finalOut;
+  if (!out) return FLUHIP_OK;                    // size query
+  const double *wtab = nullptr, *ttab = nullptr;
+  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
+  if (rc) return rc;
+  rc = get_twiddle(ctx, fft, &ttab);
+  if (rc) return rc;
+  DevBuf dm, dp, spec, frames, dout;
+  HIPCHK(ctx, dm.alloc((size_t) T * F * sizeof(float), false, s));
+  HIPCHK(ctx, dp.alloc((size_t) T * F * sizeof(float), false, s));
+  HIPCHK(ctx, spec.alloc((size_t) T * F * 2 * sizeof(double), false, s));
+  HIPCHK(ctx, frames.alloc((size_t) T * win * sizeof(double), false, s));
+  HIPCHK(ctx, dout.alloc((size_t) finalOut * sizeof(float), false, s));
+  HIPCHK(ctx, hipMemcpyAsync(dm.p, mag, (size_t) T * F * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(dp.p, phase, (size_t) T * F * sizeof(float), hipMemcpyHostToDevice, s));
+  launch_polar_to_spec(dm.as<float>(), dp.as<float>(), (int) T, (int) F, spec.as<double>(), s);
+  ResynthArgs ra;
+  ra.spec = spec.as<double>(); ra.Wf = nullptr; ra.H1 = nullptr; ra.Vhat = nullptr; ra.ldV = 0; ra.Kp = 0; ra.k = 0;
+  ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) T; ra.F = (int) F;
+  ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr;
+  ra.out32 = dout.as<float>(); ra.n = finalOut; ra.trim = pad;
+  launch_resynth(ra, s);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, dout.p, (size_t) finalOut * sizeof(float), hipMemcpyDeviceToHost, s));
+  HIPCHK(ctx, hipStreamSynchronize(s));
   return FLUHIP_OK;
 }
 
@@ -1052,7 +1151,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   HIPCHK(ctx, hipMemcpyAsync(dDct.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
   // buffers are processed in chunks that keep the magnitude scratch around 2 GiB
   const int64_t perBuf = Tp * Fp * (int64_t) sizeof(double);
-  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(count, (2LL << 30) / perBuf));
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(count, 65535), (2LL << 30) / perBuf));
   HIPCHK(ctx, dAudio.alloc((size_t) chunk * n * sizeof(float), false, s));
   HIPCHK(ctx, dMag.alloc((size_t) chunk * perBuf, true, s));
   HIPCHK(ctx, dOut.alloc((size_t) chunk * nOut * T * sizeof(float), false, s));

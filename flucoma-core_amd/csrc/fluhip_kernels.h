@@ -144,7 +144,13 @@ struct ResynthArgs
   double* out;          // [n] f64 overlap-added, normalised, trimmed
   float* out32;         // [n] or nullptr
   int64_t n;
+  int64_t trim;         // leading samples dropped: win/2 for ISTFT::process, `padding` for BufSTFT
 };
+// Wf == nullptr: no ratio mask (plain inverse STFT of `spec`)
 void launch_resynth(const ResynthArgs& a, hipStream_t s);
+
+// BufSTFT plumbing: spec [T][F] c128 <-> float magnitude / phase, bin-major [F][T]
+void launch_spec_to_magphase(const double* spec, int T, int F, float* mag, float* phase, hipStream_t s);
+void launch_polar_to_spec(const float* mag, const float* phase, int T, int F, double* spec, hipStream_t s);
 
 } // namespace fluhip

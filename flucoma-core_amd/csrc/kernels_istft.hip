@@ -44,14 +44,18 @@ __global__ __launch_bounds__(256) void resynth_frames_kernel(ResynthArgs a)
   const int t = blockIdx.x;
   const double* spec = a.spec + (int64_t) t * a.F * 2;
   const double* vhat = a.Vhat + (int64_t) t * a.ldV;
-  const double hk = a.H1[(int64_t) t * a.Kp + a.k];
+  const bool useMask = a.Wf != nullptr;
+  const double hk = useMask ? a.H1[(int64_t) t * a.Kp + a.k] : 0.0;
 
   auto masked = [&](int f) -> d2 {
-    const double est = hk * a.Wf[(int64_t) f * a.Kp + a.k];   // NMF.hpp:41
-    const double mult = 1.0 / fmax(vhat[f], kEpsilon);          // RatioMask.hpp:39-41
-    const double m = fmin(est * mult, 1.0);                     // RatioMask.hpp:52-56 (exponent 1)
     d2 x = reinterpret_cast<const d2*>(spec)[f];
-    x = d2{x[0] * m, x[1] * m};
+    if (useMask)
+    {
+      const double est = hk * a.Wf[(int64_t) f * a.Kp + a.k];   // NMF.hpp:41
+      const double mult = 1.0 / fmax(vhat[f], kEpsilon);          // RatioMask.hpp:39-41
+      const double m = fmin(est * mult, 1.0);                     // RatioMask.hpp:52-56 (exponent 1)
+      x = d2{x[0] * m, x[1] * m};
+    }
     if (f == 0 || f == nc) x[1] = 0.0;                          // util/FFT.hpp:155-160 packed DC / Nyquist
     return x;
   };
@@ -135,7 +139,7 @@ __global__ void resynth_ola_kernel(ResynthArgs a)
 {
   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  const int64_t p = i + a.win / 2; // position in the padded output (alg/STFT.hpp:197)
+  const int64_t p = i + a.trim; // position in the padded output (alg/STFT.hpp:197; BufSTFTClient.hpp:272)
   // frames t with t*hop <= p < t*hop + win
   int64_t tlo = (p - a.win + a.hop) / a.hop; // ceil((p - win + 1) / hop) for p - win + 1 > 0
   if (p - a.win + 1 <= 0) tlo = 0;
@@ -164,6 +168,76 @@ void launch_resynth(const ResynthArgs& a, hipStream_t s)
   if (threads > 256) threads = 256;
   hipLaunchKernelGGL(resynth_frames_kernel, dim3((unsigned) a.T), dim3((unsigned) threads), shmem, s, a);
   hipLaunchKernelGGL(resynth_ola_kernel, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, s, a);
+}
+
+// ---- BufSTFT plumbing --------------------------------------------------------------------
+__global__ void spec_to_magphase_kernel(const double* spec, int T, int F, float* mag, float* phase)
+{
+  // tile transpose [T][F] -> [F][T] so both sides are coalesced
+  __shared__ float tm[32][33], tp[32][33];
+  const int f0 = blockIdx.x * 32, t0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int t = t0 + j, f = f0 + tx;
+    float m = 0.f, p = 0.f;
+    if (t < T && f < F)
+    {
+      const d2 x = reinterpret_cast<const d2*>(spec)[(int64_t) t * F + f];
+      m = (float) sqrt(x[0] * x[0] + x[1] * x[1]); // alg/STFT.hpp:61-66
+      p = (float) atan2(x[1], x[0]);                // alg/STFT.hpp:75-79 (arg)
+    }
+    tm[j][tx] = m;
+    tp[j][tx] = p;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int f = f0 + j, t = t0 + tx;
+    if (f < F && t < T)
+    {
+      if (mag) mag[(int64_t) f * T + t] = tm[tx][j];
+      if (phase) phase[(int64_t) f * T + t] = tp[tx][j];
+    }
+  }
+}
+
+void launch_spec_to_magphase(const double* spec, int T, int F, float* mag, float* phase, hipStream_t s)
+{
+  dim3 g((unsigned) ((F + 31) / 32), (unsigned) ((T + 31) / 32));
+  hipLaunchKernelGGL(spec_to_magphase_kernel, g, dim3(256), 0, s, spec, T, F, mag, phase);
+}
+
+__global__ void polar_to_spec_kernel(const float* mag, const float* phase, int T, int F, double* spec)
+{
+  __shared__ double tr[32][33], ti[32][33];
+  const int t0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int f = f0 + j, t = t0 + tx;
+    double re = 0.0, im = 0.0;
+    if (f < F && t < T)
+    {
+      const double m = (double) mag[(int64_t) f * T + t], p = (double) phase[(int64_t) f * T + t];
+      re = m * cos(p); // std::polar(m, p), nrt/BufSTFTClient.hpp:248-250
+      im = m * sin(p);
+    }
+    tr[j][tx] = re;
+    ti[j][tx] = im;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+  {
+    const int t = t0 + j, f = f0 + tx;
+    if (t < T && f < F) reinterpret_cast<d2*>(spec)[(int64_t) t * F + f] = d2{tr[tx][j], ti[tx][j]};
+  }
+}
+
+void launch_polar_to_spec(const float* mag, const float* phase, int T, int F, double* spec, hipStream_t s)
+{
+  dim3 g((unsigned) ((T + 31) / 32), (unsigned) ((F + 31) / 32));
+  hipLaunchKernelGGL(polar_to_spec_kernel, g, dim3(256), 0, s, mag, phase, T, F, spec);
 }
 
 } // namespace fluhip

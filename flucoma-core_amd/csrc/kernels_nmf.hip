@@ -526,9 +526,10 @@ void launch_acts_f32(const double* H1, int64_t strideH, float* acts, int64_t str
 __global__ void vhat_kernel(const double* Wf, int64_t strideW, const double* H1, int64_t strideH,
                             double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp)
 {
-  const int b = blockIdx.z;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int t = blockIdx.y;
+  const int b = blockIdx.y;
+  const int fblocks = (F + blockDim.x - 1) / blockDim.x;
+  const int t = blockIdx.x / fblocks;
+  const int f = (blockIdx.x % fblocks) * blockDim.x + threadIdx.x;
   if (f >= F) return;
   const double* w = Wf + (int64_t) b * strideW + (int64_t) f * Kp;
   const double* h = H1 + (int64_t) b * strideH + (int64_t) t * Kp;
@@ -541,16 +542,17 @@ void launch_vhat(const double* Wf, int64_t strideW, const double* H1, int64_t st
                  double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp, int B,
                  hipStream_t s)
 {
-  dim3 g((unsigned) ((F + 255) / 256), (unsigned) T, (unsigned) B);
+  dim3 g((unsigned) (((F + 255) / 256) * (int64_t) T), (unsigned) B);
   hipLaunchKernelGGL(vhat_kernel, g, dim3(256), 0, s, Wf, strideW, H1, strideH, Vhat, ldV, strideV, T, F, Kp);
 }
 
 __global__ void pad_copy_kernel(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
                                 int64_t lddst, int64_t strideDst, int rows, int cols)
 {
-  const int b = blockIdx.z;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  const int r = blockIdx.y;
+  const int b = blockIdx.y;
+  const int cblocks = (cols + blockDim.x - 1) / blockDim.x;
+  const int r = blockIdx.x / cblocks;
+  const int c = (blockIdx.x % cblocks) * blockDim.x + threadIdx.x;
   if (c >= cols) return;
   dst[(int64_t) b * strideDst + (int64_t) r * lddst + c] = src[(int64_t) b * strideSrc + (int64_t) r * ldsrc + c];
 }
@@ -558,7 +560,7 @@ __global__ void pad_copy_kernel(const double* src, int64_t ldsrc, int64_t stride
 void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
                      int64_t lddst, int64_t strideDst, int rows, int cols, int B, hipStream_t s)
 {
-  dim3 g((unsigned) ((cols + 255) / 256), (unsigned) rows, (unsigned) B);
+  dim3 g((unsigned) (((cols + 255) / 256) * (int64_t) rows), (unsigned) B);
   hipLaunchKernelGGL(pad_copy_kernel, g, dim3(256), 0, s, src, ldsrc, strideSrc, dst, lddst, strideDst, rows, cols);
 }
 

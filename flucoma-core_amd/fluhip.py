@@ -27,6 +27,7 @@ EXPORTS = [
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
     "fluhip_nmf_process_f64", "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
+    "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
@@ -76,6 +77,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                          ctypes.c_int, ctypes.c_int, _fp, _ip]
     L.fluhip_bufmfcc_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
                                      _fp, _ip]
+    L.fluhip_bufstft_forward_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _fp, _ip]
+    L.fluhip_bufstft_inverse_f32.argtypes = [_vp, _fp, _fp, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _ip]
     L.fluhip_corpus_create.argtypes = [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
     L.fluhip_corpus_destroy.argtypes = [_vp]
     L.fluhip_corpus_destroy.restype = None
@@ -233,6 +236,35 @@ class Context:
         self._check(self.lib.fluhip_bufmelbands_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr,
                                                     int(normalize), int(scale_db), _f(out), ctypes.byref(Tr)))
         assert Tr.value == T
+        return out
+
+    # ---- BufSTFT ----------------------------------------------------------------------------
+    def bufstft_forward(self, audio, win, fft, hop, padding_mode=1):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = audio.shape[0]
+        pad = [0, win >> 1, win - hop][padding_mode]
+        padded = n + 2 * pad
+        if padding_mode == 2:
+            padded = -(-padded // hop) * hop
+        T, F = 1 + (padded - win) // hop, fft // 2 + 1
+        mag = np.empty((F, T), dtype=np.float32)
+        ph = np.empty((F, T), dtype=np.float32)
+        Tr = _i64(0)
+        self._check(self.lib.fluhip_bufstft_forward_f32(self.h, _f(audio), n, 1, win, fft, hop, padding_mode,
+                                                        _f(mag), _f(ph), ctypes.byref(Tr)))
+        assert Tr.value == T
+        return mag, ph
+
+    def bufstft_inverse(self, mag, phase, win, fft, hop, padding_mode=1):
+        mag = np.ascontiguousarray(mag, dtype=np.float32)
+        phase = np.ascontiguousarray(phase, dtype=np.float32)
+        F, T = mag.shape
+        nout = _i64(0)
+        self._check(self.lib.fluhip_bufstft_inverse_f32(self.h, _f(mag), _f(phase), T, win, fft, hop, padding_mode,
+                                                        None, ctypes.byref(nout)))
+        out = np.empty(nout.value, dtype=np.float32)
+        self._check(self.lib.fluhip_bufstft_inverse_f32(self.h, _f(mag), _f(phase), T, win, fft, hop, padding_mode,
+                                                        _f(out), ctypes.byref(nout)))
         return out
 
     # ---- profiling ----------------------------------------------------------------------

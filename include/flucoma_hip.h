@@ -119,6 +119,20 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
                               const float* acts_seed, float* bases_out, float* acts_out,
                               float* resynth_out, fluhip_progress_fn progress, void* user);
 
+/* ---- client::bufstft::BufferSTFTClient ----------------------------------------------------------- */
+/* Replaces processFwd, clients/nrt/BufSTFTClient.hpp:81-184: padding_mode None/Default/Full = 0/1/2
+ * (padding = 0, win/2, win-hop: clients/common/ParameterTypes.hpp:315-323), hops = 1 + (padded - win)/hop,
+ * frame i = padded[i*hop, i*hop + win).  mag / phase (either may be NULL): bins x hops floats, one bin per
+ * buffer channel like mags.allFrames().transpose() <<= tmpMags (:168-178). */
+int fluhip_bufstft_forward_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                               int64_t fft, int64_t hop, int padding_mode, float* mag, float* phase,
+                               int64_t* hops_out);
+/* Replaces processInverse, :186-276: std::polar(mag, phase) -> ISTFT::processFrame -> overlap-add /
+ * window^2 normaliser -> drop `padding` leading samples.  out: (hops-1)*hop + win - padding floats
+ * (call with out == NULL to query *n_out). */
+int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* phase, int64_t hops, int64_t win,
+                               int64_t fft, int64_t hop, int padding_mode, float* out, int64_t* n_out);
+
 /* ---- feature pipeline: BufMelBands / BufMFCC (BASELINE config 5) ------------------------------ */
 /* Replaces, for `count` equal-length mono buffers at once, the offline-wrapped real-time clients
  *   NRTThreadedMelBandsClient  clients/rt/MelBandsClient.hpp:77-119  (MelBands::processFrame, alg/MelBands.hpp:79-97)

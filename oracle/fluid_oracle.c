@@ -699,3 +699,106 @@ int64_t fo_bufmfcc_channel(const float* audio, int64_t n, int64_t win, int64_t f
   free(mag); free(filt); free(bands); free(dct);
   return T;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* BufSTFT                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+static int64_t bufstft_padding(int64_t win, int64_t hop, int mode)
+{
+  /* cc/ParameterTypes.hpp:315-323 */
+  return mode == 0 ? 0 : (mode == 1 ? win >> 1 : win - hop);
+}
+
+int64_t fo_bufstft_num_hops(int64_t n, int64_t win, int64_t hop, int padding_mode)
+{
+  const int64_t pad = bufstft_padding(win, hop, padding_mode);
+  int64_t padded = n + 2 * pad;                                     /* nrt/BufSTFTClient.hpp:121-124 */
+  if (padding_mode == 2) padded = ((padded + hop - 1) / hop) * hop;  /* :125-127 ceil to a whole hop */
+  if (padded < win) return 0;
+  return 1 + (padded - win) / hop;                                   /* :129-130 */
+}
+
+int64_t fo_bufstft_forward(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int padding_mode,
+                           float* mag, float* phase)
+{
+  const int64_t F = fft / 2 + 1, pad = bufstft_padding(win, hop, padding_mode);
+  const int64_t T = fo_bufstft_num_hops(n, win, hop, padding_mode);
+  double* w = (double*) malloc((size_t) win * sizeof(double));
+  double* re = (double*) malloc((size_t) fft * sizeof(double));
+  double* im = (double*) malloc((size_t) fft * sizeof(double));
+  double* twr = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  double* twi = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  fo_window_hann(win, w);
+  for (int64_t k = 0; k < fft / 2; k++)
+  {
+    twr[k] = cos(-2.0 * M_PI * (double) k / (double) fft);
+    twi[k] = sin(-2.0 * M_PI * (double) k / (double) fft);
+  }
+  for (int64_t t = 0; t < T; t++)
+  {
+    for (int64_t i = 0; i < fft; i++)
+    {
+      const int64_t p = t * hop + i - pad; /* :151-162 paddedInput(Slice(padding, n)) <<= input */
+      re[i] = (i < win && p >= 0 && p < n) ? (double) audio[p] * w[i] : 0.0;
+      im[i] = 0;
+    }
+    fft_c2c(re, im, fft, twr, twi);
+    for (int64_t k = 0; k < F; k++)
+    {
+      const double xi = (k == 0 || k == F - 1) ? 0 : im[k];
+      if (mag) mag[k * T + t] = (float) hypot(re[k], xi);   /* :168-172, buffer is [bins as channels][hops] */
+      if (phase) phase[k * T + t] = (float) atan2(xi, re[k]); /* :174-178, alg/STFT.hpp:75-79 */
+    }
+  }
+  free(w); free(re); free(im); free(twr); free(twi);
+  return T;
+}
+
+int64_t fo_bufstft_inverse(const float* mag, const float* phase, int64_t T, int64_t win, int64_t fft, int64_t hop,
+                           int padding_mode, double* out)
+{
+  const double eps = FO_EPSILON;
+  const int64_t F = fft / 2 + 1, pad = bufstft_padding(win, hop, padding_mode);
+  const int64_t paddedOut = (T - 1) * hop + win; /* :233 */
+  const int64_t finalOut = paddedOut - pad;      /* :234 */
+  double* acc = (double*) calloc((size_t) paddedOut, sizeof(double));
+  double* nrm = (double*) calloc((size_t) paddedOut, sizeof(double));
+  double* w = (double*) malloc((size_t) win * sizeof(double));
+  double* re = (double*) malloc((size_t) fft * sizeof(double));
+  double* im = (double*) malloc((size_t) fft * sizeof(double));
+  double* twr = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  double* twi = (double*) malloc((size_t) (fft / 2 + 1) * sizeof(double));
+  const double scale = 1 / (double) fft;
+  fo_window_hann(win, w);
+  for (int64_t k = 0; k < fft / 2; k++)
+  {
+    twr[k] = cos(-2.0 * M_PI * (double) k / (double) fft);
+    twi[k] = sin(-2.0 * M_PI * (double) k / (double) fft);
+  }
+  for (int64_t t = 0; t < T; t++)
+  {
+    for (int64_t f = 0; f < F; f++)
+    {
+      /* :248-250 std::polar(m, p) on the float samples promoted to double */
+      const double m = (double) mag[f * T + t], ph = (double) phase[f * T + t];
+      double yr = m * cos(ph), yi = m * sin(ph);
+      if (f == 0 || f == F - 1) yi = 0; /* util/FFT.hpp:155-160 */
+      re[f] = yr; im[f] = -yi;
+      if (f > 0 && f < F - 1) { re[fft - f] = yr; im[fft - f] = yi; }
+    }
+    fft_c2c(re, im, fft, twr, twi);
+    for (int64_t i = 0; i < win; i++)
+    {
+      acc[t * hop + i] += re[i] * w[i] * scale; /* alg/STFT.hpp:201-208 processFrame; :259-263 */
+      nrm[t * hop + i] += w[i] * w[i];
+    }
+  }
+  for (int64_t i = 0; i < finalOut; i++)
+  {
+    const double d = nrm[pad + i] > eps ? nrm[pad + i] : eps; /* :265-270 */
+    out[i] = acc[pad + i] / d;                                 /* :272 */
+  }
+  free(acc); free(nrm); free(w); free(re); free(im); free(twr); free(twi);
+  return finalOut;
+}

@@ -110,6 +110,20 @@ int64_t fo_bufmelbands_channel(const float* audio, int64_t n, int64_t win, int64
                                int64_t nBands, double minFreq, double maxFreq, double sampleRate,
                                int normalize, int scaleDb, float* out);
 
+/* ---- "next" rows: BufSTFT ----------------------------------------------------- */
+/* nrt/BufSTFTClient.hpp:81-184 processFwd: padding = {0, win/2, win-hop}[mode]
+ * (cc/ParameterTypes.hpp:315-323), numHops = 1 + (paddedLength - win)/hop, frame i = padded[i*hop, +win);
+ * magnitude (alg/STFT.hpp:61-66) and phase (alg/STFT.hpp:75-79: arg) as float, bin-major [F][numHops].
+ * Returns numHops. */
+int64_t fo_bufstft_forward(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int padding_mode,
+                           float* mag, float* phase);
+int64_t fo_bufstft_num_hops(int64_t n, int64_t win, int64_t hop, int padding_mode);
+/* nrt/BufSTFTClient.hpp:186-276 processInverse: std::polar(mag, phase) -> ISTFT::processFrame ->
+ * overlap-add with window^2 normaliser -> drop `padding` leading samples.
+ * mag/phase: [F][T] floats.  out: (T-1)*hop + win - padding doubles.  Returns that length. */
+int64_t fo_bufstft_inverse(const float* mag, const float* phase, int64_t T, int64_t win, int64_t fft, int64_t hop,
+                           int padding_mode, double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,12 @@ class Oracle:
         L.fo_bufmelbands_channel.argtypes = [_fp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
                                              ctypes.c_int, ctypes.c_int, _fp]
         L.fo_bufmelbands_channel.restype = _i64
+        L.fo_bufstft_num_hops.argtypes = [_i64, _i64, _i64, ctypes.c_int]
+        L.fo_bufstft_num_hops.restype = _i64
+        L.fo_bufstft_forward.argtypes = [_fp, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _fp]
+        L.fo_bufstft_forward.restype = _i64
+        L.fo_bufstft_inverse.argtypes = [_fp, _fp, _i64, _i64, _i64, _i64, ctypes.c_int, _dp]
+        L.fo_bufstft_inverse.restype = _i64
 
     # ---- wrappers returning numpy arrays ------------------------------------------------
     def hann(self, win):
@@ -212,6 +218,26 @@ class Oracle:
         Tr = self.lib.fo_bufmelbands_channel(_f(audio), n, win, fft, hop, n_bands, lo, hi, sr, int(normalize),
                                              int(scale_db), _f(out))
         assert Tr == T
+        return out
+
+
+    def bufstft_forward(self, audio, win, fft, hop, padding_mode=1):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = audio.shape[0]
+        T, F = int(self.lib.fo_bufstft_num_hops(n, win, hop, padding_mode)), fft // 2 + 1
+        mag = np.empty((F, T), dtype=np.float32)
+        ph = np.empty((F, T), dtype=np.float32)
+        self.lib.fo_bufstft_forward(_f(audio), n, win, fft, hop, padding_mode, _f(mag), _f(ph))
+        return mag, ph
+
+    def bufstft_inverse(self, mag, phase, win, fft, hop, padding_mode=1):
+        mag = np.ascontiguousarray(mag, dtype=np.float32)
+        phase = np.ascontiguousarray(phase, dtype=np.float32)
+        F, T = mag.shape
+        pad = [0, win >> 1, win - hop][padding_mode]
+        out = np.empty((T - 1) * hop + win - pad)
+        n = self.lib.fo_bufstft_inverse(_f(mag), _f(phase), T, win, fft, hop, padding_mode, _d(out))
+        assert n == out.shape[0]
         return out
 
 

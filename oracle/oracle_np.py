@@ -310,3 +310,43 @@ def bufmfcc_channel(audio_f32, win, fft, hop, n_bands=40, n_coefs=13, start_coef
     take = max(0, min(n_coefs, n_out - start_coeff))
     out[:, :take] = coefs[:, start_coeff:start_coeff + take]
     return out.T.astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# BufSTFT: nrt/BufSTFTClient.hpp:81-276
+# --------------------------------------------------------------------------------------
+def bufstft_padding(win, hop, mode):
+    return [0, win >> 1, win - hop][mode]
+
+
+def bufstft_forward(audio_f32, win, fft, hop, padding_mode=1):
+    x = np.asarray(audio_f32, dtype=np.float32).astype(np.float64)
+    n = x.shape[0]
+    pad = bufstft_padding(win, hop, padding_mode)
+    padded_len = n + 2 * pad
+    if padding_mode == 2:
+        padded_len = -(-padded_len // hop) * hop
+    padded = np.zeros(padded_len)
+    padded[pad:pad + n] = x
+    T = 1 + (padded_len - win) // hop
+    idx = np.arange(T)[:, None] * hop + np.arange(win)[None, :]
+    spec = np.fft.rfft(padded[idx] * hann(win)[None, :], n=fft, axis=1)
+    spec[:, 0] = spec[:, 0].real
+    spec[:, -1] = spec[:, -1].real
+    return np.abs(spec).T.astype(np.float32), np.angle(spec).T.astype(np.float32)
+
+
+def bufstft_inverse(mag, phase, win, fft, hop, padding_mode=1):
+    mag = np.asarray(mag, dtype=np.float32).astype(np.float64)
+    phase = np.asarray(phase, dtype=np.float32).astype(np.float64)
+    F, T = mag.shape
+    pad = bufstft_padding(win, hop, padding_mode)
+    spec = (mag * np.exp(1j * phase)).T
+    frames = np.fft.irfft(spec, n=fft, axis=1)[:, :win] * hann(win)[None, :]
+    size = (T - 1) * hop + win
+    acc, nrm = np.zeros(size), np.zeros(size)
+    w2 = hann(win) ** 2
+    for t in range(T):
+        acc[t * hop:t * hop + win] += frames[t]
+        nrm[t * hop:t * hop + win] += w2
+    return (acc / np.maximum(nrm, EPS))[pad:]

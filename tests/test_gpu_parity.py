@@ -412,3 +412,25 @@ def test_bufmfcc_batch_matches_single(ctx, onp):
     batch = ctx.bufmfcc(audio, 1024, 1024, 512)
     for b in (0, 3, 4):
         assert np.array_equal(batch[b], ctx.bufmfcc(audio[b], 1024, 1024, 512)[0])
+
+
+# ---------------------------------------------------------------------------------------
+# BufSTFT: nrt/BufSTFTClient.hpp forward (mag + phase) and inverse
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("n,win,fft,hop", [(20000, 1024, 1024, 512), (9999, 512, 1024, 100), (50000, 2048, 2048, 512)])
+def test_bufstft_forward_inverse(ctx, oracle, onp, mode, n, win, fft, hop):
+    x = onp.synth_audio(n, 31)
+    mag, ph = ctx.bufstft_forward(x, win, fft, hop, mode)
+    rmag, rph = oracle.bufstft_forward(x, win, fft, hop, mode)
+    assert mag.shape == rmag.shape                                   # hop count: exact
+    assert np.abs(mag - rmag).max() / rmag.max() < 1e-6
+    big = rmag > 1e-4 * rmag.max()                                   # phase is ill-conditioned on empty bins
+    dphi = np.abs(np.angle(np.exp(1j * (ph.astype(np.float64) - rph))))
+    assert dphi[big].max() < 1e-5
+    y = ctx.bufstft_inverse(rmag, rph, win, fft, hop, mode)
+    ry = oracle.bufstft_inverse(rmag, rph, win, fft, hop, mode)
+    assert y.shape == ry.shape
+    assert np.abs(y - ry).max() < 1e-6
+    m = min(len(y), n)
+    assert np.abs(y[win:m - win] - x[win:m - win]).max() < 1e-5      # round trip away from the edges
