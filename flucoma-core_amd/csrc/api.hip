@@ -249,7 +249,9 @@ static int choose_split4(int64_t B, int C, int R, int Kp)
   if (forceS > 0) return (int) std::min<int64_t>(forceS, std::max<int64_t>(1, nSteps / 2));
   const int64_t waves = B * nmf_update4_waves_per_buffer(C, Kp, (int) B);
   if (waves >= 768) return 1;
-  int64_t s = (1024 + waves - 1) / waves;
+  // one wavefront per SIMD (the kernel's register footprint allows no more): never exceed 1024 in
+  // total, a 1025th wavefront would wait for a whole pass of the others
+  const int64_t s = 1024 / waves;
   return (int) std::max<int64_t>(1, std::min(s, smax));
 }
 

@@ -338,7 +338,7 @@ static int max_groups(int M)
 {
   if (M <= 8) return 9;
   if (M <= 16) return 4;
-  return 1;
+  return 2;
 }
 
 // strips (wavefronts) per buffer: fill the 1024 SIMDs in whole rounds, then as few strips as the

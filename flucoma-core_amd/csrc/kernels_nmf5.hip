@@ -144,8 +144,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     int p = 64 * j + lane;
     int row = p / SPR, pos = p % SPR;
     if (row > 3) row = 3;
-    const int c = (pos - row + SPR) % SPR; // slot pos of row `row` holds chunk c
-    moffs[j] = row * KP + c * 2;
+    const int cs = (pos - row + SPR) % SPR;          // undo the per-row rotation ...
+    const int c = cs ^ (((cs >> 4) & 3) << 2);         // ... and the XOR of slot bits 2-3 with bits 4-5
+    moffs[j] = row * KP + c * 2;                       // slot pos of row `row` holds chunk c
   }
 
   const int s0 = split * a.stepsPerSplit;
@@ -178,13 +179,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   for (int m = 0; m < M; m++) dsum[m] = 0.0;
 
   // ---- LDS read addresses (bytes within a stage) ------------------------------------------------
-  // ma: row x, chunks M/2*y .. ; mb: row y, chunks M/2*x .. ; chunk c of row r sits at slot (c + r) % SPR
+  // ma: row x, chunks M/2*y .. ; mb: row y, chunks M/2*x ..  Chunk c of row r sits at slot
+  // ((c ^ (((c >> 4) & 3) << 2)) + r) % SPR: the rotation separates the 4 rows, the XOR separates
+  // chunks 16 apart (rows longer than 256 B), so both distributions are conflict free per lane group.
+  auto slot_of = [](int c, int r) { return ((c ^ (((c >> 4) & 3) << 2)) + r) % SPR; };
   int maOff[M / 2], mbOff[M / 2];
 #pragma unroll
   for (int j = 0; j < M / 2; j++)
   {
-    maOff[j] = x * (KP * 8) + (((M / 2) * y + j + x) % SPR) * 16;
-    mbOff[j] = y * (KP * 8) + (((M / 2) * x + j + y) % SPR) * 16;
+    maOff[j] = x * (KP * 8) + slot_of((M / 2) * y + j, x) * 16;
+    mbOff[j] = y * (KP * 8) + slot_of((M / 2) * x + j, y) * 16;
   }
   const int vOff = y * (NG * 128) + (4 * blk + x) * 8;
 
@@ -212,13 +216,31 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vp + g * 128);
   };
 
+  // Q for one 4-row step.  A dependent v_mfma_f64_4x4x4 cannot issue back to back on its own
+  // accumulator, so each group's contraction over m is split into P interleaved partial chains
+  // (>= 8 independent accumulators in flight, the count at which the probe reaches 73 TFLOP/s).
+  constexpr int P = (NG >= 5) ? 1 : (NG >= 3 ? 2 : (NG >= 2 ? 4 : 8));
+  static_assert(M % P == 0 || M < P, "partial chains");
   auto q_phase = [&](const double (&ma)[M], double (&q)[NG]) {
+    constexpr int PP = (P <= M) ? P : M;
+    double qp[NG][PP];
 #pragma unroll
-    for (int g = 0; g < NG; g++) q[g] = 0.0;
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+      for (int p = 0; p < PP; p++) qp[g][p] = 0.0;
 #pragma unroll
     for (int m = 0; m < M; m++)
 #pragma unroll
-      for (int g = 0; g < NG; g++) q[g] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], q[g], 0, 0, 0);
+      for (int g = 0; g < NG; g++)
+        qp[g][m % PP] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], qp[g][m % PP], 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+    {
+      double t = qp[g][0];
+#pragma unroll
+      for (int p = 1; p < PP; p++) t += qp[g][p];
+      q[g] = t;
+    }
   };
   // V / max(Q, eps), stage by stage across the NG independent quotients:
   // v_rcp_f64 (~24 bits) -> one Newton step -> quotient -> residual correction (error ~2^-96)
@@ -395,7 +417,7 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
   }
 }
 
-bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32; }
+bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
 
 // strips per buffer for WPS wavefronts per SIMD: WPS x the one-wave plan, as long as every strip
 // keeps at least one group
@@ -423,6 +445,8 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     {
     case 4: launch5_ng<4, 9, 1>(a, w, ng, s); break;
     case 8: launch5_ng<8, 9, 1>(a, w, ng, s); break;
+    case 16: launch5_ng<16, 4, 1>(a, w, ng, s); break;
+    case 32: launch5_ng<32, 2, 1>(a, w, ng, s); break;
     default: break;
     }
   }
