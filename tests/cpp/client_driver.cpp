@@ -188,6 +188,12 @@ int main(int argc, char** argv)
     }
     p.bases = bases;
     p.activations = acts;
+    auto resynth = makeBuffer(1, 1);
+    if (std::getenv("CLIENT_RESYNTH"))
+    {
+      p.resynth = resynth;
+      p.resynthMode = 1;
+    }
     Result r;
     if (!async)
     {
@@ -214,6 +220,7 @@ int main(int argc, char** argv)
     report("result", r);
     writeBuffer(prefix + "_bases.bin", bases);
     writeBuffer(prefix + "_acts.bin", acts);
+    if (p.resynthMode) writeBuffer(prefix + "_resynth.bin", resynth);
     return 0;
   }
   return 2;

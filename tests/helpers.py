@@ -3,8 +3,9 @@ import numpy as np
 
 def rel_err(a, b):
     """max |a-b| / max |b| : the normwise relative error the parity bars are stated in."""
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
+    a, b = np.asarray(a), np.asarray(b)
+    if not (np.iscomplexobj(a) or np.iscomplexobj(b)):
+        a, b = a.astype(np.float64), b.astype(np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 

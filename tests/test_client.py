@@ -27,8 +27,10 @@ def driver(fluhip_lib_path):
     return mod.build_host_tests()
 
 
-def run(driver, *args):
-    out = subprocess.run([driver, *map(str, args)], capture_output=True, text=True, timeout=300)
+def run(driver, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([driver, *map(str, args)], capture_output=True, text=True, timeout=300, env=e)
     assert out.returncode == 0, out.stderr
     res = {}
     for line in out.stdout.splitlines():
@@ -127,3 +129,23 @@ def test_client_cancel(driver, ctx):
     assert r["process"][0] == OK
     assert r["progress_before_cancel"][0] == 1     # progress was moving and below 1
     assert r["cancelled"] == (CANCELLED, "")       # :273-274
+
+
+@pytest.mark.gpu
+def test_client_resynthesis(driver, oracle, onp, tmp_path, ctx):
+    """resynthMode 1 through the host client: buffer shape nFrames x (rank * channels) at the source
+    sample rate (nrt/NMFClient.hpp:178-185), components add back up to the source."""
+    frames = 20000
+    audio = np.stack([onp.synth_audio(frames, 600 + c) for c in range(2)], axis=1)
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    win, hop, fft, K, iters = 1024, 256, 1024, 3, 20
+    prefix = str(tmp_path / "out")
+    r = run(driver, "run", inp, frames, 2, win, hop, fft, K, iters, 42, 0, 0, 1, 0, -1, 0, -1, prefix,
+            env={"CLIENT_RESYNTH": "1"})
+    assert r["result"] == (OK, "")
+    res, sr = read_buffer(prefix + "_resynth.bin")
+    assert res.shape == (2 * K, frames) and sr == 44100.0
+    for c in range(2):
+        total = res[c * K:(c + 1) * K].sum(axis=0)
+        assert np.abs(total[win:-win] - audio[win:-win, c]).max() < 0.02

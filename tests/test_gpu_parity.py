@@ -434,3 +434,38 @@ def test_bufstft_forward_inverse(ctx, oracle, onp, mode, n, win, fft, hop):
     assert np.abs(y - ry).max() < 1e-6
     m = min(len(y), n)
     assert np.abs(y[win:m - win] - x[win:m - win]).max() < 1e-5      # round trip away from the edges
+
+
+# ---------------------------------------------------------------------------------------
+# window types of algorithm::WindowFuncs (the STFT entry point takes windowType like STFT::STFT)
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("wtype", [0, 1, 2, 3])
+def test_stft_window_types(ctx, wtype):
+    """alg/WindowFuncs.hpp:41-65: Hann, HannD, Hamming, Blackman-Harris (as written there: the three
+    cosine terms share one argument)"""
+    rs = np.random.RandomState(wtype)
+    x = rs.standard_normal(6000)
+    win, fft, hop = 512, 512, 128
+    i = np.arange(win)
+    arg = 2 * np.pi * i / win
+    w = [0.5 - 0.5 * np.cos(arg), (np.pi / win) * np.sin(arg), 0.54 - 0.46 * np.cos(arg),
+         0.35875 - 0.48829 * np.cos(arg) + 0.14128 * np.cos(arg) + 0.01168 * np.cos(arg)][wtype]
+    spec, mag = ctx.stft(x, win, fft, hop, window_type=wtype)
+    padded = np.zeros(len(x) + win + hop)
+    padded[win // 2: win // 2 + len(x)] = x
+    T = (len(x) + hop) // hop
+    idx = np.arange(T)[:, None] * hop + i[None, :]
+    ref = np.fft.rfft(padded[idx] * w[None, :], axis=1)
+    ref[:, 0] = ref[:, 0].real
+    ref[:, -1] = ref[:, -1].real
+    assert np.abs(spec - ref).max() / np.abs(ref).max() < 1e-12
+    assert np.abs(mag - np.abs(ref)).max() / np.abs(ref).max() < 1e-12
+
+
+def test_stft_gaussian_window_needs_odd_size(ctx):
+    import fluhip
+    x = np.zeros(4000)
+    with pytest.raises(fluhip.FluhipError):
+        ctx.stft(x, 512, 512, 128, window_type=4)      # alg/WindowFuncs.hpp:69 assert(size % 2)
+    spec, mag = ctx.stft(x + 1.0, 511, 512, 128, window_type=4)
+    assert np.isfinite(mag).all()
