@@ -296,8 +296,8 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   {
     const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
     HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
-    HIPCHK(ctx, c->dpart.alloc(B * ns * c->Kp * sizeof(double), true, s));
   }
+  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * ns * c->Kp * sizeof(double)), true, s));
   return FLUHIP_OK;
 }
 
@@ -1208,6 +1208,14 @@ int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64
 }
 
 // ---- profiling ------------------------------------------------------------------------
+// debugging aid for FLUHIP_K5_INSTR: first 8 words of the split-denominator scratch
+int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out8)
+{
+  if (!c || !out8 || !c->dpart.p) return FLUHIP_ERROR;
+  HIPCHK(c->ctx, hipMemcpy(out8, c->dpart.p, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return FLUHIP_OK;
+}
+
 int fluhip_prof_enable(fluhip_ctx* ctx, int on)
 {
   if (!ctx) return FLUHIP_ERROR;

@@ -324,32 +324,36 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
 __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int checkMax,
                                 const double* part, int nch)
 {
-  extern __shared__ double sh[]; // [Kp] totals, [Kp] maxima
+  extern __shared__ double sh[]; // [nch][2*Kp] partials, then [Kp] totals + [Kp] maxima
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  // all partials of this buffer in one burst of independent loads, then a fixed-order combine from LDS
+  const double* p = part + (int64_t) b * nch * 2 * Kp;
+  for (int i = threadIdx.x; i < nch * 2 * Kp; i += blockDim.x) sh[i] = p[i];
+  __syncthreads();
+  double* tot = sh + (size_t) nch * 2 * Kp;
   if (rg == 0)
   {
-    double tot = 0.0, m = -INFINITY;
-    const double* p = part + (int64_t) b * nch * 2 * Kp;
+    double t = 0.0, m = -INFINITY;
     for (int j = 0; j < nch; j++)
     {
-      tot += p[(int64_t) j * 2 * Kp + k];
-      m = fmax(m, p[(int64_t) j * 2 * Kp + Kp + k]);
+      t += sh[j * 2 * Kp + k];
+      m = fmax(m, sh[j * 2 * Kp + Kp + k]);
     }
-    sh[k] = tot;
-    sh[Kp + k] = (k < K) ? m : -INFINITY;
+    tot[k] = t;
+    tot[Kp + k] = (k < K) ? m : -INFINITY;
   }
   __syncthreads();
   if (checkMax)
   {
     double gmax = -INFINITY;
-    for (int j = 0; j < Kp; j++) gmax = fmax(gmax, sh[Kp + j]);
+    for (int j = 0; j < Kp; j++) gmax = fmax(gmax, tot[Kp + j]);
     if (!(gmax > kEpsilon)) return; // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
   }
   if (k >= K) return;
-  const double nrm = sqrt(sh[k]);
+  const double nrm = sqrt(tot[k]);
   const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
   for (int r = rbeg + rg; r < rend; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
 }
@@ -366,8 +370,8 @@ void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, boo
   dim3 grid((unsigned) nch, (unsigned) B);
   hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
                      strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
-  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) 2 * Kp * sizeof(double), s, S,
-                     strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) (nch + 1) * 2 * Kp * sizeof(double), s,
+                     S, strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
 }
 
 // ---------------------------------------------------------------------------------------

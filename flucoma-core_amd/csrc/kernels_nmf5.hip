@@ -57,7 +57,7 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
   }
 }
 
-template <int M, int NG, int NS, int WPS>
+template <int M, int NG, int NS, int WPS, int INSTR = 0>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
@@ -127,7 +127,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // V stage chunk i = 64 j + lane: row = i / (8 NG), 16-byte column chunk cc = i % (8 NG); chunks of
   // groups this strip does not own (tail strips) and the slack of the last instruction re-read
   // valid data of the strip instead of running off the row.
-  int64_t voffs[NJV];
+  // byte offsets relative to a wave-uniform base, so the DMA takes "scalar base + 32-bit lane offset"
+  // addressing and no 64-bit vector address arithmetic is left in the loop
+  unsigned voffs[NJV];
 #pragma unroll
   for (int j = 0; j < NJV; j++)
   {
@@ -135,9 +137,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     int row = i / (8 * NG), cc = i % (8 * NG);
     if (row > 3) { row = 3; }
     cc = min(cc, 8 * ng - 1);
-    voffs[j] = (int64_t) row * a.ldv + (int64_t) g0 * 16 + cc * 2;
+    voffs[j] = (unsigned) ((row * a.ldv + cc * 2) * 8);
   }
-  int moffs[NJM];
+  unsigned moffs[NJM];
 #pragma unroll
   for (int j = 0; j < NJM; j++)
   {
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     if (row > 3) row = 3;
     const int cs = (pos - row + SPR) % SPR;          // undo the per-row rotation ...
     const int c = cs ^ (((cs >> 4) & 3) << 2);         // ... and the XOR of slot bits 2-3 with bits 4-5
-    moffs[j] = row * KP + c * 2;                       // slot pos of row `row` holds chunk c
+    moffs[j] = (unsigned) ((row * KP + c * 2) * 8);    // slot pos of row `row` holds chunk c
   }
 
   const int s0 = split * a.stepsPerSplit;
@@ -156,8 +158,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   auto issue_stage = [&](int st) {
     const int sc = min(st, sLast); // past the end: harmless re-read of the last step
     const int slot = st % NS;
-    const double* vsrc = V + (int64_t) sc * 4 * a.ldv;
-    const double* msrc = Mv + (int64_t) sc * 4 * KP;
+    const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16); // uniform
+    const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);                        // uniform
 #pragma unroll
     for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + slot * VSTAGE + j * 1024);
 #pragma unroll
@@ -202,7 +204,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       ma[2 * j + 1] = t[1];
     }
   };
-  auto read_mbv = [&](int st, double (&mb)[M], double (&v)[NG]) {
+  auto read_v = [&](int st, double (&v)[NG]) {
+    const char* vp = vring + (st % NS) * VSTAGE + vOff;
+#pragma unroll
+    for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vp + g * 128);
+  };
+  auto read_mb = [&](int st, double (&mb)[M]) {
     const char* mp = mring + (st % NS) * MSTAGE;
 #pragma unroll
     for (int j = 0; j < M / 2; j++)
@@ -211,9 +218,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       mb[2 * j] = t[0];
       mb[2 * j + 1] = t[1];
     }
-    const char* vp = vring + (st % NS) * VSTAGE + vOff;
-#pragma unroll
-    for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vp + g * 128);
   };
 
   // Q for one 4-row step.  A dependent v_mfma_f64_4x4x4 cannot issue back to back on its own
@@ -282,29 +286,55 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 1) * IPS) : "memory");
     read_ma(s0, ma);
     q_phase(ma, qA);
+    long long tWait = 0, tRead = 0, tRatio = 0, tQ = 0, tOut = 0, tDma = 0;
+    auto tick = [&]() -> long long {
+      if constexpr (INSTR) { __builtin_amdgcn_sched_barrier(0); long long c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return c; }
+      return 0;
+    };
+    // Each half-iteration: wait for stage s+1 -> LDS reads of step s (and ma of s+1) -> as soon as they
+    // have landed in registers the slot of stage s is free, so its refill (stage s+NS) is issued
+    // right away and the DMA instructions can overlap the matrix work that follows.
     for (int s = s0; s < s1; s += 2)
     {
+      long long c0 = tick();
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+      long long c1 = tick();
+      read_v(s, v);
       read_ma(s + 1, ma);
-      read_mbv(s, mb, v);
-      ratio_phase(v, qA, ratio);
-      q_phase(ma, qB);
-      out_phase(ratio, mb);
+      read_mb(s, mb);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // every ds_read of stage s has returned
+      long long c2 = tick();
       issue_stage(s + NS);
+      long long c3 = tick();
+      ratio_phase(v, qA, ratio);
+      long long c4 = tick();
+      q_phase(ma, qB);
+      long long c5 = tick();
+      out_phase(ratio, mb);
+      long long c6 = tick();
+      if constexpr (INSTR) { tWait += c1 - c0; tRead += c2 - c1; tDma += c3 - c2; tRatio += c4 - c3; tQ += c5 - c4; tOut += c6 - c5; }
       if (s + 1 < s1)
       {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+        read_v(s + 1, v);
         read_ma(s + 2, ma);
-        read_mbv(s + 1, mb, v);
+        read_mb(s + 1, mb);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        issue_stage(s + 1 + NS);
         ratio_phase(v, qB, ratio);
         q_phase(ma, qA);
         out_phase(ratio, mb);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        issue_stage(s + 1 + NS);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the run-ahead DMAs before the LDS is released
+    if constexpr (INSTR)
+    {
+      if (blockIdx.x == 17 && threadIdx.x == 0 && a.dpart)
+      {
+        long long* o = reinterpret_cast<long long*>(a.dpart);
+        o[0] = tWait; o[1] = tRead; o[2] = tRatio; o[3] = tQ; o[4] = tOut; o[5] = tDma; o[6] = (s1 - s0 + 1) / 2;
+      }
+    }
   }
 
 #pragma unroll
@@ -361,7 +391,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
                             int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
 
-template <int M, int NG, int NS, int WPS>
+template <int M, int NG, int NS, int WPS, int INSTR = 0>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
@@ -383,7 +413,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
   constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  auto kern = nmf_update5_kernel<M, NG, NS, WPS>;
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int) shmem);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
@@ -411,6 +441,12 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, WPS>();
+      if constexpr (M == 8 && NG == 9 && WPS == 1)
+      {
+        // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
+        static const int instr = [] { const char* e = std::getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();
+        if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return; }
+      }
       launch5_t<M, NG, NS, WPS>(a, w, s);
     }
     else launch5_ng<M, NG - 1, WPS>(a, w, ng, s);

@@ -1,0 +1,22 @@
+"""Per-phase cycle breakdown of one wavefront of the W-update (FLUHIP_K5_INSTR=1 build path)."""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+os.environ["FLUHIP_K5_INSTR"] = "1"
+import fluhip, oracle_np
+ctx = fluhip.Context(0)
+B, n = 128, 441000
+x = oracle_np.synth_audio(n, 1000)
+c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, 32)
+c.set_audio(np.tile(x, (B, 1))); c.stft(); c.nmf(3, seed=42, updateH=False); ctx.synchronize()
+out = (ctypes.c_int64 * 8)()
+ctx.lib.fluhip_corpus_debug_words.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
+assert ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0
+names = ["wait_dma", "lds_read", "ratio", "q_phase", "out_phase", "dma_issue"]
+iters = out[6]
+tot = sum(out[i] for i in range(6))
+print("half-iterations measured:", iters, " (first half of each 2-step loop body)")
+for i, nme in enumerate(names):
+    print(f"  {nme:10s} {out[i]/iters:8.0f} cycles/step  {100*out[i]/tot:5.1f} %")
+print(f"  total      {tot/iters:8.0f} cycles/step")
