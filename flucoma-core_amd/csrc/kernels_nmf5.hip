@@ -45,6 +45,21 @@ struct Upd5Args
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (src),          \
                                    (__attribute__((address_space(3))) void*) (dst), 16, 0, 0)
 
+// LDS-DMA in the "scalar base + 32-bit lane offset" form, spelled out: left to the compiler the builtin
+// takes a 64-bit vector address, i.e. one v_lshl_add_u64 per copy -- a VALU instruction in the middle of
+// the MFMA stream costs ~14 cycles there (tools/mfma_coissue_probe.hip).
+__device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigned ldsAddr)
+{
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+               :
+               : "s"(ldsAddr), "v"(voff), "s"(sbase)
+               : "memory");   // m0 is written; the compiler keeps nothing live in it around LDS-DMA code (gfx9 LDS ops do not use it)
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p)
+{
+  return (unsigned) (size_t) (__attribute__((address_space(3))) const void*) p;
+}
+
 template <int N>
 __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
 {
@@ -57,7 +72,7 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
   }
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
@@ -278,6 +293,177 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // stages s0 .. s0+NS-1 in flight; iteration s consumes stage s (mb, v) and stage s+1 (ma), then
   // refills the slot of stage s with stage s+NS.  Completion is in issue order, so "stage s+1 has
   // landed" == at most (NS-2) stages outstanding.
+  if constexpr (MODE == 1)
+  {
+    // ---- overlapped form ------------------------------------------------------------------------
+    // Measured on the device (tools/mfma_coissue_probe.hip): inside a stream of independent 4x4x4 f64
+    // MFMAs a ds_read costs ~5 cycles of issue, a 16-byte-per-lane VMEM instruction ~30, and ANY VALU
+    // instruction ~14 (pipe switch) -- so the operand reads of step s+1 and the DMA refill of slot s are
+    // spread between step s's MFMAs, into a second operand register set, with every LDS address a
+    // loop-invariant VGPR plus an immediate: the loop is unrolled over the ring so that slot numbers are
+    // compile-time constants and no address arithmetic is left on the VALU.  Slots are numbered from s0.
+    if (s0 < s1)
+    {
+      static_assert(NS >= 4 && NS % 2 == 0, "overlapped pipeline: even ring depth >= 4");
+      auto issue_slot = [&](int st, int slot) {
+        const int sc = min(st, sLast);
+        const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
+        const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+#pragma unroll
+        for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + slot * VSTAGE + j * 1024);
+#pragma unroll
+        for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
+      };
+#pragma unroll
+      for (int t = 0; t < NS; t++) issue_slot(s0 + t, t);
+      const unsigned vringA = __builtin_amdgcn_readfirstlane(lds_addr(vring));
+      const unsigned mringA = __builtin_amdgcn_readfirstlane(lds_addr(mring));
+      // loop-invariant per-lane LDS addresses
+      const char* vAddr = vring + vOff;
+      const char* maAddr[M / 2];
+      const char* mbAddr[M / 2];
+#pragma unroll
+      for (int j = 0; j < M / 2; j++) { maAddr[j] = mring + maOff[j]; mbAddr[j] = mring + mbOff[j]; }
+
+      double vX[NG], maX[M], mbX[M], vY[NG], maY[M], mbY[M], qA[NG], qB[NG];
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+      auto read_set = [&](int slotV, int slotA, double (&v)[NG], double (&ma)[M], double (&mb)[M], bool wantV) {
+        if (wantV)
+        {
+#pragma unroll
+          for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vAddr + slotV * VSTAGE + g * 128);
+#pragma unroll
+          for (int j = 0; j < M / 2; j++)
+          {
+            d2 t = *reinterpret_cast<const d2*>(mbAddr[j] + slotV * MSTAGE);
+            mb[2 * j] = t[0]; mb[2 * j + 1] = t[1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < M / 2; j++)
+        {
+          d2 t = *reinterpret_cast<const d2*>(maAddr[j] + slotA * MSTAGE);
+          ma[2 * j] = t[0]; ma[2 * j + 1] = t[1];
+        }
+      };
+      read_set(0, 0, vX, maX, mbX, false);
+      q_phase(maX, qA);
+      read_set(0, 1, vX, maX, mbX, true);
+
+      constexpr int NRD = NG + M;                   // ds_read instructions per operand set
+      constexpr int NMF = M * NG;                   // MFMAs per phase
+      constexpr int RDSTEP = (NMF / NRD) >= 2 ? 2 : 1;
+      constexpr int DMASTEP = NMF / IPS > 0 ? NMF / IPS : 1;
+      long long tWait = 0, tRatio = 0, tQ = 0, tOut = 0, tReal = 0;
+      auto tick = [&]() -> long long {
+        if constexpr (INSTR) { __builtin_amdgcn_sched_barrier(0); long long c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return c; }
+        return 0;
+      };
+      if constexpr (INSTR) tReal = -(long long) __builtin_amdgcn_s_memrealtime();
+      // step s sits in slot u; reads stage s+1 (slot u1) and the ma part of stage s+2 (slot u2); refills slot u
+      auto half = [&](int s, int u, int u1, int u2, const double (&v)[NG], const double (&ma)[M], const double (&mb)[M],
+                      double (&vn)[NG], double (&man)[M], double (&mbn)[M], const double (&qc)[NG],
+                      double (&qn)[NG]) {
+        double ratio[NG];
+        const long long c0 = tick();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory"); // stages s+1, s+2 landed
+        const long long c1 = tick();
+        ratio_phase(v, qc, ratio);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long c2 = tick();
+        {
+          constexpr int PP = (P <= M) ? P : M;
+          double qp[NG][PP];
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int p = 0; p < PP; p++) qp[g][p] = 0.0;
+#pragma unroll
+          for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+            {
+              qp[g][m % PP] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], qp[g][m % PP], 0, 0, 0);
+              const int i = m * NG + g;
+              if (i % RDSTEP == RDSTEP - 1 && i / RDSTEP < NRD)
+              {
+                const int r = i / RDSTEP;
+                if (r < NG) vn[r] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + r * 128);
+                else if (r < NG + M / 2)
+                {
+                  d2 t = *reinterpret_cast<const d2*>(mbAddr[r - NG] + u1 * MSTAGE);
+                  mbn[2 * (r - NG)] = t[0];
+                  mbn[2 * (r - NG) + 1] = t[1];
+                }
+                else
+                {
+                  d2 t = *reinterpret_cast<const d2*>(maAddr[r - NG - M / 2] + u2 * MSTAGE);
+                  man[2 * (r - NG - M / 2)] = t[0];
+                  man[2 * (r - NG - M / 2) + 1] = t[1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+          {
+            double t = qp[g][0];
+#pragma unroll
+            for (int p = 1; p < PP; p++) t += qp[g][p];
+            qn[g] = t;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const long long c3 = tick();
+        {
+          const int sc = min(s + NS, sLast);
+          const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
+          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int m = 0; m < M; m++)
+            {
+              acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ratio[g], mb[m], acc[g][m], 0, 0, 0);
+              const int i = g * M + m;
+              if (i % DMASTEP == DMASTEP / 2 && i / DMASTEP < IPS)
+              {
+                const int j = i / DMASTEP;
+                if (j < NJV) glds16(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
+                else glds16(msrc, moffs[j - NJV], mringA + u * MSTAGE + (j - NJV) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+          for (int m = 0; m < M; m++) dsum[m] += mb[m];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const long long c4 = tick();
+        if constexpr (INSTR) { tWait += c1 - c0; tRatio += c2 - c1; tQ += c3 - c2; tOut += c4 - c3; }
+      };
+      for (int s = s0; s < s1; s += NS)
+      {
+#pragma unroll
+        for (int u = 0; u < NS; u++)
+        {
+          if (s + u >= s1) break;
+          if (u % 2 == 0) half(s + u, u, (u + 1) % NS, (u + 2) % NS, vX, maX, mbX, vY, maY, mbY, qA, qB);
+          else half(s + u, u, (u + 1) % NS, (u + 2) % NS, vY, maY, mbY, vX, maX, mbX, qB, qA);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (INSTR)
+      {
+        tReal += (long long) __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 17 && threadIdx.x == 0 && a.dpart)
+        {
+          long long* o = reinterpret_cast<long long*>(a.dpart);
+          o[0] = tWait; o[1] = 0; o[2] = tRatio; o[3] = tQ; o[4] = tOut; o[5] = 0; o[6] = s1 - s0; o[7] = tReal;
+        }
+      }
+    }
+  }
+  else
   if (s0 < s1)
   {
 #pragma unroll
@@ -391,7 +577,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
                             int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
@@ -413,7 +599,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
   constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR>;
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int) shmem);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
@@ -445,7 +631,15 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
       {
         // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
         static const int instr = [] { const char* e = std::getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();
+        static const int imode = [] { const char* e = std::getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : 1; }();
+        if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return; }
         if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return; }
+      }
+      if constexpr (WPS == 1 && NS >= 4 && NS % 2 == 0 && M <= 16) // <32,2> would spill with the second operand set
+      {
+        // FLUHIP_K5_MODE=0 selects the non-overlapped pipeline (A/B measurements)
+        static const int mode = [] { const char* e = std::getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : 1; }();
+        if (mode == 1) { launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s); return; }
       }
       launch5_t<M, NG, NS, WPS>(a, w, s);
     }

@@ -20,3 +20,6 @@ print("half-iterations measured:", iters, " (first half of each 2-step loop body
 for i, nme in enumerate(names):
     print(f"  {nme:10s} {out[i]/iters:8.0f} cycles/step  {100*out[i]/tot:5.1f} %")
 print(f"  total      {tot/iters:8.0f} cycles/step")
+if out[7]:
+    us = out[7] / 100.0   # s_memrealtime counts at 100 MHz
+    print(f"  loop wall  {us:8.1f} us  -> shader clock {tot/us/1e3:6.3f} GHz if s_memtime counts shader cycles")
