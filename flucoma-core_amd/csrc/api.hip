@@ -217,6 +217,7 @@ struct fluhip_corpus
   const float* audioDev = nullptr; // borrowed or owned (audioOwn)
   DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
   int nsplitW = 1, nsplitH = 1;
+  bool sideW = false; // Nyquist bin of the W update handled as a side column (fluhip_kernels.h)
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
@@ -284,6 +285,18 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
     c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
+    // Nyquist bin as a side column of the W update (fluhip_kernels.h SideColumn) when that shortens
+    // the widest strip of the MFMA kernel
+    static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    c->sideW = false;
+    if (!sideOff && update_variant((int) c->Kp) == 5 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
+        c->nsplitW == 1 && choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp) == 1)
+    {
+      const int G = ((int) c->F + 15) / 16, G1 = G - 1;
+      const int w = nmf_update4_waves_per_buffer((int) c->F, (int) c->Kp, (int) c->B);
+      const int w1 = nmf_update4_waves_per_buffer((int) c->F - 1, (int) c->Kp, (int) c->B);
+      c->sideW = (G1 + w1 - 1) / w1 < (G + w - 1) / w && w1 <= w;
+    }
   }
   else
   {
@@ -493,7 +506,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.V = c->mag.as<double>(); a.ldv = c->Fp; a.strideV = c->Tp * c->Fp;
     a.Mv = c->H1.as<double>(); a.strideM = c->Tp * c->Kp;
     a.S = c->Wf.as<double>(); a.strideS = c->Fp * c->Kp;
-    a.R = (int) c->T; a.C = (int) c->F; a.B = B; a.Kp = (int) c->Kp;
+    a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp);
     {
@@ -504,8 +517,10 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
       else launch_nmf_update(a, s);
     }
     // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
+    SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
+                  (int) c->T};
     launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
-                   c->normScratch.as<double>(), s);
+                   c->normScratch.as<double>(), s, c->sideW ? &sc : nullptr);
   }
   if (updateH)
   {

@@ -82,8 +82,23 @@ bool nmf_update5_supported(int Kp);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
 // divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).
+//
+// Side column: every power-of-two FFT has F = 16 m + 1 bins, so in the W update the Nyquist bin would cost
+// each wavefront of the MFMA kernel a whole extra 16-column group (9 instead of 8 at fft 2048).  When
+// `side` is given, the update kernel was launched on the first C-1 columns only and the block of the
+// statistics pass that owns row C-1 first computes that row's update itself (same formula, scalar FMAs,
+// fixed summation order), then proceeds as usual.
+struct SideColumn
+{
+  const double* vcol; // the R values V[:, C-1] of buffer 0, contiguous (a row of the transposed copy)
+  int64_t strideV;    // buffer stride of vcol
+  const double* Mv;   // moving factor [B][>=R][Kp] as it was during the update
+  int64_t strideM;
+  int R;
+};
+bool nmf_side_column_supported(int R, int C, int Kp);
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s);
+                    bool checkMax, double* scratch, hipStream_t s, const SideColumn* side = nullptr);
 int colnorm_scratch_doubles(int C, int Kp, int B);
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]

@@ -282,15 +282,63 @@ void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
 // ---------------------------------------------------------------------------------------
 constexpr int kNormRows = 64; // rows per chunk
 
+// Side column (fluhip_kernels.h): row C-1 of S gets the factor update of kernels_nmf5.hip for a single
+// column, spread over the statistics blocks of the buffer.  Block `chunk` takes a slice of the R
+// contraction rows.  Pass 1, one thread per row r: ratio[r] = V[r][C-1] / max(sum_j Mv[r][j] S[C-1][j], eps).
+// Pass 2, thread = (row group, k): num_k += ratio[r] Mv[r][k], den_k += Mv[r][k] (operands loaded up
+// front, beside the pass-1 rows, so the block pays one memory latency); row groups are combined in fixed
+// order and the block's (num, den) go to scratch.  colscale_kernel adds
+// the slices in chunk order, forms S[C-1][k] = S_old[C-1][k] num_k / max(den_k, eps), includes it in
+// the column statistics and writes it (normalised).  No atomics: run-to-run bit-identical.
+constexpr int kSideUnr = 16; // rows of a side-column slice per row group (held in registers)
+
 __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
-                                double* part, int nch)
+                                double* part, int nch, SideColumn side, int B)
 {
-  extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima (+ [slice rows] quotients)
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
+  const bool haveSide = side.vcol != nullptr;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
-  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
+
+  // ---- side column, loads first: every global load of this block is issued before anything waits ----
+  const double* Mv = side.Mv + (int64_t) b * side.strideM;
+  const double* wrow = S + (int64_t) (C - 1) * Kp;
+  const int RS = haveSide ? (side.R + nch - 1) / nch : 0;
+  const int r0 = chunk * RS, r1 = haveSide ? min(r0 + RS, side.R) : 0;
+  double* ratio = sh + 2 * nrg * Kp;
+  double m2[kSideUnr];
+  double q = 0.0, vr = 0.0;
+  if (haveSide)
+  {
+#pragma unroll
+    for (int u = 0; u < kSideUnr; u++)
+    {
+      const int r = r0 + u * nrg + rg;
+      m2[u] = r < r1 ? Mv[(int64_t) r * Kp + k] : 0.0; // pass-2 operand, thread = (row group, k)
+    }
+    const int r = r0 + (int) threadIdx.x;               // pass 1: one thread per row of the slice (RS <= blockDim)
+    if (r < r1)
+    {
+      const double* m = Mv + (int64_t) r * Kp;
+      double q0 = 0.0, q1 = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < Kp; j += 2)
+      {
+        const d2 t = *reinterpret_cast<const d2*>(m + j);
+        const d2 w = *reinterpret_cast<const d2*>(wrow + j);
+        q0 = fma(t[0], w[0], q0);
+        q1 = fma(t[1], w[1], q1);
+      }
+      q = q0 + q1;
+      vr = side.vcol[(int64_t) b * side.strideV + r];
+    }
+  }
+
+  // ---- column statistics of this chunk's rows (row C-1 is added by colscale when it is the side column)
+  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, haveSide ? C - 1 : C);
   double ss = 0.0, mx = -INFINITY;
   if (k < K)
     for (int r = rbeg + rg; r < rend; r += nrg)
@@ -304,6 +352,38 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
       ss += x * x;
       mx = fmax(mx, x);
     }
+
+  if (haveSide)
+  {
+    if (r0 + (int) threadIdx.x < r1) ratio[threadIdx.x] = vr / fmax(q, kEpsilon);
+    __syncthreads();
+    double num = 0.0, den = 0.0;
+#pragma unroll
+    for (int u = 0; u < kSideUnr; u++)
+    {
+      const int r = r0 + u * nrg + rg;
+      num = fma(r < r1 ? ratio[r - r0] : 0.0, m2[u], num);
+      den += m2[u];
+    }
+    sh[rg * Kp + k] = num;
+    sh[(nrg + rg) * Kp + k] = den;
+    __syncthreads();
+    if (rg == 0)
+    {
+      double n = 0.0, d = 0.0;
+      for (int j = 0; j < nrg; j++)
+      {
+        n += sh[j * Kp + k];
+        d += sh[(nrg + j) * Kp + k];
+      }
+      double* p = part + (int64_t) B * nch * 2 * Kp + ((int64_t) b * nch + chunk) * 2 * Kp;
+      p[k] = n;
+      p[Kp + k] = d;
+      if (chunk == (C - 1) / kNormRows) part[(int64_t) B * nch * 4 * Kp + (int64_t) b * Kp + k] = wrow[k];
+    }
+    __syncthreads();
+  }
+
   sh[rg * Kp + k] = ss;
   sh[(nrg + rg) * Kp + k] = mx;
   __syncthreads();
@@ -322,18 +402,25 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
 }
 
 __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int checkMax,
-                                const double* part, int nch)
+                                const double* part, int nch, int haveSide, int B)
 {
-  extern __shared__ double sh[]; // [nch][2*Kp] partials, then [Kp] totals + [Kp] maxima
+  extern __shared__ double sh[]; // [nch][2*Kp] partials (x2 with a side column), then [Kp] totals + [Kp] maxima + [Kp] side row
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
   // all partials of this buffer in one burst of independent loads, then a fixed-order combine from LDS
-  const double* p = part + (int64_t) b * nch * 2 * Kp;
-  for (int i = threadIdx.x; i < nch * 2 * Kp; i += blockDim.x) sh[i] = p[i];
+  const int np = nch * 2 * Kp;
+  const double* p = part + (int64_t) b * np;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) sh[i] = p[i];
+  double* sideSh = sh + np;
+  if (haveSide)
+  {
+    const double* q = part + (int64_t) B * np + (int64_t) b * np;
+    for (int i = threadIdx.x; i < np; i += blockDim.x) sideSh[i] = q[i];
+  }
   __syncthreads();
-  double* tot = sh + (size_t) nch * 2 * Kp;
+  double* tot = sh + (size_t) (haveSide ? 2 : 1) * np;
   if (rg == 0)
   {
     double t = 0.0, m = -INFINITY;
@@ -345,33 +432,75 @@ __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, in
     tot[k] = t;
     tot[Kp + k] = (k < K) ? m : -INFINITY;
   }
+  if (haveSide && rg == nrg - 1) // another row group (the same one when there is only one): runs beside the combine above
+  {
+    double n = 0.0, d = 0.0;
+    for (int j = 0; j < nch; j++)
+    {
+      n += sideSh[j * 2 * Kp + k];
+      d += sideSh[j * 2 * Kp + Kp + k];
+    }
+    const double wold = part[(int64_t) B * np * 2 + (int64_t) b * Kp + k];
+    tot[2 * Kp + k] = (k < K) ? (wold * n) / fmax(d, kEpsilon) : 0.0;
+  }
   __syncthreads();
+  if (haveSide && rg == 0)
+  {
+    const double wnew = tot[2 * Kp + k];
+    tot[k] += wnew * wnew;
+    if (k < K) tot[Kp + k] = fmax(tot[Kp + k], wnew);
+  }
+  if (haveSide) __syncthreads();
+  const bool owner = haveSide && chunk == (C - 1) / kNormRows;
   if (checkMax)
   {
     double gmax = -INFINITY;
     for (int j = 0; j < Kp; j++) gmax = fmax(gmax, tot[Kp + j]);
-    if (!(gmax > kEpsilon)) return; // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
+    if (!(gmax > kEpsilon)) // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
+    {
+      if (owner && rg == 0 && k < K) S[(int64_t) (C - 1) * Kp + k] = tot[2 * Kp + k];
+      return;
+    }
   }
   if (k >= K) return;
   const double nrm = sqrt(tot[k]);
   const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
-  for (int r = rbeg + rg; r < rend; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
+  for (int r = rbeg + rg; r < rend; r += nrg)
+  {
+    const double x = (haveSide && r == C - 1) ? tot[2 * Kp + k] : S[(int64_t) r * Kp + k];
+    S[(int64_t) r * Kp + k] = x / nrm;
+  }
 }
 
-int colnorm_scratch_doubles(int C, int Kp, int B) { return ((C + kNormRows - 1) / kNormRows) * 2 * Kp * B; }
+// [B][nch][2 Kp] column statistics + [B][nch][2 Kp] side-column slices + [B][Kp] old side row
+int colnorm_scratch_doubles(int C, int Kp, int B) { return (((C + kNormRows - 1) / kNormRows) * 4 * Kp + Kp) * B; }
+
+// the side column is spread over the ceil(C/64) statistics blocks of the buffer; a block keeps its slice of
+// the contraction in registers (single huge buffers take the split-R path anyway)
+bool nmf_side_column_supported(int R, int C, int Kp)
+{
+  const int nch = (C + kNormRows - 1) / kNormRows;
+  const int nrg = Kp <= 256 ? 256 / Kp : 1;
+  return C % 16 == 1 && C > 16 && Kp <= 64 && (R + nch - 1) / nch <= nrg * kSideUnr;
+}
 
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s)
+                    bool checkMax, double* scratch, hipStream_t s, const SideColumn* side)
 {
   int nrg = 256 / Kp;
   if (nrg < 1) nrg = 1;
   const int threads = nrg * Kp;
   const int nch = (C + kNormRows - 1) / kNormRows;
   dim3 grid((unsigned) nch, (unsigned) B);
-  hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
-                     strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
-  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) (nch + 1) * 2 * Kp * sizeof(double), s,
-                     S, strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
+  SideColumn sc{nullptr, 0, nullptr, 0, 0};
+  if (side) sc = *side;
+  const int sliceRows = side ? (sc.R + nch - 1) / nch : 0;
+  hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads),
+                     (size_t) (2 * nrg * Kp + sliceRows) * sizeof(double), s, S, strideS, C, K, Kp, clampEps ? 1 : 0,
+                     scratch, nch, sc, B);
+  const size_t shScale = ((size_t) (side ? 2 : 1) * nch * 2 * Kp + 3 * Kp) * sizeof(double);
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), shScale, s, S, strideS, C, K, Kp,
+                     checkMax ? 1 : 0, scratch, nch, side ? 1 : 0, B);
 }
 
 // ---------------------------------------------------------------------------------------
