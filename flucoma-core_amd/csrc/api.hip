@@ -217,7 +217,12 @@ struct fluhip_corpus
   const float* audioDev = nullptr; // borrowed or owned (audioOwn)
   DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
   int nsplitW = 1, nsplitH = 1;
-  bool sideW = false; // Nyquist bin of the W update handled as a side column (fluhip_kernels.h)
+  // deferred normalisation of W inside the iteration loop (fluhip_kernels.h UpdateArgs::nrm)
+  bool lazy = false;     // the shape takes the two-launch-per-factor fast path
+  bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
+  bool wPending = false; // W in memory is W' = W diag(wnorm)
+  int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
+  DevBuf wnorm, wscratch;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
@@ -285,18 +290,22 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
     c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
-    // Nyquist bin as a side column of the W update (fluhip_kernels.h SideColumn) when that shortens
-    // the widest strip of the MFMA kernel
+    // Fast path: W stays un-normalised in memory during the loop (UpdateArgs::nrm), the column statistics
+    // come out of the update kernel's epilogue and the Nyquist bin is a side column when that shortens the
+    // widest strip of the MFMA kernel (fluhip_kernels.h SideColumn).
+    static const int lazyOff = [] { const char* e = std::getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
     static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    c->lazy = !lazyOff && update_variant((int) c->Kp) == 5 && c->nsplitW == 1 && c->nsplitH == 1;
     c->sideW = false;
-    if (!sideOff && update_variant((int) c->Kp) == 5 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
-        c->nsplitW == 1 && choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp) == 1)
+    if (c->lazy && !sideOff && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
+        choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp) == 1)
     {
       const int G = ((int) c->F + 15) / 16, G1 = G - 1;
-      const int w = nmf_update4_waves_per_buffer((int) c->F, (int) c->Kp, (int) c->B);
-      const int w1 = nmf_update4_waves_per_buffer((int) c->F - 1, (int) c->Kp, (int) c->B);
+      const int w = nmf_update5_strips((int) c->F, (int) c->Kp, (int) c->B);
+      const int w1 = nmf_update5_strips((int) c->F - 1, (int) c->Kp, (int) c->B);
       c->sideW = (G1 + w1 - 1) / w1 < (G + w - 1) / w && w1 <= w;
     }
+    c->stripsW = nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
   }
   else
   {
@@ -311,6 +320,12 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
     HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
   }
   HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * ns * c->Kp * sizeof(double)), true, s));
+  if (c->lazy)
+  {
+    HIPCHK(ctx, c->wnorm.alloc(B * c->Kp * sizeof(double), false, s));
+    launch_fill_ones(c->wnorm.as<double>(), (int64_t) (B * c->Kp), s);
+    HIPCHK(ctx, c->wscratch.alloc((size_t) wnorm_scratch_doubles((int) c->Kp, (int) B, c->stripsW) * sizeof(double), true, s));
+  }
   return FLUHIP_OK;
 }
 
@@ -509,18 +524,33 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp);
+    if (c->lazy)
     {
+      // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
+      // and its per-wavefront column statistics; [side column ->] new wnorm.  alg/NMF.hpp:162 is then
+      // implicit in every later use of (W', wnorm).
       ProfScope p(ctx, 1);
-      const int uv = update_variant(a.Kp);
-      if (uv == 5) launch_nmf_update5(a, s);
-      else if (uv == 4) launch_nmf_update4(a, s);
-      else launch_nmf_update(a, s);
+      a.nrm = c->wnorm.as<double>(); a.nrmMode = 1; a.statPart = c->wscratch.as<double>();
+      launch_nmf_update5(a, s);
+      SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
+                    (int) c->T};
+      launch_wnorm_combine(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, c->stripsW,
+                           c->wscratch.as<double>(), c->wnorm.as<double>(), c->sideW ? &sc : nullptr, s);
+      c->wPending = true;
     }
-    // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
-    SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
-                  (int) c->T};
-    launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
-                   c->normScratch.as<double>(), s, c->sideW ? &sc : nullptr);
+    else
+    {
+      {
+        ProfScope p(ctx, 1);
+        const int uv = update_variant(a.Kp);
+        if (uv == 5) launch_nmf_update5(a, s);
+        else if (uv == 4) launch_nmf_update4(a, s);
+        else launch_nmf_update(a, s);
+      }
+      // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
+      launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
+                     c->normScratch.as<double>(), s);
+    }
   }
   if (updateH)
   {
@@ -532,6 +562,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.R = (int) c->F; a.C = (int) c->T; a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp);
+    if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
     if (uv == 5) launch_nmf_update5(a, s);
@@ -543,8 +574,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
 // alg/NMF.hpp:154-181 loop + :175-176 callbacks.  Iterations are enqueued back to back; when a
 // progress callback is present the stream is drained every `chunk` iterations and the callback
 // is invoked once per completed iteration, in order, on the calling thread.
-static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
-                          fluhip_progress_fn progress, void* user)
+static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
+                               fluhip_progress_fn progress, void* user)
 {
   fluhip_ctx* ctx = c->ctx;
   if (!progress)
@@ -569,6 +600,20 @@ static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool up
     else if (ms > 8.0 && chunk > 1) chunk /= 2;
   }
   return FLUHIP_OK;
+}
+
+static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
+                          fluhip_progress_fn progress, void* user)
+{
+  const int rc = corpus_iterate_loop(c, iters, updateW, updateH, progress, user);
+  if (c->wPending)
+  {
+    // leave the deferred form on every exit (also a cancelled run hands back W, alg/NMF.hpp:175-176)
+    launch_wnorm_apply(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->Kp, (int) c->B, c->wnorm.as<double>(),
+                       c->ctx->stream);
+    c->wPending = false;
+  }
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------

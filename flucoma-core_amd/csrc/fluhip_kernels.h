@@ -67,6 +67,14 @@ struct UpdateArgs
   double* part;     // [B][nsplit][Cp][Kp]
   double* dpart;    // [B][nsplit][Kp]
   int64_t Cp;
+  // Deferred column normalisation of W (kernels_nmf5.hip only; see "normalisation" in DESIGN.md): W stays in
+  // memory as written by its update, W' = W * diag(nrm), with nrm [B][Kp] beside it.
+  //   nrmMode 1 (W update, S = W'): the stationary rows are divided by nrm as they are loaded.
+  //   nrmMode 2 (H update, Mv = W'): Q = W' (H / nrm)^T, numerator and denominator are divided by nrm.
+  const double* nrm = nullptr;
+  int nrmMode = 0;
+  // W update: per-wavefront column statistics of the rows it wrote, [B][wavesPerBuf][2][Kp] (sum x^2, max x)
+  double* statPart = nullptr;
 };
 
 // S[c][k] <- S[c][k] * (sum_r (V[r][c] / max(sum_j Mv[r][j] S[c][j], eps)) * Mv[r][k])
@@ -82,12 +90,15 @@ bool nmf_update5_supported(int Kp);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
 // divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).
-//
+void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
+                    bool checkMax, double* scratch, hipStream_t s);
+int colnorm_scratch_doubles(int C, int Kp, int B);
+
+// ---- deferred normalisation of W (UpdateArgs::nrm) ------------------------------------------------
 // Side column: every power-of-two FFT has F = 16 m + 1 bins, so in the W update the Nyquist bin would cost
-// each wavefront of the MFMA kernel a whole extra 16-column group (9 instead of 8 at fft 2048).  When
-// `side` is given, the update kernel was launched on the first C-1 columns only and the block of the
-// statistics pass that owns row C-1 first computes that row's update itself (same formula, scalar FMAs,
-// fixed summation order), then proceeds as usual.
+// each wavefront of the MFMA kernel a whole extra 16-column group (9 instead of 8 at fft 2048).  With a
+// side column the update kernel is launched on the first C-1 columns and row C-1 of S is updated by
+// launch_wnorm_combine (same formula, scalar FMAs, fixed summation order).
 struct SideColumn
 {
   const double* vcol; // the R values V[:, C-1] of buffer 0, contiguous (a row of the transposed copy)
@@ -97,9 +108,15 @@ struct SideColumn
   int R;
 };
 bool nmf_side_column_supported(int R, int C, int Kp);
-void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s, const SideColumn* side = nullptr);
-int colnorm_scratch_doubles(int C, int Kp, int B);
+// after a W update launched with UpdateArgs::statPart = scratch and nStrips wavefronts per buffer:
+// [side column ->] new nrm [B][Kp] (1 where alg/NMF.hpp:162 would skip the normalisation)
+int wnorm_scratch_doubles(int Kp, int B, int nStrips);
+void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
+                          double* nrm, const SideColumn* side, hipStream_t s);
+// S = S / nrm in memory, nrm = 1
+void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);
+void launch_fill_ones(double* p, int64_t n, hipStream_t s);
+int nmf_update5_strips(int C, int Kp, int B); // wavefronts per buffer launch_nmf_update5 uses (nsplit == 1)
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,

@@ -282,63 +282,15 @@ void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
 // ---------------------------------------------------------------------------------------
 constexpr int kNormRows = 64; // rows per chunk
 
-// Side column (fluhip_kernels.h): row C-1 of S gets the factor update of kernels_nmf5.hip for a single
-// column, spread over the statistics blocks of the buffer.  Block `chunk` takes a slice of the R
-// contraction rows.  Pass 1, one thread per row r: ratio[r] = V[r][C-1] / max(sum_j Mv[r][j] S[C-1][j], eps).
-// Pass 2, thread = (row group, k): num_k += ratio[r] Mv[r][k], den_k += Mv[r][k] (operands loaded up
-// front, beside the pass-1 rows, so the block pays one memory latency); row groups are combined in fixed
-// order and the block's (num, den) go to scratch.  colscale_kernel adds
-// the slices in chunk order, forms S[C-1][k] = S_old[C-1][k] num_k / max(den_k, eps), includes it in
-// the column statistics and writes it (normalised).  No atomics: run-to-run bit-identical.
-constexpr int kSideUnr = 16; // rows of a side-column slice per row group (held in registers)
-
 __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
-                                double* part, int nch, SideColumn side, int B)
+                                double* part, int nch)
 {
-  typedef double d2 __attribute__((ext_vector_type(2)));
-  extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima (+ [slice rows] quotients)
+  extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
-  const bool haveSide = side.vcol != nullptr;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
-
-  // ---- side column, loads first: every global load of this block is issued before anything waits ----
-  const double* Mv = side.Mv + (int64_t) b * side.strideM;
-  const double* wrow = S + (int64_t) (C - 1) * Kp;
-  const int RS = haveSide ? (side.R + nch - 1) / nch : 0;
-  const int r0 = chunk * RS, r1 = haveSide ? min(r0 + RS, side.R) : 0;
-  double* ratio = sh + 2 * nrg * Kp;
-  double m2[kSideUnr];
-  double q = 0.0, vr = 0.0;
-  if (haveSide)
-  {
-#pragma unroll
-    for (int u = 0; u < kSideUnr; u++)
-    {
-      const int r = r0 + u * nrg + rg;
-      m2[u] = r < r1 ? Mv[(int64_t) r * Kp + k] : 0.0; // pass-2 operand, thread = (row group, k)
-    }
-    const int r = r0 + (int) threadIdx.x;               // pass 1: one thread per row of the slice (RS <= blockDim)
-    if (r < r1)
-    {
-      const double* m = Mv + (int64_t) r * Kp;
-      double q0 = 0.0, q1 = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < Kp; j += 2)
-      {
-        const d2 t = *reinterpret_cast<const d2*>(m + j);
-        const d2 w = *reinterpret_cast<const d2*>(wrow + j);
-        q0 = fma(t[0], w[0], q0);
-        q1 = fma(t[1], w[1], q1);
-      }
-      q = q0 + q1;
-      vr = side.vcol[(int64_t) b * side.strideV + r];
-    }
-  }
-
-  // ---- column statistics of this chunk's rows (row C-1 is added by colscale when it is the side column)
-  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, haveSide ? C - 1 : C);
+  const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
   double ss = 0.0, mx = -INFINITY;
   if (k < K)
     for (int r = rbeg + rg; r < rend; r += nrg)
@@ -352,38 +304,6 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
       ss += x * x;
       mx = fmax(mx, x);
     }
-
-  if (haveSide)
-  {
-    if (r0 + (int) threadIdx.x < r1) ratio[threadIdx.x] = vr / fmax(q, kEpsilon);
-    __syncthreads();
-    double num = 0.0, den = 0.0;
-#pragma unroll
-    for (int u = 0; u < kSideUnr; u++)
-    {
-      const int r = r0 + u * nrg + rg;
-      num = fma(r < r1 ? ratio[r - r0] : 0.0, m2[u], num);
-      den += m2[u];
-    }
-    sh[rg * Kp + k] = num;
-    sh[(nrg + rg) * Kp + k] = den;
-    __syncthreads();
-    if (rg == 0)
-    {
-      double n = 0.0, d = 0.0;
-      for (int j = 0; j < nrg; j++)
-      {
-        n += sh[j * Kp + k];
-        d += sh[(nrg + j) * Kp + k];
-      }
-      double* p = part + (int64_t) B * nch * 2 * Kp + ((int64_t) b * nch + chunk) * 2 * Kp;
-      p[k] = n;
-      p[Kp + k] = d;
-      if (chunk == (C - 1) / kNormRows) part[(int64_t) B * nch * 4 * Kp + (int64_t) b * Kp + k] = wrow[k];
-    }
-    __syncthreads();
-  }
-
   sh[rg * Kp + k] = ss;
   sh[(nrg + rg) * Kp + k] = mx;
   __syncthreads();
@@ -402,25 +322,18 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
 }
 
 __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int checkMax,
-                                const double* part, int nch, int haveSide, int B)
+                                const double* part, int nch)
 {
-  extern __shared__ double sh[]; // [nch][2*Kp] partials (x2 with a side column), then [Kp] totals + [Kp] maxima + [Kp] side row
+  extern __shared__ double sh[]; // [nch][2*Kp] partials, then [Kp] totals + [Kp] maxima
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
   // all partials of this buffer in one burst of independent loads, then a fixed-order combine from LDS
-  const int np = nch * 2 * Kp;
-  const double* p = part + (int64_t) b * np;
-  for (int i = threadIdx.x; i < np; i += blockDim.x) sh[i] = p[i];
-  double* sideSh = sh + np;
-  if (haveSide)
-  {
-    const double* q = part + (int64_t) B * np + (int64_t) b * np;
-    for (int i = threadIdx.x; i < np; i += blockDim.x) sideSh[i] = q[i];
-  }
+  const double* p = part + (int64_t) b * nch * 2 * Kp;
+  for (int i = threadIdx.x; i < nch * 2 * Kp; i += blockDim.x) sh[i] = p[i];
   __syncthreads();
-  double* tot = sh + (size_t) (haveSide ? 2 : 1) * np;
+  double* tot = sh + (size_t) nch * 2 * Kp;
   if (rg == 0)
   {
     double t = 0.0, m = -INFINITY;
@@ -432,75 +345,251 @@ __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, in
     tot[k] = t;
     tot[Kp + k] = (k < K) ? m : -INFINITY;
   }
-  if (haveSide && rg == nrg - 1) // another row group (the same one when there is only one): runs beside the combine above
-  {
-    double n = 0.0, d = 0.0;
-    for (int j = 0; j < nch; j++)
-    {
-      n += sideSh[j * 2 * Kp + k];
-      d += sideSh[j * 2 * Kp + Kp + k];
-    }
-    const double wold = part[(int64_t) B * np * 2 + (int64_t) b * Kp + k];
-    tot[2 * Kp + k] = (k < K) ? (wold * n) / fmax(d, kEpsilon) : 0.0;
-  }
   __syncthreads();
-  if (haveSide && rg == 0)
-  {
-    const double wnew = tot[2 * Kp + k];
-    tot[k] += wnew * wnew;
-    if (k < K) tot[Kp + k] = fmax(tot[Kp + k], wnew);
-  }
-  if (haveSide) __syncthreads();
-  const bool owner = haveSide && chunk == (C - 1) / kNormRows;
   if (checkMax)
   {
     double gmax = -INFINITY;
     for (int j = 0; j < Kp; j++) gmax = fmax(gmax, tot[Kp + j]);
-    if (!(gmax > kEpsilon)) // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
-    {
-      if (owner && rg == 0 && k < K) S[(int64_t) (C - 1) * Kp + k] = tot[2 * Kp + k];
-      return;
-    }
+    if (!(gmax > kEpsilon)) return; // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon)
   }
   if (k >= K) return;
   const double nrm = sqrt(tot[k]);
   const int rbeg = chunk * kNormRows, rend = min(rbeg + kNormRows, C);
-  for (int r = rbeg + rg; r < rend; r += nrg)
-  {
-    const double x = (haveSide && r == C - 1) ? tot[2 * Kp + k] : S[(int64_t) r * Kp + k];
-    S[(int64_t) r * Kp + k] = x / nrm;
-  }
+  for (int r = rbeg + rg; r < rend; r += nrg) S[(int64_t) r * Kp + k] /= nrm;
 }
 
-// [B][nch][2 Kp] column statistics + [B][nch][2 Kp] side-column slices + [B][Kp] old side row
-int colnorm_scratch_doubles(int C, int Kp, int B) { return (((C + kNormRows - 1) / kNormRows) * 4 * Kp + Kp) * B; }
-
-// the side column is spread over the ceil(C/64) statistics blocks of the buffer; a block keeps its slice of
-// the contraction in registers (single huge buffers take the split-R path anyway)
-bool nmf_side_column_supported(int R, int C, int Kp)
-{
-  const int nch = (C + kNormRows - 1) / kNormRows;
-  const int nrg = Kp <= 256 ? 256 / Kp : 1;
-  return C % 16 == 1 && C > 16 && Kp <= 64 && (R + nch - 1) / nch <= nrg * kSideUnr;
-}
+int colnorm_scratch_doubles(int C, int Kp, int B) { return ((C + kNormRows - 1) / kNormRows) * 2 * Kp * B; }
 
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s, const SideColumn* side)
+                    bool checkMax, double* scratch, hipStream_t s)
 {
   int nrg = 256 / Kp;
   if (nrg < 1) nrg = 1;
   const int threads = nrg * Kp;
   const int nch = (C + kNormRows - 1) / kNormRows;
   dim3 grid((unsigned) nch, (unsigned) B);
-  SideColumn sc{nullptr, 0, nullptr, 0, 0};
-  if (side) sc = *side;
-  const int sliceRows = side ? (sc.R + nch - 1) / nch : 0;
-  hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads),
-                     (size_t) (2 * nrg * Kp + sliceRows) * sizeof(double), s, S, strideS, C, K, Kp, clampEps ? 1 : 0,
-                     scratch, nch, sc, B);
-  const size_t shScale = ((size_t) (side ? 2 : 1) * nch * 2 * Kp + 3 * Kp) * sizeof(double);
-  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), shScale, s, S, strideS, C, K, Kp,
-                     checkMax ? 1 : 0, scratch, nch, side ? 1 : 0, B);
+  hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
+                     strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) (nch + 1) * 2 * Kp * sizeof(double), s,
+                     S, strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
+}
+
+// ---------------------------------------------------------------------------------------
+// Deferred normalisation of W (UpdateArgs::nrm) -- the small kernels between the two factor updates
+// ---------------------------------------------------------------------------------------
+// Side column: row C-1 of S gets the factor update of kernels_nmf5.hip for a single column, its
+// contraction over R cut into nsl slices, one workgroup each.  Pass 1, one thread per row r of the slice:
+// ratio[r] = V[r][C-1] / max(sum_j Mv[r][j] S[C-1][j], eps).  Pass 2, thread = (row group, k):
+// num_k += ratio[r] Mv[r][k], den_k += Mv[r][k] (operands loaded up front, beside the pass-1 rows, so the
+// block pays one memory latency); row groups are combined in fixed order and the slice's (num, den) go
+// to scratch for wnorm_combine_kernel.  No atomics: run-to-run bit-identical.
+constexpr int kSideUnr = 8;    // rows of a slice per row group (held in registers)
+constexpr int kSideSlices = 16;
+
+template <int Kp>
+__global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, int64_t strideS, int C, SideColumn side,
+                                                          const double* nrm, double* sidePart, double* wold)
+{
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  extern __shared__ double sh[]; // [nrg][Kp] num, [nrg][Kp] den, [Kp] side row, [slice rows] quotients
+  const int slice = blockIdx.x, nsl = gridDim.x, b = blockIdx.y;
+  const double* S = Sbase + (int64_t) b * strideS;
+  const int nrg = blockDim.x / Kp;
+  const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  const double* Mv = side.Mv + (int64_t) b * side.strideM;
+  const int RS = (side.R + nsl - 1) / nsl;
+  const int r0 = slice * RS, r1 = min(r0 + RS, side.R);
+  double* wsh = sh + 2 * nrg * Kp;
+  double* ratio = wsh + Kp;
+  double m2[kSideUnr];
+#pragma unroll
+  for (int u = 0; u < kSideUnr; u++)
+  {
+    const int r = r0 + u * nrg + rg;
+    m2[u] = r < r1 ? Mv[(int64_t) r * Kp + k] : 0.0;
+  }
+  // the stationary row, normalised the way the update kernel normalises its rows (S = W' / nrm)
+  if (rg == 0)
+  {
+    const double w = S[(int64_t) (C - 1) * Kp + k] / (nrm ? nrm[(int64_t) b * Kp + k] : 1.0);
+    wsh[k] = w;
+    if (slice == 0) wold[(int64_t) b * Kp + k] = w;
+  }
+  const int r = r0 + (int) threadIdx.x; // RS <= blockDim
+  double mrow[Kp];
+  double vr = 0.0;
+  if (r < r1)
+  {
+    const double* m = Mv + (int64_t) r * Kp;
+#pragma unroll
+    for (int j = 0; j < Kp; j += 2)
+    {
+      const d2 t = *reinterpret_cast<const d2*>(m + j);
+      mrow[j] = t[0];
+      mrow[j + 1] = t[1];
+    }
+    vr = side.vcol[(int64_t) b * side.strideV + r];
+  }
+  __syncthreads();
+  if (r < r1)
+  {
+    double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < Kp; j += 2)
+    {
+      q0 = fma(mrow[j], wsh[j], q0);
+      q1 = fma(mrow[j + 1], wsh[j + 1], q1);
+    }
+    ratio[threadIdx.x] = vr / fmax(q0 + q1, kEpsilon);
+  }
+  __syncthreads();
+  double num = 0.0, den = 0.0;
+#pragma unroll
+  for (int u = 0; u < kSideUnr; u++)
+  {
+    const int rr = r0 + u * nrg + rg;
+    num = fma(rr < r1 ? ratio[rr - r0] : 0.0, m2[u], num);
+    den += m2[u];
+  }
+  sh[rg * Kp + k] = num;
+  sh[(nrg + rg) * Kp + k] = den;
+  __syncthreads();
+  if (rg == 0)
+  {
+    double n = 0.0, d = 0.0;
+    for (int j = 0; j < nrg; j++)
+    {
+      n += sh[j * Kp + k];
+      d += sh[(nrg + j) * Kp + k];
+    }
+    double* p = sidePart + ((int64_t) b * nsl + slice) * 2 * Kp;
+    p[k] = n;
+    p[Kp + k] = d;
+  }
+}
+
+// One small workgroup per buffer: adds the per-wavefront column statistics of the W update in strip order
+// and the side-column slices in slice order, writes the side row (S[C-1][k] = S_old[C-1][k] num_k /
+// max(den_k, eps), not normalised like every other row of W') and the new nrm:
+// alg/NMF.hpp:162  if (W.maxCoeff() > epsilon) W.colwise().normalize()  ->  nrm_k = sqrt(sum_c W'[c][k]^2), else 1.
+__global__ __launch_bounds__(128) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, const double* statPart,
+                                     int nStrips, const double* sidePart, int nsl, const double* wold, double* nrm)
+{
+  __shared__ double smax[128];
+  const int b = blockIdx.x, k = threadIdx.x; // blockDim == Kp <= 128
+  // every partial in one burst of independent loads (fixed maximum counts), then fixed-order sums
+  constexpr int kMaxStrips = 16;
+  double ps[kMaxStrips], pm[kMaxStrips], pn[kSideSlices], pd[kSideSlices];
+#pragma unroll
+  for (int st = 0; st < kMaxStrips; st++)
+  {
+    const double* p = statPart + ((int64_t) b * nStrips + (st < nStrips ? st : 0)) * 2 * Kp;
+    ps[st] = p[k];
+    pm[st] = p[Kp + k];
+  }
+  double wo = 0.0;
+  if (sidePart)
+  {
+#pragma unroll
+    for (int j = 0; j < kSideSlices; j++)
+    {
+      const double* p = sidePart + ((int64_t) b * kSideSlices + j) * 2 * Kp;
+      pn[j] = p[k];
+      pd[j] = p[Kp + k];
+    }
+    wo = wold[(int64_t) b * Kp + k];
+  }
+  double t = 0.0, m = -INFINITY;
+#pragma unroll
+  for (int st = 0; st < kMaxStrips; st++)
+    if (st < nStrips)
+    {
+      t += ps[st];
+      m = fmax(m, pm[st]);
+    }
+  for (int st = kMaxStrips; st < nStrips; st++) // wider plans than the burst covers
+  {
+    const double* p = statPart + ((int64_t) b * nStrips + st) * 2 * Kp;
+    t += p[k];
+    m = fmax(m, p[Kp + k]);
+  }
+  if (sidePart)
+  {
+    double n = 0.0, d = 0.0;
+#pragma unroll
+    for (int j = 0; j < kSideSlices; j++)
+    {
+      n += pn[j];
+      d += pd[j];
+    }
+    const double wnew = (k < K) ? (wo * n) / fmax(d, kEpsilon) : 0.0;
+    Sbase[(int64_t) b * strideS + (int64_t) (C - 1) * Kp + k] = wnew;
+    t += wnew * wnew;
+    m = fmax(m, wnew);
+  }
+  smax[k] = (k < K) ? m : -INFINITY;
+  __syncthreads();
+  double gmax = -INFINITY;
+  for (int j = 0; j < Kp; j++) gmax = fmax(gmax, smax[j]);
+  nrm[(int64_t) b * Kp + k] = (k < K && gmax > kEpsilon) ? sqrt(t) : 1.0;
+}
+
+// W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
+// outside the two update kernels reads W)
+__global__ void wnorm_apply_kernel(double* Sbase, int64_t strideS, int C, int Kp, double* nrm)
+{
+  const int b = blockIdx.y;
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t) C * Kp)
+  {
+    double* p = Sbase + (int64_t) b * strideS + i;
+    *p = *p / nrm[(int64_t) b * Kp + (i % Kp)];
+  }
+}
+__global__ void fill_ones_kernel(double* p, int64_t n)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 1.0;
+}
+
+bool nmf_side_column_supported(int R, int C, int Kp)
+{
+  const int nrg = Kp <= 256 ? 256 / Kp : 1;
+  return C % 16 == 1 && C > 16 && Kp <= 64 && (R + kSideSlices - 1) / kSideSlices <= nrg * kSideUnr;
+}
+int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp); }
+
+void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
+                          double* nrm, const SideColumn* side, hipStream_t s)
+{
+  double* statPart = scratch;
+  double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;
+  double* wold = sidePart + (int64_t) B * kSideSlices * 2 * Kp;
+  if (side)
+  {
+    const int nrg = 256 / Kp;
+    const int RS = (side->R + kSideSlices - 1) / kSideSlices;
+    const dim3 grid(kSideSlices, (unsigned) B), block((unsigned) (nrg * Kp));
+    const size_t sh = (size_t) (2 * nrg * Kp + Kp + RS) * sizeof(double);
+    if (Kp == 16) hipLaunchKernelGGL(side_slices_kernel<16>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+  }
+  hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, S, strideS, C, K, Kp,
+                     statPart, nStrips, side ? sidePart : nullptr, kSideSlices, wold, nrm);
+}
+
+void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)
+{
+  const int64_t n = (int64_t) C * Kp;
+  hipLaunchKernelGGL(wnorm_apply_kernel, dim3((unsigned) ((n + 255) / 256), (unsigned) B), dim3(256), 0, s, S, strideS,
+                     C, Kp, nrm);
+  launch_fill_ones(nrm, (int64_t) B * Kp, s);
+}
+
+void launch_fill_ones(double* p, int64_t n, hipStream_t s)
+{
+  hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -39,7 +39,22 @@ struct Upd5Args
   double* dpart;
   int64_t Cp;
   int xcdMap;
+  const double* nrm;
+  int nrmMode;
+  double* statPart;
 };
+
+// v / d for d > 0, v >= 0 in the normal range: v_rcp_f64 -> one Newton step -> quotient -> residual correction
+// (error ~2^-96 before the final rounding; exact when d == 1)
+__device__ __forceinline__ double fdiv_pos(double v, double d)
+{
+  double y = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, y, 1.0);
+  y = __builtin_fma(y, e, y);
+  const double r = v * y;
+  const double res = __builtin_fma(-d, r, v);
+  return __builtin_fma(res, y, r);
+}
 
 #define FLUHIP_GLDS(src, dst)                                                                     \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (src),          \
@@ -190,6 +205,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
     for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
     if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KP + M * y);
+  }
+  if (a.nrmMode)
+  {
+    // deferred normalisation: W update -> the stationary rows are W' / nrm = W; H update -> Q = W' (H / nrm)^T
+    double nr[M];
+    load_vec5<M>(nr, a.nrm + (int64_t) buf * KP + M * y);
+#pragma unroll
+    for (int g = 0; g < NG; g++)
+#pragma unroll
+      for (int m = 0; m < M; m++) sb[g][m] = fdiv_pos(sb[g][m], nr[m]);
   }
   double dsum[M];
 #pragma unroll
@@ -534,6 +559,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 
   if (a.nsplit == 1)
   {
+    double nrE[M], ss[M], mx[M];
+    if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
+    if (a.nrmMode == 2)
+    {
+#pragma unroll
+      for (int m = 0; m < M; m++) dsum[m] = fdiv_pos(dsum[m], nrE[m]); // sum_r W[r][k] = (sum_r W'[r][k]) / nrm_k
+    }
+#pragma unroll
+    for (int m = 0; m < M; m++) { ss[m] = 0.0; mx[m] = -INFINITY; }
 #pragma unroll
     for (int g = 0; g < NG; g++)
     {
@@ -546,8 +580,41 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
           double sold[M];
           load_vec5<M>(sold, sp);
 #pragma unroll
-          for (int m = 0; m < M; m++) sp[m] = (sold[m] * acc[g][m]) / fmax(dsum[m], kEpsilon);
+          for (int m = 0; m < M; m++)
+          {
+            double so = sold[m], num = acc[g][m];
+            if (a.nrmMode == 1) so = fdiv_pos(so, nrE[m]);
+            if (a.nrmMode == 2) num = fdiv_pos(num, nrE[m]);
+            const double r = (so * num) / fmax(dsum[m], kEpsilon);
+            sp[m] = r;
+            ss[m] = __builtin_fma(r, r, ss[m]);
+            mx[m] = fmax(mx[m], r);
+          }
         }
+      }
+    }
+    if (a.statPart)
+    {
+      // column statistics of the rows this wavefront wrote: lanes of equal x hold the same k = M x + m;
+      // fixed butterfly over (blk, y), then lanes 0..3 store
+#pragma unroll
+      for (int m = 0; m < M; m++)
+      {
+        double t = ss[m], u = mx[m];
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1)
+        {
+          t += __shfl_xor(t, off);
+          u = fmax(u, __shfl_xor(u, off));
+        }
+        ss[m] = t;
+        mx[m] = u;
+      }
+      if (lane < 4)
+      {
+        double* sp = a.statPart + ((int64_t) buf * a.wavesPerBuf + strip) * 2 * KP + M * x;
+#pragma unroll
+        for (int m = 0; m < M; m++) { sp[m] = ss[m]; sp[KP + m] = mx[m]; }
       }
     }
   }
@@ -592,6 +659,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   k.nsplit = a.nsplit < 1 ? 1 : a.nsplit;
   k.stepsPerSplit = (k.nSteps + k.nsplit - 1) / k.nsplit;
   k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
+  k.nrm = a.nrm; k.nrmMode = a.nsplit > 1 ? 0 : a.nrmMode; k.statPart = a.nsplit > 1 ? nullptr : a.statPart;
   k.xcdMap = a.B >= 8 ? 1 : 0;
   const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
@@ -648,17 +716,27 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 }
 
 bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
+static int k5_wps()
+{
+  // two wavefronts per SIMD measured no faster than one (profiles/r01/update_kernel_notes.md)
+  static const int wps = [] { const char* e = std::getenv("FLUHIP_K5_WPS"); return e ? std::atoi(e) : 1; }();
+  return wps;
+}
+int nmf_update5_strips(int C, int Kp, int B)
+{
+  const int G = (C + 15) / 16;
+  const int w = nmf_update4_waves_per_buffer(C, Kp, B);
+  const bool two = k5_wps() == 2 && (Kp == 16 || Kp == 32) && 2 * w <= G && (G + 2 * w - 1) / (2 * w) <= 4;
+  return two ? 2 * w : w;
+}
 
 // strips per buffer for WPS wavefronts per SIMD: WPS x the one-wave plan, as long as every strip
 // keeps at least one group
 void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
-  // two wavefronts per SIMD measured no faster than one (profiles/r01/update_kernel_notes.md)
-  static const int wps = [] { const char* e = std::getenv("FLUHIP_K5_WPS"); return e ? std::atoi(e) : 1; }();
   const int G = (a.C + 15) / 16;
-  int w = nmf_update4_waves_per_buffer(a.C, a.Kp, a.B);
-  const bool two = wps == 2 && 2 * w <= G && (G + 2 * w - 1) / (2 * w) <= 4;
-  if (two) w *= 2;
+  const int w = nmf_update5_strips(a.C, a.Kp, a.B);
+  const bool two = w != nmf_update4_waves_per_buffer(a.C, a.Kp, a.B);
   const int ng = (G + w - 1) / w;
   if (two)
   {
