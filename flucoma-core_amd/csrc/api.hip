@@ -529,9 +529,12 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
       // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
       // and its per-wavefront column statistics; [side column ->] new wnorm.  alg/NMF.hpp:162 is then
       // implicit in every later use of (W', wnorm).
-      ProfScope p(ctx, 1);
       a.nrm = c->wnorm.as<double>(); a.nrmMode = 1; a.statPart = c->wscratch.as<double>();
-      launch_nmf_update5(a, s);
+      {
+        ProfScope p(ctx, 1);
+        launch_nmf_update5(a, s);
+      }
+      ProfScope p(ctx, 3);
       SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
                     (int) c->T};
       launch_wnorm_combine(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, c->stripsW,
@@ -1265,6 +1268,20 @@ int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64
 {
   return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
                          max_freq, sample_rate, 0, 0, out, frames_out);
+}
+
+int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
+{
+  if (!c || !out8) return FLUHIP_ERROR;
+  out8[0] = update_variant((int) c->Kp);
+  out8[1] = c->nsplitW;
+  out8[2] = c->nsplitH;
+  out8[3] = c->lazy ? 1 : 0;
+  out8[4] = c->sideW ? 1 : 0;
+  out8[5] = c->stripsW;
+  out8[6] = c->Kp;
+  out8[7] = 0;
+  return FLUHIP_OK;
 }
 
 // ---- profiling ------------------------------------------------------------------------

@@ -6,6 +6,7 @@ is no numpy / torch fallback anywhere.
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -32,7 +33,7 @@ EXPORTS = [
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
-    "fluhip_corpus_writeback_host", "fluhip_corpus_read_f64", "fluhip_prof_enable",
+    "fluhip_corpus_writeback_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read",
 ]
 
@@ -92,6 +93,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_writeback_dev.argtypes = [_vp, _vp, _vp]
     L.fluhip_corpus_writeback_host.argtypes = [_vp, _fp, _fp]
     L.fluhip_corpus_read_f64.argtypes = [_vp, _dp, _dp, _dp]
+    L.fluhip_corpus_plan.argtypes = [_vp, _ip]
     L.fluhip_prof_enable.argtypes = [_vp, ctypes.c_int]
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
@@ -126,6 +128,11 @@ class Context:
 
     def close(self):
         if self.h:
+            # a corpus must not outlive its context (its device buffers are freed on the context's stream)
+            for ref in list(getattr(self, "_corpora", [])):
+                c = ref()
+                if c is not None:
+                    c.close()
             self.lib.fluhip_ctx_destroy(self.h)
             self.h = None
 
@@ -289,12 +296,16 @@ class Corpus:
         h = _vp()
         ctx._check(ctx.lib.fluhip_corpus_create(ctx.h, count, n, win, fft, hop, K, ctypes.byref(h)))
         self.h = h
+        if not hasattr(ctx, "_corpora"):
+            ctx._corpora = []
+        ctx._corpora.append(weakref.ref(self))
         self.T = int(ctx.lib.fluhip_corpus_frames(h))
         self.F = int(ctx.lib.fluhip_corpus_bins(h))
 
     def close(self):
         if self.h:
-            self.ctx.lib.fluhip_corpus_destroy(self.h)
+            if self.ctx.h:
+                self.ctx.lib.fluhip_corpus_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -333,6 +344,12 @@ class Corpus:
         acts = np.empty((self.count, self.K, self.T), dtype=np.float32)
         self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_host(self.h, _f(bases), _f(acts)))
         return bases, acts
+
+    def plan(self):
+        out = (ctypes.c_int64 * 8)()
+        self.ctx._check(self.ctx.lib.fluhip_corpus_plan(self.h, out))
+        keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank")
+        return dict(zip(keys, [int(v) for v in out]))
 
     def read_f64(self, mag=True, factors=True):
         m = np.empty((self.count, self.T, self.F)) if mag else None

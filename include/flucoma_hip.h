@@ -175,11 +175,17 @@ int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_
 int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts);
 /* raw f64 results for parity tests: mag count x T x F, W1 count x K x F, H1 count x T x K */
 int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1);
+/* How the factor updates of this corpus are scheduled on the device (introspection for tests, benchmarks and
+ * bug reports; no effect on results beyond summation order): out8 = { kernel form (5 = 4x4x4 MFMA + LDS-DMA,
+ * 4 = 4x4x4 register-staged, 16 = 16x16x4), contraction splits of the W update, of the H update,
+ * deferred column normalisation of W (alg/NMF.hpp:162 applied on load) 0/1, Nyquist bin as a side column 0/1,
+ * wavefronts per buffer of the W update, padded rank, 0 }. */
+int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 
 /* ---- live kernel timing (HIP events on the context stream) ----------------------------- */
 /* When enabled, every launch of the two dominant kernel classes is bracketed by hipEvents on
  * the stream it is launched on.  Classes: 0 = stft_r2c_mag, 1 = nmf_update (both factor
- * updates share one kernel).  fluhip_prof_read synchronises and returns the launch count and
+ * updates share one kernel), 2 = feature kernels, 3 = the small kernels between the factor updates.  fluhip_prof_read synchronises and returns the launch count and
  * the summed duration since the last reset. */
 int fluhip_prof_enable(fluhip_ctx* ctx, int on);
 int fluhip_prof_reset(fluhip_ctx* ctx);

@@ -282,6 +282,36 @@ def test_corpus_matches_per_buffer_oracle(ctx, oracle, onp):
     c.close()
 
 
+def test_corpus_fast_path_partial_updates(ctx, oracle, onp):
+    """c4's per-buffer shape class (fft 2048, rank 32) in the batched regime: the plan must be the two-launch
+    fast path (deferred column normalisation of W, Nyquist bin as a side column), and W-only / H-only runs --
+    consecutive W updates read back their own un-normalised W' -- must match the oracle like full runs do."""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 128, 220500, 2048, 2048, 512, 32, 12
+    distinct = [onp.synth_audio(n, 4000 + b) for b in range(16)]
+    audio = np.stack([distinct[b % 16] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    plan = c.plan()
+    assert plan["kernel"] == 5 and plan["split_w"] == 1 and plan["split_h"] == 1
+    assert plan["deferred_norm"] == 1 and plan["side_column"] == 1, plan
+    c.set_audio(audio); c.stft()
+    mag = c.read_f64(factors=False)[0]
+    for uw, uh in ((True, False), (False, True), (True, True)):
+        c.nmf(iters, seed=5063, updateW=uw, updateH=uh)
+        _, W1, H1 = c.read_f64(mag=False)
+        for b in (0, 7, 127):
+            rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, uw, uh, 5063)
+            assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (uw, uh, b)
+    # a cancelled run still hands back a normalised dictionary (the deferred form never leaks)
+    # (how many iterations ran before the cancel took effect is not observable in the reference either:
+    # clients/nrt/NMFClient.hpp:273-274 returns kCancelled without writing any output)
+    c.nmf(50, seed=42, progress=lambda it: it < 5)
+    _, Wc, Hc = c.read_f64(mag=False)
+    assert np.isfinite(Wc).all() and np.isfinite(Hc).all()
+    assert np.allclose(np.sqrt((Wc * Wc).sum(axis=2)), 1.0, atol=1e-12)
+    c.close()
+
+
 def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
     """sharding property: a buffer's result does not depend on which batch (or rank) holds it"""
     import fluhip
