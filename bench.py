@@ -185,6 +185,7 @@ def main():
     elapsed = time.perf_counter() - t0
     n_upd, ms_upd = ctx.prof_read(1)
     n_stft, ms_stft = ctx.prof_read(0)
+    n_mid, ms_mid = ctx.prof_read(3)
     ctx.prof_enable(False)
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -199,7 +200,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
         value = world * B * iters * args.steps / elapsed_max
-        # dominant kernel: nmf_update (one launch = one factor update of all B buffers)
+        # dominant kernel: nmf_update (one launch = one factor update of all B buffers; when the Nyquist bin is a
+        # side column 1/F of the W update's flops run in the slice kernel between the updates -- not subtracted)
         flop_per_launch = 4.0 * F * T * K * B
         bytes_per_launch = (F * T * 8.0 + 2.0 * (F * K + K * T) * 8.0) * B
         avg_ms = ms_upd / max(n_upd, 1)
@@ -238,6 +240,7 @@ def main():
                               "achieved": stft_bytes / (stft_ms * 1e-3) / 1e9 if stft_ms > 0 else None,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": (stft_bytes / (stft_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if stft_ms > 0 else None},
+            "schedule": dict(corpus.plan(), between_updates_ms_per_iteration=(ms_mid / max(n_mid, 1))),
             "device": {"name": name, "arch": arch, "compute_units": cus,
                        "corpus_device_bytes": corpus.device_bytes()},
             "result_finite": finite,

@@ -196,6 +196,26 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
   };
 
+  if constexpr (MODE == 1)
+  {
+    // ring fill first: its HBM latency runs under the stationary loads and their normalisation below
+    // (slots are numbered from s0 in the overlapped pipeline)
+    if (s0 < s1)
+    {
+#pragma unroll
+      for (int t = 0; t < NS; t++)
+      {
+        const int sc = min(s0 + t, sLast);
+        const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
+        const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+#pragma unroll
+        for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + t * VSTAGE + j * 1024);
+#pragma unroll
+        for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + t * MSTAGE + j * 1024);
+      }
+    }
+  }
+
   // ---- stationary operand + accumulators ------------------------------------------------------
   double sb[NG][M];
   double acc[NG][M];
@@ -330,17 +350,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     if (s0 < s1)
     {
       static_assert(NS >= 4 && NS % 2 == 0, "overlapped pipeline: even ring depth >= 4");
-      auto issue_slot = [&](int st, int slot) {
-        const int sc = min(st, sLast);
-        const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
-        const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
-#pragma unroll
-        for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + slot * VSTAGE + j * 1024);
-#pragma unroll
-        for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
-      };
-#pragma unroll
-      for (int t = 0; t < NS; t++) issue_slot(s0 + t, t);
       const unsigned vringA = __builtin_amdgcn_readfirstlane(lds_addr(vring));
       const unsigned mringA = __builtin_amdgcn_readfirstlane(lds_addr(mring));
       // loop-invariant per-lane LDS addresses
@@ -566,8 +575,18 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
       for (int m = 0; m < M; m++) dsum[m] = fdiv_pos(dsum[m], nrE[m]); // sum_r W[r][k] = (sum_r W'[r][k]) / nrm_k
     }
+    // the M denominators are shared by every column of the strip: one reciprocal + Newton step each, then
+    // quotient + residual correction per element (as in fdiv_pos)
+    double dd[M], dy[M];
 #pragma unroll
-    for (int m = 0; m < M; m++) { ss[m] = 0.0; mx[m] = -INFINITY; }
+    for (int m = 0; m < M; m++)
+    {
+      dd[m] = fmax(dsum[m], kEpsilon);
+      double y0 = __builtin_amdgcn_rcp(dd[m]);
+      dy[m] = __builtin_fma(y0, __builtin_fma(-dd[m], y0, 1.0), y0);
+      ss[m] = 0.0;
+      mx[m] = -INFINITY;
+    }
 #pragma unroll
     for (int g = 0; g < NG; g++)
     {
@@ -585,7 +604,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             double so = sold[m], num = acc[g][m];
             if (a.nrmMode == 1) so = fdiv_pos(so, nrE[m]);
             if (a.nrmMode == 2) num = fdiv_pos(num, nrE[m]);
-            const double r = (so * num) / fmax(dsum[m], kEpsilon);
+            const double v = so * num;
+            const double r0 = v * dy[m];
+            const double r = __builtin_fma(__builtin_fma(-dd[m], r0, v), dy[m], r0);
             sp[m] = r;
             ss[m] = __builtin_fma(r, r, ss[m]);
             mx[m] = fmax(mx[m], r);
