@@ -984,6 +984,90 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
   return cancelled ? FLUHIP_CANCELLED : FLUHIP_OK;
 }
 
+// alg/NMF.hpp:45-89 over every row of X: the H update with the dictionary fixed, from the processFrame
+// initial state (clamped x, clamped + row-normalised W, clamped un-normalised h).
+int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                                  const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
+  if (!W0 || K < 1) return fail(ctx, "bad dictionary");
+  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
+  if (iters < 0) return fail(ctx, "negative iteration count");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.K = K;
+  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
+  c.T = T; c.F = F;
+  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = round_up(K, 16);
+  HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
+  HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
+  HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
+  if (update_variant((int) c.Kp) != 16)
+    c.nsplitH = choose_split4(1, (int) T, (int) F, (int) c.Kp);
+  else
+  {
+    const int cpw = nmf_update_cols_per_wave((int) c.Kp);
+    c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
+  }
+  if (c.nsplitH > 1)
+  {
+    HIPCHK(ctx, c.part.alloc((size_t) c.nsplitH * std::max(c.Fp, c.Tp) * c.Kp * sizeof(double), true, s));
+    HIPCHK(ctx, c.dpart.alloc((size_t) c.nsplitH * c.Kp * sizeof(double), true, s));
+  }
+  // :57-58, 61  v0 = max(x, eps)
+  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
+                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
+  launch_clamp_eps(c.mag.as<double>(), c.Fp, 0, (int) T, (int) F, 1, s);
+  launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T,
+                   (int) F, 1, s);
+  // :59, 64-65  W = max(W, eps), every component divided by its L2 norm over the bins
+  HIPCHK(ctx, c.stage.alloc((size_t) K * F * sizeof(double), false, s));
+  HIPCHK(ctx, hipMemcpyAsync(c.stage.p, W0, (size_t) K * F * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_scatter_factor(c.stage.as<double>(), 0, c.Wf.as<double>(), c.Fp * c.Kp, (int) F, (int) K, (int) c.Kp, 1,
+                        true, s);
+  HIPCHK(ctx, c.normScratch.alloc((size_t) colnorm_scratch_doubles((int) F, (int) c.Kp, 1) * sizeof(double), false, s));
+  launch_colnorm(c.Wf.as<double>(), c.Fp * c.Kp, (int) F, (int) K, (int) c.Kp, 1, true, false,
+                 c.normScratch.as<double>(), s);
+  // :55-56, 60  h = max(uniform(0,1)^K, eps): the same K draws for every frame when seeded
+  std::vector<double> h0, rows((size_t) T * K);
+  if (seed >= 0)
+  {
+    draw_uniform(seed, (size_t) K, h0);
+    for (int64_t t = 0; t < T; t++) std::memcpy(&rows[(size_t) t * K], h0.data(), (size_t) K * sizeof(double));
+  }
+  else
+    draw_uniform(seed, (size_t) T * K, rows);
+  DevBuf hs;
+  HIPCHK(ctx, hs.alloc((size_t) T * K * sizeof(double), false, s));
+  HIPCHK(ctx, hipMemcpyAsync(hs.p, rows.data(), (size_t) T * K * sizeof(double), hipMemcpyHostToDevice, s));
+  launch_scatter_factor(hs.as<double>(), 0, c.H1.as<double>(), c.Tp * c.Kp, (int) T, (int) K, (int) c.Kp, 1, false, s);
+  launch_clamp_eps(c.H1.as<double>(), c.Kp, 0, (int) T, (int) K, 1, s);
+  HIPCHK(ctx, hipStreamSynchronize(s)); // host staging vectors go out of use
+  c.haveMag = c.haveFactors = true;
+  // :71-79  nIterations of the H update
+  int rc = corpus_iterate(&c, iters, false, true, nullptr, nullptr);
+  if (rc != FLUHIP_OK) return rc;
+  DevBuf dh, dv;
+  if (H)
+  {
+    HIPCHK(ctx, dh.alloc((size_t) T * K * sizeof(double), false, s));
+    launch_gather_h_f64(c.H1.as<double>(), 0, dh.as<double>(), 0, (int) T, (int) K, (int) c.Kp, 1, s);
+    HIPCHK(ctx, hipMemcpyAsync(H, dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  if (V) // :87  v = W^T h
+  {
+    HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
+    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F, (int) c.Kp, 1, s);
+    HIPCHK(ctx, hipMemcpyAsync(V, dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(s));
+  return FLUHIP_OK;
+}
+
 int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride,
                               int64_t win, int64_t fft, int64_t hop, int64_t K, int64_t iters,
                               int update_w, int update_h, int64_t seed, const float* bases_seed,

@@ -141,6 +141,8 @@ void launch_vhat(const double* Wf, int64_t strideW, const double* H1, int64_t st
                  double* Vhat, int64_t ldV, int64_t strideV, int T, int F, int Kp, int B,
                  hipStream_t s);
 // dst[b][t][f] (ld) = src[b][t*ldsrc + f] : strided host-layout copy into the padded layout
+// p[b][r][c] = max(p[b][r][c], eps) over the valid rows x cols only (the padding stays zero)
+void launch_clamp_eps(double* p, int64_t ld, int64_t stride, int rows, int cols, int B, hipStream_t s);
 void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double* dst,
                      int64_t lddst, int64_t strideDst, int rows, int cols, int B, hipStream_t s);
 

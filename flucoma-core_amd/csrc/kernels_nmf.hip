@@ -786,6 +786,23 @@ void launch_pad_copy(const double* src, int64_t ldsrc, int64_t strideSrc, double
   hipLaunchKernelGGL(pad_copy_kernel, g, dim3(256), 0, s, src, ldsrc, strideSrc, dst, lddst, strideDst, rows, cols);
 }
 
+__global__ void clamp_eps_kernel(double* p, int64_t ld, int64_t stride, int rows, int cols)
+{
+  const int b = blockIdx.y;
+  const int cblocks = (cols + blockDim.x - 1) / blockDim.x;
+  const int r = blockIdx.x / cblocks;
+  const int c = (blockIdx.x % cblocks) * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  double* q = p + (int64_t) b * stride + (int64_t) r * ld + c;
+  *q = fmax(*q, kEpsilon);
+}
+
+void launch_clamp_eps(double* p, int64_t ld, int64_t stride, int rows, int cols, int B, hipStream_t s)
+{
+  dim3 g((unsigned) (((cols + 255) / 256) * (int64_t) rows), (unsigned) B);
+  hipLaunchKernelGGL(clamp_eps_kernel, g, dim3(256), 0, s, p, ld, stride, rows, cols);
+}
+
 __global__ void transpose_kernel(const double* in, int64_t ldin, int64_t strideIn, double* out,
                                  int64_t ldout, int64_t strideOut, int R, int C)
 {

@@ -27,7 +27,7 @@ EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
-    "fluhip_nmf_process_f64", "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
+    "fluhip_nmf_process_f64", "fluhip_nmf_process_frames_f64", "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
@@ -70,6 +70,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_stft_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _dp, _dp, _ip]
     L.fluhip_nmf_process_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                          ctypes.c_int, _i64, _dp, _dp, _dp, _dp, _dp, PROGRESS_FN, _vp]
+    L.fluhip_nmf_process_frames_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _dp, _i64, _i64, _i64, _dp, _dp]
     L.fluhip_bufnmf_channel_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                             ctypes.c_int, ctypes.c_int, _i64, _fp, _fp, _fp, _fp,
                                             _fp, PROGRESS_FN, _vp]
@@ -195,6 +196,20 @@ class Context:
                                              _d(W1), _d(H1), _d(V1), cb, None)
         self._check(rc, allow=(OK, CANCELLED))
         return W1, H1, V1, rc
+
+    def nmf_process_frames(self, X, W0, iters, seed=42, want_v=True):
+        """NMF::processFrame (alg/NMF.hpp:45-89) on every row of X [T,F] with the dictionary W0 [K,F]."""
+        X = np.asarray(X, dtype=np.float64)
+        assert X.ndim == 2 and X.strides[1] == 8
+        T, F = X.shape
+        W0c = np.ascontiguousarray(W0, dtype=np.float64)
+        K = W0c.shape[0]
+        assert W0c.shape == (K, F)
+        H = np.empty((T, K))
+        V = np.empty((T, F)) if want_v else None
+        self._check(self.lib.fluhip_nmf_process_frames_f64(self.h, X.ctypes.data_as(_dp), T, F, X.strides[0] // 8,
+                                                           _d(W0c), K, iters, seed, _d(H), _d(V)))
+        return H, V
 
     # ---- one BufNMF channel -------------------------------------------------------------
     def bufnmf_channel(self, audio, win, fft, hop, K, iters, seed, updateW=True, updateH=True,

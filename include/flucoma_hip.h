@@ -104,6 +104,19 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
                            const double* W0, const double* H0, double* W1, double* H1,
                            double* V1, fluhip_progress_fn progress, void* user);
 
+/* Replaces NMF::processFrame(x, W0, out, nIterations, v, randomSeed, alloc) (algorithms/public/NMF.hpp:45-89)
+ * applied to every row of X at once -- the per-frame activation solve that
+ * clients/rt/NMFMatchClient.hpp:113-118 (10 iterations, no estimate) and clients/rt/NMFFilterClient.hpp:102-116
+ * (kIterations, estimate kept for the ratio mask) run on each spectral frame.  Frames are independent, so the
+ * whole matrix is one batch of the H update with the dictionary fixed.
+ * X: T x F magnitudes with row stride ldx.  W0: K x F dictionary (read only here; the reference clamps and
+ * row-normalises its argument in place -- pass a copy there, the result is the same).
+ * H (may be NULL): T x K activations.  V (may be NULL): T x F estimates W^T h.
+ * seed >= 0: every frame starts from the same K draws, like the reference's fresh generator per call;
+ * seed < 0: std::random_device. */
+int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                                  const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V);
+
 /* ---- client::bufnmf::NMFClient::process, one channel ---------------------------------- */
 /* Replaces the body of the channel loop, clients/nrt/NMFClient.hpp:240-300 (STFT -> magnitude
  * -> NMF -> float write-back with H/max(H)), without a host round trip in between.

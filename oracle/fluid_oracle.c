@@ -390,6 +390,64 @@ static int multiplicative_updates(double* V, double* W, double* H, int64_t F, in
   return cancelled;
 }
 
+/* alg/NMF.hpp:45-89 */
+void fo_nmf_process_frame(const double* x, const double* W0, int64_t K, int64_t F, int64_t iters, int64_t seed,
+                          double* h_out, double* v_out)
+{
+  double* W = (double*) malloc((size_t) (K * F) * sizeof(double));
+  double* h = (double*) malloc((size_t) K * sizeof(double));
+  double* v0 = (double*) malloc((size_t) F * sizeof(double));
+  double* v1 = (double*) malloc((size_t) F * sizeof(double));
+  double* den = (double*) malloc((size_t) K * sizeof(double));
+  fo_rng_uniform01((uint64_t) seed, K, h);                              /* :55-56 */
+  for (int64_t f = 0; f < F; f++) v0[f] = x[f] > FO_EPSILON ? x[f] : FO_EPSILON; /* :58, 61 */
+  for (int64_t k = 0; k < K; k++)
+  {
+    double ss = 0.0;
+    for (int64_t f = 0; f < F; f++)
+    {
+      const double w = W0[k * F + f] > FO_EPSILON ? W0[k * F + f] : FO_EPSILON; /* :59 */
+      W[k * F + f] = w;
+      ss += w * w;
+    }
+    const double nrm = sqrt(ss);                                         /* :64-65 rowwise norm */
+    for (int64_t f = 0; f < F; f++) W[k * F + f] /= nrm;
+    if (h[k] < FO_EPSILON) h[k] = FO_EPSILON;                            /* :60 */
+  }
+  for (int64_t k = 0; k < K; k++)                                       /* :77 hDen = W * ones */
+  {
+    double d = 0.0;
+    for (int64_t f = 0; f < F; f++) d += W[k * F + f];
+    den[k] = d > FO_EPSILON ? d : FO_EPSILON;
+  }
+  for (int64_t it = 0; it < iters; it++)
+  {
+    for (int64_t f = 0; f < F; f++) v1[f] = 0.0;
+    for (int64_t k = 0; k < K; k++)                                     /* :73 v1 = W^T h */
+      for (int64_t f = 0; f < F; f++) v1[f] += W[k * F + f] * h[k];
+    for (int64_t f = 0; f < F; f++)
+    {
+      const double q = v1[f] > FO_EPSILON ? v1[f] : FO_EPSILON;        /* :74 */
+      v1[f] = v0[f] / q;                                                /* :75 vRatio */
+    }
+    for (int64_t k = 0; k < K; k++)                                     /* :76, 78 */
+    {
+      double num = 0.0;
+      for (int64_t f = 0; f < F; f++) num += W[k * F + f] * v1[f];
+      h[k] = h[k] * num / den[k];
+    }
+  }
+  for (int64_t k = 0; k < K; k++) h_out[k] = h[k];                      /* :84-85 */
+  if (v_out)                                                             /* :87 */
+    for (int64_t f = 0; f < F; f++)
+    {
+      double a = 0.0;
+      for (int64_t k = 0; k < K; k++) a += W[k * F + f] * h[k];
+      v_out[f] = a;
+    }
+  free(W); free(h); free(v0); free(v1); free(den);
+}
+
 int fo_nmf_process(const double* X, int64_t T, int64_t F, int64_t K, int64_t iters,
                    int updateW, int updateH, int64_t seed, const double* W0,
                    const double* H0, double* W1, double* H1, double* V1, int faithful,

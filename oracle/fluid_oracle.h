@@ -79,6 +79,16 @@ int64_t fo_bufnmf_channel(const float* audio, int64_t n, int64_t win, int64_t ff
                           int64_t K, int64_t iters, int64_t seed, int faithful,
                           float* bases_out, float* acts_out, double* mag_out);
 
+/* ---- "next" rows: per-frame activations of a fixed dictionary ------------------------ */
+/* alg/NMF.hpp:45-89 processFrame (what rt/NMFMatchClient.hpp:113-118 and rt/NMFFilterClient.hpp:102-116 run
+ * on every spectral frame): h = uniform(0,1)^K from a fresh generator of `seed`, W = max(W0, eps) with every
+ * row (component) divided by its L2 norm, v0 = max(x, eps); nIterations of
+ *   v1 = max(W^T h, eps); h = h * (W (v0 / v1)) / max(W 1, eps).
+ * x: F.  W0: K x F row-major (not modified here; the reference normalises its argument in place).
+ * h_out: K.  v_out (may be NULL): F = W^T h. */
+void fo_nmf_process_frame(const double* x, const double* W0, int64_t K, int64_t F, int64_t iters, int64_t seed,
+                          double* h_out, double* v_out);
+
 /* ---- "next" rows: resynthesis ------------------------------------------ */
 /* alg/NMF.hpp:33-42 + alg/RatioMask.hpp:33-57 + alg/STFT.hpp:178-199 for component k.
  * spec: T*F interleaved complex; W1 KxF; H1 TxK; V1 TxF (= W*H estimate);

@@ -85,6 +85,8 @@ class Oracle:
                                      _i64, _dp, _dp, _dp, _dp, _dp, ctypes.c_int, PROGRESS_FN,
                                      ctypes.c_void_p]
         L.fo_nmf_process.restype = ctypes.c_int
+        L.fo_nmf_process_frame.argtypes = [_dp, _dp, _i64, _i64, _i64, _i64, _dp, _dp]
+        L.fo_nmf_process_frame.restype = None
         L.fo_bufnmf_writeback.argtypes = [_dp, _dp, _i64, _i64, _i64, _fp, _fp]
         L.fo_bufnmf_channel.argtypes = [_fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                         ctypes.c_int, _fp, _fp, _dp]
@@ -151,6 +153,17 @@ class Oracle:
                                      _d(W0c), _d(H0c), _d(W1), _d(H1), _d(V1), int(faithful),
                                      cb, None)
         return W1, H1, V1, rc
+
+    def nmf_process_frames(self, X, W0, iters, seed):
+        """alg/NMF.hpp:45-89 on every row of X [T,F] with the dictionary W0 [K,F]: H [T,K], V [T,F]."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        W0 = np.ascontiguousarray(W0, dtype=np.float64)
+        T, F = X.shape
+        K = W0.shape[0]
+        H, V = np.empty((T, K)), np.empty((T, F))
+        for t in range(T):
+            self.lib.fo_nmf_process_frame(_d(X[t]), _d(W0), K, F, iters, seed, _d(H[t]), _d(V[t]))
+        return H, V
 
     def bufnmf_writeback(self, W1, H1):
         K, F = W1.shape

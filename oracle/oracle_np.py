@@ -150,6 +150,21 @@ def nmf_process(X, K, iters, updateW=True, updateH=True, seed=42, W0=None, H0=No
     return W.T.copy(), H.T.copy(), Vout.T.copy()
 
 
+def nmf_process_frame(x, W0, iters, seed):
+    """alg/NMF.hpp:45-89: activations h [K] of the dictionary W0 [K,F] in one magnitude frame x [F], and the
+    estimate W^T h [F]."""
+    W = np.maximum(np.asarray(W0, dtype=np.float64), EPS)
+    K = W.shape[0]
+    h = np.maximum(rng_uniform01(seed, K), EPS)
+    v0 = np.maximum(np.asarray(x, dtype=np.float64), EPS)
+    W = W / np.sqrt((W * W).sum(axis=1, keepdims=True))
+    den = np.maximum(W.sum(axis=1), EPS)
+    for _ in range(iters):
+        v1 = np.maximum(W.T @ h, EPS)
+        h = h * (W @ (v0 / v1)) / den
+    return h, W.T @ h
+
+
 def bufnmf_writeback(W1, H1):
     """nrt/NMFClient.hpp:277-300: bases [K,F] f32; activations [K,T] f32 (float multiply)."""
     bases = W1.astype(np.float32)

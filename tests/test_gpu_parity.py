@@ -260,6 +260,27 @@ def test_bufnmf_seeded_and_fixed_bases(ctx, oracle, onp):
     assert rel_err(acts, ra) < 1e-6 and rel_err(bases, rb) < 1e-6
 
 
+@pytest.mark.parametrize("T,F,K,iters,seed", [(50, 513, 5, 10, 42), (300, 1025, 32, 10, 5063), (7, 33, 3, 25, 1),
+                                              (2000, 513, 16, 10, 42)])
+def test_process_frames_vs_oracle(ctx, oracle, T, F, K, iters, seed):
+    """SURVEY 8 f4: NMF::processFrame (alg/NMF.hpp:45-89) on every frame of a magnitude matrix, the solve
+    NMFMatch / NMFFilter run per spectral frame (10 iterations by default, rt/NMFMatchClient.hpp:116)"""
+    rng = np.random.default_rng(T + K)
+    W0 = rng.random((K, F)) ** 3
+    acts = rng.random((T, K)) * (rng.random((T, K)) < 0.4)
+    X = acts @ W0 + 1e-3 * rng.random((T, F))
+    X[0, :7] = 0.0                                   # exercises the max(x, eps) clamp
+    W0[0, :3] = 0.0                                  # and the max(W, eps) clamp
+    H, V = ctx.nmf_process_frames(X, W0, iters, seed)
+    rH, rV = oracle.nmf_process_frames(X[: min(T, 64)], W0, iters, seed)
+    n = rH.shape[0]
+    assert rel_err(H[:n], rH) < TOL_FACTORS_TIGHT and rel_err(V[:n], rV) < TOL_FACTORS_TIGHT
+    assert np.isfinite(H).all() and (H >= 0).all()
+    # frames are independent: a frame's activations do not depend on its neighbours
+    H2, _ = ctx.nmf_process_frames(X[::-1].copy(), W0, iters, seed, want_v=False)
+    assert rel_err(H2[::-1], H) < 1e-12
+
+
 def test_corpus_matches_per_buffer_oracle(ctx, oracle, onp):
     """the batched (corpus) form against independent per-buffer oracle runs, c4's fft/rank"""
     import fluhip

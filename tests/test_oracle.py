@@ -228,3 +228,26 @@ def test_reference_wav_c1_when_available(oracle, onp):
     assert mag.shape == (887, 513)
     assert rel_err(mag, m2) < 1e-12
     assert rel_err(bases, b2) < 1e-6 and rel_err(acts, a2) < 1e-6
+
+
+def test_process_frame_c_vs_numpy():
+    """alg/NMF.hpp:45-89 restated twice (C and numpy) must agree; and the update must not move a frame
+    that the dictionary already explains exactly (fixed point of the KL multiplicative update)."""
+    import oracle_c, oracle_np
+    o = oracle_c.get("native")
+    rng = np.random.default_rng(3)
+    K, F = 4, 65
+    W0 = rng.random((K, F))
+    X = rng.random((6, F))
+    X[1, :5] = 0.0
+    H, V = o.nmf_process_frames(X, W0, 10, 42)
+    for t in range(X.shape[0]):
+        h, v = oracle_np.nmf_process_frame(X[t], W0, 10, 42)
+        assert np.allclose(H[t], h, rtol=1e-12, atol=0) and np.allclose(V[t], v, rtol=1e-12, atol=0)
+    # same seed => same start for every frame (a fresh generator per call, util/EigenRandom.hpp:80)
+    H0, _ = o.nmf_process_frames(np.vstack([X[2], X[2]]), W0, 0, 42)
+    assert np.array_equal(H0[0], H0[1]) and np.array_equal(H0[0], np.maximum(oracle_np.rng_uniform01(42, K), 2.220446049250313e-16))
+    Wn = W0 / np.sqrt((W0 * W0).sum(axis=1, keepdims=True))
+    htrue = np.array([0.5, 1.5, 0.25, 2.0])
+    hfit, vfit = oracle_np.nmf_process_frame(htrue @ Wn, W0, 2000, 7)
+    assert np.allclose(vfit, htrue @ Wn, rtol=1e-6)
