@@ -222,7 +222,7 @@ struct fluhip_corpus
   bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
-  DevBuf wnorm, wscratch;
+  DevBuf wnorm, wscratch, csumScratch;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
@@ -272,6 +272,24 @@ static int choose_split(int64_t B, int64_t nCW, int64_t nRt)
   return (int) std::max<int64_t>(1, s);
 }
 
+// workspaces of the factor updates: split-contraction partials, denominators, column-sum pre-pass
+static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  const size_t B = (size_t) c->B;
+  const int ns = std::max(c->nsplitW, c->nsplitH);
+  if (ns > 1)
+  {
+    const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
+    HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
+  }
+  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * ns * c->Kp * sizeof(double)), true, s));
+  if (c->Kp > 64)
+    HIPCHK(ctx, c->csumScratch.alloc((size_t) colsum_scratch_doubles((int) std::max(c->T, c->F), (int) c->Kp, (int) B) *
+                                         sizeof(double), false, s));
+  return FLUHIP_OK;
+}
+
 static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
@@ -313,13 +331,7 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
     c->nsplitW = choose_split(c->B, (c->F + 4 * cpw - 1) / (4 * cpw), (c->T + 15) / 16);
     c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
   }
-  const int ns = std::max(c->nsplitW, c->nsplitH);
-  if (ns > 1)
-  {
-    const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
-    HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
-  }
-  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * ns * c->Kp * sizeof(double)), true, s));
+  if (int rc = alloc_update_scratch(ctx, c)) return rc;
   if (c->lazy)
   {
     HIPCHK(ctx, c->wnorm.alloc(B * c->Kp * sizeof(double), false, s));
@@ -523,7 +535,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.S = c->Wf.as<double>(); a.strideS = c->Fp * c->Kp;
     a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
-    a.Cp = std::max(c->Fp, c->Tp);
+    a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     if (c->lazy)
     {
       // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
@@ -564,7 +576,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     a.S = c->H1.as<double>(); a.strideS = c->Tp * c->Kp;
     a.R = (int) c->F; a.C = (int) c->T; a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
-    a.Cp = std::max(c->Fp, c->Tp);
+    a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
@@ -937,13 +949,7 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
       c.nsplitW = choose_split(1, (F + 4 * cpw - 1) / (4 * cpw), (T + 15) / 16);
       c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
     }
-    const int ns = std::max(c.nsplitW, c.nsplitH);
-    if (ns > 1)
-    {
-      const size_t Cp = (size_t) std::max(c.Fp, c.Tp);
-      HIPCHK(ctx, c.part.alloc((size_t) ns * Cp * c.Kp * sizeof(double), true, s));
-      HIPCHK(ctx, c.dpart.alloc((size_t) ns * c.Kp * sizeof(double), true, s));
-    }
+    if (int rc2 = alloc_update_scratch(ctx, &c)) return rc2;
   }
   // alg/NMF.hpp:125  V = X^T (same bytes as the T x F row-major view)
   HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
@@ -1012,11 +1018,7 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
     const int cpw = nmf_update_cols_per_wave((int) c.Kp);
     c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
   }
-  if (c.nsplitH > 1)
-  {
-    HIPCHK(ctx, c.part.alloc((size_t) c.nsplitH * std::max(c.Fp, c.Tp) * c.Kp * sizeof(double), true, s));
-    HIPCHK(ctx, c.dpart.alloc((size_t) c.nsplitH * c.Kp * sizeof(double), true, s));
-  }
+  if (int rc2 = alloc_update_scratch(ctx, &c)) return rc2;
   // :57-58, 61  v0 = max(x, eps)
   HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
                                (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));

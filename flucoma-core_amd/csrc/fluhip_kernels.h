@@ -75,7 +75,15 @@ struct UpdateArgs
   int nrmMode = 0;
   // W update: per-wavefront column statistics of the rows it wrote, [B][wavesPerBuf][2][Kp] (sum x^2, max x)
   double* statPart = nullptr;
+  // rank 65..128: workspace of colsum_scratch_doubles() for the column sums of Mv (see launch_colsum); also
+  // needs dpart of at least B * nsplit * Kp doubles
+  double* colsumScratch = nullptr;
 };
+
+// out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine
+int colsum_scratch_doubles(int R, int Kp, int B);
+void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, double* out, int64_t outStride,
+                   double* scratch, hipStream_t s);
 
 // S[c][k] <- S[c][k] * (sum_r (V[r][c] / max(sum_j Mv[r][j] S[c][j], eps)) * Mv[r][k])
 //                    / max(sum_r Mv[r][k], eps)

@@ -322,25 +322,30 @@ __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, in
 }
 
 __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int checkMax,
-                                const double* part, int nch)
+                                const double* part, int nch, int stageInLds)
 {
-  extern __shared__ double sh[]; // [nch][2*Kp] partials, then [Kp] totals + [Kp] maxima
+  extern __shared__ double sh[]; // [nch][2*Kp] partials (when they fit), then [Kp] totals + [Kp] maxima
   const int chunk = blockIdx.x, b = blockIdx.y;
   double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
-  // all partials of this buffer in one burst of independent loads, then a fixed-order combine from LDS
   const double* p = part + (int64_t) b * nch * 2 * Kp;
-  for (int i = threadIdx.x; i < nch * 2 * Kp; i += blockDim.x) sh[i] = p[i];
-  __syncthreads();
-  double* tot = sh + (size_t) nch * 2 * Kp;
+  double* tot = sh;
+  if (stageInLds)
+  {
+    // all partials of this buffer in one burst of independent loads, then a fixed-order combine from LDS
+    for (int i = threadIdx.x; i < nch * 2 * Kp; i += blockDim.x) sh[i] = p[i];
+    __syncthreads();
+    p = sh;
+    tot = sh + (size_t) nch * 2 * Kp;
+  }
   if (rg == 0)
   {
     double t = 0.0, m = -INFINITY;
-    for (int j = 0; j < nch; j++)
+    for (int j = 0; j < nch; j++) // same order either way
     {
-      t += sh[j * 2 * Kp + k];
-      m = fmax(m, sh[j * 2 * Kp + Kp + k]);
+      t += p[j * 2 * Kp + k];
+      m = fmax(m, p[j * 2 * Kp + Kp + k]);
     }
     tot[k] = t;
     tot[Kp + k] = (k < K) ? m : -INFINITY;
@@ -370,8 +375,69 @@ void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, boo
   dim3 grid((unsigned) nch, (unsigned) B);
   hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
                      strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
-  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), (size_t) (nch + 1) * 2 * Kp * sizeof(double), s,
-                     S, strideS, C, K, Kp, checkMax ? 1 : 0, scratch, nch);
+  // very long factors (c3: 404 chunks x rank 128) do not fit the partials in LDS: combine from global there
+  const bool stage = (size_t) (nch + 1) * 2 * Kp * sizeof(double) <= 48 * 1024;
+  const size_t shScale = (size_t) ((stage ? nch : 0) + 1) * 2 * Kp * sizeof(double);
+  hipLaunchKernelGGL(colscale_kernel, grid, dim3((unsigned) threads), shScale, s, S, strideS, C, K, Kp,
+                     checkMax ? 1 : 0, scratch, nch, stage ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// column sums of a factor (denominator of the other factor's update) for the kernel forms that do not
+// accumulate them themselves
+// ---------------------------------------------------------------------------------------
+constexpr int kSumRows = 256;
+
+__global__ void colsum_part_kernel(const double* Mvbase, int64_t strideM, int R, int Kp, double* part, int nch)
+{
+  extern __shared__ double sh[]; // [nrg][Kp]
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const double* Mv = Mvbase + (int64_t) b * strideM;
+  const int nrg = blockDim.x / Kp;
+  const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
+  const int rbeg = chunk * kSumRows, rend = min(rbeg + kSumRows, R);
+  double t = 0.0;
+  for (int r = rbeg + rg; r < rend; r += nrg) t += Mv[(int64_t) r * Kp + k];
+  sh[rg * Kp + k] = t;
+  __syncthreads();
+  if (rg == 0)
+  {
+    double tot = 0.0;
+    for (int j = 0; j < nrg; j++) tot += sh[j * Kp + k];
+    part[((int64_t) b * nch + chunk) * Kp + k] = tot;
+  }
+}
+
+__global__ void colsum_combine_kernel(const double* part, int nch, int Kp, double* out, int64_t outStride)
+{
+  const int b = blockIdx.x, k = threadIdx.x;
+  const double* p = part + (int64_t) b * nch * Kp + k;
+  double t = 0.0;
+  int j = 0;
+  for (; j + 8 <= nch; j += 8) // eight independent loads in flight, summed in index order
+  {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p[(int64_t) (j + u) * Kp];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t += v[u];
+  }
+  for (; j < nch; j++) t += p[(int64_t) j * Kp];
+  out[(int64_t) b * outStride + k] = t;
+}
+
+int colsum_scratch_doubles(int R, int Kp, int B) { return ((R + kSumRows - 1) / kSumRows) * Kp * B; }
+
+void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, double* out, int64_t outStride,
+                   double* scratch, hipStream_t s)
+{
+  int nrg = 256 / Kp;
+  if (nrg < 1) nrg = 1;
+  const int nch = (R + kSumRows - 1) / kSumRows;
+  hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned) nch, (unsigned) B), dim3((unsigned) (nrg * Kp)),
+                     (size_t) nrg * Kp * sizeof(double), s, Mv, strideM, R, Kp, scratch, nch);
+  hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, scratch, nch, Kp, out,
+                     outStride);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -87,7 +87,7 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
   }
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
   };
 
-  if constexpr (MODE == 1)
+  if constexpr (MODE >= 1)
   {
     // ring fill first: its HBM latency runs under the stationary loads and their normalisation below
     // (slots are numbered from s0 in the overlapped pipeline)
@@ -331,13 +331,150 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
       for (int m = 0; m < M; m++) acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ratio[g], mb[m], acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < M; m++) dsum[m] += mb[m];
+    for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
   };
 
   // ---- pipeline -------------------------------------------------------------------------------
   // stages s0 .. s0+NS-1 in flight; iteration s consumes stage s (mb, v) and stage s+1 (ma), then
   // refills the slot of stage s with stage s+NS.  Completion is in issue order, so "stage s+1 has
   // landed" == at most (NS-2) stages outstanding.
+  if constexpr (MODE == 2)
+  {
+    // ---- overlapped form, one operand register set refilled in place -------------------------------
+    // As MODE 1 below, but without the second operand set: the Q-phase walks m upwards and every 16-byte
+    // chunk of ma (step s+1) is dead once its MFMAs have issued, so the same registers take the chunk of
+    // step s+2 right behind them; the out-phase runs m-outer for the same reason and refills mb with step
+    // s+1; v of step s+1 is read at the head of the Q-phase (v(s) died in the quotient block).  The reads
+    // still have a whole step to land.  The column sums of Mv move to the head of the step, into the VALU
+    // block, where mb(s) is complete.  This is what lets Kp = 64 / 128 (M = 16 / 32) run overlapped.
+    if (s0 < s1)
+    {
+      static_assert(NS >= 4, "overlapped pipeline: ring depth >= 4");
+      const unsigned vringA = __builtin_amdgcn_readfirstlane(lds_addr(vring));
+      const unsigned mringA = __builtin_amdgcn_readfirstlane(lds_addr(mring));
+      const char* vAddr = vring + vOff;
+      const char* maAddr[M / 2];
+      const char* mbAddr[M / 2];
+#pragma unroll
+      for (int j = 0; j < M / 2; j++) { maAddr[j] = mring + maOff[j]; mbAddr[j] = mring + mbOff[j]; }
+      double v[NG], ma[M], mb[M], qA[NG], qB[NG];
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+#pragma unroll
+      for (int j = 0; j < M / 2; j++)
+      {
+        d2 t = *reinterpret_cast<const d2*>(maAddr[j]);
+        ma[2 * j] = t[0]; ma[2 * j + 1] = t[1];
+      }
+      q_phase(ma, qA);
+#pragma unroll
+      for (int g = 0; g < NG; g++) v[g] = *reinterpret_cast<const double*>(vAddr + g * 128);
+#pragma unroll
+      for (int j = 0; j < M / 2; j++)
+      {
+        d2 t = *reinterpret_cast<const d2*>(mbAddr[j]);
+        mb[2 * j] = t[0]; mb[2 * j + 1] = t[1];
+        d2 t2 = *reinterpret_cast<const d2*>(maAddr[j] + MSTAGE);
+        ma[2 * j] = t2[0]; ma[2 * j + 1] = t2[1];
+      }
+      constexpr int NMF = M * NG;
+      constexpr int DMASTEP = NMF / IPS > 0 ? NMF / IPS : 1;
+      constexpr int VSTEP = (NMF / 2) / NG > 0 ? (NMF / 2) / NG : 1; // v reads over the first half of the Q-phase
+      constexpr int QREADS = NG + M / 2;                             // ds_reads issued in the Q-phase
+      auto half = [&](int s, int u, int u1, int u2, const double (&qc)[NG], double (&qn)[NG]) {
+        double ratio[NG];
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory"); // stages s+1, s+2 landed
+        ratio_phase(v, qc, ratio);
+#pragma unroll
+        for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          constexpr int PP = (P <= M) ? P : M;
+          double qp[NG][PP];
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int p = 0; p < PP; p++) qp[g][p] = 0.0;
+#pragma unroll
+          for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+            {
+              qp[g][m % PP] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], qp[g][m % PP], 0, 0, 0);
+              const int i = m * NG + g;
+              if (i % VSTEP == VSTEP - 1 && i / VSTEP < NG)
+              {
+                const int r = i / VSTEP;
+                v[r] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + r * 128);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              if ((m & 1) && g == NG - 1) // chunk m/2 of ma(s+1) is spent: its registers take ma(s+2)
+              {
+                __builtin_amdgcn_sched_barrier(0);
+                d2 t = *reinterpret_cast<const d2*>(maAddr[m / 2] + u2 * MSTAGE);
+                ma[m - 1] = t[0];
+                ma[m] = t[1];
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+          {
+            double t = qp[g][0];
+#pragma unroll
+            for (int p = 1; p < PP; p++) t += qp[g][p];
+            qn[g] = t;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int sc = min(s + NS, sLast);
+          const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
+          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+          // every ds_read of slot u was issued in earlier steps; the Q-phase above issued QREADS newer ones
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
+#pragma unroll
+          for (int m = 0; m < M; m++)
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+            {
+              acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ratio[g], mb[m], acc[g][m], 0, 0, 0);
+              const int i = m * NG + g;
+              if (i % DMASTEP == DMASTEP / 2 && i / DMASTEP < IPS)
+              {
+                const int j = i / DMASTEP;
+                if (j < NJV) glds16(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
+                else glds16(msrc, moffs[j - NJV], mringA + u * MSTAGE + (j - NJV) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              if ((m & 1) && g == NG - 1) // chunk m/2 of mb(s) is spent: its registers take mb(s+1)
+              {
+                __builtin_amdgcn_sched_barrier(0);
+                d2 t = *reinterpret_cast<const d2*>(mbAddr[m / 2] + u1 * MSTAGE);
+                mb[m - 1] = t[0];
+                mb[m] = t[1];
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      constexpr int UNR = (NS % 2 == 0) ? NS : 2 * NS; // slots and the qA/qB roles repeat together
+      for (int s = s0; s < s1; s += UNR)
+      {
+#pragma unroll
+        for (int w = 0; w < UNR; w++)
+        {
+          if (s + w >= s1) break;
+          const int u = w % NS;
+          if (w % 2 == 0) half(s + w, u, (u + 1) % NS, (u + 2) % NS, qA, qB);
+          else half(s + w, u, (u + 1) % NS, (u + 2) % NS, qB, qA);
+        }
+      }
+      // the last step's column sums were taken at its head; mb now holds a step past the end
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  }
+  else
   if constexpr (MODE == 1)
   {
     // ---- overlapped form ------------------------------------------------------------------------
@@ -469,7 +606,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
             }
 #pragma unroll
-          for (int m = 0; m < M; m++) dsum[m] += mb[m];
+          for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
         }
         __builtin_amdgcn_sched_barrier(0);
         const long long c4 = tick();
@@ -557,13 +694,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     }
   }
 
-#pragma unroll
-  for (int m = 0; m < M; m++)
+  if constexpr (DS)
   {
-    double d = dsum[m];
-    d += __shfl_xor(d, 16);
-    d += __shfl_xor(d, 32);
-    dsum[m] = d;
+#pragma unroll
+    for (int m = 0; m < M; m++)
+    {
+      double d = dsum[m];
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      dsum[m] = d;
+    }
+  }
+  else if (a.nsplit == 1)
+  {
+    // DS == 0: the column sums of Mv were taken by launch_colsum into slot (buf, split 0) of dpart (the wide
+    // ranks have no registers to spare for M accumulators every wavefront would hold identically)
+    load_vec5<M>(dsum, a.dpart + (int64_t) buf * KP + M * x);
   }
 
   if (a.nsplit == 1)
@@ -653,7 +799,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         for (int m = 0; m < M; m++) pp[m] = acc[g][m];
       }
     }
-    if (strip == 0 && blk == 0 && y == 0)
+    if (DS && strip == 0 && blk == 0 && y == 0)
     {
       double* dp = a.dpart + ((int64_t) buf * a.nsplit + split) * KP + M * x;
 #pragma unroll
@@ -665,7 +811,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
                             int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
@@ -688,7 +834,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
   constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE>;
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int) shmem);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
@@ -724,11 +870,29 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return; }
         if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return; }
       }
-      if constexpr (WPS == 1 && NS >= 4 && NS % 2 == 0 && M <= 16) // <32,2> would spill with the second operand set
+      if constexpr (WPS == 1 && NS >= 4 && NS % 2 == 0)
       {
-        // FLUHIP_K5_MODE=0 selects the non-overlapped pipeline (A/B measurements)
-        static const int mode = [] { const char* e = std::getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : 1; }();
-        if (mode == 1) { launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s); return; }
+        // FLUHIP_K5_MODE: 0 = grouped reads/refill (the first LDS-DMA form), 1 = overlapped with a second
+        // operand set, 2 = overlapped with one set refilled in place (the only overlapped form that fits
+        // M = 32); default: 2 for M >= 16, 1 below
+        static const int mode = [] { const char* e = std::getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : -1; }();
+        const int eff = mode >= 0 ? mode : (M >= 16 ? 2 : 1);
+        if constexpr (M == 32)
+        {
+          // rank 65..128: the in-place overlapped form only fits without the M column-sum accumulators;
+          // they are taken once per launch by a small pre-pass instead (DS = 0)
+          if (eff == 2 && a.colsumScratch)
+          {
+            const int ns = a.nsplit < 1 ? 1 : a.nsplit;
+            (void) hipMemsetAsync(a.dpart, 0, (size_t) a.B * ns * a.Kp * sizeof(double), s);
+            launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s);
+            launch5_t<M, NG, NS, WPS, 0, 2, 0>(a, w, s);
+            return;
+          }
+        }
+        else if (eff == 2) { launch5_t<M, NG, NS, WPS, 0, 2>(a, w, s); return; }
+        if constexpr (M <= 16)
+          if (eff == 1) { launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s); return; }
       }
       launch5_t<M, NG, NS, WPS>(a, w, s);
     }

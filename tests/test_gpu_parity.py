@@ -211,6 +211,18 @@ def test_nmf_single_buffer_large_uses_split_path(ctx, oracle):
     assert np.array_equal(W1, W2) and np.array_equal(H1, H2)
 
 
+def test_nmf_long_factor_rank128(ctx, oracle):
+    """c3's extremes at a size the oracle finishes in seconds: rank 128 (the widest kernel form) and a
+    factor with tens of thousands of rows (the column-normalisation partials no longer fit in LDS)"""
+    rs = np.random.RandomState(22)
+    T, F, K = 26000, 129, 128
+    X = np.abs(rs.standard_normal((T, 9)) @ rs.standard_normal((9, F))) + 0.001
+    W1, H1, V1, _ = ctx.nmf_process(X, K, 3, True, True, 42)
+    rW, rH, rV, _ = oracle.nmf_process(X, K, 3, True, True, 42)
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
+    assert rel_err(V1, rV) < TOL_FACTORS_TIGHT
+
+
 # ---------------------------------------------------------------------------------------
 # BufNMF channel + corpus
 # ---------------------------------------------------------------------------------------
