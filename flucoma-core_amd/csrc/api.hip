@@ -1372,10 +1372,10 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
 
 // ---- profiling ------------------------------------------------------------------------
 // debugging aid for FLUHIP_K5_INSTR: first 8 words of the split-denominator scratch
-int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out8)
+int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
 {
-  if (!c || !out8 || !c->dpart.p) return FLUHIP_ERROR;
-  HIPCHK(c->ctx, hipMemcpy(out8, c->dpart.p, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (!c || !out32 || !c->dpart.p) return FLUHIP_ERROR;
+  HIPCHK(c->ctx, hipMemcpy(out32, c->dpart.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return FLUHIP_OK;
 }
 

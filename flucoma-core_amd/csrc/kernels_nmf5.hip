@@ -119,6 +119,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     buf = id / (a.nsplit * a.wgPerBuf);
   }
   if (buf >= a.B) return;
+  long long tEntry = 0;
+  if constexpr (INSTR) tEntry = (long long) __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int WPB = 4 * WPS; // wavefronts per workgroup
@@ -196,14 +198,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + slot * MSTAGE + j * 1024);
   };
 
-  if constexpr (MODE >= 1)
-  {
-    // ring fill first: its HBM latency runs under the stationary loads and their normalisation below
-    // (slots are numbered from s0 in the overlapped pipeline)
+  // ring fill of the overlapped pipeline (slots numbered from s0), in two parts: the first two stages go out
+  // ahead of the stationary rows -- the prologue needs them first -- the rest behind them, so that the
+  // stationary rows do not queue behind 6 stages of streaming data at every wavefront at once
+  auto fill_slots = [&](int t0, int t1) {
     if (s0 < s1)
     {
 #pragma unroll
-      for (int t = 0; t < NS; t++)
+      for (int t = t0; t < t1; t++)
       {
         const int sc = min(s0 + t, sLast);
         const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
@@ -214,7 +216,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         for (int j = 0; j < NJM; j++) FLUHIP_GLDS(msrc + moffs[j], mring + t * MSTAGE + j * 1024);
       }
     }
-  }
+  };
+  long long tP1 = 0, tP2 = 0, tP3 = 0;
+  if constexpr (INSTR) tP1 = (long long) __builtin_amdgcn_s_memrealtime();
+  if constexpr (MODE >= 1) fill_slots(0, 2);
 
   // ---- stationary operand + accumulators ------------------------------------------------------
   double sb[NG][M];
@@ -236,6 +241,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
       for (int m = 0; m < M; m++) sb[g][m] = fdiv_pos(sb[g][m], nr[m]);
   }
+  if constexpr (INSTR)
+  {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::"v"(sb[0][0]), "v"(sb[NG - 1][M - 1])); // the stationary rows are in registers here
+    tP2 = (long long) __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (MODE >= 1) fill_slots(2, NS);
   double dsum[M];
 #pragma unroll
   for (int m = 0; m < M; m++) dsum[m] = 0.0;
@@ -498,6 +511,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 
       double vX[NG], maX[M], mbX[M], vY[NG], maY[M], mbY[M], qA[NG], qB[NG];
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * IPS) : "memory");
+      if constexpr (INSTR) tP3 = (long long) __builtin_amdgcn_s_memrealtime();
       auto read_set = [&](int slotV, int slotA, double (&v)[NG], double (&ma)[M], double (&mb)[M], bool wantV) {
         if (wantV)
         {
@@ -530,7 +544,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         if constexpr (INSTR) { __builtin_amdgcn_sched_barrier(0); long long c = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); return c; }
         return 0;
       };
-      if constexpr (INSTR) tReal = -(long long) __builtin_amdgcn_s_memrealtime();
+      long long tLoop0 = 0;
+      if constexpr (INSTR) { tLoop0 = (long long) __builtin_amdgcn_s_memrealtime(); tReal = -tLoop0; }
       // step s sits in slot u; reads stage s+1 (slot u1) and the ma part of stage s+2 (slot u2); refills slot u
       auto half = [&](int s, int u, int u1, int u2, const double (&v)[NG], const double (&ma)[M], const double (&mb)[M],
                       double (&vn)[NG], double (&man)[M], double (&mbn)[M], const double (&qc)[NG],
@@ -625,11 +640,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if constexpr (INSTR)
       {
-        tReal += (long long) __builtin_amdgcn_s_memrealtime();
+        const long long tLoop1 = (long long) __builtin_amdgcn_s_memrealtime();
+        tReal += tLoop1;
         if (blockIdx.x == 17 && threadIdx.x == 0 && a.dpart)
         {
           long long* o = reinterpret_cast<long long*>(a.dpart);
           o[0] = tWait; o[1] = 0; o[2] = tRatio; o[3] = tQ; o[4] = tOut; o[5] = 0; o[6] = s1 - s0; o[7] = tReal;
+        }
+        // timeline samples (100 MHz ticks): entry, loop start, loop end of wavefront 0 of a few workgroups
+        if (threadIdx.x == 0 && a.dpart && (blockIdx.x & 63) == 17)
+        {
+          long long* o = reinterpret_cast<long long*>(a.dpart) + 16 + 4 * (blockIdx.x >> 6);
+          o[0] = tEntry; o[1] = tLoop0; o[2] = tLoop1;
+          if (blockIdx.x == 17) { long long* q = reinterpret_cast<long long*>(a.dpart) + 12; q[0] = tP1; q[1] = tP2; q[2] = tP3; }
         }
       }
     }
@@ -733,29 +756,68 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       ss[m] = 0.0;
       mx[m] = -INFINITY;
     }
+    // S_old comes from the stationary registers, not from memory: sb holds S (already divided by nrm when the
+    // normalisation is deferred) as (col 4 blk + x, k = M y + m); the result layout is (col 4 blk + y,
+    // k = M x + m) -- the same block with x and y exchanged, one lane permutation.  At the end of the loop
+    // all 1024 wavefronts stand here at once, so every byte not moved is time: re-reading S was a third
+    // of the epilogue's traffic.  (H update with deferred normalisation: (H/nrm) acc == H (acc/nrm) up
+    // to rounding, so the divided rows serve there too.)
+    const int srcLane = y + 4 * blk + 16 * x;
+    // The results leave through LDS: in the MFMA result layout a lane holds 64 bytes of a row and a store
+    // instruction would write four 16-byte pieces 64 bytes apart per row -- quarter-filled write requests,
+    // measured at ~1.7 TB/s with every wavefront storing at once.  A group's 16 rows are contiguous in memory
+    // (16 x Kp doubles), so they are laid out in the wavefront's (now idle) ring with the rows 16 bytes apart in
+    // bank phase, read back linearly and stored as whole kilobytes per instruction.
+    constexpr int ROWB = KP * 8 + 16;
+    constexpr int GRPB = 16 * ROWB;
+    constexpr int GB = (WAVE_LDS / GRPB) >= NG ? NG : (WAVE_LDS / GRPB);
+    static_assert(GB >= 1, "result staging does not fit the ring");
+    constexpr int CPR = KP / 2;            // 16-byte chunks per row
+    constexpr int NST = 16 * CPR / 64;     // store instructions per group
+    char* stg = lds + wave * WAVE_LDS;
 #pragma unroll
-    for (int g = 0; g < NG; g++)
+    for (int gb = 0; gb < NG; gb += GB)
     {
-      if (g < ng)
+#pragma unroll
+      for (int g = gb; g < gb + GB && g < NG; g++)
       {
         const int col = (g0 + g) * 16 + 4 * blk + y;
-        if (col < a.C)
-        {
-          double* sp = S + (int64_t) col * KP + M * x;
-          double sold[M];
-          load_vec5<M>(sold, sp);
+        const bool live = g < ng && col < a.C;
+        char* row = stg + (g - gb) * GRPB + (4 * blk + y) * ROWB + (M * x) * 8;
 #pragma unroll
-          for (int m = 0; m < M; m++)
+        for (int m = 0; m < M; m += 2)
+        {
+          double r2[2];
+#pragma unroll
+          for (int e = 0; e < 2; e++)
           {
-            double so = sold[m], num = acc[g][m];
-            if (a.nrmMode == 1) so = fdiv_pos(so, nrE[m]);
-            if (a.nrmMode == 2) num = fdiv_pos(num, nrE[m]);
-            const double v = so * num;
-            const double r0 = v * dy[m];
-            const double r = __builtin_fma(__builtin_fma(-dd[m], r0, v), dy[m], r0);
-            sp[m] = r;
-            ss[m] = __builtin_fma(r, r, ss[m]);
-            mx[m] = fmax(mx[m], r);
+            const double so = __shfl(sb[g][m + e], srcLane);
+            const double v = so * acc[g][m + e];
+            const double r0 = v * dy[m + e];
+            const double r = __builtin_fma(__builtin_fma(-dd[m + e], r0, v), dy[m + e], r0);
+            r2[e] = r;
+            if (live)
+            {
+              ss[m + e] = __builtin_fma(r, r, ss[m + e]);
+              mx[m + e] = fmax(mx[m + e], r);
+            }
+          }
+          *reinterpret_cast<d2*>(row + m * 8) = d2{r2[0], r2[1]};
+        }
+      }
+#pragma unroll
+      for (int g = gb; g < gb + GB && g < NG; g++)
+      {
+        if (g < ng)
+        {
+#pragma unroll
+          for (int j = 0; j < NST; j++)
+          {
+            const int c = 64 * j + lane;
+            const int r = c / CPR, piece = c % CPR;
+            const d2 t = *reinterpret_cast<const d2*>(stg + (g - gb) * GRPB + r * ROWB + piece * 16);
+            const int col = (g0 + g) * 16 + r;
+            if (col < a.C) *reinterpret_cast<d2*>(S + (int64_t) col * KP + piece * 2) = t;
           }
         }
       }
@@ -805,6 +867,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
       for (int m = 0; m < M; m++) dp[m] = dsum[m];
     }
+  }
+  if constexpr (INSTR)
+  {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (threadIdx.x == 0 && a.dpart && (blockIdx.x & 63) == 17)
+      reinterpret_cast<long long*>(a.dpart)[16 + 4 * (blockIdx.x >> 6) + 3] = (long long) __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -862,7 +930,7 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, WPS>();
-      if constexpr (M == 8 && NG == 9 && WPS == 1)
+      if constexpr (M == 8 && (NG == 9 || NG == 8) && WPS == 1)
       {
         // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
         static const int instr = [] { const char* e = std::getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();

@@ -10,7 +10,7 @@ B, n = 128, 441000
 x = oracle_np.synth_audio(n, 1000)
 c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, 32)
 c.set_audio(np.tile(x, (B, 1))); c.stft(); c.nmf(3, seed=42, updateH=False); ctx.synchronize()
-out = (ctypes.c_int64 * 8)()
+out = (ctypes.c_int64 * 32)()
 ctx.lib.fluhip_corpus_debug_words.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
 assert ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0
 names = ["wait_dma", "lds_read", "ratio", "q_phase", "out_phase", "dma_issue"]
@@ -23,3 +23,16 @@ print(f"  total      {tot/iters:8.0f} cycles/step")
 if out[7]:
     us = out[7] / 100.0   # s_memrealtime counts at 100 MHz
     print(f"  loop wall  {us:8.1f} us  -> shader clock {tot/us/1e3:6.3f} GHz if s_memtime counts shader cycles")
+
+# timeline of wavefront 0 of workgroups 17, 81, 145, 209 (s_memrealtime, 10 ns ticks), relative to the earliest entry
+ent = [out[16 + 4 * i] for i in range(4)]
+if all(ent):
+    t0 = min(ent)
+    for i in range(4):
+        e, l0, l1, x = (out[16 + 4 * i + j] for j in range(4))
+        print(f"  wg {17 + 64 * i:3d}: entry +{(e - t0) / 100:6.2f} us  prologue {(l0 - e) / 100:6.2f} us  loop {(l1 - l0) / 100:7.2f} us  "
+              f"epilogue {(x - l1) / 100:6.2f} us  exit +{(x - t0) / 100:7.2f} us")
+if out[12] and ent[0]:
+    e = out[16]
+    print(f"  wg  17 prologue: strip bookkeeping {(out[12]-e)/100:5.2f} us | first 2 stages issued + stationary rows loaded and normalised "
+          f"{(out[13]-out[12])/100:5.2f} us | rest of the ring issued, stages 0-1 landed {(out[14]-out[13])/100:5.2f} us | first Q + operand reads {(out[17]-out[14])/100:5.2f} us")
