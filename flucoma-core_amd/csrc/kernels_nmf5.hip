@@ -395,7 +395,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       constexpr int QREADS = NG + M / 2;                             // ds_reads issued in the Q-phase
       auto half = [&](int s, int u, int u1, int u2, const double (&qc)[NG], double (&qn)[NG]) {
         double ratio[NG];
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory"); // stages s+1, s+2 landed
+        // stages s+1, s+2 landed.  (Refills past the last step re-read the last step's rows -- L2 hits; skipping
+        // them was measured slower both ways: a branch per DMA splits the MFMA stream into basic blocks, and
+        // issuing them under EXEC = 0 stalls on every EXEC write.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
         ratio_phase(v, qc, ratio);
 #pragma unroll
         for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
@@ -552,7 +555,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
                       double (&qn)[NG]) {
         double ratio[NG];
         const long long c0 = tick();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory"); // stages s+1, s+2 landed
+        // stages s+1, s+2 landed.  (Refills past the last step re-read the last step's rows -- L2 hits; skipping
+        // them was measured slower both ways: a branch per DMA splits the MFMA stream into basic blocks, and
+        // issuing them under EXEC = 0 stalls on every EXEC write.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
         const long long c1 = tick();
         ratio_phase(v, qc, ratio);
         __builtin_amdgcn_sched_barrier(0);
