@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libflucoma_hip.so")
+# FLUHIP_LIB: another build of the library (A/B timing of two source states on one GPU box)
+LIB_PATH = os.environ.get("FLUHIP_LIB") or os.path.join(_HERE, "lib", "libflucoma_hip.so")
 
 OK, WARNING, ERROR, CANCELLED = 0, 1, 2, 3
 
