@@ -123,6 +123,23 @@ struct ProfScope
   }
 };
 
+// Strided host view -> contiguous device copy (clients/nrt/NMFClient.hpp:240 `tmp <<= samps(...)`).
+// A contiguous source is one plain copy; a strided one (a channel of a frame-interleaved host buffer) is gathered
+// on the host first -- a 2-D copy with element-sized rows would be issued row by row.
+static hipError_t upload_strided(void* dst, const void* src, size_t n, size_t stride, size_t esz, hipStream_t s)
+{
+  if (stride == 1) return hipMemcpyAsync(dst, src, n * esz, hipMemcpyHostToDevice, s);
+  std::vector<char> tmp(n * esz);
+  const char* p = static_cast<const char*>(src);
+  if (esz == 4)
+    for (size_t i = 0; i < n; i++) reinterpret_cast<float*>(tmp.data())[i] = reinterpret_cast<const float*>(p)[i * stride];
+  else
+    for (size_t i = 0; i < n; i++) reinterpret_cast<double*>(tmp.data())[i] = reinterpret_cast<const double*>(p)[i * stride];
+  hipError_t e = hipMemcpyAsync(dst, tmp.data(), n * esz, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  return hipStreamSynchronize(s); // tmp goes out of scope
+}
+
 // ---------------------------------------------------------------------------------------
 // tables: window (alg/WindowFuncs.hpp:38-72) and FFT twiddles, computed on the host in f64
 // ---------------------------------------------------------------------------------------
@@ -885,8 +902,8 @@ static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int
   DevBuf in;
   const size_t esz = a32 ? sizeof(float) : sizeof(double);
   HIPCHK(ctx, in.alloc((size_t) n * esz, false, ctx->stream));
-  HIPCHK(ctx, hipMemcpy2DAsync(in.p, esz, a32 ? (const void*) a32 : (const void*) a64, (size_t) stride * esz,
-                               esz, (size_t) n, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, upload_strided(in.p, a32 ? (const void*) a32 : (const void*) a64, (size_t) n, (size_t) stride, esz,
+                             ctx->stream));
   rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n);
   if (rc) return rc;
   if (frames_out) *frames_out = c.T;
@@ -1091,8 +1108,7 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
   if (rc) return rc;
   DevBuf in;
   HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
-  HIPCHK(ctx, hipMemcpy2DAsync(in.p, sizeof(float), audio, (size_t) stride * sizeof(float), sizeof(float),
-                               (size_t) n, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), s));
   rc = corpus_stft(&c, in.as<float>(), nullptr, n); // nrt/NMFClient.hpp:240-242
   if (rc) return rc;
   FactorInit fi;
@@ -1171,8 +1187,7 @@ int fluhip_bufstft_forward_f32(fluhip_ctx* ctx, const float* audio, int64_t n, i
   if (rc) return rc;
   DevBuf in, spec, dm, dp;
   HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
-  HIPCHK(ctx, hipMemcpy2DAsync(in.p, sizeof(float), audio, (size_t) stride * sizeof(float), sizeof(float),
-                               (size_t) n, hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), s));
   HIPCHK(ctx, spec.alloc((size_t) T * F * 2 * sizeof(double), false, s));
   if (mag) HIPCHK(ctx, dm.alloc((size_t) T * F * sizeof(float), false, s));
   if (phase) HIPCHK(ctx, dp.alloc((size_t) T * F * sizeof(float), false, s));
