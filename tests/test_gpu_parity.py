@@ -5,6 +5,7 @@ Bars (BASELINE.json north_star): frame indexing bit-exact; spectrogram <= 1e-12 
 vs f64); W, H within 1e-5 relative -- the f64 kernels are expected to sit many orders below
 that, which the *_tight assertions record.
 """
+import os
 import numpy as np
 import pytest
 
@@ -291,6 +292,15 @@ def test_process_frames_vs_oracle(ctx, oracle, T, F, K, iters, seed):
     # frames are independent: a frame's activations do not depend on its neighbours
     H2, _ = ctx.nmf_process_frames(X[::-1].copy(), W0, iters, seed, want_v=False)
     assert rel_err(H2[::-1], H) < 1e-12
+
+
+def test_process_frames_golden(ctx):
+    """the HIP path against the committed G7 vectors directly (no oracle in the loop)"""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))
+    for seed, iters in ((42, 10), (5063, 10), (42, 0), (7, 100)):
+        H, V = ctx.nmf_process_frames(g["g7_X"], g["g7_W0"], iters, seed)
+        assert rel_err(H, g[f"g7_s{seed}_i{iters}_H"]) < TOL_FACTORS_TIGHT
+        assert rel_err(V, g[f"g7_s{seed}_i{iters}_V"]) < TOL_FACTORS_TIGHT
 
 
 def test_corpus_matches_per_buffer_oracle(ctx, oracle, onp):

@@ -251,3 +251,12 @@ def test_process_frame_c_vs_numpy():
     htrue = np.array([0.5, 1.5, 0.25, 2.0])
     hfit, vfit = oracle_np.nmf_process_frame(htrue @ Wn, W0, 2000, 7)
     assert np.allclose(vfit, htrue @ Wn, rtol=1e-6)
+
+
+@pytest.mark.parametrize("seed,iters", [(42, 10), (5063, 10), (42, 0), (7, 100)])
+def test_process_frame_golden(seed, iters):
+    """G7: the C restatement of NMF::processFrame against the committed vectors (tools/make_golden.py --frames)"""
+    import oracle_c
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))
+    H, V = oracle_c.get("native").nmf_process_frames(g["g7_X"], g["g7_W0"], iters, seed)
+    assert rel_err(H, g[f"g7_s{seed}_i{iters}_H"]) < 1e-12 and rel_err(V, g[f"g7_s{seed}_i{iters}_V"]) < 1e-12

@@ -128,5 +128,30 @@ def main():
     print("wrote", OUT, os.path.getsize(OUT), "bytes,", len(g), "arrays")
 
 
+def frames():
+    """G7 (SURVEY 8 f4): NMF::processFrame, kept in its own file so that G1..G6 stay byte-identical."""
+    import oracle_np as onp
+    g = {}
+    rs = np.random.RandomState(11)
+    K, F, T = 5, 129, 12
+    W0 = rs.uniform(0, 1, (K, F)) ** 3
+    W0[1, :4] = 0.0
+    acts = rs.uniform(0, 2, (T, K)) * (rs.uniform(0, 1, (T, K)) < 0.5)
+    X = acts @ W0 + 1e-3 * rs.uniform(0, 1, (T, F))
+    X[2, :9] = 0.0
+    g["g7_W0"], g["g7_X"] = W0, X
+    for seed, iters in ((42, 10), (5063, 10), (42, 0), (7, 100)):
+        H = np.empty((T, K)); V = np.empty((T, F))
+        for t in range(T):
+            H[t], V[t] = onp.nmf_process_frame(X[t], W0, iters, seed)
+        g[f"g7_s{seed}_i{iters}_H"], g[f"g7_s{seed}_i{iters}_V"] = H, V
+    out = os.path.join(os.path.dirname(OUT), "golden_frames_v1.npz")
+    np.savez_compressed(out, **g)
+    print("wrote", out, os.path.getsize(out), "bytes,", len(g), "arrays")
+
+
 if __name__ == "__main__":
-    main()
+    if "--frames" in sys.argv:
+        frames()
+    else:
+        main()
