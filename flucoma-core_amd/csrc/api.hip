@@ -307,20 +307,12 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
   return FLUHIP_OK;
 }
 
-static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
+// how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
+// workspaces; needs B, T, F, Tp, Fp, Kp
+static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
-  c->T = (c->n + c->hop) / c->hop; // alg/STFT.hpp:98-99; nrt/NMFClient.hpp:111-112
-  c->F = c->fft / 2 + 1;
-  c->Tp = round_up(c->T, 32);
-  c->Fp = round_up(c->F, 32);
-  c->Kp = round_up(c->K, 16);
   const size_t B = (size_t) c->B;
-  HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
-  HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
-  HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
-  HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
-  HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
   if (update_variant((int) c->Kp) != 16)
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
@@ -330,9 +322,9 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
     // widest strip of the MFMA kernel (fluhip_kernels.h SideColumn).
     static const int lazyOff = [] { const char* e = std::getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
     static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
-    c->lazy = !lazyOff && update_variant((int) c->Kp) == 5 && c->nsplitW == 1 && c->nsplitH == 1;
+    c->lazy = !lazyOff && update_variant((int) c->Kp) == 5;
     c->sideW = false;
-    if (c->lazy && !sideOff && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
+    if (c->lazy && !sideOff && c->nsplitW == 1 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
         choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp) == 1)
     {
       const int G = ((int) c->F + 15) / 16, G1 = G - 1;
@@ -340,7 +332,10 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
       const int w1 = nmf_update5_strips((int) c->F - 1, (int) c->Kp, (int) c->B);
       c->sideW = (G1 + w1 - 1) / w1 < (G + w - 1) / w && w1 <= w;
     }
-    c->stripsW = nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
+    // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
+    // finalize kernel when the contraction is split
+    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F)
+                                : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
   }
   else
   {
@@ -355,6 +350,24 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
     launch_fill_ones(c->wnorm.as<double>(), (int64_t) (B * c->Kp), s);
     HIPCHK(ctx, c->wscratch.alloc((size_t) wnorm_scratch_doubles((int) c->Kp, (int) B, c->stripsW) * sizeof(double), true, s));
   }
+  return FLUHIP_OK;
+}
+
+static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  c->T = (c->n + c->hop) / c->hop; // alg/STFT.hpp:98-99; nrt/NMFClient.hpp:111-112
+  c->F = c->fft / 2 + 1;
+  c->Tp = round_up(c->T, 32);
+  c->Fp = round_up(c->F, 32);
+  c->Kp = round_up(c->K, 16);
+  const size_t B = (size_t) c->B;
+  HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
+  HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
+  HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
+  if (int rc = plan_updates(ctx, c)) return rc;
   return FLUHIP_OK;
 }
 
@@ -955,18 +968,7 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
     HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
     HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
-    if (update_variant((int) c.Kp) != 16)
-    {
-      c.nsplitW = choose_split4(1, (int) F, (int) T, (int) c.Kp);
-      c.nsplitH = choose_split4(1, (int) T, (int) F, (int) c.Kp);
-    }
-    else
-    {
-      const int cpw = nmf_update_cols_per_wave((int) c.Kp);
-      c.nsplitW = choose_split(1, (F + 4 * cpw - 1) / (4 * cpw), (T + 15) / 16);
-      c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
-    }
-    if (int rc2 = alloc_update_scratch(ctx, &c)) return rc2;
+    if (int rc2 = plan_updates(ctx, &c)) return rc2;
   }
   // alg/NMF.hpp:125  V = X^T (same bytes as the T x F row-major view)
   HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
@@ -1028,14 +1030,7 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
   HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
   HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
-  if (update_variant((int) c.Kp) != 16)
-    c.nsplitH = choose_split4(1, (int) T, (int) F, (int) c.Kp);
-  else
-  {
-    const int cpw = nmf_update_cols_per_wave((int) c.Kp);
-    c.nsplitH = choose_split(1, (T + 4 * cpw - 1) / (4 * cpw), (F + 15) / 16);
-  }
-  if (int rc2 = alloc_update_scratch(ctx, &c)) return rc2;
+  if (int rc2 = plan_updates(ctx, &c)) return rc2;
   // :57-58, 61  v0 = max(x, eps)
   HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
                                (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));

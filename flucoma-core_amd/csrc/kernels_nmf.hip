@@ -207,32 +207,127 @@ __global__ __launch_bounds__(256, MINW) void nmf_update_kernel(UpdKArgs a)
   }
 }
 
-// split-R epilogue: fixed-order reduction of the partials, then the multiplicative step
+constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
+
+// split-R epilogue: fixed-order reduction of the partials, then the multiplicative step.  One block per
+// (16-row chunk, buffer), thread = (split group sg of 4, row group, k): a thread adds its quarter of the nsplit
+// partials in index order (eight loads in flight), the four quarter sums are combined in fixed order through
+// LDS -- single-buffer problems have few rows and many splits, so the parallelism has to come from the splits.
+// With deferred normalisation (UpdateArgs::nrm) the step is the one of the un-split kernel's epilogue, and
+// for the W update the block leaves its column statistics (sum x^2, max) for wnorm_combine_kernel.
+constexpr int kFinRows = 16;
+constexpr int kFinSG = 4;
+
 __global__ void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
                                            const double* dpart, int C, int Kp, int64_t Cp,
-                                           int nsplit)
+                                           int nsplit, const double* nrm, int nrmMode, double* statPart, int nch)
 {
-  const int buf = blockIdx.y;
-  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t) C * Kp) return;
-  const int k = (int) (idx % Kp);
-  double num = 0.0, den = 0.0;
-  for (int s = 0; s < nsplit; s++)
+  extern __shared__ double sh[]; // [kFinSG][nrg][Kp] quarter sums; then [nrg][Kp] x 2 for the statistics
+  const int chunk = blockIdx.x, buf = blockIdx.y;
+  const int nrg = blockDim.x / (Kp * kFinSG);
+  const int k = threadIdx.x % Kp, rg = (threadIdx.x / Kp) % nrg, sg = threadIdx.x / (Kp * nrg);
+  const int per = (nsplit + kFinSG - 1) / kFinSG;
+  const int sb = sg * per, se = min(nsplit, sb + per);
+  // denominators: the same quarter-and-combine scheme (a plain loop would be nsplit dependent load latencies)
+  double den = 0.0, nk = 1.0;
+  if (rg == 0)
   {
-    num += part[((int64_t) buf * nsplit + s) * Cp * Kp + idx];
-    den += dpart[((int64_t) buf * nsplit + s) * Kp + k];
+    const double* dp = dpart + (int64_t) buf * nsplit * Kp + k;
+    int s = sb;
+    for (; s + 8 <= se; s += 8)
+    {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = dp[(int64_t) (s + u) * Kp];
+#pragma unroll
+      for (int u = 0; u < 8; u++) den += v[u];
+    }
+    for (; s < se; s++) den += dp[(int64_t) s * Kp];
+    sh[sg * Kp + k] = den;
   }
-  double* sp = S + (int64_t) buf * strideS + idx;
-  *sp = (*sp * num) / fmax(den, kEpsilon);
+  __syncthreads();
+  if (sg == 0)
+  {
+    den = sh[k];
+#pragma unroll
+    for (int g = 1; g < kFinSG; g++) den += sh[g * Kp + k];
+    nk = nrmMode ? nrm[(int64_t) buf * Kp + k] : 1.0;
+    if (nrmMode == 2) den = den / nk;
+    den = fmax(den, kEpsilon);
+  }
+  __syncthreads();
+  const double* p0 = part + (int64_t) buf * nsplit * Cp * Kp;
+  const int64_t sstride = Cp * Kp;
+  double ss = 0.0, mx = -INFINITY;
+  const int rbeg = chunk * kFinRows, rend = min(rbeg + kFinRows, C);
+  for (int r0 = rbeg; r0 < rend; r0 += nrg)
+  {
+    const int r = r0 + rg;
+    const int64_t idx = (int64_t) r * Kp + k;
+    double num = 0.0;
+    if (r < rend)
+    {
+      int s = sb;
+      for (; s + 8 <= se; s += 8)
+      {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p0[(int64_t) (s + u) * sstride + idx];
+#pragma unroll
+        for (int u = 0; u < 8; u++) num += v[u];
+      }
+      for (; s < se; s++) num += p0[(int64_t) s * sstride + idx];
+    }
+    sh[(sg * nrg + rg) * Kp + k] = num;
+    __syncthreads();
+    if (sg == 0 && r < rend)
+    {
+      double t = sh[rg * Kp + k];
+#pragma unroll
+      for (int g = 1; g < kFinSG; g++) t += sh[(g * nrg + rg) * Kp + k];
+      double* sp = S + (int64_t) buf * strideS + idx;
+      double so = *sp;
+      if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
+      const double x = (so * t) / den;
+      *sp = x;
+      ss += x * x;
+      mx = fmax(mx, x);
+    }
+    __syncthreads();
+  }
+  if (!statPart) return;
+  if (sg == 0)
+  {
+    sh[rg * Kp + k] = ss;
+    sh[(nrg + rg) * Kp + k] = mx;
+  }
+  __syncthreads();
+  if (sg == 0 && rg == 0)
+  {
+    double tot = 0.0, m = -INFINITY;
+    for (int j = 0; j < nrg; j++)
+    {
+      tot += sh[j * Kp + k];
+      m = fmax(m, sh[(nrg + j) * Kp + k]);
+    }
+    double* q = statPart + ((int64_t) buf * nch + chunk) * 2 * Kp;
+    q[k] = tot;
+    q[Kp + k] = m;
+  }
 }
 
+int update_finalize_parts(int C) { return (C + kFinRows - 1) / kFinRows; }
+
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
-                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s)
+                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s, const double* nrm,
+                            int nrmMode, double* statPart)
 {
-  const int64_t total = (int64_t) C * Kp;
-  dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
-  hipLaunchKernelGGL(nmf_update_finalize_kernel, g, dim3(256), 0, s, S, strideS, part, dpart, C, Kp,
-                     Cp, nsplit);
+  int nrg = 256 / Kp;
+  if (nrg < 1) nrg = 1;
+  const int nch = update_finalize_parts(C);
+  hipLaunchKernelGGL(nmf_update_finalize_kernel, dim3((unsigned) nch, (unsigned) B),
+                     dim3((unsigned) (kFinSG * nrg * Kp)), (size_t) kFinSG * nrg * Kp * sizeof(double), s, S, strideS,
+                     part, dpart, C, Kp, Cp, nsplit, nrm, nrmMode, statPart, nch);
 }
 
 template <int NB, int CB, int MINW>
@@ -280,7 +375,6 @@ void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
 // then a fixed-order combine + scale.  Deterministic: no atomics, the same summation tree on
 // every run and for every buffer.
 // ---------------------------------------------------------------------------------------
-constexpr int kNormRows = 64; // rows per chunk
 
 __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
                                 double* part, int nch)
@@ -534,70 +628,75 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
   }
 }
 
-// One small workgroup per buffer: adds the per-wavefront column statistics of the W update in strip order
-// and the side-column slices in slice order, writes the side row (S[C-1][k] = S_old[C-1][k] num_k /
-// max(den_k, eps), not normalised like every other row of W') and the new nrm:
+// One workgroup per buffer, thread = (part group pg, k): adds the column statistics of the W update (one part per
+// wavefront, or per finalize chunk when the contraction was split) -- each thread a contiguous run of parts in
+// index order, the runs combined in fixed order -- and the side-column slices in slice order; writes the side
+// row (S[C-1][k] = S_old[C-1][k] num_k / max(den_k, eps), not normalised like every other row of W') and the new nrm:
 // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon) W.colwise().normalize()  ->  nrm_k = sqrt(sum_c W'[c][k]^2), else 1.
-__global__ __launch_bounds__(128) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, const double* statPart,
-                                     int nStrips, const double* sidePart, int nsl, const double* wold, double* nrm)
+__global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
+                                                            const double* statPart, int nParts, const double* sidePart,
+                                                            int nsl, const double* wold, double* nrm)
 {
-  __shared__ double smax[128];
-  const int b = blockIdx.x, k = threadIdx.x; // blockDim == Kp <= 128
-  // every partial in one burst of independent loads (fixed maximum counts), then fixed-order sums
-  constexpr int kMaxStrips = 16;
-  double ps[kMaxStrips], pm[kMaxStrips], pn[kSideSlices], pd[kSideSlices];
+  __shared__ double shs[256], shm[256], smax[128];
+  const int b = blockIdx.x;
+  const int npg = blockDim.x / Kp;
+  const int k = threadIdx.x % Kp, pg = threadIdx.x / Kp;
+  const int per = (nParts + npg - 1) / npg;
+  const int p0 = pg * per, p1 = min(nParts, p0 + per);
+  double t = 0.0, m = -INFINITY;
+  {
+    const double* p = statPart + (int64_t) b * nParts * 2 * Kp;
+    int j = p0;
+    for (; j + 8 <= p1; j += 8)
+    {
+      double vs[8], vm[8];
 #pragma unroll
-  for (int st = 0; st < kMaxStrips; st++)
-  {
-    const double* p = statPart + ((int64_t) b * nStrips + (st < nStrips ? st : 0)) * 2 * Kp;
-    ps[st] = p[k];
-    pm[st] = p[Kp + k];
+      for (int u = 0; u < 8; u++) { vs[u] = p[(int64_t) (j + u) * 2 * Kp + k]; vm[u] = p[(int64_t) (j + u) * 2 * Kp + Kp + k]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { t += vs[u]; m = fmax(m, vm[u]); }
+    }
+    for (; j < p1; j++) { t += p[(int64_t) j * 2 * Kp + k]; m = fmax(m, p[(int64_t) j * 2 * Kp + Kp + k]); }
   }
-  double wo = 0.0;
-  if (sidePart)
+  shs[threadIdx.x] = t;
+  shm[threadIdx.x] = m;
+  double n = 0.0, d = 0.0, wo = 0.0;
+  if (sidePart && pg == 0)
   {
+    double pn[kSideSlices], pd[kSideSlices];
 #pragma unroll
     for (int j = 0; j < kSideSlices; j++)
     {
-      const double* p = sidePart + ((int64_t) b * kSideSlices + j) * 2 * Kp;
+      const double* p = sidePart + ((int64_t) b * nsl + (j < nsl ? j : 0)) * 2 * Kp;
       pn[j] = p[k];
       pd[j] = p[Kp + k];
     }
     wo = wold[(int64_t) b * Kp + k];
-  }
-  double t = 0.0, m = -INFINITY;
-#pragma unroll
-  for (int st = 0; st < kMaxStrips; st++)
-    if (st < nStrips)
-    {
-      t += ps[st];
-      m = fmax(m, pm[st]);
-    }
-  for (int st = kMaxStrips; st < nStrips; st++) // wider plans than the burst covers
-  {
-    const double* p = statPart + ((int64_t) b * nStrips + st) * 2 * Kp;
-    t += p[k];
-    m = fmax(m, p[Kp + k]);
-  }
-  if (sidePart)
-  {
-    double n = 0.0, d = 0.0;
 #pragma unroll
     for (int j = 0; j < kSideSlices; j++)
-    {
-      n += pn[j];
-      d += pd[j];
-    }
-    const double wnew = (k < K) ? (wo * n) / fmax(d, kEpsilon) : 0.0;
-    Sbase[(int64_t) b * strideS + (int64_t) (C - 1) * Kp + k] = wnew;
-    t += wnew * wnew;
-    m = fmax(m, wnew);
+      if (j < nsl) { n += pn[j]; d += pd[j]; }
   }
-  smax[k] = (k < K) ? m : -INFINITY;
   __syncthreads();
-  double gmax = -INFINITY;
-  for (int j = 0; j < Kp; j++) gmax = fmax(gmax, smax[j]);
-  nrm[(int64_t) b * Kp + k] = (k < K && gmax > kEpsilon) ? sqrt(t) : 1.0;
+  if (pg == 0)
+  {
+    t = shs[k];
+    m = shm[k];
+    for (int g = 1; g < npg; g++) { t += shs[g * Kp + k]; m = fmax(m, shm[g * Kp + k]); }
+    if (sidePart)
+    {
+      const double wnew = (k < K) ? (wo * n) / fmax(d, kEpsilon) : 0.0;
+      Sbase[(int64_t) b * strideS + (int64_t) (C - 1) * Kp + k] = wnew;
+      t += wnew * wnew;
+      m = fmax(m, wnew);
+    }
+    smax[k] = (k < K) ? m : -INFINITY;
+  }
+  __syncthreads();
+  if (pg == 0)
+  {
+    double gmax = -INFINITY;
+    for (int j = 0; j < Kp; j++) gmax = fmax(gmax, smax[j]);
+    nrm[(int64_t) b * Kp + k] = (k < K && gmax > kEpsilon) ? sqrt(t) : 1.0;
+  }
 }
 
 // W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
@@ -641,8 +740,8 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
     else hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
   }
-  hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, S, strideS, C, K, Kp,
-                     statPart, nStrips, side ? sidePart : nullptr, kSideSlices, wold, nrm);
+  hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
+                     nStrips, side ? sidePart : nullptr, kSideSlices, wold, nrm);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)

@@ -307,8 +307,6 @@ __global__ __launch_bounds__(256, 1) void nmf_update4_kernel(Upd4Args a)
 }
 
 // defined in kernels_nmf.hip
-void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
-                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
 
 template <int M, int NG, int VAR = 0>
 static void launch4_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)

@@ -882,8 +882,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   }
 }
 
-void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
-                            int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s);
 
 template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
@@ -900,7 +898,9 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   k.nsplit = a.nsplit < 1 ? 1 : a.nsplit;
   k.stepsPerSplit = (k.nSteps + k.nsplit - 1) / k.nsplit;
   k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
-  k.nrm = a.nrm; k.nrmMode = a.nsplit > 1 ? 0 : a.nrmMode; k.statPart = a.nsplit > 1 ? nullptr : a.statPart;
+  // split contraction: the stationary rows are normalised on load all the same; the rest of the deferred form
+  // (epilogue arithmetic, statistics) is the finalize kernel's
+  k.nrm = a.nrm; k.nrmMode = a.nrmMode; k.statPart = a.nsplit > 1 ? nullptr : a.statPart;
   k.xcdMap = a.B >= 8 ? 1 : 0;
   const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
@@ -913,7 +913,8 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
                              (int) shmem);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
   if (k.nsplit > 1)
-    launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s);
+    launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s, a.nrm, a.nrmMode,
+                           a.statPart);
 }
 
 int nmf_update4_waves_per_buffer(int C, int Kp, int B);
