@@ -35,7 +35,7 @@ EXPORTS = [
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
     "fluhip_corpus_writeback_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
-    "fluhip_prof_reset", "fluhip_prof_read",
+    "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words",
 ]
 
 
@@ -99,6 +99,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_prof_enable.argtypes = [_vp, ctypes.c_int]
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
+    L.fluhip_corpus_debug_words.argtypes = [_vp, _ip]
     return L
 
 

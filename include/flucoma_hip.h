@@ -198,11 +198,17 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 /* ---- live kernel timing (HIP events on the context stream) ----------------------------- */
 /* When enabled, every launch of the two dominant kernel classes is bracketed by hipEvents on
  * the stream it is launched on.  Classes: 0 = stft_r2c_mag, 1 = nmf_update (both factor
- * updates share one kernel), 2 = feature kernels, 3 = the small kernels between the factor updates.  fluhip_prof_read synchronises and returns the launch count and
- * the summed duration since the last reset. */
+ * updates share one kernel), 2 = feature kernels, 3 = the small kernels between the factor
+ * updates.  fluhip_prof_read synchronises and returns the launch count and the summed duration
+ * since the last reset. */
 int fluhip_prof_enable(fluhip_ctx* ctx, int on);
 int fluhip_prof_reset(fluhip_ctx* ctx);
 int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms);
+/* Kernel-developer diagnostic: with FLUHIP_K5_INSTR=1 in the environment the factor-update kernel of the
+ * c4-shaped schedules runs an instrumented build that leaves cycle counters and a timeline of one wavefront in the
+ * corpus' scratch; this copies the first 32 words out (tools/phase_breakdown.py decodes them).  Without the
+ * environment variable the words are whatever the scratch holds. */
+int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32);
 
 #ifdef __cplusplus
 }

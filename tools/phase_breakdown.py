@@ -11,7 +11,6 @@ x = oracle_np.synth_audio(n, 1000)
 c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, 32)
 c.set_audio(np.tile(x, (B, 1))); c.stft(); c.nmf(3, seed=42, updateH=False); ctx.synchronize()
 out = (ctypes.c_int64 * 32)()
-ctx.lib.fluhip_corpus_debug_words.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)]
 assert ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0
 names = ["wait_dma", "lds_read", "ratio", "q_phase", "out_phase", "dma_issue"]
 iters = out[6]
