@@ -1,0 +1,56 @@
+"""Seeded sweep over shapes and schedules: whatever plan the library picks for a shape (contraction splits,
+deferred normalisation, side column, narrow or wide kernel forms, rank padding) the factors must match the oracle.
+Small problems, many of them: the edges are where schedules change (rank 16/17, 64/65, one frame, one bin group,
+batches that fill the chip or not)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import TOL_FACTORS_TIGHT, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    # FLUHIP_SWEEP="seed,count" runs a different / larger sweep ad hoc (the committed default is 2024,36)
+    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP", "2024,36").split(","))
+    rs = np.random.RandomState(seed)
+    out = []
+    ffts = [64, 128, 256, 512, 1024, 2048]
+    ranks = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 64, 65, 100, 128]
+    for i in range(count):
+        fft = ffts[rs.randint(len(ffts))]
+        win = fft if rs.rand() < 0.7 else fft // 2
+        hop = [win // 2, win // 4, win, win // 2 + 3][rs.randint(4)]
+        K = ranks[rs.randint(len(ranks))]
+        B = [1, 1, 2, 9, 40, 130][rs.randint(6)]
+        frames = [1, 2, 7, 33, 120, 400][rs.randint(6)]
+        if K > 64 and (B > 9 or frames > 120 or fft > 512):
+            B, frames, fft, win = min(B, 2), min(frames, 60), 256, 256  # keep the oracle's share of the run short
+            hop = 128
+        n = max(1, frames * hop - rs.randint(0, hop))
+        iters = int(rs.randint(0, 9))
+        uw, uh = [(True, True), (True, True), (True, False), (False, True)][rs.randint(4)]
+        out.append((i, B, n, win, fft, hop, K, iters, uw, uh))
+    return out
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: "c%d_B%d_n%d_w%d_f%d_h%d_K%d_i%d_%d%d" % c)
+def test_random_shape(ctx, oracle, onp, case):
+    import fluhip
+    _, B, n, win, fft, hop, K, iters, uw, uh = case
+    distinct = [onp.synth_audio(n, 7000 + b) for b in range(min(B, 3))]
+    audio = np.stack([distinct[b % len(distinct)] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    assert c.T == (n + hop) // hop and c.F == fft // 2 + 1
+    c.set_audio(audio); c.stft()
+    c.nmf(iters, seed=42, updateW=uw, updateH=uh)
+    mag, W1, H1 = c.read_f64()
+    plan = c.plan()
+    c.close()
+    for b in sorted({0, B - 1, min(B - 1, 2)}):
+        _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
+        assert rel_err(mag[b], rmag) < 1e-12, plan
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, plan
