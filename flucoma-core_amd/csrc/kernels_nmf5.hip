@@ -17,6 +17,16 @@
 //             (row y, chunks of x) -- both hit distinct banks within a ds_read_b128 lane group.
 //             The rotation is applied on the per-lane *source* address; the LDS destination of an
 //             LDS-DMA is always base + lane*16.
+//
+// Pipeline forms (template MODE; the launcher picks, FLUHIP_K5_MODE overrides for A/B):
+//   0  reads and ring refill grouped between the phases                      (first LDS-DMA form; NG = 1 strips)
+//   1  reads of step s+1 and refill of slot s interleaved into step s's MFMAs, second operand set   (Kp <= 32)
+//   2  the same with one operand set refilled in place behind its consumers                          (Kp >= 64)
+// Other template switches: DS = 0 takes the column sums of Mv from a pre-pass (Kp = 128 has no registers for
+// them), INSTR = 1 adds cycle counters and a timeline (tools/phase_breakdown.py), WPS = 2 is the two-wavefronts-
+// per-SIMD experiment.  Deferred column normalisation (UpdateArgs::nrm), per-wavefront column statistics, the
+// LDS-staged result stores and the split-contraction partial stores live in the common prologue / epilogue.
+// DESIGN.md section 3 and profiles/r01/update_kernel_notes.md carry the measurements behind each of these.
 #include "fluhip_kernels.h"
 
 #include <cstdlib>
