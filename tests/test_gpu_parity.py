@@ -385,6 +385,38 @@ def test_corpus_per_buffer_seeds(ctx, oracle, onp):
     c.close()
 
 
+@pytest.mark.parametrize("name,n,win,fft,hop,K,iters", [("c2", 2646000, 2048, 2048, 512, 16, 60),
+                                                       ("c3", 26460000, 4096, 4096, 1024, 128, 12)])
+def test_single_buffer_full_size_properties(ctx, onp, name, n, win, fft, hop, K, iters):
+    """BASELINE configs 2 and 3 at their full per-channel size (60 s rank 16; 10 min rank 128 -- the split-
+    contraction schedule, the widest kernel form, the column-sum pre-pass), through size-independent properties:
+    frame count, unit-norm dictionary columns, non-negativity, KL divergence not increasing, bit-identical repeat."""
+    import fluhip
+    base = onp.synth_audio(441000, 1000)
+    x = np.tile(base, n // len(base) + 1)[:n].astype(np.float32)
+    c = fluhip.Corpus(ctx, 1, n, win, fft, hop, K)
+    assert (c.T, c.F) == ((n + hop) // hop, fft // 2 + 1)
+    c.set_audio(x[None, :]); c.stft()
+
+    def kl_rows(V, W1, H1, rows):
+        P = np.maximum(H1[rows] @ W1, 1e-300)
+        Vs = np.maximum(V[rows], 1e-300)
+        return float((V[rows] * np.log(Vs / P) - V[rows] + P).sum())
+
+    c.nmf(iters // 3, seed=42)
+    mag, Wa, Ha = c.read_f64()
+    c.nmf(iters, seed=42)
+    _, Wb, Hb = c.read_f64(mag=False)
+    c.nmf(iters, seed=42)
+    _, Wc, Hc = c.read_f64(mag=False)
+    c.close()
+    assert np.array_equal(Wb, Wc) and np.array_equal(Hb, Hc)
+    assert np.isfinite(Wb).all() and np.isfinite(Hb).all() and (Wb >= 0).all() and (Hb >= 0).all()
+    assert np.allclose(np.sqrt((Wb[0] * Wb[0]).sum(axis=1)), 1.0, atol=1e-12)
+    rows = np.arange(0, mag.shape[1], max(1, mag.shape[1] // 2000))   # a frame subset keeps the host side light
+    assert kl_rows(mag[0], Wb[0], Hb[0], rows) <= kl_rows(mag[0], Wa[0], Ha[0], rows) * (1 + 1e-9)
+
+
 def test_corpus_c4_shape_properties(ctx, onp):
     """BASELINE config 4 shape at full per-buffer size (10 s, fft 2048, rank 32, 200 iterations),
     checked through size-independent properties: unit-norm dictionary columns, non-negativity,
