@@ -1082,6 +1082,229 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   return FLUHIP_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// NNDSVD (alg/NNDSVD.hpp) -- the SVD by one-sided Jacobi on the device (kernels_svd.hip), the O(k (F + T))
+// construction on the host
+// ---------------------------------------------------------------------------------------
+// G: device [F][ldg], row f = bin f over the T frames (the transposed magnitude copy; destroyed).  Top factors
+// to the host: s [min(F,T)] descending, U [k][F] (row j = u_j), VT [k][T]; k from the coverage rule.
+static int nndsvd_device(fluhip_ctx* ctx, double* G, int64_t F, int64_t T, int64_t ldg, int64_t minRank, int64_t maxRank,
+                         double amount, std::vector<double>& s, std::vector<double>& U, std::vector<double>& VT,
+                         int64_t* kOut)
+{
+  hipStream_t st = ctx->stream;
+  DevBuf dJ, dN, dFlag;
+  HIPCHK(ctx, dJ.alloc((size_t) F * F * sizeof(double), false, st));
+  HIPCHK(ctx, dN.alloc((size_t) F * sizeof(double), false, st));
+  HIPCHK(ctx, dFlag.alloc(sizeof(unsigned), true, st));
+  const int sweeps = launch_jacobi_svd(G, ldg, (int) F, (int) T, dJ.as<double>(), dN.as<double>(), dFlag.as<unsigned>(),
+                                       40, st);
+  HIPCHK(ctx, hipGetLastError());
+  if (sweeps < 0) return fail(ctx, "the SVD did not converge");
+  std::vector<double> norms((size_t) F);
+  HIPCHK(ctx, hipMemcpyAsync(norms.data(), dN.p, (size_t) F * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  std::vector<int64_t> order((size_t) F);
+  for (int64_t i = 0; i < F; i++) order[(size_t) i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return norms[(size_t) a] > norms[(size_t) b]; });
+  const int64_t r = std::min(F, T);
+  s.resize((size_t) r);
+  for (int64_t i = 0; i < r; i++) s[(size_t) i] = norms[(size_t) order[(size_t) i]];
+  // alg/NNDSVD.hpp:47-58
+  int64_t k = 0;
+  if (amount == 0) k = minRank;
+  else
+  {
+    double current = 0, total = 0;
+    for (double v : s) total += v;
+    while ((current / total) < amount && k < r) current += s[(size_t) k++];
+  }
+  if (k < minRank) k = minRank;
+  if (k > maxRank) k = maxRank;
+  if (k > r) return fail(ctx, "rank above min(bins, frames)");
+  *kOut = k;
+  U.assign((size_t) std::max<int64_t>(k, 1) * F, 0.0);
+  VT.assign((size_t) std::max<int64_t>(k, 1) * T, 0.0);
+  for (int64_t j = 0; j < k; j++)
+  {
+    const int64_t row = order[(size_t) j];
+    HIPCHK(ctx, hipMemcpyAsync(&U[(size_t) j * F], dJ.as<double>() + row * F, (size_t) F * sizeof(double),
+                               hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipMemcpyAsync(&VT[(size_t) j * T], G + row * ldg, (size_t) T * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  for (int64_t j = 0; j < k; j++)
+  {
+    const double sj = s[(size_t) j];
+    if (sj > 0)
+      for (int64_t t = 0; t < T; t++) VT[(size_t) j * T + t] /= sj;
+  }
+  return FLUHIP_OK;
+}
+
+// alg/NNDSVD.hpp:60-129 from (U, s, V^T).  W: wRows x F row-major, H: T x wRows row-major.
+static void nndsvd_construct(const std::vector<double>& s, const std::vector<double>& U, const std::vector<double>& VT,
+                             int64_t F, int64_t T, int64_t k, int64_t wRows, int method, int64_t seed, double mean,
+                             double* W, double* H)
+{
+  const double eps = kEpsilon;
+  std::fill(W, W + wRows * F, 0.0);
+  std::fill(H, H + T * wRows, 0.0);
+  auto u = [&](int64_t j) { return &U[(size_t) j * F]; };
+  auto v = [&](int64_t j) { return &VT[(size_t) j * T]; };
+  if (method == 0)
+  {
+    for (int64_t j = 0; j < k; j++)
+    {
+      for (int64_t f = 0; f < F; f++) W[j * F + f] = std::fabs(u(j)[f]);
+      for (int64_t t = 0; t < T; t++) H[t * wRows + j] = std::fabs(s[(size_t) j] * v(j)[t]);
+    }
+    return;
+  }
+  if (k > 0)
+  {
+    for (int64_t f = 0; f < F; f++) W[f] = std::fabs(u(0)[f]);                                  // :68
+    const double sq = std::sqrt(s[0]);
+    for (int64_t t = 0; t < T; t++) H[t * wRows] = sq * std::fabs(v(0)[t]);                       // :69
+  }
+  for (int64_t j = 1; j < k; j++)
+  {
+    double xP = 0, yP = 0, xN = 0;
+    for (int64_t f = 0; f < F; f++) { const double x = u(j)[f]; if (x > 0) xP += x * x; else xN += x * x; }
+    for (int64_t t = 0; t < T; t++) { const double y = v(j)[t]; if (y > 0) yP += y * y; }
+    const double xPn = std::sqrt(xP), yPn = std::sqrt(yP), xNn = std::sqrt(xN);
+    const double yNn = xNn;                                                                       // :85 as written
+    const double mP = xPn * yPn, mN = xNn * yNn;
+    const bool pos = mP > mN;
+    const double sigma = pos ? mP : mN;
+    const double lbd = std::sqrt(s[(size_t) j] * sigma);
+    const double xn = pos ? xPn : xNn, yn = pos ? yPn : yNn; // :90-100 (yNn is ||xN||, see above)
+    for (int64_t f = 0; f < F; f++)
+    {
+      const double x = u(j)[f];
+      W[j * F + f] = (pos ? std::max(x, 0.0) : std::fabs(std::min(x, 0.0))) / xn;
+    }
+    for (int64_t t = 0; t < T; t++)
+    {
+      const double y = v(j)[t];
+      H[t * wRows + j] = lbd * ((pos ? std::max(y, 0.0) : std::fabs(std::min(y, 0.0))) / yn);
+    }
+  }
+  if (method == 1)
+  {
+    // :107-116: the lazily evaluated random matrix is only sampled where the condition holds, in the assignment's
+    // column-major traversal (WT is F x wRows, HT is wRows x T); a fresh generator of the same seed for each
+    std::random_device rd;
+    const double lo = eps, hi = mean * 0.001;
+    {
+      std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
+      std::uniform_real_distribution<double> d{lo, hi};
+      for (int64_t j = 0; j < wRows; j++)
+        for (int64_t f = 0; f < F; f++)
+          if (W[j * F + f] < eps) W[j * F + f] = d(g);
+    }
+    {
+      std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
+      std::uniform_real_distribution<double> d{lo, hi};
+      for (int64_t t = 0; t < T; t++)
+        for (int64_t j = 0; j < wRows; j++)
+          if (H[t * wRows + j] < eps) H[t * wRows + j] = d(g);
+    }
+  }
+  else if (method == 2)
+  {
+    for (int64_t i = 0; i < wRows * F; i++) if (W[i] < eps) W[i] = mean;
+    for (int64_t i = 0; i < T * wRows; i++) if (H[i] < eps) H[i] = mean;
+  }
+}
+
+int fluhip_nndsvd_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx, int64_t w_rows,
+                      int64_t min_rank, int64_t max_rank, double amount, int method, int64_t seed, double* W,
+                      double* H, int64_t* rank_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!X || !W || !H || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad matrix arguments");
+  if (method < 0 || method > 3) return fail(ctx, "method must be 0..3");
+  if (!(amount > 0 || min_rank > 0)) return fail(ctx, "coverage or minimum rank must be positive"); // :40 assert
+  if (amount > 1) return fail(ctx, "coverage must be <= 1");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  DevBuf A, G;
+  HIPCHK(ctx, A.alloc((size_t) T * F * sizeof(double), false, st));
+  HIPCHK(ctx, G.alloc((size_t) F * T * sizeof(double), false, st));
+  HIPCHK(ctx, hipMemcpy2DAsync(A.p, (size_t) F * sizeof(double), X, (size_t) ldx * sizeof(double),
+                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, st));
+  launch_transpose(A.as<double>(), F, 0, G.as<double>(), T, 0, (int) T, (int) F, 1, st); // one bin per row
+  std::vector<double> s, U, VT;
+  int64_t k = 0;
+  if (int rc = nndsvd_device(ctx, G.as<double>(), F, T, T, min_rank, max_rank, amount, s, U, VT, &k)) return rc;
+  if (k > w_rows) return fail(ctx, "rank exceeds the rows of W");
+  double mean = 0;
+  for (int64_t t = 0; t < T; t++)
+    for (int64_t f = 0; f < F; f++) mean += X[t * ldx + f];
+  mean /= (double) (T * F);
+  nndsvd_construct(s, U, VT, F, T, k, w_rows, method, seed, mean, W, H);
+  if (rank_out) *rank_out = k;
+  return FLUHIP_OK;
+}
+
+int fluhip_bufnmfseed_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                          int64_t fft, int64_t hop, int64_t min_rank, int64_t max_rank, double coverage,
+                          int method, int64_t seed, float* bases_out, float* acts_out, int64_t* rank_out)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!audio) return fail(ctx, "null audio");
+  if (stride < 1) return fail(ctx, "stride must be >= 1");
+  if (max_rank < 1) return fail(ctx, "maximum rank must be >= 1");
+  int rc = check_shape(ctx, n, win, fft, hop, 1);
+  if (rc) return rc;
+  if (method < 0 || method > 3) return fail(ctx, "method must be 0..3");
+  if (!(coverage > 0 || min_rank > 0)) return fail(ctx, "coverage or minimum rank must be positive");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = 1;
+  rc = corpus_alloc(ctx, &c);
+  if (rc) return rc;
+  DevBuf in;
+  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, st));
+  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), st));
+  rc = corpus_stft(&c, in.as<float>(), nullptr, n); // NMFSeedClient.hpp:97-98
+  if (rc) return rc;
+  const int64_t T = c.T, F = c.F;
+  // mean of the magnitudes for methods 1 and 2 (alg/NNDSVD.hpp:105): on the host from a copy of the
+  // spectrogram (it is small next to the SVD)
+  std::vector<double> mag((size_t) T * F);
+  HIPCHK(ctx, hipMemcpy2DAsync(mag.data(), (size_t) F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
+                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  double mean = 0;
+  for (double v : mag) mean += v;
+  mean /= (double) (T * F);
+  std::vector<double> s, U, VT;
+  int64_t k = 0;
+  // the transposed copy holds one bin per row, as the Jacobi kernels want it; they work in place
+  rc = nndsvd_device(ctx, c.magT.as<double>(), F, T, c.Tp, min_rank, max_rank, coverage, s, U, VT, &k);
+  if (rc) return rc;
+  std::vector<double> W((size_t) max_rank * F), H((size_t) T * max_rank);
+  nndsvd_construct(s, U, VT, F, T, k, max_rank, method, seed, mean, W.data(), H.data());
+  // NMFSeedClient.hpp:108-128
+  if (bases_out)
+    for (int64_t i = 0; i < max_rank * F; i++) bases_out[i] = i < k * F ? (float) W[(size_t) i] : 0.f;
+  if (acts_out)
+  {
+    double maxH = H[0];
+    for (double v : H) maxH = std::max(maxH, v);
+    const float scale = (float) (1.0 / maxH);
+    for (int64_t j = 0; j < max_rank; j++)
+      for (int64_t t = 0; t < T; t++)
+        acts_out[j * T + t] = j < k ? (float) H[(size_t) t * max_rank + j] * scale : 0.f;
+  }
+  if (rank_out) *rank_out = k;
+  return FLUHIP_OK;
+}
+
 int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride,
                               int64_t win, int64_t fft, int64_t hop, int64_t K, int64_t iters,
                               int update_w, int update_h, int64_t seed, const float* bases_seed,

@@ -202,4 +202,9 @@ void launch_resynth(const ResynthArgs& a, hipStream_t s);
 void launch_spec_to_magphase(const double* spec, int T, int F, float* mag, float* phase, hipStream_t s);
 void launch_polar_to_spec(const float* mag, const float* phase, int T, int F, double* spec, hipStream_t s);
 
+// one-sided Jacobi SVD of the n x T matrix whose rows are G's (kernels_svd.hip): G <- S V^T row by row (unsorted),
+// Jt <- U^T, norms <- singular values in row order; returns the number of sweeps or -1
+int launch_jacobi_svd(double* G, int64_t ldg, int n, int T, double* Jt, double* norms, unsigned* flag, int maxSweeps,
+                      hipStream_t s);
+
 } // namespace fluhip

@@ -28,7 +28,8 @@ EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
-    "fluhip_nmf_process_f64", "fluhip_nmf_process_frames_f64", "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
+    "fluhip_nmf_process_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
+    "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
@@ -72,10 +73,13 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_nmf_process_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                          ctypes.c_int, _i64, _dp, _dp, _dp, _dp, _dp, PROGRESS_FN, _vp]
     L.fluhip_nmf_process_frames_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _dp, _i64, _i64, _i64, _dp, _dp]
+    _dbl = ctypes.c_double
+    L.fluhip_nndsvd_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, ctypes.c_int, _i64, _dp, _dp, _ip]
+    L.fluhip_bufnmfseed_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, ctypes.c_int, _i64,
+                                        _fp, _fp, _ip]
     L.fluhip_bufnmf_channel_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
                                             ctypes.c_int, ctypes.c_int, _i64, _fp, _fp, _fp, _fp,
                                             _fp, PROGRESS_FN, _vp]
-    _dbl = ctypes.c_double
     L.fluhip_bufmelbands_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
                                          ctypes.c_int, ctypes.c_int, _fp, _ip]
     L.fluhip_bufmfcc_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
@@ -212,6 +216,29 @@ class Context:
         self._check(self.lib.fluhip_nmf_process_frames_f64(self.h, X.ctypes.data_as(_dp), T, F, X.strides[0] // 8,
                                                            _d(W0c), K, iters, seed, _d(H), _d(V)))
         return H, V
+
+    def nndsvd(self, X, w_rows, min_rank=0, max_rank=200, amount=0.8, method=0, seed=-1):
+        """NNDSVD::process (alg/NNDSVD.hpp:30-132): W [w_rows,F], H [T,w_rows], rank."""
+        X = np.asarray(X, dtype=np.float64)
+        assert X.ndim == 2 and X.strides[1] == 8
+        T, F = X.shape
+        W, H = np.empty((w_rows, F)), np.empty((T, w_rows))
+        k = ctypes.c_int64(0)
+        self._check(self.lib.fluhip_nndsvd_f64(self.h, X.ctypes.data_as(_dp), T, F, X.strides[0] // 8, w_rows, min_rank,
+                                               max_rank, amount, method, seed, _d(W), _d(H), ctypes.byref(k)))
+        return W, H, int(k.value)
+
+    def bufnmfseed(self, audio, win, fft, hop, min_rank=1, max_rank=200, coverage=0.5, method=0, seed=-1, stride=1):
+        """BufNMFSeed (nrt/NMFSeedClient.hpp): bases [max_rank,F] f32, activations [max_rank,T] f32, rank."""
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        n = (audio.shape[0] + stride - 1) // stride
+        T, F = (n + hop) // hop, fft // 2 + 1
+        bases = np.empty((max_rank, F), dtype=np.float32)
+        acts = np.empty((max_rank, T), dtype=np.float32)
+        k = ctypes.c_int64(0)
+        self._check(self.lib.fluhip_bufnmfseed_f32(self.h, _f(audio), n, stride, win, fft, hop, min_rank, max_rank,
+                                                   coverage, method, seed, _f(bases), _f(acts), ctypes.byref(k)))
+        return bases, acts, int(k.value)
 
     # ---- one BufNMF channel -------------------------------------------------------------
     def bufnmf_channel(self, audio, win, fft, hop, K, iters, seed, updateW=True, updateH=True,

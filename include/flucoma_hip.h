@@ -117,6 +117,29 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
 int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
                                   const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V);
 
+/* ---- algorithm::NNDSVD / client::nndsvd::NMFSeedClient ------------------------------------------ */
+/* Replaces NNDSVD::process(X, W, H, minRank, maxRank, amount, method, seed) (algorithms/public/NNDSVD.hpp:30-132):
+ * thin SVD of X^T (bins x frames), rank k = the smallest number of leading singular values covering `amount`
+ * of their sum (clamped to [min_rank, max_rank]; amount == 0 => min_rank), then the non-negative factors
+ * method 0 (NMF-SVD): W = |U_k|, H = |S_k V_k^T|;  1 (NNDSVDar) / 2 (NNDSVDa) / 3 (NNDSVD): positive/negative
+ * split of every singular pair, zeros filled with small random values / the mean / left at zero.
+ * X: T x F with row stride ldx.  W: w_rows x F, H: T x w_rows (the reference's W.rows(); rows / columns >= k are
+ * zero, or filled like the rest for methods 1 and 2, exactly as the reference treats its zero-initialised
+ * outputs); k is returned in *rank_out and must not exceed w_rows.
+ * The SVD is a one-sided Jacobi iteration on the device (kernels_svd.hip).  A singular pair is only defined up to a
+ * common sign:
+ * method 0 does not depend on it, methods 1..3 do (in the reference as well -- they follow whatever Eigen's
+ * BDCSVD returns), so for those only the construction from a given SVD is pinned by the tests. */
+int fluhip_nndsvd_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx, int64_t w_rows,
+                      int64_t min_rank, int64_t max_rank, double amount, int method, int64_t seed, double* W,
+                      double* H, int64_t* rank_out);
+/* Replaces NMFSeedClient::process (clients/nrt/NMFSeedClient.hpp:73-131; BufNMFSeed): STFT -> magnitude ->
+ * NNDSVD -> bases (max_rank x F floats, rows >= rank untouched by the reference's resize-to-rank: here zero) and
+ * activations (max_rank x T floats, scaled by 1 / max over the whole T x max_rank envelope matrix, :120-128). */
+int fluhip_bufnmfseed_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
+                          int64_t fft, int64_t hop, int64_t min_rank, int64_t max_rank, double coverage,
+                          int method, int64_t seed, float* bases_out, float* acts_out, int64_t* rank_out);
+
 /* ---- client::bufnmf::NMFClient::process, one channel ---------------------------------- */
 /* Replaces the body of the channel loop, clients/nrt/NMFClient.hpp:240-300 (STFT -> magnitude
  * -> NMF -> float write-back with H/max(H)), without a host round trip in between.

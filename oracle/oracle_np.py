@@ -165,6 +165,72 @@ def nmf_process_frame(x, W0, iters, seed):
     return h, W.T @ h
 
 
+def nndsvd_rank(s, min_rank, max_rank, amount):
+    """alg/NNDSVD.hpp:47-58: smallest k whose leading singular values cover `amount` of their sum, clamped."""
+    if amount == 0:
+        k = min_rank
+    else:
+        k, current, total = 0, 0.0, float(np.sum(s))
+        while current / total < amount:
+            current += float(s[k])
+            k += 1
+    return int(min(max(k, min_rank), max_rank))
+
+
+def nndsvd_from_svd(U, s, VT, X, W_rows, min_rank, max_rank, amount, method, seed):
+    """alg/NNDSVD.hpp:44-129 after the SVD: U [F,r], s [r], VT [r,T] of X^T (F x T).  Returns W [W_rows,F],
+    H [T,W_rows] (rows / columns beyond k stay zero like the reference's zero-initialised outputs) and k.
+    Methods 1..3 depend on the sign convention of the SVD (and carry the reference's `yNNorm = xN.norm()`,
+    :85); method 0 (|U|, |S V^T|) does not."""
+    F, T = U.shape[0], VT.shape[1]
+    k = nndsvd_rank(s, min_rank, max_rank, amount)
+    WT = np.zeros((F, W_rows))
+    HT = np.zeros((W_rows, T))
+    if method == 0:
+        WT[:, :k] = np.abs(U[:, :k])
+        HT[:k, :] = np.abs(s[:k, None] * VT[:k, :])
+    else:
+        WT[:, 0] = np.abs(U[:, 0])
+        HT[0, :] = np.sqrt(s[0]) * np.abs(VT[0, :])
+        for j in range(1, k):
+            x, y = U[:, j], VT[j, :]
+            xP, yP = np.maximum(x, 0.0), np.maximum(y, 0.0)
+            xN, yN = np.abs(np.minimum(x, 0.0)), np.abs(np.minimum(y, 0.0))
+            xPn, yPn, xNn = np.sqrt((xP * xP).sum()), np.sqrt((yP * yP).sum()), np.sqrt((xN * xN).sum())
+            yNn = xNn                                       # :85 as written in the reference
+            mP, mN = xPn * yPn, xNn * yNn
+            if mP > mN:
+                u, v, sigma = xP / xPn, yP / yPn, mP
+            else:
+                u, v, sigma = xN / xNn, yN / yNn, mN
+            WT[:, j] = u
+            HT[j, :] = np.sqrt(s[j] * sigma) * v
+        mean = float(np.mean(X))
+        if method == 1:
+            # :107-116: EigenRandom(..., Range{eps, mean*0.001}) is a lazy NullaryExpr inside select(): the generator
+            # is only called where the condition holds, in the assignment's column-major traversal -- the n-th
+            # draw lands on the n-th sub-epsilon coefficient; (max - min) * u + min like libstdc++
+            lo, hi = EPS, mean * 0.001
+            for M_ in (WT, HT):
+                flat = M_.T.reshape(-1)                      # column-major view of M_
+                idx = np.flatnonzero(flat < EPS)
+                draws = (hi - lo) * rng_uniform01(seed, idx.size) + lo
+                colmajor = M_.T.copy().reshape(-1)
+                colmajor[idx] = draws
+                M_[...] = colmajor.reshape(M_.shape[1], M_.shape[0]).T
+        elif method == 2:
+            WT = np.where(WT < EPS, mean, WT)
+            HT = np.where(HT < EPS, mean, HT)
+    return WT.T.copy(), HT.T.copy(), k
+
+
+def nndsvd(X, W_rows, min_rank=0, max_rank=200, amount=0.8, method=0, seed=-1):
+    """alg/NNDSVD.hpp:30-132 with LAPACK's SVD in place of Eigen's BDCSVD.  X: [T,F] magnitudes."""
+    X = np.asarray(X, dtype=np.float64)
+    U, s, VT = np.linalg.svd(X.T, full_matrices=False)
+    return nndsvd_from_svd(U, s, VT, X, W_rows, min_rank, max_rank, amount, method, seed) + (U, s, VT)
+
+
 def bufnmf_writeback(W1, H1):
     """nrt/NMFClient.hpp:277-300: bases [K,F] f32; activations [K,T] f32 (float multiply)."""
     bases = W1.astype(np.float32)

@@ -294,6 +294,71 @@ def test_process_frames_vs_oracle(ctx, oracle, T, F, K, iters, seed):
     assert rel_err(H2[::-1], H) < 1e-12
 
 
+def _lowrank_spectrogram(T, F, r, seed):
+    rs = np.random.RandomState(seed)
+    scales = np.linspace(3.0, 0.3, r)            # well separated singular values: the vectors are well conditioned
+    return (np.abs(rs.standard_normal((T, r))) * scales) @ np.abs(rs.standard_normal((r, F))) + 1e-3 * rs.uniform(0, 1, (T, F))
+
+
+@pytest.mark.parametrize("T,F,amount,min_rank,max_rank", [(60, 33, 0.8, 0, 10), (200, 129, 0.5, 2, 16), (40, 65, 0.0, 3, 8),
+                                                           (300, 513, 0.9, 1, 24)])
+def test_nndsvd_method0_vs_oracle(ctx, onp, T, F, amount, min_rank, max_rank):
+    """SURVEY 8 f4: NNDSVD::process, method 0 (|U_k|, |S_k V_k^T|) -- independent of the SVD's sign convention, so
+    rocSOLVER's factors must give what LAPACK's give; the rank rule (coverage of the singular-value sum) too"""
+    X = _lowrank_spectrogram(T, F, 12, T + F)
+    W, H, k = ctx.nndsvd(X, max_rank, min_rank, max_rank, amount, 0, 42)
+    rW, rH, rk, U, s, VT = onp.nndsvd(X, max_rank, min_rank, max_rank, amount, 0, 42)
+    assert k == rk and W.shape == rW.shape and H.shape == rH.shape
+    assert rel_err(W, rW) < 1e-8 and rel_err(H, rH) < 1e-8
+    assert (W[k:] == 0).all() and (H[:, k:] == 0).all()
+
+
+@pytest.mark.parametrize("method", [1, 2, 3])
+def test_nndsvd_split_methods(ctx, onp, method):
+    """methods 1..3 follow the sign of each singular pair (as the reference follows Eigen's): every component must
+    equal the oracle's construction for one of the two signs; zero fills as specified"""
+    T, F, K = 120, 65, 8
+    X = _lowrank_spectrogram(T, F, 10, 5)
+    W, H, k = ctx.nndsvd(X, K, K, K, 0.0, method, 42)
+    assert k == K
+    _, s_, _ = np.linalg.svd(X.T, full_matrices=False)[0:3]
+    U, s, VT = np.linalg.svd(X.T, full_matrices=False)
+    eps, mean = 2.220446049250313e-16, float(X.mean())
+    for j in range(K):
+        best = np.inf
+        for sign in (1.0, -1.0):
+            Uj, VTj = U.copy(), VT.copy()
+            Uj[:, j] *= sign; VTj[j] *= sign
+            cW, cH, _ = onp.nndsvd_from_svd(Uj, s, VTj, X, K, K, K, 0.0, 3, 42)   # un-filled construction
+            mw, mh = cW[j] >= eps, cH[:, j] >= eps
+            err = max(np.abs(W[j][mw] - cW[j][mw]).max() / np.abs(cW[j]).max(),
+                      np.abs(H[:, j][mh] - cH[:, j][mh]).max() / np.abs(cH[:, j]).max())
+            if err < best:
+                best, zw, zh = err, ~mw, ~mh
+        assert best < 1e-8, (j, best)
+        if method == 1:
+            assert ((W[j][zw] >= eps) & (W[j][zw] <= mean * 0.001)).all() and ((H[:, j][zh] >= eps) & (H[:, j][zh] <= mean * 0.001)).all()
+        elif method == 2:
+            assert np.allclose(W[j][zw], mean, rtol=1e-12) and np.allclose(H[:, j][zh], mean, rtol=1e-12)
+        else:
+            assert (W[j][zw] < eps).all() and (H[:, j][zh] < eps).all()
+
+
+def test_bufnmfseed_vs_oracle(ctx, oracle, onp):
+    """BufNMFSeed (nrt/NMFSeedClient.hpp:73-131): STFT -> magnitude -> NNDSVD (method 0) -> float bases and
+    activations scaled by 1 / max(H)"""
+    x = onp.synth_audio(30000, 77)
+    win, fft, hop, max_rank = 1024, 1024, 256, 12
+    bases, acts, k = ctx.bufnmfseed(x, win, fft, hop, 1, max_rank, 0.7, 0, 42)
+    _, mag = oracle.stft_f32(x, win, fft, hop)
+    rW, rH, rk, *_ = onp.nndsvd(mag, max_rank, 1, max_rank, 0.7, 0, 42)
+    assert k == rk and bases.shape == (max_rank, 513) and acts.shape == (max_rank, mag.shape[0])
+    ra = (rH.T.astype(np.float32) * np.float32(1.0 / rH.max()))
+    assert rel_err(bases[:k], rW[:k].astype(np.float32)) < 1e-5 and rel_err(acts[:k], ra[:k]) < 1e-5
+    assert (bases[k:] == 0).all() and (acts[k:] == 0).all()
+    assert abs(float(acts.max()) - 1.0) < 1e-6
+
+
 def test_process_frames_golden(ctx):
     """the HIP path against the committed G7 vectors directly (no oracle in the loop)"""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))

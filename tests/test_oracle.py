@@ -260,3 +260,24 @@ def test_process_frame_golden(seed, iters):
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))
     H, V = oracle_c.get("native").nmf_process_frames(g["g7_X"], g["g7_W0"], iters, seed)
     assert rel_err(H, g[f"g7_s{seed}_i{iters}_H"]) < 1e-12 and rel_err(V, g[f"g7_s{seed}_i{iters}_V"]) < 1e-12
+
+
+def test_nndsvd_oracle_properties():
+    """the numpy restatement of NNDSVD (alg/NNDSVD.hpp:30-132): rank rule, non-negativity, method 0
+    reproduces |U S V^T| term by term, the lazily sampled random fill of method 1 consumes one draw per
+    sub-epsilon coefficient in column-major order"""
+    import oracle_np as onp
+    rs = np.random.RandomState(4)
+    X = np.abs(rs.standard_normal((50, 6))) @ np.abs(rs.standard_normal((6, 33))) + 1e-3
+    W, H, k, U, s, VT = onp.nndsvd(X, 10, 0, 10, 0.9, 0, 42)
+    assert k == onp.nndsvd_rank(s, 0, 10, 0.9) and 1 <= k <= 10
+    assert (W >= 0).all() and (H >= 0).all() and (W[k:] == 0).all() and (H[:, k:] == 0).all()
+    assert np.allclose(W[:k], np.abs(U[:, :k].T)) and np.allclose(H[:, :k], np.abs((s[:k, None] * VT[:k]).T))
+    assert onp.nndsvd_rank(s, 3, 10, 0.0) == 3 and onp.nndsvd_rank(s, 0, 2, 0.999) == 2
+    W3, H3, _ = onp.nndsvd_from_svd(U, s, VT, X, 10, 4, 4, 0.0, 3, 42)
+    W1, H1, _ = onp.nndsvd_from_svd(U, s, VT, X, 10, 4, 4, 0.0, 1, 42)
+    eps = 2.220446049250313e-16
+    holes = np.flatnonzero(W3.reshape(-1) < eps)            # W3 [rows, F] row-major == WT column-major
+    draws = (X.mean() * 0.001 - eps) * onp.rng_uniform01(42, holes.size) + eps
+    assert np.array_equal(W1.reshape(-1)[holes], draws)
+    assert np.array_equal(W1.reshape(-1)[W3.reshape(-1) >= eps], W3.reshape(-1)[W3.reshape(-1) >= eps])
