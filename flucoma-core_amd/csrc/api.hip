@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <optional>
 #include <random>
 #include <string>
@@ -62,27 +63,118 @@ static int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERR
       return fail(ctx, std::string("HIP error: ") + hipGetErrorString(e__) + " in " #expr);      \
   } while (0)
 
+// Device allocations go through a small caching pool: a BufNMF call allocates and frees a dozen buffers, and
+// hipMalloc / the device-synchronising hipFree each time were a millisecond or two of a 2-15 ms call.  Freed blocks
+// are kept per device (up to kPoolCap bytes) and handed out again to requests of about their size; a block is
+// returned to the pool only after the stream it was used on has drained.  (HIP's own stream-ordered pool --
+// hipMallocAsync -- was tried first and returned corrupted tails of result buffers from the third call of a
+// shape on; not pursued.)  FLUHIP_NO_POOL=1 goes back to plain hipMalloc / hipFree.
+struct BlockPool
+{
+  static constexpr size_t kPoolCap = (size_t) 8 << 30;
+  std::mutex m;
+  std::multimap<size_t, void*> freeBlocks[16];
+  size_t cached = 0;
+  static bool enabled()
+  {
+    static const bool on = [] { const char* e = std::getenv("FLUHIP_NO_POOL"); return !(e && std::atoi(e)); }();
+    return on;
+  }
+  void* take(int dev, size_t n, size_t* got)
+  {
+    std::lock_guard<std::mutex> g(m);
+    auto& f = freeBlocks[dev & 15];
+    auto it = f.lower_bound(n);
+    if (it == f.end() || it->first > 2 * n + ((size_t) 1 << 20)) return nullptr;
+    void* p = it->second;
+    *got = it->first;
+    cached -= it->first;
+    f.erase(it);
+    return p;
+  }
+  bool give(int dev, size_t n, void* p)
+  {
+    std::lock_guard<std::mutex> g(m);
+    if (cached + n > kPoolCap) return false;
+    freeBlocks[dev & 15].emplace(n, p);
+    cached += n;
+    return true;
+  }
+  void trim(int dev)
+  {
+    std::lock_guard<std::mutex> g(m);
+    for (auto& kv : freeBlocks[dev & 15]) { (void) hipFree(kv.second); cached -= kv.first; }
+    freeBlocks[dev & 15].clear();
+  }
+};
+static BlockPool g_pool;
+
 struct DevBuf
 {
   void* p = nullptr;
-  size_t bytes = 0;
+  size_t bytes = 0;     // requested
+  size_t capacity = 0;  // of the block behind it
+  int dev = 0;
+  hipStream_t owner = nullptr;
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
+  // FLUHIP_CANARY=1 (debugging): every buffer gets a 64 KiB guard band behind the requested bytes, filled with a
+  // pattern at allocation and checked when the buffer is released; a kernel that writes past its buffer aborts
+  // the process with the size of the buffer it trampled.
+  static bool canary()
+  {
+    static const bool on = [] { const char* e = std::getenv("FLUHIP_CANARY"); return e && std::atoi(e); }();
+    return on;
+  }
+  void check_canary()
+  {
+    if (!canary() || !p) return;
+    std::vector<unsigned char> h(65536);
+    (void) hipStreamSynchronize(owner);
+    if (hipMemcpy(h.data(), static_cast<char*>(p) + bytes, 65536, hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (size_t i = 0; i < h.size(); i++)
+      if (h[i] != 0xA5)
+      {
+        std::fprintf(stderr, "fluhip: write past the end of a %zu-byte device buffer (offset +%zu)\n", bytes, i);
+        std::abort();
+      }
+  }
   void release()
   {
-    if (p) (void) hipFree(p);
+    if (p)
+    {
+      check_canary();
+      bool kept = false;
+      if (BlockPool::enabled() && hipStreamSynchronize(owner) == hipSuccess) kept = g_pool.give(dev, capacity, p);
+      if (!kept) (void) hipFree(p);
+    }
     p = nullptr;
-    bytes = 0;
+    bytes = capacity = 0;
   }
   hipError_t alloc(size_t n, bool zero, hipStream_t s)
   {
     release();
     if (n == 0) n = 16;
-    hipError_t e = hipMalloc(&p, n);
-    if (e != hipSuccess) { p = nullptr; return e; }
+    const size_t want = ((n + 65535) & ~(size_t) 65535) + (canary() ? 131072 : 0); // 64 KiB granules: near-equal requests share blocks
+    (void) hipGetDevice(&dev);
+    hipError_t e = hipSuccess;
+    capacity = want;
+    if (BlockPool::enabled()) p = g_pool.take(dev, want, &capacity);
+    if (!p)
+    {
+      e = hipMalloc(&p, want);
+      if (e != hipSuccess && BlockPool::enabled())
+      {
+        g_pool.trim(dev); // the cache may be what stands in the way
+        e = hipMalloc(&p, want);
+      }
+      if (e != hipSuccess) { p = nullptr; return e; }
+    }
     bytes = n;
+    owner = s;
+    if (canary()) (void) hipMemsetAsync(static_cast<char*>(p) + n, 0xA5, 65536, s);
     if (zero) e = hipMemsetAsync(p, 0, n, s);
     return e;
   }
@@ -128,7 +220,12 @@ struct ProfScope
 // on the host first -- a 2-D copy with element-sized rows would be issued row by row.
 static hipError_t upload_strided(void* dst, const void* src, size_t n, size_t stride, size_t esz, hipStream_t s)
 {
-  if (stride == 1) return hipMemcpyAsync(dst, src, n * esz, hipMemcpyHostToDevice, s);
+  if (stride == 1)
+  {
+    hipError_t e = hipMemcpyAsync(dst, src, n * esz, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+  }
   std::vector<char> tmp(n * esz);
   const char* p = static_cast<const char*>(src);
   if (esz == 4)
@@ -700,6 +797,7 @@ void fluhip_ctx_destroy(fluhip_ctx* ctx)
   for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
   for (auto e : ctx->eventPool) (void) hipEventDestroy(e);
   if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+  g_pool.trim(ctx->device); // cached device blocks go with the context
   delete ctx;
 }
 
@@ -1608,6 +1706,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
 int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
 {
   if (!c || !out32 || !c->dpart.p) return FLUHIP_ERROR;
+  HIPCHK(c->ctx, hipStreamSynchronize(c->ctx->stream));
   HIPCHK(c->ctx, hipMemcpy(out32, c->dpart.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return FLUHIP_OK;
 }
