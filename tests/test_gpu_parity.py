@@ -359,6 +359,36 @@ def test_bufnmfseed_vs_oracle(ctx, oracle, onp):
     assert abs(float(acts.max()) - 1.0) < 1e-6
 
 
+def test_concurrent_contexts(onp):
+    """the reference runs one std::thread per job (FluidNRTClientWrapper.hpp:1048): four host threads, each with
+    its own context, must get bit-identical results to the serial run (shared block pool, per-context streams)"""
+    import threading
+    import fluhip
+    jobs = [(onp.synth_audio(20000 + 3000 * i, 300 + i), 512, 512, 128, 3 + i, 12, 42) for i in range(4)]
+    serial = []
+    c0 = fluhip.Context(0)
+    for j in jobs:
+        serial.append(c0.bufnmf_channel(*j)[:2])
+    c0.close()
+    out, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            c = fluhip.Context(0)
+            for _ in range(3):
+                out[i] = c.bufnmf_channel(*jobs[i])[:2]
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for i in range(4):
+        assert np.array_equal(out[i][0], serial[i][0]) and np.array_equal(out[i][1], serial[i][1])
+
+
 def test_process_frames_golden(ctx):
     """the HIP path against the committed G7 vectors directly (no oracle in the loop)"""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))
