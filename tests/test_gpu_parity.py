@@ -389,6 +389,25 @@ def test_concurrent_contexts(onp):
         assert np.array_equal(out[i][0], serial[i][0]) and np.array_equal(out[i][1], serial[i][1])
 
 
+def test_reference_testnmf_cases(ctx, oracle):
+    """the two cases of the reference's own tests/algorithms/public/TestNMF.cpp, same inputs, through the HIP path:
+    :11-46 (3x3 matrix, rank 2, 1 iteration, seeds 42 / 5063: equal for equal seeds, different otherwise) and
+    :48-73 (processFrame, 0 iterations, seeds 42 / 7863) -- and equal to the oracle's values"""
+    X = np.array([[1.0, 2, 3], [4, 5, 6], [7, 8, 9]])
+    r = [ctx.nmf_process(X, 2, 1, True, True, sd)[:3] for sd in (42, 42, 5063, 5063)]
+    for a, b in ((0, 1), (2, 3)):
+        assert all(np.array_equal(r[a][i], r[b][i]) for i in range(3))
+    assert all(not np.array_equal(r[1][i], r[2][i]) for i in range(3))
+    oW, oH, oV, _ = oracle.nmf_process(X, 2, 1, True, True, 42)
+    assert rel_err(r[0][0], oW) < TOL_FACTORS_TIGHT and rel_err(r[0][1], oH) < TOL_FACTORS_TIGHT
+    assert rel_err(r[0][2], oV) < TOL_FACTORS_TIGHT
+    x = np.array([[1.0, 0, 1, 0]])
+    bases = np.array([[0.0, 0, 1, 0], [1, 0, 0, 0]])
+    h = [ctx.nmf_process_frames(x, bases, 0, sd)[0] for sd in (42, 42, 7863)]
+    assert np.array_equal(h[0], h[1]) and not np.array_equal(h[1], h[2])
+    assert np.array_equal(h[0], oracle.nmf_process_frames(x, bases, 0, 42)[0])
+
+
 def test_process_frames_golden(ctx):
     """the HIP path against the committed G7 vectors directly (no oracle in the loop)"""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))

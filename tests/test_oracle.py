@@ -281,3 +281,31 @@ def test_nndsvd_oracle_properties():
     draws = (X.mean() * 0.001 - eps) * onp.rng_uniform01(42, holes.size) + eps
     assert np.array_equal(W1.reshape(-1)[holes], draws)
     assert np.array_equal(W1.reshape(-1)[W3.reshape(-1) >= eps], W3.reshape(-1)[W3.reshape(-1) >= eps])
+
+
+@pytest.mark.parametrize("frame", [32, 64, 256, 1024, 8192])
+def test_hann_cola_like_reference_buffered_process(oracle, frame):
+    """tests/clients/common/TestBufferedProcess.cpp:20-70: the reference checks that its Hann window
+    (0.5 - 0.5 cos(2 pi i / N), the formula the oracle's window must be) overlap-adds to the input at hop = N/2
+    to 1e-12.  Same property, same sizes, on the oracle's table; and at hop = N/4 the squared window sums to 1.5
+    (the normaliser the ISTFT divides by, alg/STFT.hpp:196)."""
+    w = oracle.hann(frame)
+    i = np.arange(frame)
+    assert np.array_equal(w, 0.5 - 0.5 * np.cos((2 * np.pi * i) / frame))
+    hop = frame // 2
+    ola = w[:hop] + w[hop:]
+    assert np.abs(ola - 1.0).max() < 1e-12
+    q = frame // 4
+    sq = sum((w[j * q:(j + 1) * q]) ** 2 for j in range(4))
+    assert np.abs(sq - 1.5).max() < 1e-12
+
+
+def test_reference_testnmf_processframe_case(oracle):
+    """tests/algorithms/public/TestNMF.cpp:48-73, same inputs: processFrame with 0 iterations returns the seeded
+    start; same seed => same output, another seed => another output"""
+    x = np.array([1.0, 0, 1, 0])
+    bases = np.array([[0.0, 0, 1, 0], [1, 0, 0, 0]])
+    a, _ = oracle.nmf_process_frames(x[None, :], bases, 0, 42)
+    b, _ = oracle.nmf_process_frames(x[None, :], bases, 0, 42)
+    c, _ = oracle.nmf_process_frames(x[None, :], bases, 0, 7863)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
