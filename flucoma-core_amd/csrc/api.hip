@@ -938,6 +938,71 @@ int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_
   return FLUHIP_OK;
 }
 
+// clients/nrt/NMFClient.hpp:302-334 for every buffer of the corpus: estimate -> ratio mask -> ISTFT per component
+int fluhip_corpus_keep_spectrum(fluhip_corpus* c, int on)
+{
+  if (!c) return FLUHIP_ERROR;
+  c->keepSpec = on != 0;
+  if (!c->keepSpec) c->spec.release();
+  c->haveMag = c->haveMag && !(c->keepSpec && !c->spec.p); // a later resynthesis needs the STFT to run again
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
+{
+  if (!c || !out_dev) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  if (!c->haveFactors) return fail(ctx, "corpus has no factors: call fluhip_corpus_nmf first");
+  if (!c->keepSpec || !c->spec.p)
+    return fail(ctx, "resynthesis needs the complex spectrogram: fluhip_corpus_keep_spectrum(c, 1) before fluhip_corpus_stft");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  const double *wtab = nullptr, *ttab = nullptr;
+  int rc = get_window(ctx, c->win, c->fft, c->windowType, &wtab);
+  if (rc) return rc;
+  rc = get_twiddle(ctx, c->fft, &ttab);
+  if (rc) return rc;
+  DevBuf vhat, frames;
+  HIPCHK(ctx, vhat.alloc((size_t) c->T * c->F * sizeof(double), false, s));
+  HIPCHK(ctx, frames.alloc((size_t) c->T * c->win * sizeof(double), false, s));
+  for (int64_t b = 0; b < c->B; b++)
+  {
+    const double* Wb = c->Wf.as<double>() + b * c->Fp * c->Kp;
+    const double* Hb = c->H1.as<double>() + b * c->Tp * c->Kp;
+    launch_vhat(Wb, 0, Hb, 0, vhat.as<double>(), c->F, 0, (int) c->T, (int) c->F, (int) c->Kp, 1, s);
+    ResynthArgs ra;
+    ra.spec = c->spec.as<double>() + b * c->T * c->F * 2; ra.Wf = Wb; ra.H1 = Hb;
+    ra.Vhat = vhat.as<double>(); ra.ldV = c->F; ra.Kp = (int) c->Kp;
+    ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = (int) c->T; ra.F = (int) c->F;
+    ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = c->n;
+    ra.trim = c->win / 2;
+    for (int64_t k = 0; k < c->K; k++)
+    {
+      ra.k = (int) k;
+      ra.out32 = out_dev + (b * c->K + k) * c->n;
+      launch_resynth(ra, s);
+    }
+  }
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(s)); // vhat / frames go out of scope
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out)
+{
+  if (!c || !out) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  const size_t nb = (size_t) c->B * c->K * c->n * sizeof(float);
+  HIPCHK(ctx, d.alloc(nb, false, ctx->stream));
+  int rc = fluhip_corpus_resynth_dev(c, d.as<float>());
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(out, d.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
 int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts)
 {
   if (!c) return FLUHIP_ERROR;

@@ -35,7 +35,8 @@ EXPORTS = [
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
-    "fluhip_corpus_writeback_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
+    "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
+    "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words",
 ]
 
@@ -100,6 +101,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_writeback_host.argtypes = [_vp, _fp, _fp]
     L.fluhip_corpus_read_f64.argtypes = [_vp, _dp, _dp, _dp]
     L.fluhip_corpus_plan.argtypes = [_vp, _ip]
+    L.fluhip_corpus_keep_spectrum.argtypes = [_vp, ctypes.c_int]
+    L.fluhip_corpus_resynth_dev.argtypes = [_vp, _vp]
+    L.fluhip_corpus_resynth_host.argtypes = [_vp, _fp]
     L.fluhip_prof_enable.argtypes = [_vp, ctypes.c_int]
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
@@ -388,6 +392,15 @@ class Corpus:
         acts = np.empty((self.count, self.K, self.T), dtype=np.float32)
         self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_host(self.h, _f(bases), _f(acts)))
         return bases, acts
+
+    def keep_spectrum(self, on=True):
+        self.ctx._check(self.ctx.lib.fluhip_corpus_keep_spectrum(self.h, int(on)))
+
+    def resynth(self):
+        """[count, K, n] f32: every component of every buffer resynthesised (NMFClient.hpp:302-334)"""
+        out = np.empty((self.count, self.K, self.n), dtype=np.float32)
+        self.ctx._check(self.ctx.lib.fluhip_corpus_resynth_host(self.h, _f(out)))
+        return out
 
     def plan(self):
         out = (ctypes.c_int64 * 8)()

@@ -209,6 +209,12 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
  * bases: count x K x F, acts: count x K x T.  Either may be NULL. */
 int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev);
 int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts);
+/* Resynthesis of every component of every buffer (clients/nrt/NMFClient.hpp:302-334: NMF::estimate -> RatioMask ->
+ * ISTFT): out = count x K x n floats.  The complex spectrogram has to be kept for it: switch that on before
+ * fluhip_corpus_stft (it costs count x T x F x 16 bytes of HBM). */
+int fluhip_corpus_keep_spectrum(fluhip_corpus* c, int on);
+int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev);
+int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out);
 /* raw f64 results for parity tests: mag count x T x F, W1 count x K x F, H1 count x T x K */
 int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1);
 /* How the factor updates of this corpus are scheduled on the device (introspection for tests, benchmarks and

@@ -469,6 +469,27 @@ def test_corpus_fast_path_partial_updates(ctx, oracle, onp):
     c.close()
 
 
+def test_corpus_resynthesis_matches_single_channel_path(ctx, onp):
+    """the corpus form of the resynthesis (third BufNMF output) against the single-channel entry point, which is
+    itself checked against the oracle (test_resynthesis_vs_oracle)"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 3, 12000, 512, 512, 128, 4, 15
+    audio = np.stack([onp.synth_audio(n, 5000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    with pytest.raises(fluhip.FluhipError):
+        c.set_audio(audio); c.stft(); c.nmf(2, seed=42); c.resynth()       # spectrum not kept
+    c.keep_spectrum(True)
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    out = c.resynth()
+    c.close()
+    assert out.shape == (B, K, n)
+    for b in range(B):
+        _, _, res, _ = ctx.bufnmf_channel(audio[b], win, fft, hop, K, iters, 42, resynth=True)
+        assert rel_err(out[b], res) < 1e-6
+    # the components sum back to the input where the mask is a partition of unity (exponent 1 ratio masks)
+    assert rel_err(out.sum(axis=1), audio) < 1e-4
+
+
 def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
     """sharding property: a buffer's result does not depend on which batch (or rank) holds it"""
     import fluhip
