@@ -1677,6 +1677,27 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
       }
     }
   }
+  // the filter bank over each band's support only (kernels_feat.hip): first non-zero bin and packed weights
+  std::vector<int> bandLo((size_t) bandsPad, 0);
+  int64_t maxLen = 1;
+  {
+    std::vector<int64_t> hi((size_t) bandsPad, -1);
+    for (int64_t b = 0; b < nBands; b++)
+    {
+      int64_t lo = -1;
+      for (int64_t f = 0; f < F; f++)
+        if (filtT[(size_t) (f * bandsPad + b)] != 0.0) { if (lo < 0) lo = f; hi[(size_t) b] = f; }
+      bandLo[(size_t) b] = (int) std::max<int64_t>(lo, 0);
+      if (lo >= 0) maxLen = std::max(maxLen, hi[(size_t) b] - lo + 1);
+    }
+  }
+  std::vector<double> wpack((size_t) maxLen * bandsPad, 0.0);
+  for (int64_t b = 0; b < nBands; b++)
+    for (int64_t j = 0; j < maxLen; j++)
+    {
+      const int64_t f = bandLo[(size_t) b] + j;
+      if (f < F) wpack[(size_t) (j * bandsPad + b)] = filtT[(size_t) (f * bandsPad + b)];
+    }
   const int64_t nDct = mfcc ? std::min(nCoefs + startCoeff, nBands) : 0; // rt/MFCCClient.hpp:104-105
   std::vector<double> dct((size_t) std::max<int64_t>(1, nDct * nBands));
   for (int64_t i = 0; i < nDct; i++) // alg/DCT.hpp:53-61
@@ -1691,7 +1712,11 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   if (rc) return rc;
   rc = get_twiddle(ctx, fft, &ttab);
   if (rc) return rc;
-  DevBuf dFilt, dDct, dAudio, dMag, dOut;
+  DevBuf dFilt, dDct, dAudio, dMag, dOut, dLo, dPack;
+  HIPCHK(ctx, dLo.alloc(bandLo.size() * sizeof(int), false, s));
+  HIPCHK(ctx, dPack.alloc(wpack.size() * sizeof(double), false, s));
+  HIPCHK(ctx, hipMemcpyAsync(dLo.p, bandLo.data(), bandLo.size() * sizeof(int), hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(dPack.p, wpack.data(), wpack.size() * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(ctx, dFilt.alloc(filtT.size() * sizeof(double), false, s));
   HIPCHK(ctx, dDct.alloc(dct.size() * sizeof(double), false, s));
   HIPCHK(ctx, hipMemcpyAsync(dFilt.p, filtT.data(), filtT.size() * sizeof(double), hipMemcpyHostToDevice, s));
@@ -1705,7 +1730,8 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   for (int64_t b0 = 0; b0 < count; b0 += chunk)
   {
     const int64_t nb = std::min(chunk, count - b0);
-    HIPCHK(ctx, hipMemcpyAsync(dAudio.p, audio + b0 * n, (size_t) nb * n * sizeof(float), hipMemcpyHostToDevice, s));
+    // hipMemcpyDefault: `audio` and `out` may be host or device pointers (a corpus already resident in HBM skips PCIe)
+    HIPCHK(ctx, hipMemcpyAsync(dAudio.p, audio + b0 * n, (size_t) nb * n * sizeof(float), hipMemcpyDefault, s));
     StftArgs sa;
     sa.audio = dAudio.as<float>(); sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
     sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = (int) nb;
@@ -1720,6 +1746,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
     fa.mag = dMag.as<double>(); fa.magStride = Tp * Fp; fa.ldMag = Fp;
     fa.T = (int) T; fa.F = (int) F; fa.B = (int) nb; fa.win = (int) win;
     fa.filtT = dFilt.as<double>(); fa.nBands = (int) nBands; fa.bandsPad = (int) bandsPad;
+    fa.bandLo = dLo.as<int>(); fa.wpack = dPack.as<double>(); fa.maxLen = (int) maxLen;
     // rt/MFCCClient.hpp:123-124 (false, false, true); rt/MelBandsClient.hpp:106-108 (normalize, false, scale == dB)
     fa.magNorm = mfcc ? 0 : (normalize ? 1 : 0); fa.usePower = 0; fa.logOutput = mfcc ? 1 : (scaleDb ? 1 : 0);
     fa.dct = mfcc ? dDct.as<double>() : nullptr; fa.nDct = (int) nDct; fa.startCoeff = (int) startCoeff;
@@ -1730,7 +1757,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out + b0 * nOut * T, dOut.p, (size_t) nb * nOut * T * sizeof(float),
-                               hipMemcpyDeviceToHost, s));
+                               hipMemcpyDefault, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
   }
   return FLUHIP_OK;

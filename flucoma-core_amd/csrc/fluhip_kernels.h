@@ -169,6 +169,11 @@ struct FeatArgs
   int T, F, B, win;
   const double* filtT;  // [F][bandsPad], bin-major mel filter bank, zero padded
   int nBands, bandsPad;
+  // the same filter bank restricted to each band's support (a triangle is non-zero on a few dozen bins of the F):
+  // band b covers bins bandLo[b] .. bandLo[b] + maxLen - 1 with weights wpack[i][b] (i-major, zero past the support)
+  const int* bandLo;    // [bandsPad]
+  const double* wpack;  // [maxLen][bandsPad]
+  int maxLen;
   int magNorm, usePower, logOutput;
   const double* dct;    // [nDct][nBands] or nullptr (MelBands output)
   int nDct, startCoeff;

@@ -5,23 +5,26 @@
 //   client glue                         include/flucoma/clients/rt/MFCCClient.hpp:122-130,
 //                                       include/flucoma/clients/rt/MelBandsClient.hpp:104-113
 //
-// One wavefront owns FT frames; lane = mel band (bands beyond 64 are walked in chunks).  The
-// filter bank is stored bin-major (filtT[f][band], band contiguous) so a lane streams its band's
-// weights with coalesced loads while the FT magnitudes of bin f are wave-uniform (scalar loads).
+// One wavefront owns FT frames; lane = mel band (bands beyond 64 are walked in chunks).  A mel filter is a triangle:
+// of the F bins a band touches a few dozen, so a lane only walks its band's support -- the magnitude rows of the
+// wavefront's frames are staged in LDS (coalesced loads) and gathered from there, the weights come from a table
+// packed over the support (i-major, band contiguous: coalesced).  Skipping the zero weights leaves the sums
+// bit-identical to the dense ascending-bin dot product (adding w = 0 terms changes nothing).
 // Sums run over bins / bands in ascending order, like a sequential dot product.
 #include "fluhip_kernels.h"
 
 namespace fluhip {
 
-constexpr int kFT = 8; // frames per wavefront
+constexpr int kFT = 4; // frames per wavefront (4 x F doubles of LDS each: 16 KB at fft 1024, 64 KB per workgroup)
 
 __global__ __launch_bounds__(256) void mel_kernel(FeatArgs a)
 {
-  extern __shared__ double lds[]; // [4 waves][kFT][bandsPad] log-band energies for the DCT
+  extern __shared__ double lds[]; // [4 waves][kFT][bandsPad] log-band energies for the DCT, then [4 waves][kFT][F] magnitude rows
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = blockIdx.y;
-  const int t0 = (blockIdx.x * 4 + wave) * kFT;
+  const int nw = blockDim.x >> 6; // wavefronts per workgroup: 4, fewer when the magnitude rows are long
+  const int t0 = (blockIdx.x * nw + wave) * kFT;
   if (t0 >= a.T) return;
   const double* mag = a.mag + (int64_t) b * a.magStride;
   double* wl = lds + (size_t) wave * kFT * a.bandsPad;
@@ -49,20 +52,29 @@ __global__ __launch_bounds__(256) void mel_kernel(FeatArgs a)
 #pragma unroll
   for (int i = 0; i < kFT; i++) bandSum[i] = 0.0;
 
+  // magnitude rows of this wavefront's frames -> LDS (behind the band scratch)
+  double* rows = lds + (size_t) nw * kFT * a.bandsPad + (size_t) wave * kFT * a.F;
+#pragma unroll
+  for (int i = 0; i < kFT; i++)
+  {
+    const int t = min(t0 + i, a.T - 1);
+    for (int f = lane; f < a.F; f += 64) rows[i * a.F + f] = mag[(int64_t) t * a.ldMag + f];
+  }
   for (int c0 = 0; c0 < a.nBands; c0 += 64)
   {
     const int band = c0 + lane;
     double acc[kFT];
 #pragma unroll
     for (int i = 0; i < kFT; i++) acc[i] = 0.0;
-    for (int f = 0; f < a.F; f++)
+    const int lo = a.bandLo[band];
+    for (int j = 0; j < a.maxLen; j++)
     {
-      const double w = a.filtT[(int64_t) f * a.bandsPad + band]; // zero beyond nBands (padded table)
+      const double w = a.wpack[(int64_t) j * a.bandsPad + band]; // zero past the band's support / beyond nBands
+      const int f = min(lo + j, a.F - 1);
 #pragma unroll
       for (int i = 0; i < kFT; i++)
       {
-        const int t = min(t0 + i, a.T - 1);
-        double m = mag[(int64_t) t * a.ldMag + f];                // wave-uniform
+        double m = rows[i * a.F + f];
         if (a.magNorm) m = m * scale1;
         if (a.usePower) m = m * m;
         acc[i] += w * m;                                          // :90-91
@@ -126,11 +138,13 @@ __global__ __launch_bounds__(256) void mel_kernel(FeatArgs a)
 
 void launch_features(const FeatArgs& a, hipStream_t s)
 {
-  const size_t shmem = (size_t) 4 * kFT * a.bandsPad * sizeof(double);
+  int nw = 4;
+  while (nw > 1 && (size_t) nw * kFT * (a.bandsPad + a.F) * sizeof(double) > 144 * 1024) nw >>= 1;
+  const size_t shmem = (size_t) nw * kFT * (a.bandsPad + a.F) * sizeof(double);
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              160 * 1024);
-  dim3 grid((unsigned) ((a.T + 4 * kFT - 1) / (4 * kFT)), (unsigned) a.B);
-  hipLaunchKernelGGL(mel_kernel, grid, dim3(256), shmem, s, a);
+  dim3 grid((unsigned) ((a.T + nw * kFT - 1) / (nw * kFT)), (unsigned) a.B);
+  hipLaunchKernelGGL(mel_kernel, grid, dim3((unsigned) (64 * nw)), shmem, s, a);
 }
 
 } // namespace fluhip

@@ -8,6 +8,11 @@ import time
 
 import numpy as np
 
+try:  # torch first when it is there: the two then share one HIP runtime (config5's device-resident variant)
+    import torch  # noqa: F401
+except ImportError:
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -71,6 +76,24 @@ def config5():
     cpu = (time.perf_counter() - t0) / 8
     print(f"c5: {count} slices x {out.shape[2]} frames: {dt*1e3:.1f} ms incl. PCIe ({frames/dt/1e6:.1f} Mframes/s); "
           f"CPU oracle {cpu*1e3:.2f} ms per slice ({out.shape[2]/cpu/1e3:.1f} kframes/s, 1 core) -> {cpu*count/dt:.0f}x")
+    try:  # the same with input and output resident in HBM (what a device-side pipeline would see)
+        import ctypes
+        if torch is None:
+            raise ImportError
+        a_dev = torch.from_numpy(audio).cuda()
+        o_dev = torch.empty(out.shape, dtype=torch.float32, device="cuda")
+        Tr = ctypes.c_int64(0)
+        def run():
+            rc = ctx.lib.fluhip_bufmfcc_f32(ctx.h, ctypes.cast(a_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), count, n,
+                                            1024, 1024, 512, 40, 13, 0, 20.0, 20000.0, 44100.0,
+                                            ctypes.cast(o_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), ctypes.byref(Tr))
+            assert rc == 0
+        run(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dd = time.perf_counter() - t0
+        assert np.array_equal(o_dev.cpu().numpy(), out)
+        print(f"c5 with audio and features resident in HBM: {dd*1e3:.1f} ms ({frames/dd/1e6:.0f} Mframes/s) -> {cpu*count/dd:.0f}x one CPU core")
+    except ImportError:
+        pass
 
 
 if __name__ == "__main__" and "c5" in sys.argv[1:]:
