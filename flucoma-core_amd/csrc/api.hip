@@ -964,7 +964,8 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   if (rc) return rc;
   DevBuf vhat, frames;
   HIPCHK(ctx, vhat.alloc((size_t) c->T * c->F * sizeof(double), false, s));
-  HIPCHK(ctx, frames.alloc((size_t) c->T * c->win * sizeof(double), false, s));
+  const int64_t compsPerLaunch = std::max<int64_t>(1, std::min<int64_t>(c->K, ((int64_t) 1 << 30) / (c->T * c->win * 8)));
+  HIPCHK(ctx, frames.alloc((size_t) compsPerLaunch * c->T * c->win * sizeof(double), false, s));
   for (int64_t b = 0; b < c->B; b++)
   {
     const double* Wb = c->Wf.as<double>() + b * c->Fp * c->Kp;
@@ -976,9 +977,10 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
     ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = (int) c->T; ra.F = (int) c->F;
     ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = c->n;
     ra.trim = c->win / 2;
-    for (int64_t k = 0; k < c->K; k++)
+    for (int64_t k = 0; k < c->K; k += compsPerLaunch)
     {
       ra.k = (int) k;
+      ra.nComp = (int) std::min(compsPerLaunch, c->K - k);
       ra.out32 = out_dev + (b * c->K + k) * c->n;
       launch_resynth(ra, s);
     }
@@ -1510,7 +1512,8 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
     if (rc) return rc;
     DevBuf vhat, frames, out32;
     HIPCHK(ctx, vhat.alloc((size_t) c.T * c.F * sizeof(double), false, s));
-    HIPCHK(ctx, frames.alloc((size_t) c.T * win * sizeof(double), false, s));
+    const int64_t compsPerLaunch = std::max<int64_t>(1, std::min<int64_t>(K, ((int64_t) 1 << 30) / (c.T * win * 8)));
+    HIPCHK(ctx, frames.alloc((size_t) compsPerLaunch * c.T * win * sizeof(double), false, s));
     HIPCHK(ctx, out32.alloc((size_t) K * n * sizeof(float), false, s));
     // mask.init(outputMags): outputMags = V1 = (W*H)^T of NMF::process (NMF.hpp:182, NMFClient.hpp:305-306)
     launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, vhat.as<double>(), c.F, 0, (int) c.T, (int) c.F,
@@ -1521,9 +1524,10 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
     ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) c.T; ra.F = (int) c.F;
     ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = n;
     ra.trim = win / 2;
-    for (int64_t k = 0; k < K; k++)
+    for (int64_t k = 0; k < K; k += compsPerLaunch) // all components of a launch share the frame grid
     {
       ra.k = (int) k;
+      ra.nComp = (int) std::min(compsPerLaunch, K - k);
       ra.out32 = out32.as<float>() + k * n;
       launch_resynth(ra, s);
     }

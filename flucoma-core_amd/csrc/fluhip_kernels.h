@@ -199,6 +199,7 @@ struct ResynthArgs
   float* out32;         // [n] or nullptr
   int64_t n;
   int64_t trim;         // leading samples dropped: win/2 for ISTFT::process, `padding` for BufSTFT
+  int nComp = 1;        // components k .. k + nComp - 1 in one launch: frames [nComp][T][win], out / out32 [nComp][n]
 };
 // Wf == nullptr: no ratio mask (plain inverse STFT of `spec`)
 void launch_resynth(const ResynthArgs& a, hipStream_t s);

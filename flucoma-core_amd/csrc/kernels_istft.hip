@@ -42,16 +42,17 @@ __global__ __launch_bounds__(256) void resynth_frames_kernel(ResynthArgs a)
   const d2* tw = reinterpret_cast<const d2*>(a.twiddle); // e^{-2 pi i m / fft}, m < fft/2 (global, L1/L2 resident)
   const int tid = threadIdx.x, nt = blockDim.x;
   const int t = blockIdx.x;
+  const int comp = a.k + blockIdx.y; // a launch covers nComp consecutive components (frames / out strided by them)
   const double* spec = a.spec + (int64_t) t * a.F * 2;
   const double* vhat = a.Vhat + (int64_t) t * a.ldV;
   const bool useMask = a.Wf != nullptr;
-  const double hk = useMask ? a.H1[(int64_t) t * a.Kp + a.k] : 0.0;
+  const double hk = useMask ? a.H1[(int64_t) t * a.Kp + comp] : 0.0;
 
   auto masked = [&](int f) -> d2 {
     d2 x = reinterpret_cast<const d2*>(spec)[f];
     if (useMask)
     {
-      const double est = hk * a.Wf[(int64_t) f * a.Kp + a.k];   // NMF.hpp:41
+      const double est = hk * a.Wf[(int64_t) f * a.Kp + comp];  // NMF.hpp:41
       const double mult = 1.0 / fmax(vhat[f], kEpsilon);          // RatioMask.hpp:39-41
       const double m = fmin(est * mult, 1.0);                     // RatioMask.hpp:52-56 (exponent 1)
       x = d2{x[0] * m, x[1] * m};
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void resynth_frames_kernel(ResynthArgs a)
   // z[m] = conj(src[m]) / nc ; x[2m] = Re z, x[2m+1] = Im z ; keep the first `win` samples
   // (alg/STFT.hpp:191), scale by 1/fft is already contained in the normalised inverse
   // (unnormalised C2R = fft * x, times mScale = 1/fft), then * window (:193)
-  double* fr = a.frames + (int64_t) t * a.win;
+  double* fr = a.frames + ((int64_t) blockIdx.y * a.T + t) * a.win;
   const double inv = 1.0 / (double) nc;
   for (int m = tid; m < nc; m += nt)
   {
@@ -139,6 +140,7 @@ __global__ void resynth_ola_kernel(ResynthArgs a)
 {
   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
+  const double* frames = a.frames + (int64_t) blockIdx.y * a.T * a.win;
   const int64_t p = i + a.trim; // position in the padded output (alg/STFT.hpp:197; BufSTFTClient.hpp:272)
   // frames t with t*hop <= p < t*hop + win
   int64_t tlo = (p - a.win + a.hop) / a.hop; // ceil((p - win + 1) / hop) for p - win + 1 > 0
@@ -150,12 +152,12 @@ __global__ void resynth_ola_kernel(ResynthArgs a)
   {
     const int64_t off = p - t * a.hop;
     const double w = a.window[off];
-    acc += a.frames[t * a.win + off];
+    acc += frames[t * a.win + off];
     nrm += w * w;
   }
   const double y = acc / fmax(nrm, kEpsilon); // :196
-  if (a.out) a.out[i] = y;
-  if (a.out32) a.out32[i] = (float) y;
+  if (a.out) a.out[(int64_t) blockIdx.y * a.n + i] = y;
+  if (a.out32) a.out32[(int64_t) blockIdx.y * a.n + i] = (float) y;
 }
 
 void launch_resynth(const ResynthArgs& a, hipStream_t s)
@@ -166,8 +168,9 @@ void launch_resynth(const ResynthArgs& a, hipStream_t s)
   int threads = a.fft / 8;
   if (threads < 64) threads = 64;
   if (threads > 256) threads = 256;
-  hipLaunchKernelGGL(resynth_frames_kernel, dim3((unsigned) a.T), dim3((unsigned) threads), shmem, s, a);
-  hipLaunchKernelGGL(resynth_ola_kernel, dim3((unsigned) ((a.n + 255) / 256)), dim3(256), 0, s, a);
+  const unsigned nc = (unsigned) (a.nComp < 1 ? 1 : a.nComp);
+  hipLaunchKernelGGL(resynth_frames_kernel, dim3((unsigned) a.T, nc), dim3((unsigned) threads), shmem, s, a);
+  hipLaunchKernelGGL(resynth_ola_kernel, dim3((unsigned) ((a.n + 255) / 256), nc), dim3(256), 0, s, a);
 }
 
 // ---- BufSTFT plumbing --------------------------------------------------------------------
