@@ -336,7 +336,7 @@ struct fluhip_corpus
   bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
-  DevBuf wnorm, wscratch, csumScratch;
+  DevBuf wnorm, wscratch, csumScratch, wideScratch;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
@@ -346,15 +346,19 @@ struct fluhip_corpus
 };
 
 // which factor-update kernel runs (FLUHIP_NMF_KERNEL forces one for A/B runs):
-//   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (default, Kp 16/32)
-//   4 = v_mfma_f64_4x4x4_4b, register-staged operands (Kp 64)
-//  16 = v_mfma_f64_16x16x4 (Kp 128, and the first version kept for comparison)
+//   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (default, Kp 16 .. 128)
+//   4 = v_mfma_f64_4x4x4_4b, register-staged operands (A/B, Kp <= 64)
+//  16 = v_mfma_f64_16x16x4 (the first version, kept for comparison)
+//   0 = un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip): any rank, used above Kp = 128
+//       (FLUHIP_NMF_KERNEL=-1 forces it: an independent second implementation for the tests)
 static int update_variant(int Kp)
 {
+  if (Kp > 128) return 0;
   static const int forced = [] {
     const char* e = std::getenv("FLUHIP_NMF_KERNEL");
     return e ? std::atoi(e) : 0;
   }();
+  if (forced == -1) return 0;
   if (forced == 16) return 16;
   if (forced == 4 && nmf_update4_supported(Kp)) return 4;
   if (nmf_update5_supported(Kp)) return 5;
@@ -410,7 +414,15 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   const size_t B = (size_t) c->B;
-  if (update_variant((int) c->Kp) != 16)
+  if (update_variant((int) c->Kp) == 0)
+  {
+    c->nsplitW = c->nsplitH = 1;
+    c->lazy = c->sideW = false;
+    const int64_t nd = std::max(nmf_update_wide_scratch_doubles((int) c->T, (int) c->F, (int) c->Kp, (int) B),
+                                nmf_update_wide_scratch_doubles((int) c->F, (int) c->T, (int) c->Kp, (int) B));
+    HIPCHK(ctx, c->wideScratch.alloc((size_t) nd * sizeof(double), false, s));
+  }
+  else if (update_variant((int) c->Kp) != 16)
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
     c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
@@ -477,7 +489,6 @@ static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int
   if (!stft_supported(win, fft))
     return fail(ctx, "fft sizes above 8192 are not supported by the gfx950 STFT kernel");
   if (K < 1) return fail(ctx, "rank must be >= 1");
-  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
   if ((n + hop) / hop > 2000000000LL / 16) return fail(ctx, "too many frames");
   return FLUHIP_OK;
 }
@@ -687,6 +698,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
         const int uv = update_variant(a.Kp);
         if (uv == 5) launch_nmf_update5(a, s);
         else if (uv == 4) launch_nmf_update4(a, s);
+        else if (uv == 0) launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
         else launch_nmf_update(a, s);
       }
       // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
@@ -709,6 +721,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
     const int uv = update_variant(a.Kp);
     if (uv == 5) launch_nmf_update5(a, s);
     else if (uv == 4) launch_nmf_update4(a, s);
+    else if (uv == 0) launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
     else launch_nmf_update(a, s);
   }
 }
@@ -1117,7 +1130,6 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
   if (!ctx) return FLUHIP_ERROR;
   if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
   if (K < 1) return fail(ctx, "rank must be >= 1");
-  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
   if (iters < 0) return fail(ctx, "negative iteration count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
@@ -1182,7 +1194,6 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   if (!ctx) return FLUHIP_ERROR;
   if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
   if (!W0 || K < 1) return fail(ctx, "bad dictionary");
-  if (K > 128) return fail(ctx, "rank above 128 is not supported by the gfx950 NMF kernel");
   if (iters < 0) return fail(ctx, "negative iteration count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;

@@ -101,6 +101,9 @@ void launch_nmf_update4(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4
 bool nmf_update4_supported(int Kp);
 int nmf_update4_waves_per_buffer(int C, int Kp, int B);
 void launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // + LDS-DMA operand streaming
+// any rank (used above Kp = 128): un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip)
+void launch_nmf_update_wide(const UpdateArgs& a, double* scratch, hipStream_t s);
+int64_t nmf_update_wide_scratch_doubles(int R, int C, int Kp, int B);
 bool nmf_update5_supported(int Kp);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)

@@ -212,6 +212,32 @@ def test_nmf_single_buffer_large_uses_split_path(ctx, oracle):
     assert np.array_equal(W1, W2) and np.array_equal(H1, H2)
 
 
+@pytest.mark.parametrize("T,F,K,iters", [(60, 65, 130, 6), (150, 129, 200, 5), (40, 257, 256, 4), (300, 33, 144, 8)])
+def test_nmf_rank_above_128(ctx, oracle, T, F, K, iters):
+    """ranks beyond the fused kernels' 128 take the un-fused path (kernels_nmf_wide.hip): same results as the oracle"""
+    rs = np.random.RandomState(K)
+    X = np.abs(rs.standard_normal((T, 12)) @ rs.standard_normal((12, F))) + 0.001
+    for uw, uh in ((True, True), (True, False), (False, True)):
+        W1, H1, V1, _ = ctx.nmf_process(X, K, iters, uw, uh, 42)
+        rW, rH, rV, _ = oracle.nmf_process(X, K, iters, uw, uh, 42)
+        assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT, (uw, uh)
+        assert rel_err(V1, rV) < TOL_FACTORS_TIGHT
+
+
+def test_bufnmf_rank_above_128_corpus(ctx, oracle, onp):
+    import fluhip
+    B, n, win, fft, hop, K, iters = 3, 9000, 256, 256, 64, 160, 5
+    audio = np.stack([onp.synth_audio(n, 8000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    assert c.plan()["kernel"] == 0
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=7)
+    mag, W1, H1 = c.read_f64()
+    c.close()
+    for b in range(B):
+        rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, True, True, 7)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
+
+
 def test_nmf_long_factor_rank128(ctx, oracle):
     """c3's extremes at a size the oracle finishes in seconds: rank 128 (the widest kernel form) and a
     factor with tens of thousands of rows (the column-normalisation partials no longer fit in LDS)"""
