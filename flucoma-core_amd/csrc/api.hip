@@ -47,9 +47,29 @@ struct fluhip_ctx
   std::vector<ProfRec> profRecs;
   std::vector<hipEvent_t> eventPool;
   hipDeviceProp_t props;
+  void* bigFft = nullptr;     // workspace of the global-memory FFT passes (fft > 8192), grown on demand
+  size_t bigFftBytes = 0;
 };
 
-static int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERROR)
+static int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERROR);
+// workspace for transforms whose frame does not fit the LDS; null (with the error set) when it cannot be had
+static double* big_fft_scratch(fluhip_ctx* ctx, int64_t win, int64_t fft, int64_t frames)
+{
+  if (!stft_needs_scratch(win, fft)) return nullptr;
+  const size_t need = (size_t) big_fft_scratch_bytes(fft, frames, nullptr);
+  if (need > ctx->bigFftBytes)
+  {
+    (void) hipStreamSynchronize(ctx->stream);
+    if (ctx->bigFft) (void) hipFree(ctx->bigFft);
+    ctx->bigFft = nullptr;
+    ctx->bigFftBytes = 0;
+    if (hipMalloc(&ctx->bigFft, need) != hipSuccess) { fail(ctx, "out of device memory for the FFT workspace"); return nullptr; }
+    ctx->bigFftBytes = need;
+  }
+  return static_cast<double*>(ctx->bigFft);
+}
+
+static int fail(fluhip_ctx* ctx, const std::string& msg, int status)
 {
   if (ctx) ctx->err = msg;
   return status;
@@ -487,7 +507,7 @@ static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int
   if (fft < 4 || (fft & (fft - 1)) || fft < win)
     return fail(ctx, "fft size must be a power of two >= window size");
   if (!stft_supported(win, fft))
-    return fail(ctx, "fft sizes above 8192 are not supported by the gfx950 STFT kernel");
+    return fail(ctx, "fft sizes above 65536 are not supported");
   if (K < 1) return fail(ctx, "rank must be >= 1");
   if ((n + hop) / hop > 2000000000LL / 16) return fail(ctx, "too many frames");
   return FLUHIP_OK;
@@ -511,6 +531,8 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
   a.mag = c->mag.as<double>(); a.magStride = c->Tp * c->Fp; a.ldMag = c->Fp;
   a.spec = c->keepSpec ? c->spec.as<double>() : nullptr; a.specStride = c->T * c->F * 2;
   a.frameOffset = 0;
+  a.bigScratch = big_fft_scratch(ctx, c->win, c->fft, c->B * c->T);
+  if (stft_needs_scratch(c->win, c->fft) && !a.bigScratch) return FLUHIP_ERROR;
   {
     ProfScope p(ctx, 0);
     launch_stft(a, ctx->stream);
@@ -805,6 +827,7 @@ void fluhip_ctx_destroy(fluhip_ctx* ctx)
   if (!ctx) return;
   (void) hipSetDevice(ctx->device);
   if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+  if (ctx->bigFft) (void) hipFree(ctx->bigFft);
   for (auto& kv : ctx->windows) (void) hipFree(kv.second);
   for (auto& kv : ctx->twiddles) (void) hipFree(kv.second);
   for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
@@ -995,6 +1018,8 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
       ra.k = (int) k;
       ra.nComp = (int) std::min(compsPerLaunch, c->K - k);
       ra.out32 = out_dev + (b * c->K + k) * c->n;
+      ra.bigScratch = big_fft_scratch(ctx, ra.win, ra.fft, ra.T);
+      if (stft_needs_scratch(ra.win, ra.fft) && !ra.bigScratch) return FLUHIP_ERROR;
       launch_resynth(ra, s);
     }
   }
@@ -1540,6 +1565,8 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
       ra.k = (int) k;
       ra.nComp = (int) std::min(compsPerLaunch, K - k);
       ra.out32 = out32.as<float>() + k * n;
+      ra.bigScratch = big_fft_scratch(ctx, ra.win, ra.fft, ra.T);
+      if (stft_needs_scratch(ra.win, ra.fft) && !ra.bigScratch) return FLUHIP_ERROR;
       launch_resynth(ra, s);
     }
     HIPCHK(ctx, hipGetLastError());
@@ -1593,6 +1620,8 @@ int fluhip_bufstft_forward_f32(fluhip_ctx* ctx, const float* audio, int64_t n, i
   sa.window = wtab; sa.twiddle = ttab; sa.mag = nullptr; sa.magStride = 0; sa.ldMag = 0;
   sa.spec = spec.as<double>(); sa.specStride = 0;
   sa.frameOffset = (int) (win / 2 - pad); // frame i starts at sample i*hop - padding (:151-162)
+  sa.bigScratch = big_fft_scratch(ctx, win, fft, T);
+  if (stft_needs_scratch(win, fft) && !sa.bigScratch) return FLUHIP_ERROR;
   launch_stft(sa, s);
   launch_spec_to_magphase(spec.as<double>(), (int) T, (int) F, mag ? dm.as<float>() : nullptr,
                           phase ? dp.as<float>() : nullptr, s);
@@ -1638,6 +1667,8 @@ int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* p
   ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) T; ra.F = (int) F;
   ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr;
   ra.out32 = dout.as<float>(); ra.n = finalOut; ra.trim = pad;
+  ra.bigScratch = big_fft_scratch(ctx, ra.win, ra.fft, ra.T);
+  if (stft_needs_scratch(ra.win, ra.fft) && !ra.bigScratch) return FLUHIP_ERROR;
   launch_resynth(ra, s);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(out, dout.p, (size_t) finalOut * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1753,6 +1784,8 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
     sa.window = wtab; sa.twiddle = ttab;
     sa.mag = dMag.as<double>(); sa.magStride = Tp * Fp; sa.ldMag = Fp;
     sa.spec = nullptr; sa.specStride = 0; sa.frameOffset = (int) frameOffset;
+    sa.bigScratch = big_fft_scratch(ctx, win, fft, nb * T);
+    if (stft_needs_scratch(win, fft) && !sa.bigScratch) return FLUHIP_ERROR;
     {
       ProfScope p(ctx, 0);
       launch_stft(sa, s);

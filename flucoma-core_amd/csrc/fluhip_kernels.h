@@ -40,13 +40,18 @@ struct StftArgs
   int64_t ldMag;        // Fp
   double* spec;         // [B][T][F] interleaved complex, or nullptr
   int64_t specStride;
+  double* bigScratch = nullptr; // big_fft_scratch_bytes() of workspace, needed when stft_needs_scratch(win, fft)
   int frameOffset;      // extra sample offset of frame 0 (0 for STFT::process; the buffered feature
                         // clients start (win/hop)*hop - win earlier when hop does not divide win)
 };
 
 void launch_stft(const StftArgs& a, hipStream_t s);
-// true when the in-LDS kernel supports this fft size
+// power-of-two fft up to 65536; sizes whose frame does not fit the LDS (above 8192) run their passes through a
+// global-memory workspace the caller provides
 bool stft_supported(int64_t win, int64_t fft);
+bool stft_needs_scratch(int64_t win, int64_t fft);
+int64_t big_fft_scratch_bytes(int64_t fft, int64_t frames, int64_t* chunkFrames);
+double* launch_big_fft_passes(double* bufA, double* bufB, int nc, int fft, const double* twiddle, int nf, hipStream_t s);
 
 // out[b][c][r] = in[b][r][c]; in [R][ldin], out [C][ldout] (valid R x C)
 void launch_transpose(const double* in, int64_t ldin, int64_t strideIn, double* out,
@@ -203,6 +208,7 @@ struct ResynthArgs
   int64_t n;
   int64_t trim;         // leading samples dropped: win/2 for ISTFT::process, `padding` for BufSTFT
   int nComp = 1;        // components k .. k + nComp - 1 in one launch: frames [nComp][T][win], out / out32 [nComp][n]
+  double* bigScratch = nullptr; // set (big_fft_scratch_bytes(fft, T)) when stft_needs_scratch(win, fft): global-memory passes
 };
 // Wf == nullptr: no ratio mask (plain inverse STFT of `spec`)
 void launch_resynth(const ResynthArgs& a, hipStream_t s);

@@ -14,6 +14,8 @@
 // so the result does not depend on scheduling -- and divides by the window-power normaliser.
 #include "fluhip_kernels.h"
 
+#include <algorithm>
+
 namespace fluhip {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -160,8 +162,84 @@ __global__ void resynth_ola_kernel(ResynthArgs a)
   if (a.out32) a.out32[(int64_t) blockIdx.y * a.n + i] = (float) y;
 }
 
+// ---- fft sizes whose frame does not fit the LDS: the inverse through the global-memory passes ---------------------
+// pack: Z[k] = conj(E[k] + i O[k]) of the masked spectrum (as in resynth_frames_kernel) for a chunk of frames of one
+// component; unpack: frame[i] = (conj(z) / nc) interleaved, times the window.
+__global__ void big_ipack_kernel(ResynthArgs a, int comp, int t0, int nf, d2* buf)
+{
+  const int nc = a.fft / 2;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) nf * nc) return;
+  const int k = (int) (idx % nc), t = t0 + (int) (idx / nc);
+  const d2* tw = reinterpret_cast<const d2*>(a.twiddle);
+  const double* spec = a.spec + (int64_t) t * a.F * 2;
+  const double* vhat = a.Vhat + (int64_t) t * a.ldV;
+  const bool useMask = a.Wf != nullptr;
+  const double hk = useMask ? a.H1[(int64_t) t * a.Kp + comp] : 0.0;
+  auto masked = [&](int f) -> d2 {
+    d2 x = reinterpret_cast<const d2*>(spec)[f];
+    if (useMask)
+    {
+      const double est = hk * a.Wf[(int64_t) f * a.Kp + comp];
+      const double m = fmin(est * (1.0 / fmax(vhat[f], kEpsilon)), 1.0);
+      x = d2{x[0] * m, x[1] * m};
+    }
+    if (f == 0 || f == nc) x[1] = 0.0;
+    return x;
+  };
+  const d2 X = masked(k), Xn = masked(nc - k);
+  const d2 Xc = d2{Xn[0], -Xn[1]};
+  const d2 E = d2{0.5 * (X[0] + Xc[0]), 0.5 * (X[1] + Xc[1])};
+  const d2 D = d2{0.5 * (X[0] - Xc[0]), 0.5 * (X[1] - Xc[1])};
+  const d2 w = tw[k];
+  const d2 O = cmul_i(D, d2{w[0], -w[1]});
+  const d2 Z = d2{E[0] - O[1], E[1] + O[0]};
+  buf[idx] = d2{Z[0], -Z[1]};
+}
+
+__global__ void big_iunpack_kernel(const d2* z, ResynthArgs a, int t0, int nf, double* frames)
+{
+  const int nc = a.fft / 2;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) nf * nc) return;
+  const int m = (int) (idx % nc), t = t0 + (int) (idx / nc);
+  const d2 v = z[idx];
+  const double inv = 1.0 / (double) nc;
+  double* fr = frames + (int64_t) t * a.win;
+  const int i0 = 2 * m, i1 = 2 * m + 1;
+  if (i0 < a.win) fr[i0] = (v[0] * inv) * a.window[i0];
+  if (i1 < a.win) fr[i1] = (-v[1] * inv) * a.window[i1];
+}
+
+static void launch_resynth_big(const ResynthArgs& a, hipStream_t s)
+{
+  const int nc = a.fft / 2;
+  int64_t cf = 1;
+  (void) big_fft_scratch_bytes(a.fft, a.T, &cf);
+  double* bufA = a.bigScratch;
+  double* bufB = a.bigScratch + cf * nc * 2;
+  const int ncomp = a.nComp < 1 ? 1 : a.nComp;
+  for (int c = 0; c < ncomp; c++)
+  {
+    double* frames = a.frames + (int64_t) c * a.T * a.win;
+    for (int t0 = 0; t0 < a.T; t0 += (int) cf)
+    {
+      const int nf = (int) std::min<int64_t>(cf, a.T - t0);
+      const int64_t np = (int64_t) nf * nc;
+      hipLaunchKernelGGL(big_ipack_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, s, a, a.k + c, t0, nf,
+                         reinterpret_cast<d2*>(bufA));
+      const double* z = launch_big_fft_passes(bufA, bufB, nc, a.fft, a.twiddle, nf, s);
+      hipLaunchKernelGGL(big_iunpack_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, s,
+                         reinterpret_cast<const d2*>(z), a, t0, nf, frames);
+    }
+  }
+  const unsigned nc2 = (unsigned) ncomp;
+  hipLaunchKernelGGL(resynth_ola_kernel, dim3((unsigned) ((a.n + 255) / 256), nc2), dim3(256), 0, s, a);
+}
+
 void launch_resynth(const ResynthArgs& a, hipStream_t s)
 {
+  if (a.bigScratch) { launch_resynth_big(a, s); return; }
   const size_t shmem = (size_t) a.fft * 2 * sizeof(double); // two complex buffers of fft/2 points
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(resynth_frames_kernel),
                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -496,6 +496,153 @@ static void launch_stft_wave(const StftKArgs& k, hipStream_t s)
   hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3((unsigned) (64 * waves)), shmem, s, k);
 }
 
+// ---------------------------------------------------------------------------------------
+// fft sizes whose frame does not fit the LDS (above 8192): the same Stockham passes through global memory, a
+// thread per butterfly over a chunk of frames, ping-ponging between two scratch buffers [frames][fft/2] complex.
+// Correctness-first (the reference's static FFT setup goes to 65536, util/FFT.hpp:113-122; such windows are rare).
+// ---------------------------------------------------------------------------------------
+__global__ void big_pack_kernel(StftKArgs a, int64_t f0, int nf, d2* buf)
+{
+  const int nc = a.nc;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) nf * nc) return;
+  const int m = (int) (idx % nc);
+  const int64_t frame = f0 + idx / nc;
+  const int b = (int) (frame / a.T), t = (int) (frame % a.T);
+  const int64_t s0 = (int64_t) t * a.hop - a.win / 2 + a.frameOffset;
+  const int i0 = 2 * m, i1 = 2 * m + 1;
+  const int64_t p0 = s0 + i0, p1 = s0 + i1;
+  double x0 = 0.0, x1 = 0.0;
+  if (a.audio)
+  {
+    const float* src = a.audio + (int64_t) b * a.audioStride;
+    if (i0 < a.win && p0 >= 0 && p0 < a.n) x0 = (double) src[p0];
+    if (i1 < a.win && p1 >= 0 && p1 < a.n) x1 = (double) src[p1];
+  }
+  else
+  {
+    const double* src = a.audio64 + (int64_t) b * a.audioStride;
+    if (i0 < a.win && p0 >= 0 && p0 < a.n) x0 = src[p0];
+    if (i1 < a.win && p1 >= 0 && p1 < a.n) x1 = src[p1];
+  }
+  if (i0 < a.win) x0 *= a.window[i0];
+  if (i1 < a.win) x1 *= a.window[i1];
+  buf[idx] = d2{x0, x1};
+}
+
+// one Stockham pass (radix 4, or 2 for the last pass of an odd log2) over nf frames of nc points
+__global__ void big_pass_kernel(const d2* src, d2* dst, int nc, int Ns, int radix, int fft, const d2* tw, int nf)
+{
+  const int per = nc / radix;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) nf * per) return;
+  const int j = (int) (idx % per);
+  const d2* in = src + (idx / per) * nc;
+  d2* out = dst + (idx / per) * nc;
+  const int k = j & (Ns - 1);
+  if (radix == 4)
+  {
+    const int tstep = fft / (Ns * 4);
+    d2 v0 = in[j], v1 = in[j + per], v2 = in[j + 2 * per], v3 = in[j + 3 * per];
+    if (k)
+    {
+      const int m1 = k * tstep;
+      v1 = cmul(v1, twid(tw, m1, nc));
+      v2 = cmul(v2, twid(tw, 2 * m1, nc));
+      v3 = cmul(v3, twid(tw, 3 * m1, nc));
+    }
+    const d2 t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3;
+    const d2 d13 = v1 - v3;
+    const d2 t3 = d2{d13[1], -d13[0]};
+    const int o = ((j - k) << 2) + k;
+    out[o] = t0 + t2;
+    out[o + Ns] = t1 + t3;
+    out[o + 2 * Ns] = t0 - t2;
+    out[o + 3 * Ns] = t1 - t3;
+  }
+  else
+  {
+    const int tstep = fft / (Ns * 2);
+    d2 v0 = in[j], v1 = in[j + per];
+    if (k) v1 = cmul(v1, twid(tw, k * tstep, nc));
+    const int o = ((j - k) << 1) + k;
+    out[o] = v0 + v1;
+    out[o + Ns] = v0 - v1;
+  }
+}
+
+__global__ void big_split_kernel(const d2* z, StftKArgs a, int64_t f0, int nf)
+{
+  const int nc = a.nc;
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t) nf * (nc + 1)) return;
+  const int k = (int) (idx % (nc + 1));
+  const int64_t fr = idx / (nc + 1), frame = f0 + fr;
+  const int b = (int) (frame / a.T), t = (int) (frame % a.T);
+  const d2* src = z + fr * nc;
+  const d2* tw = reinterpret_cast<const d2*>(a.twiddle);
+  double xr, xi;
+  if (k == 0) { const d2 v = src[0]; xr = v[0] + v[1]; xi = 0.0; }
+  else if (k == nc) { const d2 v = src[0]; xr = v[0] - v[1]; xi = 0.0; }
+  else
+  {
+    const d2 A = src[k], Bc = src[nc - k];
+    const double er = 0.5 * (A[0] + Bc[0]), ei = 0.5 * (A[1] - Bc[1]);
+    const double dr = 0.5 * (A[0] - Bc[0]), di = 0.5 * (A[1] + Bc[1]);
+    const d2 w = tw[k];
+    xr = er + (w[0] * di + w[1] * dr);
+    xi = ei - (w[0] * dr - w[1] * di);
+  }
+  if (a.mag) a.mag[(int64_t) b * a.magStride + (int64_t) t * a.ldMag + k] = sqrt(xr * xr + xi * xi);
+  if (a.spec) reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2)[k] = d2{xr, xi};
+}
+
+// the passes on their own: nf frames of nc complex points in bufA -> result in the returned buffer (A or B)
+double* launch_big_fft_passes(double* bufA, double* bufB, int nc, int fft, const double* twiddle, int nf, hipStream_t s)
+{
+  d2* src = reinterpret_cast<d2*>(bufA);
+  d2* dst = reinterpret_cast<d2*>(bufB);
+  for (int Ns = 1; Ns < nc;)
+  {
+    const int radix = (nc / Ns >= 4) ? 4 : 2;
+    const int64_t total = (int64_t) nf * (nc / radix);
+    hipLaunchKernelGGL(big_pass_kernel, dim3((unsigned) ((total + 255) / 256)), dim3(256), 0, s, src, dst, nc, Ns, radix, fft,
+                       reinterpret_cast<const d2*>(twiddle), nf);
+    Ns *= radix;
+    d2* t = src; src = dst; dst = t;
+  }
+  return reinterpret_cast<double*>(src);
+}
+
+int64_t big_fft_scratch_bytes(int64_t fft, int64_t frames, int64_t* chunkFrames)
+{
+  const int64_t perFrame = fft / 2 * 16; // one buffer
+  int64_t cf = std::max<int64_t>(1, ((int64_t) 512 << 20) / perFrame);
+  cf = std::min(cf, std::max<int64_t>(frames, 1));
+  if (chunkFrames) *chunkFrames = cf;
+  return 2 * cf * perFrame;
+}
+
+static void launch_stft_big(const StftKArgs& k, double* scratch, hipStream_t s)
+{
+  int64_t cf = 1;
+  (void) big_fft_scratch_bytes(k.fft, k.totalFrames, &cf);
+  double* bufA = scratch;
+  double* bufB = scratch + cf * k.nc * 2;
+  for (int64_t f0 = 0; f0 < k.totalFrames; f0 += cf)
+  {
+    const int nf = (int) std::min<int64_t>(cf, k.totalFrames - f0);
+    const int64_t np = (int64_t) nf * k.nc;
+    hipLaunchKernelGGL(big_pack_kernel, dim3((unsigned) ((np + 255) / 256)), dim3(256), 0, s, k, f0, nf,
+                       reinterpret_cast<d2*>(bufA));
+    const double* z = launch_big_fft_passes(bufA, bufB, k.nc, k.fft, k.twiddle, nf, s);
+    const int64_t ns = (int64_t) nf * (k.nc + 1);
+    hipLaunchKernelGGL(big_split_kernel, dim3((unsigned) ((ns + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const d2*>(z),
+                       k, f0, nf);
+  }
+}
+
+
 static size_t stft_lds_bytes(int64_t win, int64_t fft, bool twInLds, bool winInLds)
 {
   const size_t nc = (size_t) fft / 2;
@@ -505,8 +652,9 @@ static size_t stft_lds_bytes(int64_t win, int64_t fft, bool twInLds, bool winInL
 bool stft_supported(int64_t win, int64_t fft)
 {
   if (fft < 4 || (fft & (fft - 1)) || win > fft || win < 1) return false;
-  return stft_lds_bytes(win, fft, false, false) <= 160 * 1024;
+  return fft <= 65536; // util/FFT.hpp:113-122: the reference's shared setup ends there too
 }
+bool stft_needs_scratch(int64_t win, int64_t fft) { return stft_lds_bytes(win, fft, false, false) > 160 * 1024; }
 
 void launch_stft(const StftArgs& a, hipStream_t s)
 {
@@ -520,6 +668,11 @@ void launch_stft(const StftArgs& a, hipStream_t s)
   k.frameOffset = a.frameOffset;
   k.totalFrames = (int64_t) a.B * a.T;
   k.twInLds = 1; k.winInLds = 0;
+  if (stft_needs_scratch(a.win, a.fft))
+  {
+    if (a.bigScratch && k.totalFrames > 0) launch_stft_big(k, a.bigScratch, s);
+    return;
+  }
   {
     static const bool generic = std::getenv("FLUHIP_STFT_GENERIC") != nullptr;
     // wave-per-frame kernels: power-of-two fft with an even window (pairs of window values)

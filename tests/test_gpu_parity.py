@@ -39,6 +39,7 @@ def test_stft_golden(ctx, golden, wfh):
     (1, 1024, 1024, 512),       # a single sample: T = 1
     (511, 1024, 1024, 512), (512, 1024, 1024, 512), (513, 1024, 1024, 512),  # ragged around one hop
     (20000, 8192, 8192, 2048),  # largest in-LDS size (twiddles from global memory)
+    (60000, 16384, 16384, 4096), (70000, 20000, 32768, 8192), (140000, 65536, 65536, 16384),  # global-memory passes
     (3000, 256, 512, 64), (3000, 32, 2048, 8),
 ])
 def test_stft_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
@@ -95,7 +96,7 @@ def test_stft_rejects_bad_shapes(ctx):
     with pytest.raises(fluhip.FluhipError):
         ctx.stft(x, 2048, 1024, 512)      # fft < win
     with pytest.raises(fluhip.FluhipError):
-        ctx.stft(x, 1024, 32768, 512)     # beyond the in-LDS kernel
+        ctx.stft(x, 1024, 131072, 512)    # beyond the reference's own limit of 65536 (util/FFT.hpp:113-122)
 
 
 # ---------------------------------------------------------------------------------------
@@ -432,6 +433,23 @@ def test_reference_testnmf_cases(ctx, oracle):
     h = [ctx.nmf_process_frames(x, bases, 0, sd)[0] for sd in (42, 42, 7863)]
     assert np.array_equal(h[0], h[1]) and not np.array_equal(h[1], h[2])
     assert np.array_equal(h[0], oracle.nmf_process_frames(x, bases, 0, 42)[0])
+
+
+def test_large_fft_roundtrip_and_bufnmf(ctx, oracle, onp):
+    """fft sizes above the LDS-resident 8192 (the reference's shared FFT setup goes to 65536, util/FFT.hpp:113-122):
+    BufSTFT forward / inverse round trip and a BufNMF channel with resynthesis, against the oracle"""
+    x = onp.synth_audio(120000, 31)
+    win = fft = 16384
+    hop = 4096
+    mag, ph = ctx.bufstft_forward(x, win, fft, hop, 1)
+    rmag, rph = oracle.bufstft_forward(x, win, fft, hop, 1)
+    assert rel_err(mag, rmag) < 1e-5
+    y = ctx.bufstft_inverse(mag, ph, win, fft, hop, 1)
+    assert np.abs(y[:x.size] - x).max() < 1e-4
+    bases, acts, res, rc = ctx.bufnmf_channel(x, win, fft, hop, 3, 10, 42, resynth=True)
+    rb, ra = oracle.bufnmf_channel(x, win, fft, hop, 3, 10, 42)
+    assert rel_err(bases, rb) < 1e-6 and rel_err(acts, ra) < 1e-6
+    assert rel_err(res.sum(axis=0), x) < 1e-4
 
 
 def test_process_frames_golden(ctx):
