@@ -459,7 +459,9 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       const int G = ((int) c->F + 15) / 16, G1 = G - 1;
       const int w = nmf_update5_strips((int) c->F, (int) c->Kp, (int) c->B);
       const int w1 = nmf_update5_strips((int) c->F - 1, (int) c->Kp, (int) c->B);
-      c->sideW = (G1 + w1 - 1) / w1 < (G + w - 1) / w && w1 <= w;
+      // worth it when the widest strip gets shorter, or when the launch needs fewer passes over the 1024 SIMDs
+      const int64_t passes = (c->B * w + 1023) / 1024, passes1 = (c->B * w1 + 1023) / 1024;
+      c->sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
     }
     // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
     // finalize kernel when the contraction is split

@@ -23,6 +23,8 @@
 // 8*F*T*K flop per full iteration, V streamed exactly twice per iteration (once per update).
 #include "fluhip_kernels.h"
 
+#include <algorithm>
+
 namespace fluhip {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -544,7 +546,7 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
 // block pays one memory latency); row groups are combined in fixed order and the slice's (num, den) go
 // to scratch for wnorm_combine_kernel.  No atomics: run-to-run bit-identical.
 constexpr int kSideUnr = 8;    // rows of a slice per row group (held in registers)
-constexpr int kSideSlices = 16;
+constexpr int kSideSlices = 64; // at most; a launch uses as many as keep a slice within a block's capacity
 
 template <int Kp>
 __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, int64_t strideS, int C, SideColumn side,
@@ -575,14 +577,17 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
     wsh[k] = w;
     if (slice == 0) wold[(int64_t) b * Kp + k] = w;
   }
-  const int r = r0 + (int) threadIdx.x; // RS <= blockDim
-  double mrow[Kp];
+  // pass 1: HP adjacent threads per row of the slice (one up to rank 64, two at rank 128), KH values each
+  constexpr int HP = Kp > 64 ? Kp / 64 : 1, KH = Kp / HP;
+  const int rl = (int) threadIdx.x / HP, hp = (int) threadIdx.x % HP;
+  const int r = r0 + rl; // RS * HP <= blockDim
+  double mrow[KH];
   double vr = 0.0;
   if (r < r1)
   {
-    const double* m = Mv + (int64_t) r * Kp;
+    const double* m = Mv + (int64_t) r * Kp + hp * KH;
 #pragma unroll
-    for (int j = 0; j < Kp; j += 2)
+    for (int j = 0; j < KH; j += 2)
     {
       const d2 t = *reinterpret_cast<const d2*>(m + j);
       mrow[j] = t[0];
@@ -591,16 +596,20 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
     vr = side.vcol[(int64_t) b * side.strideV + r];
   }
   __syncthreads();
-  if (r < r1)
   {
     double q0 = 0.0, q1 = 0.0;
-#pragma unroll
-    for (int j = 0; j < Kp; j += 2)
+    if (r < r1)
     {
-      q0 = fma(mrow[j], wsh[j], q0);
-      q1 = fma(mrow[j + 1], wsh[j + 1], q1);
+#pragma unroll
+      for (int j = 0; j < KH; j += 2)
+      {
+        q0 = fma(mrow[j], wsh[hp * KH + j], q0);
+        q1 = fma(mrow[j + 1], wsh[hp * KH + j + 1], q1);
+      }
     }
-    ratio[threadIdx.x] = vr / fmax(q0 + q1, kEpsilon);
+    double q = q0 + q1;
+    if (HP == 2) q += __shfl_xor(q, 1);
+    if (r < r1 && hp == 0) ratio[rl] = vr / fmax(q, kEpsilon);
   }
   __syncthreads();
   double num = 0.0, den = 0.0;
@@ -662,18 +671,21 @@ __global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64
   double n = 0.0, d = 0.0, wo = 0.0;
   if (sidePart && pg == 0)
   {
-    double pn[kSideSlices], pd[kSideSlices];
-#pragma unroll
-    for (int j = 0; j < kSideSlices; j++)
+    for (int j0 = 0; j0 < nsl; j0 += 16) // sixteen slices' loads in flight at a time, summed in slice order
     {
-      const double* p = sidePart + ((int64_t) b * nsl + (j < nsl ? j : 0)) * 2 * Kp;
-      pn[j] = p[k];
-      pd[j] = p[Kp + k];
+      double pn[16], pd[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+      {
+        const double* p = sidePart + ((int64_t) b * nsl + min(j0 + j, nsl - 1)) * 2 * Kp;
+        pn[j] = p[k];
+        pd[j] = p[Kp + k];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        if (j0 + j < nsl) { n += pn[j]; d += pd[j]; }
     }
     wo = wold[(int64_t) b * Kp + k];
-#pragma unroll
-    for (int j = 0; j < kSideSlices; j++)
-      if (j < nsl) { n += pn[j]; d += pd[j]; }
   }
   __syncthreads();
   if (pg == 0)
@@ -717,10 +729,17 @@ __global__ void fill_ones_kernel(double* p, int64_t n)
   if (i < n) p[i] = 1.0;
 }
 
+// slices of the contraction per buffer: as few as keep a slice within one block's capacity (8 rows per row group in
+// pass 2, HP threads per row in pass 1), 16 at least
+static int side_slices_for(int R, int Kp)
+{
+  const int nrg = 256 / Kp;
+  const int cap = std::min(nrg * kSideUnr, 256 / (Kp > 64 ? Kp / 64 : 1));
+  return std::max(16, (R + cap - 1) / cap);
+}
 bool nmf_side_column_supported(int R, int C, int Kp)
 {
-  const int nrg = Kp <= 256 ? 256 / Kp : 1;
-  return C % 16 == 1 && C > 16 && Kp <= 64 && (R + kSideSlices - 1) / kSideSlices <= nrg * kSideUnr;
+  return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128) && side_slices_for(R, Kp) <= kSideSlices;
 }
 int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp); }
 
@@ -730,18 +749,21 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   double* statPart = scratch;
   double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;
   double* wold = sidePart + (int64_t) B * kSideSlices * 2 * Kp;
+  int nsl = 0;
   if (side)
   {
     const int nrg = 256 / Kp;
-    const int RS = (side->R + kSideSlices - 1) / kSideSlices;
-    const dim3 grid(kSideSlices, (unsigned) B), block((unsigned) (nrg * Kp));
+    nsl = side_slices_for(side->R, Kp);
+    const int RS = (side->R + nsl - 1) / nsl;
+    const dim3 grid((unsigned) nsl, (unsigned) B), block((unsigned) (nrg * Kp));
     const size_t sh = (size_t) (2 * nrg * Kp + Kp + RS) * sizeof(double);
     if (Kp == 16) hipLaunchKernelGGL(side_slices_kernel<16>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
     else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
-    else hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else if (Kp == 64) hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
   }
   hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
-                     nStrips, side ? sidePart : nullptr, kSideSlices, wold, nrm);
+                     nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)

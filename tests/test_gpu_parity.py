@@ -534,6 +534,25 @@ def test_corpus_resynthesis_matches_single_channel_path(ctx, onp):
     assert rel_err(out.sum(axis=1), audio) < 1e-4
 
 
+@pytest.mark.parametrize("K", [64, 128])
+def test_corpus_side_column_wide_ranks(ctx, oracle, onp, K):
+    """ranks 64 and 128 in the batched regime: the Nyquist side column saves a whole pass of wavefronts there (65 column
+    groups at 4 / 2 per wavefront: 17 / 33 strips per buffer -> 16 / 32), so the plan must take it, and match the oracle"""
+    import fluhip
+    B, n, win, fft, hop, iters = 128, 60000, 2048, 2048, 512, 6
+    distinct = [onp.synth_audio(n, 6000 + b) for b in range(4)]
+    audio = np.stack([distinct[b % 4] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    plan = c.plan()
+    assert plan["kernel"] == 5 and plan["deferred_norm"] == 1 and plan["side_column"] == 1, plan
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    c.close()
+    for b in (0, 1, 127):
+        rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
+
+
 def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
     """sharding property: a buffer's result does not depend on which batch (or rank) holds it"""
     import fluhip
