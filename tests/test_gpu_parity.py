@@ -452,6 +452,29 @@ def test_large_fft_roundtrip_and_bufnmf(ctx, oracle, onp):
     assert rel_err(res.sum(axis=0), x) < 1e-4
 
 
+def test_next_row_entry_points_reject_bad_arguments(ctx):
+    """error convention of the boundary (Result::Status codes + message, no exceptions across the ABI) on the
+    entry points of the "next" rows"""
+    import fluhip
+    X = np.abs(np.random.RandomState(0).standard_normal((20, 17)))
+    W0 = np.abs(np.random.RandomState(1).standard_normal((3, 17)))
+    with pytest.raises(fluhip.FluhipError):
+        ctx.nmf_process_frames(X, W0, -1, 42)                      # negative iteration count
+    with pytest.raises(AssertionError):
+        ctx.nmf_process_frames(X, W0[:, :5], 3, 42)                # dictionary of another bin count (binding check)
+    with pytest.raises(fluhip.FluhipError):
+        ctx.nndsvd(X, 4, 0, 4, 0.0, 0, 42)                         # neither coverage nor minimum rank (NNDSVD.hpp:40)
+    with pytest.raises(fluhip.FluhipError):
+        ctx.nndsvd(X, 4, 0, 4, 0.5, 7, 42)                         # unknown method
+    with pytest.raises(fluhip.FluhipError):
+        ctx.nndsvd(X, 2, 6, 8, 0.0, 0, 42)                         # rank beyond the rows of W
+    with pytest.raises(fluhip.FluhipError):
+        ctx.bufnmfseed(np.zeros(0, dtype=np.float32), 1024, 1024, 512)  # no frames
+    with pytest.raises(fluhip.FluhipError) as e:
+        ctx.bufnmf_channel(np.zeros(1000, dtype=np.float32), 1024, 1000, 512, 3, 5, 42)
+    assert "power of two" in e.value.message
+
+
 def test_process_frames_golden(ctx):
     """the HIP path against the committed G7 vectors directly (no oracle in the loop)"""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_frames_v1.npz"))
