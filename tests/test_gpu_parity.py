@@ -638,6 +638,30 @@ def test_single_buffer_full_size_properties(ctx, onp, name, n, win, fft, hop, K,
     assert kl_rows(mag[0], Wb[0], Hb[0], rows) <= kl_rows(mag[0], Wa[0], Ha[0], rows) * (1 + 1e-9)
 
 
+def test_bench_workload_matches_oracle_at_full_size(ctx, oracle, onp):
+    """the bench.py workload itself (BASELINE config 4 shard: 128 x 10 s, fft 2048 / hop 512, rank 32, 200 iterations,
+    seed 42 -- the schedule bench.py times: deferred normalisation, side column, 8 strips): two of its buffers
+    against the oracle run on the same audio for all 200 iterations"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 128, 441000, 2048, 2048, 512, 32, 200
+    distinct = [onp.synth_audio(n, 1000 + b) for b in range(2)]
+    audio = np.stack([distinct[b % 2] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    plan = c.plan()
+    assert plan["deferred_norm"] == 1 and plan["side_column"] == 1 and plan["strips_w"] == 8, plan
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    bases, acts = c.writeback()
+    c.close()
+    for b in (0, 127):
+        _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
+        assert rel_err(mag[b], rmag) < TOL_STFT
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6
+
+
 def test_corpus_c4_shape_properties(ctx, onp):
     """BASELINE config 4 shape at full per-buffer size (10 s, fft 2048, rank 32, 200 iterations),
     checked through size-independent properties: unit-norm dictionary columns, non-negativity,
