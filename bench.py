@@ -82,7 +82,7 @@ def cpu_all_cores(mag, wl, procs, iters):
         return None
 
 
-def cpu_baseline(audio_one, wl, budget_s):
+def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
     """The oracle's faithful mode (all seven GEMMs of alg/NMF.hpp:158-173 per iteration) on ONE
     buffer of the same workload, one core -- what one BufNMF job costs the reference."""
     import oracle_c
@@ -99,8 +99,16 @@ def cpu_baseline(audio_one, wl, budget_s):
     per_iter = (time.perf_counter() - t0) / 3
     iters = int(max(3, min(wl["iters"], budget_s / max(per_iter, 1e-9))))
     t0 = time.perf_counter()
-    o.nmf_process(mag, wl["rank"], iters, True, True, wl["seed"], faithful=True)
+    oW, oH, _, _ = o.nmf_process(mag, wl["rank"], iters, True, True, wl["seed"], faithful=True)
     t_nmf = time.perf_counter() - t0
+    # when the sample is the whole job of buffer 0, the timed oracle run doubles as a parity check of the very
+    # result the GPU just produced for that buffer (float outputs, nrt/NMFClient.hpp:277-300)
+    parity = None
+    if iters == wl["iters"] and gpu_bases0 is not None and gpu_acts0 is not None:
+        rb, ra = o.bufnmf_writeback(oW, oH)
+        parity = {"buffer": 0, "iterations": iters,
+                  "bases_max_rel_err": float(np.abs(gpu_bases0 - rb).max() / np.abs(rb).max()),
+                  "activations_max_rel_err": float(np.abs(gpu_acts0 - ra).max() / np.abs(ra).max())}
     # the reference's shipped Linux default is -msse4 (script/flucoma_simdcmd.cmake:20-22): short probe
     sse4_rate = None
     try:
@@ -131,7 +139,7 @@ def cpu_baseline(audio_one, wl, budget_s):
         "value_sse4_build": sse4_rate,
         "executed_gflops": executed_flop / t_nmf / 1e9,
         "bufnmf_wall_s_200iter_est": t_stft + t_nmf / iters * wl["iters"],
-        "value_many_jobs": all_rate, "many_jobs_processes": procs,
+        "value_many_jobs": all_rate, "many_jobs_processes": procs, "parity_vs_gpu": parity,
         "cpu_model": cpu_model, "host_cores_available": os.cpu_count(),
     }
 
@@ -278,7 +286,7 @@ def main():
             "result_finite": finite,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(audio[0], wl, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(audio[0], wl, args.cpu_seconds, bases[0].cpu().numpy(), a_host[0])
             gpu_job_s = elapsed_max / args.steps / B   # per-buffer share of one step
             out["cpu_baseline"]["gpu_speedup_per_buffer_job"] = (
                 out["cpu_baseline"]["bufnmf_wall_s_200iter_est"] * (iters / WORKLOAD["iters"]) / gpu_job_s)
