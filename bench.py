@@ -233,6 +233,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
 
+    # the same job with host buffers in and out (pageable memory over PCIe), once, outside the timed region:
+    # SURVEY 8(d) "end-to-end BufNMF wall-clock (H2D -> W/H D2H)"
+    fence()
+    t0 = time.perf_counter()
+    corpus.set_audio(audio)
+    corpus.stft()
+    corpus.nmf(iters, seed=wl["seed"])
+    bases_h, acts_h = corpus.writeback()
+    host_io_ms = (time.perf_counter() - t0) * 1e3
+
     # sanity on the result of the last step (not timed)
     a_host = acts.cpu().numpy()
     finite = bool(np.isfinite(a_host).all())
@@ -268,6 +278,7 @@ def main():
                                    f"fft 2048 / hop 512, rank {K}, {iters} iterations, seed 42",
                        "buffers_per_gpu": B, "samples": n, "frames": T, "bins": F, "rank": K,
                        "iterations": iters, "parallelism": f"shard{world}" if world > 1 else "single"},
+            "job_wall_ms_host_buffers_in_and_out": host_io_ms,
             "stft_frames_per_s": (T * B) / (stft_ms * 1e-3) if stft_ms > 0 else None,
             "nmf_iterations_per_s_kernel_only": B / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
             "roofline": {"bound": "mfma", "kernel": "nmf_update5_kernel (v_mfma_f64_4x4x4_4b + LDS-DMA)", "achieved": ach_tflops,
