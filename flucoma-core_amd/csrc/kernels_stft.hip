@@ -275,9 +275,13 @@ __device__ __forceinline__ int lds_pad(int i) { return i + (i >> 4); } // one 16
 // pass's own twiddle table laid out [r-1][k] (k < Ns): lanes read consecutive 16-byte slots, so
 // the reads are bank-conflict free (a single e^{-2 pi i m / fft} table is read at stride 16 r
 // slots in the middle pass: a 16-way conflict).
-template <int R, int NB, int NS_>
+// KEEP: the last pass (NS_ == points / R, so k == j and the outputs land at j + r NS_): the lane's own outputs are
+// exactly the bins k = lane + 64 i it handles in the real-FFT split, i = b + r NB -- they are handed back in `pts`
+// in that order and the split does not read them from LDS again.
+template <int R, int NB, int NS_, bool KEEP = false>
 __device__ __forceinline__ void stockham_pass(d2 (&pts)[NB * R], d2* buf, const d2* ptw, int lane)
 {
+  d2 keep[KEEP ? NB * R : 1];
 #pragma unroll
   for (int b = 0; b < NB; b++)
   {
@@ -295,6 +299,16 @@ __device__ __forceinline__ void stockham_pass(d2 (&pts)[NB * R], d2* buf, const 
     const int o = (j - k) * R + k;
 #pragma unroll
     for (int r = 0; r < R; r++) buf[lds_pad(o + r * NS_)] = v[r];
+    if constexpr (KEEP)
+    {
+#pragma unroll
+      for (int r = 0; r < R; r++) keep[b + r * NB] = v[r];
+    }
+  }
+  if constexpr (KEEP)
+  {
+#pragma unroll
+    for (int i = 0; i < NB * R; i++) pts[i] = keep[i];
   }
 }
 
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
     for (int bb = 0; bb < NB3; bb++)
 #pragma unroll
       for (int r = 0; r < R3; r++) p3[bb * R3 + r] = buf[lds_pad(lane + 64 * bb + r * (N / R3))];
-    stockham_pass<R3, NB3, R1 * R2>(p3, buf, tw3, lane);
+    stockham_pass<R3, NB3, R1 * R2, true>(p3, buf, tw3, lane);
     // ---- real split + magnitude: X[k], k = lane + 64 i (and k = N on lane 0) ------------------
     double* magRow = a.mag ? a.mag + (int64_t) b * a.magStride + (int64_t) t * a.ldMag : nullptr;
     double* specRow = a.spec ? a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2 : nullptr;
@@ -458,7 +472,7 @@ __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
     for (int i = 0; i < PPL; i++)
     {
       const int k = lane + 64 * i;
-      const d2 A = buf[lds_pad(k)], Bc = buf[lds_pad((N - k) & (N - 1))];
+      const d2 A = p3[i], Bc = buf[lds_pad((N - k) & (N - 1))]; // A: this lane's own output of the last pass
       const double er = 0.5 * (A[0] + Bc[0]), ei = 0.5 * (A[1] - Bc[1]);
       const double dr = 0.5 * (A[0] - Bc[0]), di = 0.5 * (A[1] + Bc[1]);
       const d2 w = twg[k]; // natural-order table from global memory (L1/L2 resident, coalesced)
