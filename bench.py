@@ -86,7 +86,6 @@ def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
     """The oracle's faithful mode (all seven GEMMs of alg/NMF.hpp:158-173 per iteration) on ONE
     buffer of the same workload, one core -- what one BufNMF job costs the reference."""
     import oracle_c
-    import oracle_np
     o = oracle_c.get("native")
     n = audio_one.shape[0]
     t0 = time.perf_counter()
@@ -151,11 +150,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU through
+        # torch.distributed.run, rendezvous on the loopback address (the container hostname may not resolve)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                                  f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs a torch.distributed.run launch with "
-                  f"--nproc-per-node {args.gpus}", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+        sys.exit(2)
 
     # torch first: it owns the HIP runtime the process shares; our library is loaded afterwards
     import torch
@@ -164,8 +171,10 @@ def main():
     # FLUHIP_BENCH_BACKEND=gloo is a debugging aid: it lets the N > 1 control flow run on a box with
     # fewer GPUs than ranks (ranks share devices, the gather goes through host memory).  The driver's
     # runs use the default: one rank per GPU, RCCL.
-    backend = os.environ.get("FLUHIP_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
+    # fewer GPUs than ranks (a rehearsal of the N > 1 control flow on a small box): ranks share devices and the
+    # gather goes through host memory; RCCL refuses two ranks on one device
+    backend = os.environ.get("FLUHIP_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
     if backend == "gloo":
         local = local % ndev
     assert local < ndev, f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPUs visible"
@@ -178,8 +187,8 @@ def main():
             dist.init_process_group(backend)
 
     import fluhip
-    import oracle_np
     import sharding
+    import synth
     ctx = fluhip.Context(local)
     name, arch, cus = ctx.device_info()
 
@@ -188,7 +197,7 @@ def main():
     # synthetic corpus of world*B buffers, contiguous-block sharded; global buffer g uses audio
     # seed 1000 + g
     g_begin, g_end = sharding.shard_range(world * B, world, rank)
-    audio = np.stack([oracle_np.synth_audio(n, 1000 + g) for g in range(g_begin, g_end)])
+    audio = np.stack([synth.synth_audio(n, 1000 + g) for g in range(g_begin, g_end)])
     corpus = fluhip.Corpus(ctx, B, n, wl["win"], wl["fft"], wl["hop"], K)
     T, F = corpus.T, corpus.F
     audio_dev = torch.from_numpy(audio).cuda()           # resident in HBM before the timed region
@@ -243,9 +252,15 @@ def main():
     bases_h, acts_h = corpus.writeback()
     host_io_ms = (time.perf_counter() - t0) * 1e3
 
-    # sanity on the result of the last step (not timed)
+    # sanity on the result of the last step (not timed); the checksum weights buffer g's float outputs by g + 1, over the whole
+    # corpus in global buffer order, as every rank holds them after the gather -- equal for any rank count with the same
+    # total number of buffers (tests/test_gpu_parity.py compares --gpus 2 against --gpus 1)
     a_host = acts.cpu().numpy()
     finite = bool(np.isfinite(a_host).all())
+    all_b = gathered["bases"] if world > 1 else bases
+    all_a = gathered["acts"] if world > 1 else acts
+    wts = torch.arange(1, all_b.shape[0] + 1, dtype=torch.float64, device=all_b.device)
+    checksum = float((wts * (all_b.double().sum(dim=(1, 2)) + all_a.double().sum(dim=(1, 2)))).sum().item())
 
     if rank == 0:
         ms_per_step = elapsed_max / args.steps * 1e3
@@ -259,13 +274,17 @@ def main():
         ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
         # gfx950 rocprofv3 correction + WRITE_SIZE); only quoted for the workload they were taken on
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_update_kernel.json")))
-            if (B, K, T, F) == (128, 32, 862, 1025):
-                traffic = pmc["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic, traffic_src = None, None
+        for rnd in ("r02", "r01"):
+            try:
+                path = os.path.join("profiles", rnd, "pmc_update_kernel.json")
+                pmc = json.load(open(os.path.join(ROOT, path)))
+                if (B, K, T, F) == (128, 32, 862, 1025):
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    traffic_src = f"{path}: separate rocprofv3 --pmc passes of this command, not measured in this run"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         stft_ms = ms_stft / max(n_stft, 1)
         stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
         out = {
@@ -283,7 +302,8 @@ def main():
             "nmf_iterations_per_s_kernel_only": B / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
             "roofline": {"bound": "mfma", "kernel": "nmf_update5_kernel (v_mfma_f64_4x4x4_4b + LDS-DMA)", "achieved": ach_tflops,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
-                         "traffic": traffic, "launches": int(n_upd), "avg_launch_ms": avg_ms,
+                         "traffic": traffic, "traffic_from_profile": traffic_src,
+                         "launches": int(n_upd), "avg_launch_ms": avg_ms,
                          "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": ach_gbs / PEAK_HBM_GBS}},
@@ -294,7 +314,8 @@ def main():
             "schedule": dict(corpus.plan(), between_updates_ms_per_iteration=(ms_mid / max(n_mid, 1))),
             "device": {"name": name, "arch": arch, "compute_units": cus,
                        "corpus_device_bytes": corpus.device_bytes()},
-            "result_finite": finite,
+            "result_finite": finite, "result_checksum": checksum, "total_buffers": world * B,
+            "backend": "single process" if world == 1 else ("rccl" if backend == "nccl" else backend + " (ranks share devices)"),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(audio[0], wl, args.cpu_seconds, bases[0].cpu().numpy(), a_host[0])

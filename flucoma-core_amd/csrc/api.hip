@@ -1698,7 +1698,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   const int64_t F = fft / 2 + 1;
   // StreamingControl bookkeeping (cc/FluidNRTClientWrapper.hpp:564-579, 642-644)
   const int64_t latencyHops = win / hop;
-  const int64_t T = 1 + (n + win) / hop - latencyHops;
+  const int64_t T = 1 + (n + 2 * (win / 2)) / hop - latencyHops; // paddedLength = n + win + 2 (win >> 1), :564-579
   const int64_t frameOffset = latencyHops * hop - win;
   if (T < 1) return fail(ctx, "not enough frames");
   if (frames_out) *frames_out = T;

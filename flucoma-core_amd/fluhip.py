@@ -267,7 +267,7 @@ class Context:
     # ---- feature pipeline -----------------------------------------------------------------
     @staticmethod
     def feature_frames(n, win, hop):
-        return 1 + (n + win) // hop - win // hop
+        return 1 + (n + 2 * (win // 2)) // hop - win // hop
 
     def bufmfcc(self, audio, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0,
                 sr=44100.0):

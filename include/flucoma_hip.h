@@ -174,7 +174,7 @@ int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* p
  *   NRTThreadedMelBandsClient  clients/rt/MelBandsClient.hpp:77-119  (MelBands::processFrame, alg/MelBands.hpp:79-97)
  *   NRTThreadedMFCCClient      clients/rt/MFCCClient.hpp:86-131      (+ DCT::processFrame, alg/DCT.hpp:65-75)
  * as driven by StreamingControl with the default padding (clients/common/FluidNRTClientWrapper.hpp:551-660):
- * T = 1 + (n + win)/hop - win/hop frames, frame k starting at sample (win/hop)*hop - win - win/2 + k*hop
+ * T = 1 + (n + 2 (win/2))/hop - win/hop frames, frame k starting at sample (win/hop)*hop - win - win/2 + k*hop
  * (for hop | win: [k*hop - win/2, k*hop + win/2), T = n/hop + 1).
  * audio: count x n floats.  out: count x nFeatures x T floats, feature-major per buffer like
  * BufferAdaptor::samps(feature).  Either may be a host or a device pointer (a corpus that already sits in HBM

@@ -671,7 +671,7 @@ void fo_melbands(const double* mag, int64_t T, int64_t F, const double* filt, in
  * win/hop frames are dropped.  Kept frame k starts at audio sample start0 + k*hop. */
 static int64_t feature_frames(int64_t n, int64_t win, int64_t hop, int64_t* start0)
 {
-  const int64_t nAnalysis = 1 + (n + win) / hop;
+  const int64_t nAnalysis = 1 + (n + 2 * (win / 2)) / hop; /* paddedLength = n + latency + 2 (win >> 1), :564-569 */
   const int64_t latencyHops = win / hop;
   *start0 = latencyHops * hop - win - win / 2;
   return nAnalysis - latencyHops;

@@ -109,7 +109,7 @@ void fo_melbands(const double* mag, int64_t T, int64_t F, const double* filt, in
                  int magNorm, int usePower, int logOutput, double* out);
 /* BufMFCC on one channel with the default padding mode (rt/MFCCClient.hpp:86-131 driven by
  * StreamingControl, cc/FluidNRTClientWrapper.hpp:551-660): kept frame k starts at audio sample
- * (win/hop)*hop - win - win/2 + k*hop; T = 1 + (n + win)/hop - win/hop.  For hop | win that is the
+ * (win/hop)*hop - win - win/2 + k*hop; T = 1 + (n + 2 (win/2))/hop - win/hop.  For hop | win that is the
  * framing of fo_stft: [k*hop - win/2, k*hop + win/2), T = n/hop + 1.
  * out: nCoefs x T floats (channel-major like BufferAdaptor::samps(i)).  Returns T. */
 int64_t fo_bufmfcc_channel(const float* audio, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t nBands,

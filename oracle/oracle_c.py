@@ -200,7 +200,7 @@ class Oracle:
 
 
     def _feature_T(self, n, win, hop):
-        return 1 + (n + win) // hop - win // hop
+        return 1 + (n + 2 * (win // 2)) // hop - win // hop
 
     def mel_filters(self, lo, hi, n_bands, n_bins, sr):
         f = np.empty((n_bands, n_bins))

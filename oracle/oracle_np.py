@@ -270,21 +270,12 @@ def resynth_component(spec, W1, H1, V1, k, win, fft, hop, n):
 # --------------------------------------------------------------------------------------
 # synthetic audio (SURVEY 8 d): decaying sinusoid "notes" + -40 dB noise, float32
 # --------------------------------------------------------------------------------------
-def synth_audio(n: int, seed: int, sr: float = 44100.0, notes: int = 8) -> np.ndarray:
-    rs = np.random.RandomState(seed)
-    t = np.arange(n, dtype=np.float64) / sr
-    x = np.zeros(n)
-    dur = n / sr
-    for _ in range(notes):
-        onset = rs.uniform(0, 0.8 * dur)
-        f = np.exp(rs.uniform(np.log(100.0), np.log(8000.0)))
-        decay = rs.uniform(2.0, 12.0)
-        amp = rs.uniform(0.2, 1.0)
-        tt = np.maximum(t - onset, 0.0)
-        x += np.where(t >= onset, amp * np.exp(-decay * tt) * np.sin(2 * np.pi * f * tt), 0.0)
-    x += 0.01 * rs.standard_normal(n)
-    x /= max(1.0, np.abs(x).max())
-    return x.astype(np.float32)
+# the workload generator is product-side data plumbing (bench.py, tools/), not a checker: it lives in the package and
+# is re-exported here so the tests and the fixtures' generator script keep one definition
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "flucoma-core_amd"))
+from synth import synth_audio  # noqa: E402,F401
 
 
 def drum_like(n, seed=7):
@@ -324,7 +315,7 @@ def feature_frames(n: int, win: int, hop: int):
     """(T, first-sample offset of frame 0) of the buffered feature clients with default padding:
     nAnalysisFrames = 1 + (n + 2 win - win) // hop, minus win // hop latency frames; analysis frame j
     sees padded[j hop - win, j hop), audio sits at padded[win // 2 :]."""
-    n_analysis = 1 + (n + win) // hop
+    n_analysis = 1 + (n + 2 * (win // 2)) // hop   # paddedLength = n + win + 2 (win >> 1), less one window
     latency_hops = win // hop
     T = n_analysis - latency_hops
     start0 = latency_hops * hop - win - win // 2
@@ -431,3 +422,116 @@ def bufstft_inverse(mag, phase, win, fft, hop, padding_mode=1):
         acc[t * hop:t * hop + win] += frames[t]
         nrm[t * hop:t * hop + win] += w2
     return (acc / np.maximum(nrm, EPS))[pad:]
+
+
+# --------------------------------------------------------------------------------------
+# FluidSource / FluidSink / BufferedProcess (cc/FluidSource.hpp:20-175, cc/FluidSink.hpp, cc/BufferedProcess.hpp:35-112):
+# the ring buffers every buffered real-time client frames its input with.  Restated literally so that the
+# reference's own known-answer tests of them (tests/clients/common/TestFluidSource.cpp:17-59,
+# TestBufferedProcess.cpp:20-70) can be replayed, and so that the closed-form frame bookkeeping of
+# feature_frames() above is DERIVED from the ring-buffer behaviour instead of asserted.
+# --------------------------------------------------------------------------------------
+class FluidSourceModel:
+    """cc/FluidSource.hpp: single channel; buffer of size + hostSize samples; push appends a host block at the
+    write counter (:117-127, counter advance in copyIn :159-170), pull(frame, frameTime) reads the `blocksize` samples
+    that END hostSize - frameTime samples behind the write counter (:68-90)."""
+
+    def __init__(self, size, host_size, dtype=np.float64):
+        self.size, self.host = size, host_size
+        self.buf = np.zeros(size + host_size, dtype=dtype)
+        self.counter = 0
+
+    def buffer_size(self):
+        return self.size + self.host
+
+    def push(self, block):
+        block = np.asarray(block)
+        bs, B = block.shape[0], self.buffer_size()
+        assert bs <= B
+        off = self.counter
+        size = B - off if off + bs > B else bs
+        if size:                               # copyIn (:159-170): the counter moves only when something was copied,
+            self.buf[off:off + size] = block[:size]     # to offset + size -- it may rest AT bufferSize, never wraps itself
+            self.counter = off + size
+        if bs - size:
+            self.buf[:bs - size] = block[size:]
+            self.counter = bs - size
+
+    def pull(self, blocksize, frame_time):
+        B = self.buffer_size()
+        offset = self.host - frame_time
+        if offset > B:
+            return np.zeros(blocksize, dtype=self.buf.dtype)
+        offset += blocksize
+        offset = self.counter - offset if offset <= self.counter else self.counter + B - offset
+        size = B - offset if offset + blocksize > B else blocksize
+        return np.concatenate([self.buf[offset:offset + size], self.buf[:blocksize - size]])
+
+
+class FluidSinkModel:
+    """cc/FluidSink.hpp: overlap-add ring of size + hostSize samples; push(frame, frameTime) adds a frame starting
+    frameTime samples after the read counter, pull hands out the next host block and zeroes it behind itself."""
+
+    def __init__(self, size, host_size):
+        self.size, self.host = size, host_size
+        self.buf = np.zeros(size + host_size)
+        self.counter = 0
+
+    def push(self, frame, frame_time):
+        B = self.buf.shape[0]
+        bs = frame.shape[0]
+        assert bs <= B
+        off = frame_time
+        if off + bs > B:                       # cc/FluidSink.hpp:52: a frame that would lap the ring is dropped
+            return
+        off += self.counter
+        off = off if off < B else off - B
+        size = B - off if off + bs > B else bs
+        self.buf[off:off + size] += frame[:size]
+        self.buf[:bs - size] += frame[size:]
+
+    def pull(self, blocksize):
+        B = self.buf.shape[0]
+        off = self.counter
+        size = B - off if off + blocksize > B else blocksize
+        out = np.concatenate([self.buf[off:off + size], self.buf[:blocksize - size]])
+        if size:                               # outAndZero (:141-153)
+            self.buf[off:off + size] = 0
+            self.counter = off + size
+        if blocksize - size:
+            self.buf[:blocksize - size] = 0
+            self.counter = blocksize - size
+        return out
+
+
+def streaming_control_frame_starts(n, win, hop):
+    """First audio sample index of every frame the offline-wrapped feature clients keep, found by RUNNING the model:
+    StreamingControl (cc/FluidNRTClientWrapper.hpp:551-660) pads the input by win/2 in front (userPadding.first for
+    the default padding of the analysis clients), feeds it to the client in host blocks of `hop` samples
+    (c.hostVectorSize(controlRate), :575), the client's BufferedProcess pulls a win-sample frame per hop from its
+    FluidSource (cc/BufferedProcess.hpp:78-95), and the first latency/hop output columns are dropped (:643-656).
+    The padded signal here carries sample INDICES (audio sample i -> value i + 1, padding -> 0), so the pulled frames
+    say where they came from.  Returns (T, [start sample of kept frame k])."""
+    pad = win // 2                                 # FFTParams::padding, default mode (cc/ParameterTypes.hpp:315-323)
+    latency = win                                  # analysis clients: latency() = winSize
+    padded_len = n + latency + 2 * pad             # :564-569: totalPadding = latency + 2 userPadding.first; audio at [pad, pad + n)
+    n_analysis = 1 + (padded_len - win) // hop
+    padded = np.zeros(padded_len + hop, dtype=np.int64)
+    padded[pad:pad + n] = np.arange(1, n + 1)
+    src = FluidSourceModel(win, hop, dtype=np.int64)
+    frame_time = 0
+    frames = []
+    for j in range(n_analysis):
+        src.push(padded[j * hop:(j + 1) * hop])
+        while frame_time < hop:                    # BufferedProcess::processInput
+            frames.append(src.pull(win, frame_time))
+            frame_time += hop
+        frame_time -= hop
+    latency_hops = latency // hop
+    kept = frames[latency_hops:]
+    starts = []
+    for f in kept:
+        nz = np.flatnonzero(f)
+        # a frame lying wholly in the padding carries no index; callers only compare frames that touch the audio
+        starts.append(int(f[nz[0]] - 1 - nz[0]) if nz.size else None)
+    return n_analysis - latency_hops, starts

@@ -50,6 +50,15 @@ def fluhip_lib_path():
 
 
 @pytest.fixture(scope="session")
+def driver(fluhip_lib_path):
+    """tests/cpp/client_driver.cpp built against the in-tree library: the C++17 host client as a host wrapper uses it"""
+    spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_host_tests()
+
+
+@pytest.fixture(scope="session")
 def ctx(fluhip_lib_path):
     """A fluhip context on device 0.  GPU tests must not silently pass without one."""
     import fluhip

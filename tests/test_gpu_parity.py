@@ -723,11 +723,12 @@ def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
 @pytest.mark.parametrize("n,win,fft,hop", [(88200, 1024, 1024, 512),   # config 5 slice: 173 frames
                                            (30000, 1024, 2048, 256), (20000, 2048, 2048, 512),
                                            (12345, 1000, 1024, 300),    # hop does not divide win
+                                           (5024, 301, 512, 75),        # odd window: padding 2 (win >> 1) = win - 1
                                            (5000, 256, 256, 64)])
 def test_bufmfcc_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
     audio = np.stack([onp.synth_audio(n, 7000 + b) for b in range(3)])
     got = ctx.bufmfcc(audio, win, fft, hop)
-    assert got.shape == (3, 13, 1 + (n + win) // hop - win // hop)
+    assert got.shape == (3, 13, 1 + (n + 2 * (win // 2)) // hop - win // hop)
     if (n, win, hop) == (88200, 1024, 512):
         assert got.shape[2] == 173
     for b in range(3):
@@ -819,3 +820,22 @@ def test_stft_gaussian_window_needs_odd_size(ctx):
         ctx.stft(x, 512, 512, 128, window_type=4)      # alg/WindowFuncs.hpp:69 assert(size % 2)
     spec, mag = ctx.stft(x + 1.0, 511, 512, 128, window_type=4)
     assert np.isfinite(mag).all()
+
+
+@pytest.mark.parametrize("n,win,fft,hop", [(20000, 1024, 1024, 256), (9999, 512, 512, 100), (5024, 301, 512, 75)])
+def test_feature_frame_positions_follow_fluidsource(ctx, onp, n, win, fft, hop):
+    """Frame indexing of the HIP feature path against the restated FluidSource chain
+    (tests/clients/common/TestFluidSource.cpp:17-59 pins that restatement): a unit impulse at sample p lights up exactly
+    the kept frames whose window covers p (the Hann window is zero at its first sample only)."""
+    T, starts = onp.streaming_control_frame_starts(n, win, hop)
+    for p in (0, 1, win // 2, n // 3, n - 2, n - 1):
+        x = np.zeros(n, dtype=np.float32)
+        x[p] = 1.0
+        mb = ctx.bufmelbands(x, win, fft, hop, n_bands=8, lo=20.0, hi=20000.0, normalize=False, scale_db=False)[0]
+        assert mb.shape[1] == T
+        lit = mb.sum(axis=0) > 0
+        _, start0 = onp.feature_frames(n, win, hop)
+        for k in range(T):
+            s = starts[k] if starts[k] is not None else start0 + k * hop
+            covered = s < p < s + win          # i = p - s in 1 .. win-1: non-zero window sample
+            assert bool(lit[k]) == covered, (p, k, s)

@@ -309,3 +309,73 @@ def test_reference_testnmf_processframe_case(oracle):
     b, _ = oracle.nmf_process_frames(x[None, :], bases, 0, 42)
     c, _ = oracle.nmf_process_frames(x[None, :], bases, 0, 7863)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+# ---- the reference's own known answers for the framing of the buffered clients ------------------------------
+@pytest.mark.parametrize("dtype", [np.int64, np.float64])
+@pytest.mark.parametrize("overlap", [4, 3, 2, 1])
+@pytest.mark.parametrize("frame_size", [32, 43, 64, 96, 128, 512])
+def test_reference_testfluidsource_known_delay(onp, frame_size, overlap, dtype):
+    """tests/clients/common/TestFluidSource.cpp:17-59 replayed on the restated FluidSource (oracle_np.FluidSourceModel):
+    host blocks of 64 samples of an iota signal, max frame 1024; every frame pulled at hop = frameSize / overlap
+    equals the input delayed by frameSize -- the reference's known answer, same sizes, same loop."""
+    host, max_frame = 64, 1024
+    framer = onp.FluidSourceModel(max_frame, host, dtype=dtype)
+    data = np.arange(2 * max_frame, dtype=dtype)
+    hop = frame_size // overlap
+    expected = np.zeros(data.size + frame_size, dtype=dtype)
+    expected[frame_size:] = data                                  # :41-43
+    j = k = 0
+    pulled = 0
+    for i in range(0, data.size - host, host):                    # :45
+        framer.push(data[i:i + host])
+        while j < host:                                           # :52-56
+            out = framer.pull(frame_size, j)
+            assert np.array_equal(out, expected[k:k + frame_size]), (i, j, k)
+            j += hop
+            k += hop
+            pulled += 1
+        j = j if j < host else j - host                           # :58
+    assert pulled >= (data.size - host) // hop - 1
+
+
+@pytest.mark.parametrize("frame_size", [32, 64, 256, 1024, 8192])
+def test_reference_testbufferedprocess_cola(onp, frame_size):
+    """tests/clients/common/TestBufferedProcess.cpp:20-70 replayed on the restated FluidSource + FluidSink:
+    a step signal pushed in host blocks of 64, Hann-windowed frames at hop = frameSize / 2 overlap-added back;
+    the output is the input delayed by frameSize to 1e-12 (:60-68)."""
+    host = 64
+    hop = frame_size // 2
+    src = onp.FluidSourceModel(frame_size, host)
+    snk = onp.FluidSinkModel(frame_size, host)
+    total = min(128 * frame_size, 16 * frame_size + 4096)         # the reference runs 128 frames; the tail repeats
+    x = np.zeros(total)
+    x[frame_size:] = 1.0                                          # :33
+    w = onp.hann(frame_size)
+    frame_time = 0
+    for i in range(frame_size, total - host, host):               # :45
+        src.push(x[i:i + host])
+        while frame_time < host:                                  # BufferedProcess::process, cc/BufferedProcess.hpp:52-67
+            snk.push(src.pull(frame_size, frame_time) * w, frame_time)
+            frame_time += hop
+        frame_time = frame_time if frame_time < host else frame_time - host
+        actual = snk.pull(host)
+        assert np.abs(actual - x[i - frame_size:i - frame_size + host]).max() <= 1e-12, i
+
+
+@pytest.mark.parametrize("n,win,hop", [(88200, 1024, 512), (20000, 1024, 256), (9999, 512, 100), (5000, 2048, 300),
+                                       (777, 64, 64), (4096, 1024, 1024), (30000, 4096, 1000), (5001, 301, 75),
+                                       (5024, 301, 75), (999, 33, 11)])
+def test_feature_framing_follows_from_fluidsource(oracle, onp, n, win, hop):
+    """The closed form both oracles (and the HIP path's frameOffset) use for the frames BufMFCC / BufMelBands keep --
+    T = 1 + (n + 2 (win / 2)) / hop - win / hop, frame k starts at (win / hop) hop - win - win / 2 + k hop -- derived by
+    running the restated StreamingControl -> BufferedProcess -> FluidSource chain on a signal of sample indices."""
+    T, start0 = onp.feature_frames(n, win, hop)
+    Tm, starts = onp.streaming_control_frame_starts(n, win, hop)
+    assert Tm == T
+    seen = 0
+    for k, s in enumerate(starts):
+        if s is not None:
+            assert s == start0 + k * hop, (k, s)
+            seen += 1
+    assert seen >= T - 2 - win // hop

@@ -1,100 +1,218 @@
-"""Timing of the other BASELINE configs (c1, c2, c3) through the C ABI: these are parity-test shapes,
-not bench.py lines, but their per-iteration cost shows how the single-buffer (split-R) path behaves.
-    python tools/bench_configs.py [c1 c2 c3]
+"""One JSON line per BASELINE config (c1 .. c5), through the C ABI, with the roofline computed as in bench.py.
+
+    python tools/bench_configs.py [c1] [c2] [c3] [c4x1] [c5] [--no-cpu] [--prof]
+
+The configs other than c4 are parity-test shapes, not bench.py lines; this tool is what DESIGN section 6 quotes for
+them and what the rocprofv3 summaries under profiles/ were taken on (tools/profile_configs.sh).  Work per unit is
+SURVEY 8(d)'s: one NMF iteration = 8 F T K flop and (2 F T + 4 (F K + K T)) 8 bytes; one STFT frame = hop 4 + F 8
+bytes; one MFCC frame (c5) = hop 4 bytes in + nCoefs 4 bytes out.  Times are wall-clock around a drained stream;
+the per-iteration cost is the slope between two iteration counts (the host-side factor initialisation is a fixed
+cost per call), so launch gaps between the kernels of an iteration are inside it.  `cpu_baseline` is the oracle
+(a restatement, not the Eigen binary) on one host core over a bounded sample.
 """
+import json
 import os
 import sys
 import time
 
 import numpy as np
 
-try:  # torch first when it is there: the two then share one HIP runtime (config5's device-resident variant)
+try:  # torch first when it is there: the two then share one HIP runtime (config 5's device-resident variant)
     import torch  # noqa: F401
 except ImportError:
     torch = None
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import fluhip  # noqa: E402
-import oracle_np  # noqa: E402
+import synth  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_TFLOPS = 78.6
 
 CONFIGS = {
-    "c1": dict(n=453932, win=1024, fft=1024, hop=512, K=3, iters=50),
-    "c2": dict(n=2646000, win=2048, fft=2048, hop=512, K=16, iters=200),
-    "c3": dict(n=26460000, win=4096, fft=4096, hop=1024, K=128, iters=20),  # 1 channel, 20 of 500 iterations
-    "c4x1": dict(n=441000, win=2048, fft=2048, hop=512, K=32, iters=200),
+    # name: samples, channels/buffers, win, fft, hop, rank, iterations of the config, iterations timed here
+    "c1": dict(n=453932, B=1, win=1024, fft=1024, hop=512, K=3, iters=50, timed=50,
+               what="BASELINE config 1 shape (10.3 s mono, the bundled loop's length), rank 3, 50 iterations"),
+    "c2": dict(n=2646000, B=1, win=2048, fft=2048, hop=512, K=16, iters=200, timed=200,
+               what="BASELINE config 2: 60 s mono, fft 2048 / hop 512, rank 16, 200 iterations"),
+    "c3": dict(n=26460000, B=2, win=4096, fft=4096, hop=1024, K=128, iters=500, timed=20,
+               what="BASELINE config 3: 10 min stereo (2 channels resident as one corpus), fft 4096 / hop 1024, "
+                    "rank 128; 20 of the 500 iterations timed (the cost per iteration is constant)"),
+    "c4x1": dict(n=441000, B=1, win=2048, fft=2048, hop=512, K=32, iters=200, timed=200,
+                 what="one buffer of BASELINE config 4 on its own: 10 s mono, rank 32, 200 iterations"),
 }
 
 
+def device_line(ctx):
+    name, arch, cus = ctx.device_info()
+    return {"name": name, "arch": arch, "compute_units": cus}
+
+
+def cpu_nmf(mag, K, seed, budget_s=12.0):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_c
+    o = oracle_c.get("native")
+    t0 = time.perf_counter()
+    o.nmf_process(mag, K, 1, True, True, seed, faithful=True)
+    one = time.perf_counter() - t0
+    it = int(max(1, min(20, budget_s / max(one, 1e-9))))
+    t0 = time.perf_counter()
+    o.nmf_process(mag, K, it, True, True, seed, faithful=True)
+    dt = time.perf_counter() - t0
+    return {"value": it / dt, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{it} iterations of one channel, oracle faithful mode (7 GEMMs per iteration), gcc -O3 -march=native"}
+
+
+def run_nmf_config(ctx, name, with_cpu):
+    c = CONFIGS[name]
+    B, n, K = c["B"], c["n"], c["K"]
+    # a 10 s synthetic clip per channel, tiled to the requested length
+    chans = []
+    for b in range(B):
+        base = synth.synth_audio(min(n, 441000), 1000 + b)
+        chans.append(np.tile(base, n // len(base) + 1)[:n])
+    x = np.stack(chans)
+    cor = fluhip.Corpus(ctx, B, n, c["win"], c["fft"], c["hop"], K)
+    cor.set_audio(x)
+    cor.stft(); ctx.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cor.stft()
+    ctx.synchronize()
+    t_stft = (time.perf_counter() - t0) / reps
+    ctx.prof_enable(True); ctx.prof_reset()
+    cor.stft(); ctx.synchronize()
+    _, stft_kernel_ms = ctx.prof_read(0)
+    ctx.prof_enable(False)
+    T, F = cor.T, cor.F
+    cor.nmf(2, seed=42); ctx.synchronize()
+    n2 = c["timed"]
+    n1 = max(2, n2 // 4)
+    t0 = time.perf_counter(); cor.nmf(n1, seed=42); ctx.synchronize(); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); cor.nmf(n2, seed=42); ctx.synchronize(); t2 = time.perf_counter() - t0
+    per_it = (t2 - t1) / (n2 - n1)                      # all B channels advance one iteration
+    fixed_ms = max(t2 - per_it * n2, 0.0) * 1e3
+    # kernel-only view of the same loop (HIP events on the context's stream)
+    ctx.prof_enable(True); ctx.prof_reset()
+    cor.nmf(n1, seed=42); ctx.synchronize()
+    n_upd, ms_upd = ctx.prof_read(1)
+    n_mid, ms_mid = ctx.prof_read(3)
+    ctx.prof_enable(False)
+    flop_it = 8.0 * F * T * K * B
+    bytes_it = (2.0 * F * T + 4.0 * (F * K + K * T)) * 8.0 * B
+    tf = flop_it / per_it / 1e12
+    gbs = bytes_it / per_it / 1e9
+    ai = flop_it / bytes_it
+    bound = "mfma" if ai > PEAK_FP64_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm"
+    roof = ({"bound": "mfma", "achieved": tf, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_TFLOPS}
+            if bound == "mfma" else
+            {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS})
+    roof.update({"per": "NMF iteration (all launches of it, gaps included)", "flop": flop_it, "bytes": bytes_it,
+                 "other_view": {"TFLOP/s": tf, "GB/s": gbs}, "traffic": None})
+    stft_bytes = (c["hop"] * 4.0 + F * 8.0) * T * B
+    out = {
+        "config": name, "workload": c["what"],
+        "metric": "NMF iterations/s (channel-iterations; all channels advance together)",
+        "value": B / per_it, "unit": "iterations/s", "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+        "us_per_iteration": per_it * 1e6, "fixed_ms_per_call": fixed_ms,
+        "nmf_job_ms_est": (fixed_ms + per_it * c["iters"] * 1e3),
+        "kernel_ms_per_iteration": {"updates": ms_upd / n1, "between": ms_mid / n1,
+                                    "update_launches_per_iteration": n_upd / n1},
+        "stft_frames_per_s": T * B / t_stft, "stft_ms": t_stft * 1e3, "stft_kernel_ms": stft_kernel_ms,
+        "shape": {"channels": B, "samples": n, "frames": T, "bins": F, "rank": K, "iterations": c["iters"],
+                  "iterations_timed": n2},
+        "roofline": roof,
+        "roofline_stft": {"bound": "hbm", "achieved": stft_bytes / t_stft / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": stft_bytes / t_stft / 1e9 / PEAK_HBM_GBS, "per": "STFT phase (every launch of it)",
+                          "bytes": stft_bytes},
+        "schedule": cor.plan(), "device": dict(device_line(ctx), corpus_device_bytes=cor.device_bytes()),
+    }
+    if with_cpu:
+        mag = cor.read_f64(mag=True, factors=False)[0][0] if B * T * F * 8 < (1 << 30) else None
+        if mag is None:   # c3: one channel's magnitudes come back alone
+            one = fluhip.Corpus(ctx, 1, n, c["win"], c["fft"], c["hop"], K)
+            one.set_audio(x[:1]); one.stft()
+            mag = one.read_f64(mag=True, factors=False)[0][0]
+            one.close()
+        out["cpu_baseline"] = cpu_nmf(np.ascontiguousarray(mag), K, 42)
+        out["cpu_baseline"]["gpu_speedup_per_channel_iteration"] = (1.0 / per_it) / out["cpu_baseline"]["value"]
+    cor.close()
+    print(json.dumps(out), flush=True)
+
+
+def run_c5(ctx, with_cpu):
+    """BASELINE config 5: STFT -> MelBands(40) -> MFCC(13) over 8192 x 2 s slices (clients/rt/MFCCClient.hpp defaults)."""
+    import ctypes
+    count, n, win, fft, hop, nb, nc = 8192, 88200, 1024, 1024, 512, 40, 13
+    base = np.stack([synth.synth_audio(n, 1000 + b) for b in range(64)])
+    audio = np.tile(base, (count // 64, 1))
+    ctx.bufmfcc(audio[:64], win, fft, hop)
+    t0 = time.perf_counter(); out = ctx.bufmfcc(audio, win, fft, hop); dt_host = time.perf_counter() - t0
+    T = out.shape[2]
+    frames = count * T
+    res = {"config": "c5", "workload": "BASELINE config 5: STFT -> MelBands(40) -> MFCC(13) over 8192 x 2 s mono slices, "
+                                       "fft 1024 / hop 512",
+           "metric": "feature frames/s", "unit": "frames/s", "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "shape": {"slices": count, "samples": n, "frames_per_slice": T, "bands": nb, "coefficients": nc},
+           "ms_host_buffers_in_and_out": dt_host * 1e3, "frames_per_s_host_buffers": frames / dt_host,
+           "device": device_line(ctx)}
+    if torch is not None:
+        a_dev = torch.from_numpy(audio).cuda()
+        o_dev = torch.empty(out.shape, dtype=torch.float32, device="cuda")
+        Tr = ctypes.c_int64(0)
+
+        def run():
+            rc = ctx.lib.fluhip_bufmfcc_f32(ctx.h, ctypes.cast(a_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), count, n,
+                                            win, fft, hop, nb, nc, 0, 20.0, 20000.0, 44100.0,
+                                            ctypes.cast(o_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), ctypes.byref(Tr))
+            assert rc == 0
+        run(); torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        dd = (time.perf_counter() - t0) / reps
+        assert np.array_equal(o_dev.cpu().numpy(), out)
+        ctx.prof_enable(True); ctx.prof_reset()
+        run(); torch.cuda.synchronize()
+        _, ms_stft = ctx.prof_read(0)
+        _, ms_feat = ctx.prof_read(2)
+        ctx.prof_enable(False)
+        nbytes = (hop * 4.0 + nc * 4.0) * frames
+        res.update({"value": frames / dd, "ms": dd * 1e3, "kernel_ms": {"stft": ms_stft, "features": ms_feat},
+                    "roofline": {"bound": "hbm", "achieved": nbytes / dd / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": nbytes / dd / 1e9 / PEAK_HBM_GBS, "bytes": nbytes, "traffic": None,
+                                 "per": "whole call, audio and features resident in HBM"}})
+    else:
+        res["value"] = frames / dt_host
+    if with_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_c
+        o = oracle_c.get("native")
+        t0 = time.perf_counter()
+        for b in range(32):
+            o.bufmfcc_channel(audio[b], win, fft, hop)
+        cpu = (time.perf_counter() - t0) / 32
+        res["cpu_baseline"] = {"value": T / cpu, "unit": "frames/s", "cores": 1, "kind": "port",
+                               "sample": "32 of the 8192 slices, oracle BufMFCC, gcc -O3 -march=native"}
+    print(json.dumps(res), flush=True)
+
+
 def main():
-    names = [a for a in sys.argv[1:] if a != "c5"] or ([] if "c5" in sys.argv[1:] else ["c1", "c2", "c4x1"])
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    with_cpu = "--no-cpu" not in sys.argv
+    names = args or ["c1", "c2", "c4x1"]
     ctx = fluhip.Context(0)
     for name in names:
-        c = CONFIGS[name]
-        # tile a 10 s synthetic clip to the requested length (content is irrelevant for timing)
-        base = oracle_np.synth_audio(min(c["n"], 441000), 1000)
-        x = np.tile(base, c["n"] // len(base) + 1)[:c["n"]].copy()
-        cor = fluhip.Corpus(ctx, 1, c["n"], c["win"], c["fft"], c["hop"], c["K"])
-        cor.set_audio(x[None, :])
-        cor.stft(); ctx.synchronize()
-        t0 = time.perf_counter(); cor.stft(); ctx.synchronize(); t_stft = time.perf_counter() - t0
-        cor.nmf(2, seed=42); ctx.synchronize()
-        # per-iteration cost = slope between two iteration counts (the host-side RNG init of the factors,
-        # util/EigenRandom.hpp semantics, is a fixed cost per call: ~12 ms for c3's 3.6 M draws)
-        n1 = max(2, c["iters"] // 4)
-        t0 = time.perf_counter(); cor.nmf(n1, seed=42); ctx.synchronize(); t1 = time.perf_counter() - t0
-        t0 = time.perf_counter(); cor.nmf(c["iters"], seed=42); ctx.synchronize(); t_nmf = time.perf_counter() - t0
-        per_it = (t_nmf - t1) / (c["iters"] - n1)
-        T, F, K = cor.T, cor.F, c["K"]
-        flop = 8.0 * F * T * K
-        print(f"{name}: T={T} F={F} K={K}  stft {t_stft*1e3:.2f} ms ({T/t_stft/1e6:.2f} Mframes/s)  "
-              f"nmf {c['iters']} it {t_nmf*1e3:.1f} ms; {per_it*1e6:.1f} us/iteration "
-              f"({flop/per_it/1e12:.1f} TF algorithmic), fixed {max(t_nmf - per_it*c['iters'], 0)*1e3:.1f} ms  "
-              f"device {cor.device_bytes()/1e6:.0f} MB")
-        cor.close()
+        if name == "c5":
+            run_c5(ctx, with_cpu)
+        else:
+            run_nmf_config(ctx, name, with_cpu)
+    ctx.close()
 
 
 if __name__ == "__main__":
     main()
-
-
-def config5():
-    """BASELINE config 5: STFT -> MelBands(40) -> MFCC(13) over 8192 x 2 s slices (host buffers in/out)."""
-    import oracle_c
-    ctx = fluhip.Context(0)
-    count, n = 8192, 88200
-    base = np.stack([oracle_np.synth_audio(n, 1000 + b) for b in range(64)])
-    audio = np.tile(base, (count // 64, 1))
-    ctx.bufmfcc(audio[:64], 1024, 1024, 512)
-    t0 = time.perf_counter(); out = ctx.bufmfcc(audio, 1024, 1024, 512); dt = time.perf_counter() - t0
-    frames = out.shape[0] * out.shape[2]
-    o = oracle_c.get("native")
-    t0 = time.perf_counter()
-    for b in range(8):
-        o.bufmfcc_channel(audio[b], 1024, 1024, 512)
-    cpu = (time.perf_counter() - t0) / 8
-    print(f"c5: {count} slices x {out.shape[2]} frames: {dt*1e3:.1f} ms incl. PCIe ({frames/dt/1e6:.1f} Mframes/s); "
-          f"CPU oracle {cpu*1e3:.2f} ms per slice ({out.shape[2]/cpu/1e3:.1f} kframes/s, 1 core) -> {cpu*count/dt:.0f}x")
-    try:  # the same with input and output resident in HBM (what a device-side pipeline would see)
-        import ctypes
-        if torch is None:
-            raise ImportError
-        a_dev = torch.from_numpy(audio).cuda()
-        o_dev = torch.empty(out.shape, dtype=torch.float32, device="cuda")
-        Tr = ctypes.c_int64(0)
-        def run():
-            rc = ctx.lib.fluhip_bufmfcc_f32(ctx.h, ctypes.cast(a_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), count, n,
-                                            1024, 1024, 512, 40, 13, 0, 20.0, 20000.0, 44100.0,
-                                            ctypes.cast(o_dev.data_ptr(), ctypes.POINTER(ctypes.c_float)), ctypes.byref(Tr))
-            assert rc == 0
-        run(); torch.cuda.synchronize()
-        t0 = time.perf_counter(); run(); torch.cuda.synchronize(); dd = time.perf_counter() - t0
-        assert np.array_equal(o_dev.cpu().numpy(), out)
-        print(f"c5 with audio and features resident in HBM: {dd*1e3:.1f} ms ({frames/dd/1e6:.0f} Mframes/s) -> {cpu*count/dd:.0f}x one CPU core")
-    except ImportError:
-        pass
-
-
-if __name__ == "__main__" and "c5" in sys.argv[1:]:
-    config5()

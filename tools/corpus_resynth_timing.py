@@ -4,10 +4,10 @@ import numpy as np
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import fluhip, oracle_np
+import fluhip, synth
 ctx = fluhip.Context(0)
 B, n, K = 128, 441000, 32
-base = np.stack([oracle_np.synth_audio(n, 1000 + b) for b in range(4)])
+base = np.stack([synth.synth_audio(n, 1000 + b) for b in range(4)])
 c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, K)
 c.keep_spectrum(True)
 c.set_audio(np.tile(base, (B // 4, 1))); c.stft(); c.nmf(10, seed=42); ctx.synchronize()

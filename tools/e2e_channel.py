@@ -1,9 +1,9 @@
 import sys, time, numpy as np
 sys.path.insert(0, "flucoma-core_amd"); sys.path.insert(0, "oracle")
-import fluhip, oracle_np
+import fluhip, synth
 ctx = fluhip.Context(0)
 for name, n, win, fft, hop, K, iters in (("c1", 453932, 1024, 1024, 512, 3, 50), ("c2", 2646000, 2048, 2048, 512, 16, 200), ("c4x1", 441000, 2048, 2048, 512, 32, 200)):
-    base = oracle_np.synth_audio(min(n, 441000), 1000)
+    base = synth.synth_audio(min(n, 441000), 1000)
     x = np.tile(base, n // len(base) + 1)[:n].astype(np.float32)
     ctx.bufnmf_channel(x, win, fft, hop, K, iters, 42)
     ts = []

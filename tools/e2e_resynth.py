@@ -2,10 +2,10 @@
 import sys, time, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import fluhip, oracle_np
+import fluhip, synth
 ctx = fluhip.Context(0)
 for name, n, win, fft, hop, K, iters in (("c1", 453932, 1024, 1024, 512, 3, 50), ("c2", 2646000, 2048, 2048, 512, 16, 200)):
-    base = oracle_np.synth_audio(min(n, 441000), 1000)
+    base = synth.synth_audio(min(n, 441000), 1000)
     x = np.tile(base, n // len(base) + 1)[:n].astype(np.float32)
     for rs in (False, True):
         for _ in range(3):   # first calls of a shape load kernels and grow the block cache
