@@ -535,13 +535,21 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
   a.frameOffset = 0;
   a.bigScratch = big_fft_scratch(ctx, c->win, c->fft, c->B * c->T);
   if (stft_needs_scratch(c->win, c->fft) && !a.bigScratch) return FLUHIP_ERROR;
+  // V is kept in both layouts (frame-major for the W update, bin-major for the H update).  The block form of K1
+  // writes both in one pass; shapes it does not cover take the wave / generic kernel and a transposing copy.
+  bool both = false;
   {
     ProfScope p(ctx, 0);
-    launch_stft(a, ctx->stream);
+    if (!stft_needs_scratch(c->win, c->fft))
+      both = launch_stft_block(a, c->magT.as<double>(), c->Fp * c->Tp, c->Tp, ctx->stream);
+    if (!both) launch_stft(a, ctx->stream);
   }
-  // second copy of V with the frame index contiguous, for the H update
-  launch_transpose(c->mag.as<double>(), c->Fp, c->Tp * c->Fp, c->magT.as<double>(), c->Tp,
-                   c->Fp * c->Tp, (int) c->T, (int) c->F, (int) c->B, ctx->stream);
+  if (!both)
+  {
+    ProfScope p(ctx, 4);
+    launch_transpose(c->mag.as<double>(), c->Fp, c->Tp * c->Fp, c->magT.as<double>(), c->Tp,
+                     c->Fp * c->Tp, (int) c->T, (int) c->F, (int) c->B, ctx->stream);
+  }
   HIPCHK(ctx, hipGetLastError());
   c->haveMag = true;
   return FLUHIP_OK;

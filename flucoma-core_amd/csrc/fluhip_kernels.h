@@ -46,6 +46,9 @@ struct StftArgs
 };
 
 void launch_stft(const StftArgs& a, hipStream_t s);
+// block form (kernels_stft2.hip): the same transform writing the frame-major magnitudes (a.mag) AND the bin-major
+// copy magT [B][*][ldMagT] in one pass; false when the shape has no block form (launch_stft + launch_transpose then)
+bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int64_t ldMagT, hipStream_t s);
 // power-of-two fft up to 65536; sizes whose frame does not fit the LDS (above 8192) run their passes through a
 // global-memory workspace the caller provides
 bool stft_supported(int64_t win, int64_t fft);

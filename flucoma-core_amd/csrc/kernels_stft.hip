@@ -692,6 +692,8 @@ void launch_stft(const StftArgs& a, hipStream_t s)
     // wave-per-frame kernels: power-of-two fft with an even window (pairs of window values)
     if (!generic && (a.win % 2) == 0)
     {
+      // the block form (kernels_stft2.hip) without its bin-major output is the faster wave-per-frame kernel
+      if (launch_stft_block(a, nullptr, 0, 0, s)) return;
       if (a.fft == 2048) { launch_stft_wave<16, 8, 8, 8>(k, s); return; }
       if (a.fft == 1024) { launch_stft_wave<8, 8, 8, 8>(k, s); return; }
     }

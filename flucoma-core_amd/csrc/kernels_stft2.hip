@@ -1,0 +1,594 @@
+// kernels_stft2.hip -- K1 in its block form: a workgroup of NW wavefronts transforms NW CONSECUTIVE frames of one
+// buffer (one frame per wavefront, registers + a private LDS exchange buffer) and writes the magnitudes in BOTH
+// layouts the factor updates stream -- frame-major rows straight from the registers, and the bin-major copy
+// (`magT`, frame index contiguous) through an LDS staging step, NW frames of a bin at a time -- so no separate
+// pass over V is needed after the STFT (the transpose kernel read and rewrote all of V: +1.8 GB on the bench shard).
+//
+// Same mathematics and DFT convention as kernels_stft.hip (see there for the reference lines):
+//   algorithm::STFT::process / magnitude   include/flucoma/algorithms/public/STFT.hpp:90-108, 61-66
+//   algorithm::FFT::process                include/flucoma/algorithms/util/FFT.hpp:92-108
+// What changed against stft_wave_kernel (kernels_stft.hip), and what was measured (profiles/r02/stft_notes.md):
+//   * the points cross the LDS as separate real and imaginary planes through ONE 8-byte-per-point buffer (the
+//     wavefront's LDS instructions execute in order, so the imaginary plane may overwrite the real one as soon as
+//     the reads of the real plane have issued): half the LDS per wavefront, and the same buffer then stages the
+//     frame's magnitudes for the bin-major copy;
+//   * the last pass is laid out so that the two bins of every real-FFT pair (k, N - k) end up in the SAME lane
+//     (lane l owns butterflies l and Ns - l; lane 0 owns the two self-paired ones): the split needs no third
+//     exchange (transforms with one last-pass butterfly per lane fetch the partner with ds_bpermute);
+//   * the split's twiddle e^{-2 pi i k / fft}, k = j + Ns r, is (a per-lane constant) x (a compile-time constant),
+//     so nothing is loaded for it inside the frame loop;
+//   * everything the compiler would hoist out of the frame loop and keep in registers (per-point address offsets,
+//     twiddle products) is either expressed as per-lane base + compile-time offset or kept opaque: 190 registers at
+//     fft 2048 (two wavefronts per SIMD), 112 at fft 1024 (four).
+// With its stores disabled the kernel transforms the bench shard's 110 336 frames in 430 us (the FP64 VALU ~70 % busy);
+// writing V twice (1.86 GB, half of it as 64-byte pieces of 1025 different rows) brings it to 775-815 us -- against
+// 973-1030 us for the wave kernel plus the transposing copy on the same boxes.  The stores, not the transform, set
+// the pace: tools/hbm_write_probe.hip reproduces the figure with a plain FMA loop and the same two store patterns.
+#include "fluhip_kernels.h"
+
+#include <cstdlib>
+
+namespace fluhip {
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// register arithmetic runs on (re, im) scalar pairs, not on 128-bit vectors: the two planes cross the LDS separately,
+// and a vector register tuple cannot be half dead
+struct cx
+{
+  double re, im;
+};
+__device__ __forceinline__ cx operator+(cx a, cx b) { return cx{a.re + b.re, a.im + b.im}; }
+__device__ __forceinline__ cx operator-(cx a, cx b) { return cx{a.re - b.re, a.im - b.im}; }
+__device__ __forceinline__ cx tocx(d2 v) { return cx{v[0], v[1]}; }
+
+struct StftBArgs
+{
+  const float* audio;
+  const double* audio64;
+  int64_t n, audioStride;
+  int win, fft, hop, T, F, B;
+  const double* window;   // [max(win, fft)] zero past win
+  const double* twiddle;  // [fft/2] e^{-2 pi i m / fft}
+  double* mag;            // [B][*][ldMag] or nullptr
+  int64_t magStride, ldMag;
+  double* magT;           // [B][*][ldMagT] or nullptr
+  int64_t magTStride, ldMagT;
+  double* spec;
+  int64_t specStride;
+  int frameOffset;
+  int blocksPerBuf;
+  int64_t totalBlocks;
+};
+
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wavefront's global stores
+// (s_waitcnt vmcnt(0)), which here would serialise every frame's stores with the next frame's arithmetic
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+namespace {
+
+__device__ __forceinline__ cx cmul2(cx a, cx b) { return cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cx mul_mi2(cx a) { return cx{a.im, -a.re}; } // a * (-i)
+
+// sqrt(x), x >= 0: v_rsq_f64 seed + two coupled Newton steps + residual correction (rounding error only)
+__device__ __forceinline__ double mag_sqrt2(double x)
+{
+  x = fmax(x, 2.2250738585072014e-308);
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  const double d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+
+__device__ __forceinline__ void bf4(cx& a0, cx& a1, cx& a2, cx& a3)
+{
+  const cx t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, t3 = mul_mi2(a1 - a3);
+  a0 = t0 + t2; a1 = t1 + t3; a2 = t0 - t2; a3 = t1 - t3;
+}
+
+constexpr double kC1 = 0.92387953251128673848; // cos(pi/8)
+constexpr double kS1 = 0.38268343236508977173; // sin(pi/8)
+constexpr double kC2 = 0.70710678118654752440; // sqrt(2)/2
+
+template <int R>
+__device__ __forceinline__ void bfr(cx (&v)[R]);
+
+template <>
+__device__ __forceinline__ void bfr<8>(cx (&v)[8])
+{
+  cx e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+  cx o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+  bf4(e0, e1, e2, e3);
+  bf4(o0, o1, o2, o3);
+  o1 = cx{kC2 * (o1.re + o1.im), kC2 * (o1.im - o1.re)};
+  o2 = mul_mi2(o2);
+  o3 = cx{kC2 * (o3.im - o3.re), -kC2 * (o3.re + o3.im)};
+  v[0] = e0 + o0; v[4] = e0 - o0;
+  v[1] = e1 + o1; v[5] = e1 - o1;
+  v[2] = e2 + o2; v[6] = e2 - o2;
+  v[3] = e3 + o3; v[7] = e3 - o3;
+}
+
+template <>
+__device__ __forceinline__ void bfr<16>(cx (&v)[16])
+{
+  cx s[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+  {
+    s[a][0] = v[a]; s[a][1] = v[a + 4]; s[a][2] = v[a + 8]; s[a][3] = v[a + 12];
+    bf4(s[a][0], s[a][1], s[a][2], s[a][3]);
+  }
+  s[1][1] = cmul2(s[1][1], cx{kC1, -kS1});
+  s[1][2] = cx{kC2 * (s[1][2].re + s[1][2].im), kC2 * (s[1][2].im - s[1][2].re)};
+  s[1][3] = cmul2(s[1][3], cx{kS1, -kC1});
+  s[2][1] = cx{kC2 * (s[2][1].re + s[2][1].im), kC2 * (s[2][1].im - s[2][1].re)};
+  s[2][2] = mul_mi2(s[2][2]);
+  s[2][3] = cx{kC2 * (s[2][3].im - s[2][3].re), -kC2 * (s[2][3].re + s[2][3].im)};
+  s[3][1] = cmul2(s[3][1], cx{kS1, -kC1});
+  s[3][2] = cx{kC2 * (s[3][2].im - s[3][2].re), -kC2 * (s[3][2].re + s[3][2].im)};
+  s[3][3] = cmul2(s[3][3], cx{-kC1, kS1});
+#pragma unroll
+  for (int b = 0; b < 4; b++)
+  {
+    bf4(s[0][b], s[1][b], s[2][b], s[3][b]);
+    v[b] = s[0][b]; v[b + 4] = s[1][b]; v[b + 8] = s[2][b]; v[b + 12] = s[3][b];
+  }
+}
+
+__device__ __forceinline__ int xpad(int i) { return i + (i >> 4); } // one 8-byte slot of padding per 16
+
+// cos / sin of 2 pi r / (2 R) for the split's constant factor e^{-2 pi i r / (2 R)}
+template <int R>
+__device__ __forceinline__ cx split_const(int r)
+{
+  // R = 8: sixteenth roots; R = 4: eighth roots
+  constexpr double c16[8] = {1.0, kC1, kC2, kS1, 0.0, -kS1, -kC2, -kC1};
+  constexpr double s16[8] = {0.0, kS1, kC2, kC1, 1.0, kC1, kC2, kS1};
+  const int q = (R == 8) ? r : 2 * r;
+  return cx{c16[q], -s16[q]};
+}
+
+} // namespace
+
+// One frame's transform from the windowed points to the staged magnitudes, shared by the kernel forms below: pass 1,
+// exchange, pass 2, exchange, pass 3, real-FFT split, |X|.  `pts` holds the windowed points m = lane + 64 bb + r N/R1
+// (x[2m], x[2m+1]); on return the wavefront's buffer xb holds |X[k]| at xb[k], k = 0 .. N (plain index), and the
+// complex bins have been written to specRow when that is not null.
+template <int R1, int R2, int R3>
+struct FftCore
+{
+  static constexpr int N = R1 * R2 * R3, PPL = N / 64;
+  static constexpr int NB1 = N / (64 * R1), NB2 = N / (64 * R2), NB3 = N / (64 * R3);
+  static_assert(NB1 >= 1 && NB2 >= 1 && (NB3 == 1 || NB3 == 2), "tiling");
+  static constexpr int NS2 = R1, NS3 = R1 * R2;
+  static constexpr bool LOCAL = NB3 == 2;        // both bins of a split pair in one lane
+  static constexpr int BUFD = N + N / 16 + 2;    // doubles per wavefront (the + 2 staggers the buffers over the banks)
+  static constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
+  static_assert(R1 == 16 || R1 == 8, "pass-1 radix");
+  static_assert(NS2 % 8 == 0 && NS3 % 16 == 0 && (N / R2) % 16 == 0, "index arithmetic of the exchanges");
+  int lane, jA, jB;
+  cx wA, wB;
+  double* xb;
+  // LDS positions as (per-lane base) + (compile-time offset): slot i of the exchange buffer sits at i + (i >> 4)
+  double* w1p;
+  const double* r2p;
+  double* w2p;
+  const double *r3pA, *r3pB;
+  const d2 *tw2p, *tw3pA, *tw3pB;
+
+  // the pass tables [R2-1][NS2] and [R3-1][NS3] from the natural table e^{-2 pi i m / fft} (m < fft/2)
+  static __device__ __forceinline__ void fill_tables(d2* tw2, const d2* twg, int tid, int nthreads)
+  {
+    for (int i = tid; i < T2 + T3; i += nthreads)
+    {
+      int m;
+      if (i < T2) { const int r = i / NS2 + 1, k = i % NS2; m = k * r * (2 * N / (NS2 * R2)); }
+      else { const int ii = i - T2; const int r = ii / NS3 + 1, k = ii % NS3; m = k * r * (2 * N / (NS3 * R3)); }
+      d2 w = twg[m >= N ? m - N : m];
+      if (m >= N) w = d2{-w[0], -w[1]};
+      tw2[i] = w;
+    }
+  }
+
+  __device__ __forceinline__ void init(double* xb_, const d2* tw2, const d2* twg, int lane_)
+  {
+    const d2* tw3 = tw2 + T2;
+    lane = lane_;
+    xb = xb_;
+    // last-pass butterflies of this lane and the split's per-lane twiddle factors e^{-2 pi i j / fft}
+    jA = lane;
+    jB = LOCAL ? (lane == 0 ? NS3 / 2 : NS3 - lane) : 0;
+    wA = tocx(twg[jA]);
+    wB = LOCAL ? tocx(twg[jB]) : cx{0.0, 0.0};
+    //   pass-1 outputs  (lane + 64 bb) R1 + r    pass-2 inputs   lane + 64 bb + r N/R2
+    //   pass-2 outputs  (j - k) R2 + k + r NS2   pass-3 inputs   j + r NS3
+    w1p = xb + (R1 == 16 ? 17 * lane : 8 * lane + (lane >> 1));
+    r2p = xb + lane + (lane >> 4);
+    const int k2 = lane & (NS2 - 1);
+    const int hi2 = lane - k2;                                  // multiple of NS2
+    w2p = xb + hi2 * R2 + ((hi2 * R2) >> 4) + k2;
+    r3pA = xb + jA + (jA >> 4);
+    r3pB = xb + jB + (jB >> 4);
+    tw2p = tw2 + k2;
+    tw3pA = tw3 + jA;
+    tw3pB = tw3 + jB;
+  }
+
+  __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
+  {
+  SCHED_FENCE();
+  // ---- pass 1 (Ns = 1): butterfly j = lane + 64 bb, outputs at j R1 + r ------------------------------
+#pragma unroll
+  for (int bb = 0; bb < NB1; bb++)
+  {
+    cx v[R1];
+#pragma unroll
+    for (int r = 0; r < R1; r++) v[r] = pts[bb * R1 + r];
+    bfr<R1>(v);
+#pragma unroll
+    for (int r = 0; r < R1; r++) pts[bb * R1 + r] = v[r];
+  }
+  SCHED_FENCE();
+  cx p2[PPL];
+  // exchange 1 -> distribution of pass 2 (butterfly j = lane + 64 bb reads j + r N/R2): real plane, then imaginary
+#pragma unroll
+  for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+    for (int r = 0; r < R1; r++) w1p[(64 * R1 + 4 * R1) * bb + ((R1 == 8 && r >= 8) ? 0 : r)] = pts[bb * R1 + r].re;
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+    for (int r = 0; r < R2; r++) p2[bb * R2 + r].re = r2p[68 * bb + (N / R2 + N / R2 / 16) * r];
+#pragma unroll
+  for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+    for (int r = 0; r < R1; r++) w1p[(64 * R1 + 4 * R1) * bb + ((R1 == 8 && r >= 8) ? 0 : r)] = pts[bb * R1 + r].im;
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+    for (int r = 0; r < R2; r++) p2[bb * R2 + r].im = r2p[68 * bb + (N / R2 + N / R2 / 16) * r];
+  SCHED_FENCE();
+  // ---- pass 2 (Ns = R1): twiddle e^{-2 pi i k r / (R1 R2)}, k = j mod R1 = lane mod R1 -----------------
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+  {
+    cx v[R2];
+    v[0] = p2[bb * R2];
+#pragma unroll
+    for (int r = 1; r < R2; r++) v[r] = cmul2(p2[bb * R2 + r], tocx(tw2p[(r - 1) * NS2]));
+    bfr<R2>(v);
+#pragma unroll
+    for (int r = 0; r < R2; r++) p2[bb * R2 + r] = v[r];
+  }
+  SCHED_FENCE();
+  // exchange 2 -> distribution of pass 3: outputs of butterfly j at (j - k) R2 + k + r NS2
+  cx p3[PPL];
+  auto in3 = [&](int bb, int r) -> const double* {
+    return (LOCAL && bb == 1 ? r3pB : r3pA) + (NS3 + NS3 / 16) * r;
+  };
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+    for (int r = 0; r < R2; r++)
+      w2p[(64 * R2 + 4 * R2) * bb + NS2 * r + ((NS2 * r) >> 4)] = p2[bb * R2 + r].re;
+#pragma unroll
+  for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[bb * R3 + r].re = *in3(bb, r);
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+    for (int r = 0; r < R2; r++)
+      w2p[(64 * R2 + 4 * R2) * bb + NS2 * r + ((NS2 * r) >> 4)] = p2[bb * R2 + r].im;
+#pragma unroll
+  for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[bb * R3 + r].im = *in3(bb, r);
+  SCHED_FENCE();
+  // ---- pass 3 (Ns = R1 R2 = N / R3, so k = j): the outputs are the bins j + r NS3 and stay in registers -----
+#pragma unroll
+  for (int bb = 0; bb < NB3; bb++)
+  {
+    const int j = LOCAL ? (bb == 0 ? jA : jB) : lane + 64 * bb;
+    cx v[R3];
+    v[0] = p3[bb * R3];
+#pragma unroll
+    for (int r = 1; r < R3; r++) v[r] = cmul2(p3[bb * R3 + r], tocx((LOCAL && bb == 1 ? tw3pB : tw3pA)[(r - 1) * NS3]));
+    bfr<R3>(v);
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[bb * R3 + r] = v[r];
+  }
+  SCHED_FENCE();
+  // ---- real-FFT split (util/FFT.hpp:99-106) + magnitude (alg/STFT.hpp:61-66) ------------------------------
+  // bin k = j + r NS3 pairs with N - k = (NS3 - j) + (R3 - 1 - r) NS3  (j > 0), or r -> R3 - r for j = 0
+  // the products of the per-lane factors with the compile-time constants are loop invariant, and hoisted they
+  // would sit in 56 registers for the whole frame loop: keep the factors opaque so they are formed where used
+  asm volatile("" : "+v"(wA.re), "+v"(wA.im), "+v"(wB.re), "+v"(wB.im));
+  const bool l0 = lane == 0;
+  const int srcAddr = ((64 - lane) & 63) * 4;
+  (void) srcAddr;
+  auto partner = [&](int bb, int r) -> cx {
+    if constexpr (LOCAL)
+    {
+      // lane 0: butterfly 0 pairs within itself (r <-> R3 - r, bin 0 with itself), butterfly NS3/2 within itself
+      if (bb == 0)
+      {
+        const cx x0 = p3[(R3 - r) & (R3 - 1)], x1 = p3[R3 + R3 - 1 - r];
+        return cx{l0 ? x0.re : x1.re, l0 ? x0.im : x1.im};
+      }
+      const cx x1 = p3[R3 + R3 - 1 - r], y1 = p3[R3 - 1 - r];
+      return cx{l0 ? x1.re : y1.re, l0 ? x1.im : y1.im};
+    }
+    else
+    {
+      // one butterfly per lane: the partner bin lives in lane 64 - l (register R3 - 1 - r); lane 0 pairs within itself
+      const cx z = p3[R3 - 1 - r];
+      const int lo0 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.re) & 0xffffffff));
+      const int hi0 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.re) >> 32));
+      const int lo1 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.im) & 0xffffffff));
+      const int hi1 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.im) >> 32));
+      const double re = __longlong_as_double(((long long) hi0 << 32) | (unsigned) lo0);
+      const double im = __longlong_as_double(((long long) hi1 << 32) | (unsigned) lo1);
+      const cx own = p3[(R3 - r) & (R3 - 1)];
+      return cx{l0 ? own.re : re, l0 ? own.im : im};
+    }
+  };
+#pragma unroll
+  for (int bb = 0; bb < NB3; bb++)
+  {
+    const int j = LOCAL ? (bb == 0 ? jA : jB) : lane;
+    const cx wj = (LOCAL && bb == 1) ? wB : wA;
+#pragma unroll
+    for (int r = 0; r < R3; r++)
+    {
+      const int i = bb * R3 + r;
+      const cx A = p3[i], Bc = partner(bb, r);
+      const double er = 0.5 * (A.re + Bc.re), ei = 0.5 * (A.im - Bc.im);
+      const double dr = 0.5 * (A.re - Bc.re), di = 0.5 * (A.im + Bc.im);
+      const cx w = r == 0 ? wj : cmul2(wj, split_const<R3>(r));
+      const double xr = er + (w.re * di + w.im * dr);
+      double xi = ei - (w.re * dr - w.im * di);
+      const int k = j + r * NS3;
+      if (k == 0) xi = 0.0;                     // DC is purely real (util/FFT.hpp:99-101)
+      const double m = mag_sqrt2(xr * xr + xi * xi);
+      xb[k] = m;                                // staged (the exchange buffer is idle now)
+      if (specRow) specRow[k] = d2{xr, xi};
+      if (r & 1) SCHED_FENCE();                 // two bins' chains in flight, not sixteen
+    }
+  }
+  if (lane == 0)
+  {
+    const cx z = p3[0];                         // Z[0]: Nyquist = Re - Im, purely real
+    const double xr = z.re - z.im;
+    xb[N] = fabs(xr);
+    if (specRow) specRow[N] = d2{xr, 0.0};
+  }
+  }
+};
+
+template <int R1, int R2, int R3, int NW, int WINLDS>
+__global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
+{
+  constexpr int N = R1 * R2 * R3;  // complex points per frame = fft / 2
+  constexpr int PPL = N / 64;      // points per lane
+  constexpr int NB1 = N / (64 * R1), NB2 = N / (64 * R2), NB3 = N / (64 * R3);
+  static_assert(NB1 >= 1 && NB2 >= 1 && (NB3 == 1 || NB3 == 2), "tiling");
+  constexpr int NS2 = R1, NS3 = R1 * R2;
+  constexpr bool LOCAL = NB3 == 2;            // both bins of a split pair in one lane
+  constexpr int BUFD = N + N / 16 + 2;        // doubles per wavefront (the + 2 staggers the wavefronts' buffers over the banks)
+  constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  d2* tw2 = reinterpret_cast<d2*>(lds);       // [R2-1][NS2]
+  d2* tw3 = tw2 + T2;                         // [R3-1][NS3]
+  d2* wl = tw3 + T3;                          // [N] window pairs when WINLDS
+  double* xall = reinterpret_cast<double*>(wl + (WINLDS ? N : 0));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xb = xall + wave * BUFD;
+
+  const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
+  FftCore<R1, R2, R3>::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
+  const d2* wsrc = reinterpret_cast<const d2*>(a.window);
+  if (WINLDS)
+  {
+    for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = wsrc[m];
+    wsrc = wl;
+  }
+  __syncthreads();
+
+  FftCore<R1, R2, R3> core;
+  core.init(xb, tw2, twg, lane);
+  const int halfWin = a.win / 2;
+  const int nthreads = 64 * NW;
+
+  // blocks are dealt so that workgroups on one XCD (blockIdx & 7) take neighbouring blocks of a buffer: their
+  // segments of a bin-major row fall into the same L2
+  const int64_t chunk = (a.totalBlocks + 7) / 8;
+  // block L of the dealing order -> (buffer, first frame); false past the end
+  auto decode = [&](int64_t L, int& b, int& t0) -> bool {
+    const int64_t slot = L >> 3;
+    const int64_t blk = (L & 7) * chunk + slot;
+    if (slot >= chunk || blk >= a.totalBlocks) return false;
+    b = (int) (blk / a.blocksPerBuf);
+    t0 = (int) (blk % a.blocksPerBuf) * NW;
+    return true;
+  };
+  for (int64_t L = blockIdx.x;; L += gridDim.x)
+  {
+    int b, t0;
+    if ((L >> 3) >= chunk) break;
+    if (!decode(L, b, t0)) continue;
+    const int t = t0 + wave;
+    const bool active = t < a.T;
+
+    if (active)
+    {
+      const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset;
+      cx pts[PPL];
+      // ---- gather + window: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 --------------------
+      // sample positions are 32-bit offsets from the frame's first sample (a wave-uniform 64-bit base); only frames
+      // that stick out of the buffer (or an odd base) take the clamped path
+      const int lo = s0 < 0 ? (int) (-s0 < 2 * N ? -s0 : 2 * N) : 0;                 // first valid offset
+      const int64_t room = a.n - s0;
+      const int hi = room < 2 * N ? (int) (room > 0 ? room : 0) : 2 * N;             // one past the last valid offset
+      if (a.audio)
+      {
+        const float* fp = a.audio + (int64_t) b * a.audioStride + s0;
+        const bool fast = lo == 0 && hi == 2 * N && ((reinterpret_cast<uintptr_t>(fp) & 7) == 0);
+        if (fast)
+        {
+          const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
+#pragma unroll
+          for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+            for (int r = 0; r < R1; r++)
+            {
+              const int mo = 64 * bb + r * (N / R1);
+              const float2 x = lp[mo];
+              const d2 w = wsrc[lane + mo];
+              pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
+            }
+        }
+        else
+        {
+          int ln = lane;                       // (opaque: the per-point offsets of this rare path are not worth registers
+          asm volatile("" : "+v"(ln));         //  across the whole frame loop, where the compiler would hoist them)
+#pragma unroll
+          for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+            for (int r = 0; r < R1; r++)
+            {
+              const int mo = 64 * bb + r * (N / R1);
+              const int i0 = 2 * (ln + mo), i1 = i0 + 1;
+              const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
+              const float v0 = fp[ok0 ? i0 : lo], v1 = fp[ok1 ? i1 : lo];   // lo is a valid offset whenever hi > lo
+              const d2 w = wsrc[lane + mo];
+              pts[bb * R1 + r] = cx{(ok0 ? (double) v0 : 0.0) * w[0], (ok1 ? (double) v1 : 0.0) * w[1]};
+            }
+        }
+      }
+      else
+      {
+        const double* dp = a.audio64 + (int64_t) b * a.audioStride + s0;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+#pragma unroll
+        for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+          for (int r = 0; r < R1; r++)
+          {
+            const int mo = 64 * bb + r * (N / R1);
+            const int i0 = 2 * (ln + mo), i1 = i0 + 1;
+            const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
+            const double v0 = dp[ok0 ? i0 : lo], v1 = dp[ok1 ? i1 : lo];
+            const d2 w = wsrc[lane + mo];
+            pts[bb * R1 + r] = cx{(ok0 ? v0 : 0.0) * w[0], (ok1 ? v1 : 0.0) * w[1]};
+          }
+      }
+      SCHED_FENCE();
+      core.run(pts, a.spec ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
+    }
+    else if (a.magT)
+    {
+      // frames past the end of the buffer: zeros into the padding columns of the bin-major copy
+#pragma unroll
+      for (int i = 0; i < PPL; i++) xb[lane + 64 * i] = 0.0;
+      if (lane == 0) xb[N] = 0.0;
+    }
+
+    if (a.magT) LDS_BARRIER();                        // every wavefront of the block has staged its frame
+    if (active && a.mag)
+    {
+      // frame-major row from the wavefront's own staging buffer, 16 bytes per lane
+      double* magRow = a.mag + (int64_t) b * a.magStride + (int64_t) t * a.ldMag;
+#pragma unroll
+      for (int q = 0; q < N / 128; q++)
+      {
+        const int k = 2 * (lane + 64 * q);
+        *reinterpret_cast<d2*>(magRow + k) = *reinterpret_cast<const d2*>(xb + k);
+      }
+      if (lane == 0) magRow[N] = xb[N];
+    }
+    if (a.magT)
+    {
+      // ---- bin-major copy: NW frames of a bin leave as one piece -------------------------------------------------
+      constexpr int HP = NW / 2;                      // 16-byte pieces (two frames) per bin
+      double* outT = a.magT + (int64_t) b * a.magTStride;
+      const int items = a.F * HP;
+      for (int i = threadIdx.x; i < items; i += nthreads)
+      {
+        const int f = i / HP, p = i - f * HP;
+        const int tc = t0 + 2 * p;
+        if (tc < a.ldMagT)
+        {
+          const double v0 = xall[(2 * p) * BUFD + f], v1 = xall[(2 * p + 1) * BUFD + f];
+          *reinterpret_cast<d2*>(outT + (int64_t) f * a.ldMagT + tc) = d2{v0, v1};
+        }
+      }
+      LDS_BARRIER();
+    }
+  }
+}
+
+template <int R1, int R2, int R3, int NW, int WINLDS>
+static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
+{
+  constexpr int N = R1 * R2 * R3;
+  constexpr int BUFD = N + N / 16 + 2;
+  constexpr int TW = (R2 - 1) * R1 + (R3 - 1) * R1 * R2;
+  constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * BUFD * 8;
+  static_assert(shmem <= 160 * 1024, "LDS");
+  StftBArgs k = k0;
+  k.blocksPerBuf = (k.T + NW - 1) / NW;
+  k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
+  if (k.totalBlocks < 1) return true;
+  auto kern = stft_block_kernel<R1, R2, R3, NW, WINLDS>;
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+  const int64_t chunk = (k.totalBlocks + 7) / 8;
+  int64_t grid = 8 * chunk;
+  const int perCu = (int) ((160 * 1024) / shmem);
+  const int64_t cap = 256 * (int64_t) (perCu < 1 ? 1 : perCu);
+  if (grid > cap) grid = cap;
+  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(64 * NW), shmem, s, k);
+  return true;
+}
+
+// both magnitude layouts from one kernel; false when the shape has no block form (the caller then falls back to
+// launch_stft + launch_transpose)
+bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int64_t ldMagT, hipStream_t s)
+{
+  if ((a.win % 2) != 0 || a.win > a.fft) return false;
+  static const bool off = [] { const char* e = std::getenv("FLUHIP_STFT_BLOCK"); return e && std::atoi(e) == 0; }();
+  if (off) return false;   // A/B: the round-1 wave kernel + transposing copy
+  StftBArgs k;
+  k.audio = a.audio; k.audio64 = a.audio64; k.n = a.n; k.audioStride = a.audioStride;
+  k.win = a.win; k.fft = a.fft; k.hop = a.hop; k.T = a.T; k.F = a.F; k.B = a.B;
+  k.window = a.window; k.twiddle = a.twiddle;
+  k.mag = a.mag; k.magStride = a.magStride; k.ldMag = a.ldMag;
+  k.magT = magT; k.magTStride = magTStride; k.ldMagT = ldMagT;
+  k.spec = a.spec; k.specStride = a.specStride;
+  k.frameOffset = a.frameOffset;
+  k.blocksPerBuf = 0; k.totalBlocks = 0;
+  if (magT && (ldMagT % 2) != 0) return false;
+  if (a.fft == 2048)
+  {
+    // 8 frames per block: 224 registers, two wavefronts per SIMD (12 and 16 per workgroup spill and measured slower)
+    return launch_block_t<16, 8, 8, 8, 1>(k, s);
+  }
+  if (a.fft == 1024)
+  {
+    // 16 frames per block (128 registers, four wavefronts per SIMD): 128-byte pieces of the bin-major rows
+    return launch_block_t<8, 8, 8, 16, 1>(k, s);
+  }
+  return false;
+}
+
+} // namespace fluhip
