@@ -1777,9 +1777,152 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   HIPCHK(ctx, dDct.alloc(dct.size() * sizeof(double), false, s));
   HIPCHK(ctx, hipMemcpyAsync(dFilt.p, filtT.data(), filtT.size() * sizeof(double), hipMemcpyHostToDevice, s));
   HIPCHK(ctx, hipMemcpyAsync(dDct.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  // ---- fused form (kernels_stft2.hip stft_feat_kernel): the magnitudes never leave the chip --------------------------
+  // Every bin must lie on the rising edge of at most one band and the falling edge of the band below it, with the
+  // bins of each edge contiguous: then band b = (sum of up[f] m[f] over interval b) + (sum of dn[f] m[f] over interval
+  // b + 1), interval s = the bins between centres s and s + 1.  True of any filter bank whose triangles are wider than
+  // a bin; checked here against the dense matrix, coefficient by coefficient, and anything else takes the two-kernel path.
+  {
+    const int CH = stft_features_bins_per_lane((int) fft);
+    std::vector<double> up((size_t) 64 * CH, 0.0), dn((size_t) 64 * CH, 0.0);
+    std::vector<short> slot((size_t) 64 * CH, (short) -1);
+    std::vector<int64_t> interval((size_t) F, -1); // interval of bin f, -1: no band touches it
+    bool ok = nBands <= 64 && (!mfcc || nDct * nBands <= 4096) && !stft_needs_scratch(win, fft) && (fft == 1024 || fft == 2048) &&
+              (win % 2) == 0;
+    if (const char* e = std::getenv("FLUHIP_FEAT_FUSED")) // A/B and tests: 0 forces the two-kernel form
+      if (std::atoi(e) == 0) ok = false;
+    std::vector<int64_t> peak((size_t) nBands, 0);
+    for (int64_t b = 0; ok && b < nBands; b++)
+    {
+      double best = -1.0;
+      for (int64_t f = 0; f < F; f++)
+        if (filtT[(size_t) (f * bandsPad + b)] > best) { best = filtT[(size_t) (f * bandsPad + b)]; peak[(size_t) b] = f; }
+      if (best <= 0.0) ok = false; // a band no bin falls into
+    }
+    for (int64_t f = 0; ok && f < F; f++)
+    {
+      int64_t b1 = -1, b2 = -1, cnt = 0;
+      for (int64_t b = 0; b < nBands; b++)
+        if (filtT[(size_t) (f * bandsPad + b)] != 0.0) { if (cnt == 0) b1 = b; else b2 = b; cnt++; }
+      if (cnt == 0) continue;
+      if (cnt > 2 || (cnt == 2 && b2 != b1 + 1)) { ok = false; break; }
+      if (cnt == 2)
+      {
+        interval[(size_t) f] = b2;
+        up[(size_t) f] = filtT[(size_t) (f * bandsPad + b2)];
+        dn[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)];
+      }
+      else if (f <= peak[(size_t) b1]) { interval[(size_t) f] = b1; up[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)]; }
+      else { interval[(size_t) f] = b1 + 1; dn[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)]; }
+    }
+    // interval s starts at bin g[s].  The touched bins must be one contiguous run whose intervals ascend one at a time
+    // from some i0 up to nBands (the falling edge of the last band); intervals below i0 are empty and the running
+    // sums are still 0 at their boundaries, which therefore publish nothing.
+    std::vector<int64_t> g((size_t) nBands + 2, -1);
+    if (ok)
+    {
+      int64_t prev = -1, first = -1, last = -1;
+      bool ended = false;
+      for (int64_t f = 0; f < F && ok; f++)
+      {
+        const int64_t iv = interval[(size_t) f];
+        if (iv < 0) { if (first >= 0) ended = true; continue; }
+        if (ended) { ok = false; break; }              // touched bins are not one contiguous run
+        if (first < 0) first = f;
+        else if (iv != prev && iv != prev + 1) { ok = false; break; }
+        if (iv != prev) g[(size_t) iv] = f;
+        prev = iv;
+        last = f;
+      }
+      if (first < 0 || prev != nBands) ok = false;
+      if (ok)
+      {
+        int64_t i0 = 0;
+        while (g[(size_t) i0] < 0) i0++;
+        for (int64_t sI = 0; sI < i0; sI++) g[(size_t) sI] = first;
+        g[(size_t) nBands + 1] = last + 1;
+        for (int64_t sI = i0 + 1; sI <= nBands + 1; sI++) slot[(size_t) (g[(size_t) sI] - 1)] = (short) sI;
+      }
+      // reconstruction: the segment sums must give back the dense matrix exactly
+      for (int64_t b = 0; ok && b < nBands; b++)
+        for (int64_t f = 0; f < F; f++)
+        {
+          double w = 0.0;
+          if (f >= g[(size_t) b] && f < g[(size_t) b + 1]) w += up[(size_t) f];
+          if (f >= g[(size_t) b + 1] && f < g[(size_t) b + 2]) w += dn[(size_t) f];
+          if (w != filtT[(size_t) (f * bandsPad + b)]) { ok = false; break; }
+        }
+    }
+    if (ok)
+    {
+      DevBuf dUp, dDn, dSlot, dDct2, dAud, dOutF;
+      HIPCHK(ctx, dUp.alloc(up.size() * sizeof(double), false, s));
+      HIPCHK(ctx, dDn.alloc(dn.size() * sizeof(double), false, s));
+      HIPCHK(ctx, dSlot.alloc(slot.size() * sizeof(short), false, s));
+      HIPCHK(ctx, dDct2.alloc(dct.size() * sizeof(double), false, s));
+      HIPCHK(ctx, hipMemcpyAsync(dUp.p, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(dDn.p, dn.data(), dn.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(dSlot.p, slot.data(), slot.size() * sizeof(short), hipMemcpyHostToDevice, s));
+      HIPCHK(ctx, hipMemcpyAsync(dDct2.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
+      // device-resident audio / output are used in place; host buffers go through staging chunks of bounded size
+      hipPointerAttribute_t pa;
+      const bool audDev = hipPointerGetAttributes(&pa, audio) == hipSuccess && pa.type == hipMemoryTypeDevice;
+      const bool outDev = hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeDevice;
+      (void) hipGetLastError();
+      int64_t chunkBytes = (int64_t) 1 << 31;
+      if (const char* e = std::getenv("FLUHIP_FEAT_CHUNK_BYTES")) chunkBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
+      const int64_t chunkB = (audDev && outDev) ? count
+                                                : std::max<int64_t>(1, std::min<int64_t>(count, chunkBytes / (n * (int64_t) sizeof(float))));
+      if (!audDev) HIPCHK(ctx, dAud.alloc((size_t) chunkB * n * sizeof(float), false, s));
+      if (!outDev) HIPCHK(ctx, dOutF.alloc((size_t) chunkB * nOut * T * sizeof(float), false, s));
+      for (int64_t b0 = 0; b0 < count; b0 += chunkB)
+      {
+        const int64_t nb = std::min(chunkB, count - b0);
+        const float* aPtr = audio + b0 * n;
+        if (!audDev)
+        {
+          HIPCHK(ctx, hipMemcpyAsync(dAud.p, aPtr, (size_t) nb * n * sizeof(float), hipMemcpyDefault, s));
+          aPtr = dAud.as<float>();
+        }
+        float* oPtr = outDev ? out + b0 * nOut * T : dOutF.as<float>();
+        StftArgs sa;
+        sa.audio = aPtr; sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
+        sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = (int) nb;
+        sa.window = wtab; sa.twiddle = ttab;
+        sa.mag = nullptr; sa.magStride = 0; sa.ldMag = 0; sa.spec = nullptr; sa.specStride = 0;
+        sa.frameOffset = (int) frameOffset; sa.bigScratch = nullptr;
+        FeatArgs fa;
+        fa.mag = nullptr; fa.magStride = 0; fa.ldMag = 0;
+        fa.T = (int) T; fa.F = (int) F; fa.B = (int) nb; fa.win = (int) win;
+        fa.filtT = nullptr; fa.nBands = (int) nBands; fa.bandsPad = (int) bandsPad;
+        fa.bandLo = nullptr; fa.wpack = nullptr; fa.maxLen = 0;
+        fa.magNorm = mfcc ? 0 : (normalize ? 1 : 0); fa.usePower = 0; fa.logOutput = mfcc ? 1 : (scaleDb ? 1 : 0);
+        fa.dct = mfcc ? dDct2.as<double>() : nullptr; fa.nDct = (int) nDct; fa.startCoeff = (int) startCoeff;
+        fa.nOut = (int) nOut; fa.out = oPtr;
+        bool launched;
+        {
+          ProfScope p(ctx, 2);
+          launched = launch_stft_features(sa, fa, dUp.as<double>(), dDn.as<double>(), dSlot.as<short>(), s);
+        }
+        if (!launched) { ok = false; break; }
+        HIPCHK(ctx, hipGetLastError());
+        if (!outDev)
+          HIPCHK(ctx, hipMemcpyAsync(out + b0 * nOut * T, oPtr, (size_t) nb * nOut * T * sizeof(float), hipMemcpyDefault, s));
+        if (!audDev || !outDev) HIPCHK(ctx, hipStreamSynchronize(s));   // the staging buffers are reused by the next chunk
+      }
+      if (ok)
+      {
+        HIPCHK(ctx, hipStreamSynchronize(s));
+        return FLUHIP_OK;
+      }
+    }
+  }
+  // ---- two-kernel form: magnitudes through HBM, any filter bank / fft size -------------------------------------------
   // buffers are processed in chunks that keep the magnitude scratch around 2 GiB
   const int64_t perBuf = Tp * Fp * (int64_t) sizeof(double);
-  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(count, 65535), (2LL << 30) / perBuf));
+  int64_t scratchBytes = 2LL << 30;
+  if (const char* e = std::getenv("FLUHIP_FEAT_CHUNK_BYTES")) scratchBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
+  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(count, 65535), scratchBytes / perBuf));
   HIPCHK(ctx, dAudio.alloc((size_t) chunk * n * sizeof(float), false, s));
   HIPCHK(ctx, dMag.alloc((size_t) chunk * perBuf, true, s));
   HIPCHK(ctx, dOut.alloc((size_t) chunk * nOut * T * sizeof(float), false, s));

@@ -192,6 +192,13 @@ struct FeatArgs
   float* out;           // [B][nOut][T]
 };
 void launch_features(const FeatArgs& a, hipStream_t s);
+// fused form (kernels_stft2.hip): STFT -> mel bands [-> DCT] without the magnitudes leaving the chip.  up / dn / slot
+// [64 * stft_features_bins_per_lane(fft)]: rising- and falling-edge weight of every bin and the interval boundary a
+// bin closes (or -1); false when the shape has no fused form
+struct StftArgs;
+bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up, const double* dn, const short* slot,
+                          hipStream_t s);
+int stft_features_bins_per_lane(int fft);
 
 // resynthesis: masked inverse STFT of component k with overlap-add
 struct ResynthArgs

@@ -374,6 +374,75 @@ struct FftCore
   }
 };
 
+// gather + window of frame t of buffer b: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 (alg/STFT.hpp:94-105;
+// clients/nrt/NMFClient.hpp:240 float -> double); zero outside [0, n)
+template <int R1, int N>
+__device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, int lane, const d2* wsrc, cx (&pts)[N / 64])
+{
+  constexpr int NB1 = N / (64 * R1);
+  const int64_t s0 = (int64_t) t * a.hop - a.win / 2 + a.frameOffset;
+  // ---- gather + window: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 --------------------
+  // sample positions are 32-bit offsets from the frame's first sample (a wave-uniform 64-bit base); only frames
+  // that stick out of the buffer (or an odd base) take the clamped path
+  const int lo = s0 < 0 ? (int) (-s0 < 2 * N ? -s0 : 2 * N) : 0;                 // first valid offset
+  const int64_t room = a.n - s0;
+  const int hi = room < 2 * N ? (int) (room > 0 ? room : 0) : 2 * N;             // one past the last valid offset
+  if (a.audio)
+  {
+    const float* fp = a.audio + (int64_t) b * a.audioStride + s0;
+    const bool fast = lo == 0 && hi == 2 * N && ((reinterpret_cast<uintptr_t>(fp) & 7) == 0);
+    if (fast)
+    {
+      const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
+#pragma unroll
+      for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+        {
+          const int mo = 64 * bb + r * (N / R1);
+          const float2 x = lp[mo];
+          const d2 w = wsrc[lane + mo];
+          pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
+        }
+    }
+    else
+    {
+      int ln = lane;                       // (opaque: the per-point offsets of this rare path are not worth registers
+      asm volatile("" : "+v"(ln));         //  across the whole frame loop, where the compiler would hoist them)
+#pragma unroll
+      for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+        {
+          const int mo = 64 * bb + r * (N / R1);
+          const int i0 = 2 * (ln + mo), i1 = i0 + 1;
+          const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
+          const float v0 = fp[ok0 ? i0 : lo], v1 = fp[ok1 ? i1 : lo];   // lo is a valid offset whenever hi > lo
+          const d2 w = wsrc[lane + mo];
+          pts[bb * R1 + r] = cx{(ok0 ? (double) v0 : 0.0) * w[0], (ok1 ? (double) v1 : 0.0) * w[1]};
+        }
+    }
+  }
+  else
+  {
+    const double* dp = a.audio64 + (int64_t) b * a.audioStride + s0;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+#pragma unroll
+    for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+      for (int r = 0; r < R1; r++)
+      {
+        const int mo = 64 * bb + r * (N / R1);
+        const int i0 = 2 * (ln + mo), i1 = i0 + 1;
+        const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
+        const double v0 = dp[ok0 ? i0 : lo], v1 = dp[ok1 ? i1 : lo];
+        const d2 w = wsrc[lane + mo];
+        pts[bb * R1 + r] = cx{(ok0 ? v0 : 0.0) * w[0], (ok1 ? v1 : 0.0) * w[1]};
+      }
+  }
+}
+
 template <int R1, int R2, int R3, int NW, int WINLDS>
 __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 {
@@ -431,68 +500,8 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 
     if (active)
     {
-      const int64_t s0 = (int64_t) t * a.hop - halfWin + a.frameOffset;
       cx pts[PPL];
-      // ---- gather + window: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 --------------------
-      // sample positions are 32-bit offsets from the frame's first sample (a wave-uniform 64-bit base); only frames
-      // that stick out of the buffer (or an odd base) take the clamped path
-      const int lo = s0 < 0 ? (int) (-s0 < 2 * N ? -s0 : 2 * N) : 0;                 // first valid offset
-      const int64_t room = a.n - s0;
-      const int hi = room < 2 * N ? (int) (room > 0 ? room : 0) : 2 * N;             // one past the last valid offset
-      if (a.audio)
-      {
-        const float* fp = a.audio + (int64_t) b * a.audioStride + s0;
-        const bool fast = lo == 0 && hi == 2 * N && ((reinterpret_cast<uintptr_t>(fp) & 7) == 0);
-        if (fast)
-        {
-          const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
-#pragma unroll
-          for (int bb = 0; bb < NB1; bb++)
-#pragma unroll
-            for (int r = 0; r < R1; r++)
-            {
-              const int mo = 64 * bb + r * (N / R1);
-              const float2 x = lp[mo];
-              const d2 w = wsrc[lane + mo];
-              pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
-            }
-        }
-        else
-        {
-          int ln = lane;                       // (opaque: the per-point offsets of this rare path are not worth registers
-          asm volatile("" : "+v"(ln));         //  across the whole frame loop, where the compiler would hoist them)
-#pragma unroll
-          for (int bb = 0; bb < NB1; bb++)
-#pragma unroll
-            for (int r = 0; r < R1; r++)
-            {
-              const int mo = 64 * bb + r * (N / R1);
-              const int i0 = 2 * (ln + mo), i1 = i0 + 1;
-              const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
-              const float v0 = fp[ok0 ? i0 : lo], v1 = fp[ok1 ? i1 : lo];   // lo is a valid offset whenever hi > lo
-              const d2 w = wsrc[lane + mo];
-              pts[bb * R1 + r] = cx{(ok0 ? (double) v0 : 0.0) * w[0], (ok1 ? (double) v1 : 0.0) * w[1]};
-            }
-        }
-      }
-      else
-      {
-        const double* dp = a.audio64 + (int64_t) b * a.audioStride + s0;
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-#pragma unroll
-        for (int bb = 0; bb < NB1; bb++)
-#pragma unroll
-          for (int r = 0; r < R1; r++)
-          {
-            const int mo = 64 * bb + r * (N / R1);
-            const int i0 = 2 * (ln + mo), i1 = i0 + 1;
-            const bool ok0 = i0 >= lo && i0 < hi, ok1 = i1 >= lo && i1 < hi;
-            const double v0 = dp[ok0 ? i0 : lo], v1 = dp[ok1 ? i1 : lo];
-            const d2 w = wsrc[lane + mo];
-            pts[bb * R1 + r] = cx{(ok0 ? v0 : 0.0) * w[0], (ok1 ? v1 : 0.0) * w[1]};
-          }
-      }
+      gather_points<R1, N>(a, b, t, lane, wsrc, pts);
       SCHED_FENCE();
       core.run(pts, a.spec ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
     }
@@ -537,6 +546,211 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     }
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused feature form (BASELINE config 5: STFT -> MelBands -> MFCC): the frame's magnitudes never leave the
+// wavefront's LDS buffer -- per frame the kernel reads hop 4 bytes of samples and writes nOut 4 bytes of features.
+//   algorithm::MelBands::processFrame   include/flucoma/algorithms/public/MelBands.hpp:79-97
+//   algorithm::DCT::processFrame        include/flucoma/algorithms/public/DCT.hpp:65-75
+//   client glue                         include/flucoma/clients/rt/MFCCClient.hpp:122-130, rt/MelBandsClient.hpp:104-113
+// A mel filter bank is a row of overlapping triangles: every bin lies on the rising edge of at most one band and on the
+// falling edge of at most one (the one below).  With up[f] / dn[f] the two weights of bin f, band b is
+//   sum_{f in interval b} up[f] m[f] + sum_{f in interval b+1} dn[f] m[f],   interval s = bins between centres s and s+1,
+// two segment sums of two running sums over the bins: lane l forms the running sums of its CH consecutive bins, a
+// wavefront scan gives each lane its offset, the lanes holding the last bin before an interval boundary publish the
+// running sums there, and lane b takes band b as two differences.  (The host checks that the filter bank at hand has
+// this shape -- api.hip features_common -- and falls back to the two-kernel path otherwise.)
+// No workgroup barrier anywhere in the frame loop: wavefronts are independent.
+// ---------------------------------------------------------------------------------------------------------------
+struct FeatFusedArgs
+{
+  const double* up;    // [64 CH] rising-edge weight of bin f (0 where none)
+  const double* dn;    // [64 CH] falling-edge weight of bin f
+  const short* slot;   // [64 CH] s if bin f is the last bin before interval s starts (publishes the running sums), else -1
+  const double* dct;   // [nDct][nBands] or nullptr
+  int nBands, nDct, startCoeff, nOut;
+  int magNorm, usePower, logOutput;
+  float* out;          // [B][nOut][T]
+};
+
+template <int R1, int R2, int R3, int NW>
+__global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFusedArgs fa)
+{
+  using Core = FftCore<R1, R2, R3>;
+  constexpr int N = Core::N, PPL = Core::PPL, BUFD = Core::BUFD;
+  constexpr int CH = (N + 1 + 63) / 64;           // consecutive bins per lane in the band sums
+  constexpr int WS = 66 + 66 + 64;                // per-wavefront scratch: boundary sums (rising, falling), band values
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  d2* tw2 = reinterpret_cast<d2*>(lds);
+  d2* wl = tw2 + Core::T2 + Core::T3;             // [N] window pairs
+  double* xall = reinterpret_cast<double*>(wl + N);
+  double* scr = xall + NW * BUFD;                 // [NW][WS]
+  double* upl = scr + NW * WS;                    // [64 CH]
+  double* dnl = upl + 64 * CH;                    // [64 CH]
+  double* dctl = dnl + 64 * CH;                   // [nDct * nBands]
+  short* slotl = reinterpret_cast<short*>(dctl + (fa.dct ? fa.nDct * fa.nBands : 0));   // [64 CH]
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xb = xall + wave * BUFD;
+  double* bu = scr + wave * WS;
+  double* bd = bu + 66;
+  double* bands = bd + 66;
+
+  const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
+  Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
+  for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
+  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { upl[i] = fa.up[i]; dnl[i] = fa.dn[i]; slotl[i] = fa.slot[i]; }
+  if (fa.dct)
+    for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[i] = fa.dct[i];
+  for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
+  __syncthreads();
+
+  Core core;
+  core.init(xb, tw2, twg, lane);
+  const double scale1 = 1.0 / ((double) a.win / 4.0);                          // alg/MelBands.hpp:49
+  const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
+
+  const int64_t chunk = (a.totalBlocks + 7) / 8;
+  for (int64_t L = blockIdx.x;; L += gridDim.x)
+  {
+    const int64_t slot8 = L >> 3;
+    if (slot8 >= chunk) break;
+    const int64_t blk = (L & 7) * chunk + slot8;
+    if (blk >= a.totalBlocks) continue;
+    const int b = (int) (blk / a.blocksPerBuf);
+    const int t = (int) (blk % a.blocksPerBuf) * NW + wave;
+    if (t >= a.T) continue;
+    {
+      cx pts[PPL];
+      gather_points<R1, N>(a, b, t, lane, wl, pts);
+      SCHED_FENCE();
+      core.run(pts, nullptr);
+    }
+    SCHED_FENCE();
+    // ---- band sums ------------------------------------------------------------------------------------------
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                    // (opaque: per-bin LDS positions are recomputed, not kept)
+    double pu[CH], pd[CH];
+    double su = 0.0, sd = 0.0, en = 0.0;
+#pragma unroll
+    for (int i = 0; i < CH; i++)
+    {
+      const int f = CH * ln + i;
+      double m = f <= N ? xb[f] : 0.0;
+      if (fa.magNorm) { m *= scale1; en += m; }     // :86-90
+      if (fa.usePower) m = m * m;
+      su = __builtin_fma(upl[f], m, su);
+      sd = __builtin_fma(dnl[f], m, sd);
+      pu[i] = su;
+      pd[i] = sd;
+    }
+    // inclusive scan of the lane totals, then shifted by one lane: what the lanes below contribute
+    double xu = su, xd = sd;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+      const double tu = __shfl_up(xu, off), td = __shfl_up(xd, off);
+      if (lane >= off) { xu += tu; xd += td; }
+    }
+    double eu = __shfl_up(xu, 1), ed = __shfl_up(xd, 1);
+    if (lane == 0) { eu = 0.0; ed = 0.0; }
+#pragma unroll
+    for (int i = 0; i < CH; i++)
+    {
+      const int sl = slotl[CH * ln + i];
+      if (sl >= 0) { bu[sl] = eu + pu[i]; bd[sl] = ed + pd[i]; }
+    }
+    double v = 0.0;
+    if (lane < fa.nBands) v = (bu[lane + 1] - bu[lane]) + (bd[lane + 2] - bd[lane + 1]);
+    if (fa.magNorm)
+    {
+      // :93  bands * energy / max(eps, sum of the bands), energy = sum_f (m scale1) * scale2 (:86-87)
+      double bs = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { bs += __shfl_xor(bs, off); en += __shfl_xor(en, off); }
+      v = v * (en * scale2) / fmax(kEpsilon, bs);
+    }
+    if (fa.logOutput) v = 20.0 * log10(fmax(v, kEpsilon));   // :95
+    if (!fa.dct)
+    {
+      if (lane < fa.nBands) fa.out[((int64_t) b * fa.nOut + lane) * a.T + t] = (float) v;
+      continue;
+    }
+    bands[lane] = v;                                         // bands beyond nBands hold 0 / log(eps): never read
+    // ---- DCT-II rows startCoeff .. startCoeff + nOut - 1 (alg/DCT.hpp:73-75) -----------------------------------------
+    if (4 * fa.nOut <= 64)
+    {
+      // four lanes per coefficient, a quarter of the bands each (ascending), then two exchange-adds
+      const int j = lane >> 2, part = lane & 3;
+      const int q = (fa.nBands + 3) >> 2;
+      double sacc = 0.0;
+      if (j < fa.nOut && fa.startCoeff + j < fa.nDct)
+      {
+        const double* drow = dctl + (fa.startCoeff + j) * fa.nBands;
+        const int b1 = min((part + 1) * q, fa.nBands);
+        for (int band = part * q; band < b1; band++) sacc = __builtin_fma(drow[band], bands[band], sacc);
+      }
+      sacc += __shfl_xor(sacc, 1);
+      sacc += __shfl_xor(sacc, 2);
+      if (part == 0 && j < fa.nOut) fa.out[((int64_t) b * fa.nOut + j) * a.T + t] = (float) sacc;
+    }
+    else
+    {
+      for (int j = lane; j < fa.nOut; j += 64)
+      {
+        double sacc = 0.0;
+        if (fa.startCoeff + j < fa.nDct)
+        {
+          const double* drow = dctl + (fa.startCoeff + j) * fa.nBands;
+          for (int band = 0; band < fa.nBands; band++) sacc = __builtin_fma(drow[band], bands[band], sacc);
+        }
+        fa.out[((int64_t) b * fa.nOut + j) * a.T + t] = (float) sacc;
+      }
+    }
+  }
+}
+
+template <int R1, int R2, int R3, int NW>
+static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStream_t s)
+{
+  using Core = FftCore<R1, R2, R3>;
+  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = 66 + 66 + 64;
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
+                       (fa.dct ? (size_t) fa.nDct * fa.nBands * 8 : 0) + (size_t) 64 * CH * 2 + 16;
+  if (shmem > 160 * 1024) return false;
+  StftBArgs k = k0;
+  k.blocksPerBuf = (k.T + NW - 1) / NW;
+  k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
+  if (k.totalBlocks < 1) return true;
+  auto kern = stft_feat_kernel<R1, R2, R3, NW>;
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+  const int64_t chunk = (k.totalBlocks + 7) / 8;
+  int64_t grid = 8 * chunk;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(64 * NW), shmem, s, k, fa);
+  return true;
+}
+
+// STFT -> mel bands [-> DCT] in one kernel; false when the shape has no fused form
+bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up, const double* dn, const short* slot,
+                          hipStream_t s)
+{
+  if ((a.win % 2) != 0 || a.win > a.fft || f.nBands > 64 || f.nBands < 1) return false;
+  StftBArgs k;
+  k.audio = a.audio; k.audio64 = a.audio64; k.n = a.n; k.audioStride = a.audioStride;
+  k.win = a.win; k.fft = a.fft; k.hop = a.hop; k.T = a.T; k.F = a.F; k.B = a.B;
+  k.window = a.window; k.twiddle = a.twiddle;
+  k.mag = nullptr; k.magStride = 0; k.ldMag = 0; k.magT = nullptr; k.magTStride = 0; k.ldMagT = 0;
+  k.spec = nullptr; k.specStride = 0; k.frameOffset = a.frameOffset; k.blocksPerBuf = 0; k.totalBlocks = 0;
+  FeatFusedArgs fa;
+  fa.up = up; fa.dn = dn; fa.slot = slot; fa.dct = f.dct;
+  fa.nBands = f.nBands; fa.nDct = f.nDct; fa.startCoeff = f.startCoeff; fa.nOut = f.nOut;
+  fa.magNorm = f.magNorm; fa.usePower = f.usePower; fa.logOutput = f.logOutput; fa.out = f.out;
+  if (a.fft == 1024) return launch_feat_t<8, 8, 8, 16>(k, fa, s);
+  if (a.fft == 2048) return launch_feat_t<16, 8, 8, 8>(k, fa, s);
+  return false;
+}
+int stft_features_bins_per_lane(int fft) { return (fft / 2 + 1 + 63) / 64; }
 
 template <int R1, int R2, int R3, int NW, int WINLDS>
 static bool launch_block_t(const StftBArgs& k0, hipStream_t s)

@@ -91,27 +91,66 @@ def test_c3_decimated_twin_all_iterations_shape(driver, oracle, onp, tmp_path, c
         assert rel_err(bases[c * K:(c + 1) * K], rb) < 1e-6 and rel_err(acts[c * K:(c + 1) * K], ra) < 1e-6
 
 
-def test_c5_multi_chunk_feature_path(ctx, oracle, onp):
-    """BASELINE config 5's shape at a count that takes fluhip_bufmfcc_f32 through more than one chunk of its
-    spectrogram workspace (the chunk loop, its per-chunk offsets and synchronisation): first / boundary / last slices
-    against the oracle, every slice against the single-slice call of the same audio."""
+@pytest.mark.parametrize("fused", [1, 0])
+def test_c5_multi_chunk_feature_path(ctx, oracle, onp, fused):
+    """BASELINE config 5's shape at a count that takes fluhip_bufmfcc_f32 through several chunks of its staging
+    buffers (the chunk loop, its per-chunk offsets and synchronisation), in both forms -- the fused STFT -> mel -> DCT
+    kernel and the two-kernel form with the magnitudes in HBM: first / boundary / last slices against the oracle,
+    every slice against the single-slice call of the same audio.  (FLUHIP_FEAT_CHUNK_BYTES shrinks the chunks: at their
+    production size of 2 GiB a test would need tens of thousands of slices to cross one.)"""
     n, win, fft, hop = 88200, 1024, 1024, 512
     distinct = np.stack([onp.synth_audio(n, 1000 + b) for b in range(16)])
     count = 3000
     order = (np.arange(count) * 7) % 16          # neighbours differ, so a wrong chunk offset cannot hide
     audio = distinct[order]
-    out = ctx.bufmfcc(audio, win, fft, hop)
+    old = {k: os.environ.get(k) for k in ("FLUHIP_FEAT_CHUNK_BYTES", "FLUHIP_FEAT_FUSED")}
+    try:
+        os.environ["FLUHIP_FEAT_FUSED"] = str(fused)
+        singles = [ctx.bufmfcc(distinct[i][None, :], win, fft, hop)[0] for i in range(16)]
+        os.environ["FLUHIP_FEAT_CHUNK_BYTES"] = str(64 << 20)
+        out = ctx.bufmfcc(audio, win, fft, hop)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     T = ctx.feature_frames(n, win, hop)
     assert out.shape == (count, 13, T) and T == 173
-    singles = [ctx.bufmfcc(distinct[i][None, :], win, fft, hop)[0] for i in range(16)]
     for b in range(count):
         assert np.array_equal(out[b], singles[order[b]]), b
-    Fp, Tp = 544, 192                              # the padded spectrogram of one slice in the workspace
-    chunk = (2 << 30) // (Tp * Fp * 8)
-    assert count > chunk, "the test must cross a chunk boundary"
-    for b in {0, 1, chunk - 1, chunk, chunk + 1, count // 2, count - 1}:
+    chunk = (64 << 20) // (n * 4) if fused else (64 << 20) // (192 * 544 * 8)
+    assert 1 < chunk < count // 3, "the test must cross several chunk boundaries"
+    for b in {0, 1, chunk - 1, chunk, chunk + 1, 2 * chunk, count // 2, count - 1}:
         ref = oracle.bufmfcc_channel(audio[b], win, fft, hop)
         assert rel_err(out[b], ref) < 1e-5
+
+
+def test_c5_device_resident_corpus(ctx, onp):
+    """audio and features already in HBM (what a device-side pipeline hands over): same floats as the host-buffer call"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")          # the runtime the library under test already runs on
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    n, win, fft, hop, count = 88200, 1024, 1024, 512, 96
+    audio = np.stack([onp.synth_audio(n, 2000 + b) for b in range(count)])
+    ref = ctx.bufmfcc(audio, win, fft, hop)
+    a_dev, o_dev = ctypes.c_void_p(), ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(a_dev), audio.nbytes) == 0 and hip.hipMalloc(ctypes.byref(o_dev), ref.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(a_dev, audio.ctypes.data, audio.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        T = ctypes.c_int64(0)
+        fp = ctypes.POINTER(ctypes.c_float)
+        rc = ctx.lib.fluhip_bufmfcc_f32(ctx.h, ctypes.cast(a_dev, fp), count, n, win, fft, hop, 40, 13, 0, 20.0, 20000.0,
+                                        44100.0, ctypes.cast(o_dev, fp), ctypes.byref(T))
+        got = np.empty_like(ref)
+        assert hip.hipMemcpy(got.ctypes.data, o_dev, ref.nbytes, 2) == 0          # hipMemcpyDeviceToHost
+    finally:
+        hip.hipFree(a_dev)
+        hip.hipFree(o_dev)
+    assert rc == 0 and T.value == ref.shape[2]
+    assert np.array_equal(got, ref)
 
 
 def _bench(args, env=None):
