@@ -307,7 +307,11 @@ def main():
                          "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": ach_gbs / PEAK_HBM_GBS}},
-            "roofline_stft": {"bound": "hbm", "kernel": "stft_r2c_mag_kernel", "avg_launch_ms": stft_ms,
+            # algorithmic bytes per frame: hop 4 in + F 8 out; the kernel writes V in BOTH layouts the factor
+            # updates stream (frame-major and bin-major), i.e. 2 F 8 bytes per frame really leave the chip
+            "roofline_stft": {"bound": "hbm", "kernel": "stft_block_kernel (both magnitude layouts in one pass; no transposing copy)",
+                              "avg_launch_ms": stft_ms,
+                              "written_gbs": ((wl["hop"] * 4.0 + 2 * F * 8.0) * T * B) / (stft_ms * 1e-3) / 1e9 if stft_ms > 0 else None,
                               "achieved": stft_bytes / (stft_ms * 1e-3) / 1e9 if stft_ms > 0 else None,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": (stft_bytes / (stft_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if stft_ms > 0 else None},
