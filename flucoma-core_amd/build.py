@@ -18,7 +18,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libflucoma_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf4.hip", "kernels_nmf5.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api.hip"]
+SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf4.hip", "kernels_nmf5.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api.hip", "api_pool.cpp"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
 
 
@@ -45,7 +45,10 @@ def _compile(src):
     obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if _newer(obj, [path] + _deps() + [os.path.abspath(__file__)]):
-        cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj]
+        if src.endswith(".cpp"):   # host-only C++ above the C ABI: no device code, plain g++
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", "-c", path, "-o", obj]
+        else:
+            cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -67,7 +70,7 @@ def build(force: bool = False) -> str:
         objs = list(ex.map(_compile, srcs))
     if force or _newer(LIB, objs):
         tmp = LIB + f".tmp{os.getpid()}"
-        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs]
+        cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-pthread", "-o", tmp, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -361,7 +361,8 @@ int nmf_update4_waves_per_buffer(int C, int Kp, int B)
     if (wfill <= G / 3 || wfill <= wmin)
       w = (int) std::max<int64_t>(wmin, wfill);  // fill the chip by narrowing strips (>= 3 groups each)
     else
-      w = std::max(wmin, G / 3);                 // few buffers: ~3 groups per strip, the contraction
+      w = std::max(wmin, (G + 2) / 3);           // few buffers: at most 3 groups per strip (G / 3 rounded DOWN made the
+                                                 // widest strip 4 groups -- a quarter more work per wavefront), the contraction
                                                  // split (nsplit) supplies the rest of the parallelism
     if (w > G) w = G;
     if (w < 1) w = 1;

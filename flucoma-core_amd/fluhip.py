@@ -38,6 +38,8 @@ EXPORTS = [
     "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
     "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words",
+    "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
+    "fluhip_pool_bufnmf_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
 ]
 
 
@@ -108,6 +110,18 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
     L.fluhip_corpus_debug_words.argtypes = [_vp, _ip]
+    L.fluhip_pool_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]
+    L.fluhip_pool_destroy.argtypes = [_vp]
+    L.fluhip_pool_destroy.restype = None
+    L.fluhip_pool_size.argtypes = [_vp]
+    L.fluhip_pool_device.argtypes = [_vp, ctypes.c_int]
+    L.fluhip_pool_last_error.argtypes = [_vp]
+    L.fluhip_pool_last_error.restype = ctypes.c_char_p
+    L.fluhip_pool_bufnmf_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int,
+                                         _i64, _ip, _fp, _fp, PROGRESS_FN, _vp]
+    L.fluhip_shard_range.argtypes = [_i64, ctypes.c_int, ctypes.c_int, _ip, _ip]
+    L.fluhip_shard_range.restype = None
+    L.fluhip_balanced_assignment.argtypes = [_dp, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
     return L
 
 
@@ -414,3 +428,51 @@ class Corpus:
         H1 = np.empty((self.count, self.T, self.K)) if factors else None
         self.ctx._check(self.ctx.lib.fluhip_corpus_read_f64(self.h, _d(m), _d(W1), _d(H1)))
         return m, W1, H1
+
+
+class Pool:
+    """fluhip_pool: several devices (or several contexts on one) behind one host process."""
+
+    def __init__(self, devices=None, lib: ctypes.CDLL | None = None):
+        self.lib = lib or load_library()
+        h = _vp()
+        if devices is None:
+            rc = self.lib.fluhip_pool_create(None, 0, ctypes.byref(h))
+        else:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            rc = self.lib.fluhip_pool_create(arr, len(devices), ctypes.byref(h))
+        if rc != OK:
+            raise FluhipError(rc, "fluhip_pool_create failed (no usable device?)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.fluhip_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self):
+        return int(self.lib.fluhip_pool_size(self.h))
+
+    def devices(self):
+        return [int(self.lib.fluhip_pool_device(self.h, i)) for i in range(self.size())]
+
+    def bufnmf(self, audio, win, fft, hop, K, iters, seed=42, updateW=True, updateH=True, seeds=None, progress=None):
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        count, n = audio.shape
+        F, T = fft // 2 + 1, int(self.lib.fluhip_stft_num_frames(n, win, hop))
+        bases = np.empty((count, K, F), dtype=np.float32)
+        acts = np.empty((count, K, T), dtype=np.float32)
+        sarr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)
+        cb = _cb(progress)
+        rc = self.lib.fluhip_pool_bufnmf_f32(self.h, _f(audio), count, n, win, fft, hop, K, iters, int(updateW), int(updateH),
+                                             seed, sarr.ctypes.data_as(_ip) if sarr is not None else None, _f(bases), _f(acts),
+                                             cb, None)
+        if rc not in (OK, CANCELLED):
+            raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
+        return bases, acts, rc

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLUHIP_ABI_VERSION 1
+#define FLUHIP_ABI_VERSION 2
 
 /* clients/common/Result.hpp:24  enum class Status { kOk, kWarning, kError, kCancelled } */
 enum fluhip_status
@@ -225,6 +225,32 @@ int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1
  * deferred column normalisation of W (alg/NMF.hpp:162 applied on load) 0/1, Nyquist bin as a side column 0/1,
  * wavefronts per buffer of the W update, padded rank, 0 }. */
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
+
+/* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
+/* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of
+ * a corpus are independent jobs (clients/nrt/NMFClient.hpp:233 loop body): a pool holds one context per listed device
+ * and, per call, one host thread per device; buffers are dealt in contiguous blocks (fluhip_shard_range, remainder
+ * over the first members) and every device writes its share of the result straight into the caller's arrays.
+ * devices == NULL: every visible device.  A device may be listed more than once (two contexts on one GPU).
+ * Multi-PROCESS jobs (one rank per GPU) use the same dealing and gather with RCCL: flucoma-core_amd/sharding.py. */
+typedef struct fluhip_pool fluhip_pool;
+int         fluhip_pool_create(const int* devices, int n_devices, fluhip_pool** out);
+void        fluhip_pool_destroy(fluhip_pool* pool);
+int         fluhip_pool_size(const fluhip_pool* pool);
+int         fluhip_pool_device(const fluhip_pool* pool, int member);
+const char* fluhip_pool_last_error(const fluhip_pool* pool);
+/* BufNMF over `count` equal-length mono buffers (BASELINE config 4): audio count x n host floats; bases count x K x F,
+ * acts count x K x T host floats (either may be NULL); seeds: `count` seeds or NULL.  progress (may be NULL) is called
+ * on the calling thread with iteration = 1..iters in order, an iteration counting once every device has passed it;
+ * returning 0 cancels every device's share (FLUHIP_CANCELLED). */
+int fluhip_pool_bufnmf_f32(fluhip_pool* pool, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                           int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                           const int64_t* seeds, float* bases, float* acts, fluhip_progress_fn progress, void* user);
+/* the dealing itself (integer arithmetic, also used by the multi-process launcher): contiguous blocks [begin, end) of
+ * n_items over `world` ranks; and the greedy longest-processing-time deal for ragged corpora (cost ~ T F K per buffer,
+ * ties to the lower index / rank): rank_of_item[i] = rank of item i */
+void fluhip_shard_range(int64_t n_items, int world, int rank, int64_t* begin, int64_t* end);
+int  fluhip_balanced_assignment(const double* costs, int64_t n, int world, int32_t* rank_of_item);
 
 /* ---- live kernel timing (HIP events on the context stream) ----------------------------- */
 /* When enabled, every launch of the two dominant kernel classes is bracketed by hipEvents on

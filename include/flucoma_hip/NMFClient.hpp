@@ -16,6 +16,9 @@
 #include <algorithm>
 #include <cmath>
 #include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace fluhip {
@@ -76,6 +79,8 @@ public:
   ~NMFClient()
   {
     if (mCtx) fluhip_ctx_destroy(mCtx);
+    for (auto& pc : mPool)
+      if (pc.second) fluhip_ctx_destroy(pc.second);
   }
   NMFClient(const NMFClient&) = delete;
   NMFClient& operator=(const NMFClient&) = delete;
@@ -187,6 +192,104 @@ public:
       double        total;
     };
 
+    // ---- several devices: the channels run concurrently, one host thread + context per listed device --------------
+    // (the reference runs them one after the other on its single thread, :233; they share no state -- a fresh
+    //  algorithm::NMF per channel, :260 -- so the results are the same floats in the same buffer channels)
+    if (c.devices().size() > 1 && nChannels > 1)
+    {
+      const size_t nDev = c.devices().size();
+      if (mPool.size() != nDev) { for (auto& pc : mPool) if (pc.second) fluhip_ctx_destroy(pc.second); mPool.assign(nDev, {-1, nullptr}); }
+      for (size_t d = 0; d < nDev; ++d)
+        if (!mPool[d].second || mPool[d].first != c.devices()[d])
+        {
+          if (mPool[d].second) fluhip_ctx_destroy(mPool[d].second);
+          mPool[d] = {c.devices()[d], nullptr};
+          if (fluhip_ctx_create(c.devices()[d], &mPool[d].second) != FLUHIP_OK)
+            return {S::kError, "BufNMF: no usable MI355X device ", c.devices()[d], " (libflucoma_hip has no CPU fallback)"};
+        }
+      const size_t nc = static_cast<size_t>(nChannels);
+      std::vector<std::vector<float>> monoC(nc), seedWC(nc), seedHC(nc), outWC(nc), outHC(nc), outRC(nc);
+      for (index i = 0; i < nChannels; ++i) // all host-buffer reads on this thread, before the workers start
+      {
+        const size_t ci = static_cast<size_t>(i);
+        monoC[ci].resize(static_cast<size_t>(nFrames));
+        VectorView<float>(monoC[ci].data(), nFrames) <<= source.samps(P.startFrame, nFrames, P.startChan + i);
+        if (seedFilters) seedWC[ci].resize(static_cast<size_t>(rank * nBins));
+        if (seedEnvelopes) seedHC[ci].resize(static_cast<size_t>(rank * nWindows));
+        for (index j = 0; j < rank; ++j)
+        {
+          if (seedFilters)
+            VectorView<float>(seedWC[ci].data() + j * nBins, nBins) <<=
+                VectorView<const float>(BufferAdaptor::Access(P.bases.get()).samps(i * rank + j));
+          if (seedEnvelopes)
+            VectorView<float>(seedHC[ci].data() + j * nWindows, nWindows) <<=
+                VectorView<const float>(BufferAdaptor::Access(P.activations.get()).samps(i * rank + j));
+        }
+        if (hasFilters && !fixFilters) outWC[ci].resize(static_cast<size_t>(rank * nBins));
+        if (hasEnvelopes && !fixEnvelopes) outHC[ci].resize(static_cast<size_t>(rank * nWindows));
+        if (shouldResynth && hasResynth) outRC[ci].resize(static_cast<size_t>(rank * nFrames));
+      }
+      struct Shared
+      {
+        FluidContext* c;
+        std::mutex    m;
+        double        count{0};
+        double        total;
+      } shared{&c, {}, 0, progressTotal * static_cast<double>(nChannels)};
+      auto cbShared = [](int64_t, void* u) -> int {
+        auto* sh = static_cast<Shared*>(u);
+        if (!sh->c->task()) return 1;
+        std::lock_guard<std::mutex> g(sh->m);
+        sh->count += 1;
+        return sh->c->task()->processUpdate(sh->count, sh->total) ? 1 : 0;
+      };
+      std::vector<int>         rcs(nc, FLUHIP_OK);
+      std::vector<std::string> errs(nc);
+      std::vector<std::thread> workers;
+      const index              iters = needsAnalysis ? P.iterations : 0;
+      for (size_t d = 0; d < nDev; ++d)
+        workers.emplace_back([&, d] {
+          for (size_t ci = d; ci < nc; ci += nDev)
+          {
+            rcs[ci] = fluhip_bufnmf_channel_f32(
+                mPool[d].second, monoC[ci].data(), nFrames, 1, fftParams.winSize(), fftParams.fftSize(), hop, rank, iters,
+                !fixFilters, !fixEnvelopes, P.seed, seedFilters ? seedWC[ci].data() : nullptr,
+                seedEnvelopes ? seedHC[ci].data() : nullptr, outWC[ci].empty() ? nullptr : outWC[ci].data(),
+                outHC[ci].empty() ? nullptr : outHC[ci].data(), outRC[ci].empty() ? nullptr : outRC[ci].data(), cbShared, &shared);
+            if (rcs[ci] != FLUHIP_OK) { errs[ci] = fluhip_last_error(mPool[d].second); break; }
+          }
+        });
+      for (auto& w : workers) w.join();
+      for (size_t ci = 0; ci < nc; ++ci)
+      {
+        if (rcs[ci] == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""};
+        if (rcs[ci] != FLUHIP_OK) return {S::kError, "BufNMF: ", errs[ci]};
+      }
+      for (index i = 0; i < nChannels; ++i) // all host-buffer writes on this thread, in channel order (:277-334)
+      {
+        const size_t ci = static_cast<size_t>(i);
+        if (hasFilters && !fixFilters)
+        {
+          BufferAdaptor::Access filters(P.bases.get());
+          for (index j = 0; j < rank; ++j)
+            filters.samps(i * rank + j) <<= VectorView<const float>(outWC[ci].data() + j * nBins, nBins);
+        }
+        if (hasEnvelopes && !fixEnvelopes)
+        {
+          BufferAdaptor::Access envelopes(P.activations.get());
+          for (index j = 0; j < rank; ++j)
+            envelopes.samps(i * rank + j) <<= VectorView<const float>(outHC[ci].data() + j * nWindows, nWindows);
+        }
+        if (shouldResynth && hasResynth)
+        {
+          BufferAdaptor::Access resynth(P.resynth.get());
+          for (index j = 0; j < rank; ++j)
+            resynth.samps(i * rank + j) <<= VectorView<const float>(outRC[ci].data() + j * nFrames, nFrames);
+        }
+      }
+      return {S::kOk, ""};
+    }
+
     for (index i = 0; i < nChannels; ++i)
     {
       if (c.task() && !c.task()->iterationUpdate(static_cast<double>(i), static_cast<double>(nChannels)))
@@ -247,6 +350,7 @@ private:
   NMFParams*  mParams;
   fluhip_ctx* mCtx{nullptr};
   int         mDevice{-1};
+  std::vector<std::pair<int, fluhip_ctx*>> mPool; // (device, context) per entry of FluidContext::devices()
 };
 
 } // namespace bufnmf

@@ -49,7 +49,7 @@ public:
     if (mTask) return {};
     if (mQueue.empty()) return {Result::Status::kWarning, "Process() called on empty queue"};
     if (mSynchronous) mSynchronousDone = false;
-    mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext.device(), mSynchronous);
+    mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext, mSynchronous);
     mQueue.pop_front();
     Result result;
     if (mSynchronous)
@@ -69,7 +69,7 @@ public:
     {
       if (!mQueue.empty())
       {
-        mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext.device(), false);
+        mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext, false);
         mQueue.pop_front();
         state = kDoneStillProcessing;
       }
@@ -101,8 +101,9 @@ private:
   class ThreadedTask
   {
   public:
-    ThreadedTask(NRTJob& job, int device, bool synchronous) : mJob(job), mContext(mTaskState, device)
+    ThreadedTask(NRTJob& job, const FluidContext& host, bool synchronous) : mJob(job), mContext(mTaskState, host.device())
     {
+      mContext.devices(host.devices());
       mState = kProcessing;
       if (synchronous)
       {

@@ -10,6 +10,7 @@
 //   client::FluidContext             include/flucoma/clients/common/FluidContext.hpp:23-52
 //   client::FFTParams                include/flucoma/clients/common/ParameterTypes.hpp:260-439 (arithmetic only)
 #pragma once
+#include <vector>
 
 #include <atomic>
 #include <cassert>
@@ -156,10 +157,16 @@ public:
   void       task(FluidTask* t) { mTask = t; }
   int        device() const { return mDevice; } // which GPU the job runs on (no reference analogue)
   void       device(int d) { mDevice = d; }
+  // several GPUs for one job: the channels of a multichannel BufNMF are independent factorisations
+  // (clients/nrt/NMFClient.hpp:233) and are dealt round-robin over this list, one host thread per entry.
+  // Empty (the default): everything on device().  An id may be listed twice (two contexts on one GPU).
+  const std::vector<int>& devices() const { return mDevices; }
+  void                    devices(std::vector<int> d) { mDevices = std::move(d); }
 
 private:
-  FluidTask* mTask{nullptr};
-  int        mDevice{0};
+  FluidTask*       mTask{nullptr};
+  int              mDevice{0};
+  std::vector<int> mDevices;
 };
 
 // ---- FFTParams (arithmetic of cc/ParameterTypes.hpp:295-312) -------------------------------------

@@ -8,9 +8,11 @@
 //                     <basesMode> <actMode> <async> <startFrame> <numFrames> <startChan> <numChans>
 //                     <outprefix> [<bases_seed.f32> <acts_seed.f32>]
 //   client_driver cancel <frames>
+//   client_driver pool <count> <frames>      (fluhip_pool_* from a C++ host: two contexts on device 0 vs one)
 #include "../../include/flucoma_hip/NRTThreadingAdaptor.hpp"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -148,6 +150,35 @@ int main(int argc, char** argv)
     return 0;
   }
 
+  if (mode == "pool")
+  {
+    const idx count = std::atol(argv[2]), frames = std::atol(argv[3]);
+    std::vector<float> x((size_t) (count * frames));
+    for (idx b = 0; b < count; ++b)
+      for (idx i = 0; i < frames; ++i)
+        x[(size_t) (b * frames + i)] = 0.5f * std::sin(0.01f * (float) (b + 3) * (float) i) + 0.25f * std::sin(0.31f * (float) i + (float) b);
+    const idx win = 1024, fft = 1024, hop = 256, K = 4, iters = 10, F = fft / 2 + 1, T = fluhip_stft_num_frames(frames, win, hop);
+    auto runPool = [&](std::vector<int> devs, std::vector<float>& bases, std::vector<float>& acts) -> int {
+      fluhip_pool* pool = nullptr;
+      if (fluhip_pool_create(devs.data(), (int) devs.size(), &pool) != FLUHIP_OK) return -1;
+      bases.assign((size_t) (count * K * F), 0.f);
+      acts.assign((size_t) (count * K * T), 0.f);
+      const int rc = fluhip_pool_bufnmf_f32(pool, x.data(), count, frames, win, fft, hop, K, iters, 1, 1, 42, nullptr, bases.data(),
+                                            acts.data(), nullptr, nullptr);
+      if (rc != FLUHIP_OK) std::fprintf(stderr, "pool: %s\n", fluhip_pool_last_error(pool));
+      fluhip_pool_destroy(pool);
+      return rc;
+    };
+    std::vector<float> b1, a1, b2, a2;
+    const int rc1 = runPool({0}, b1, a1), rc2 = runPool({0, 0}, b2, a2);
+    double maxd = 0, maxv = 0;
+    for (size_t i = 0; i < b1.size(); ++i) { maxd = std::max(maxd, (double) std::fabs(b1[i] - b2[i])); maxv = std::max(maxv, (double) std::fabs(b1[i])); }
+    for (size_t i = 0; i < a1.size(); ++i) maxd = std::max(maxd, (double) std::fabs(a1[i] - a2[i]));
+    std::printf("pool_rc|%d|%d\n", rc1, rc2);
+    std::printf("pool_match|%d|%g %g\n", (maxd <= 1e-6 && maxv > 0) ? 1 : 0, maxd, maxv);
+    return 0;
+  }
+
   if (mode == "run")
   {
     if (argc < 19) return 2;
@@ -194,17 +225,30 @@ int main(int argc, char** argv)
       p.resynth = resynth;
       p.resynthMode = 1;
     }
+    // CLIENT_DEVICES=0,0 : the channels of the job dealt over several device contexts (FluidContext::devices)
+    FluidContext hostCtx;
+    if (const char* e = std::getenv("CLIENT_DEVICES"))
+    {
+      std::vector<int> devs;
+      for (const char* q = e; *q;)
+      {
+        devs.push_back(std::atoi(q));
+        while (*q && *q != ',') ++q;
+        if (*q == ',') ++q;
+      }
+      hostCtx.devices(devs);
+    }
     Result r;
     if (!async)
     {
-      NRTThreadedNMFClient adaptor(p);
+      NRTThreadedNMFClient adaptor(p, hostCtx);
       adaptor.setSynchronous(true);
       adaptor.enqueue(p);
       r = adaptor.process();
     }
     else
     {
-      NRTThreadedNMFClient adaptor(p);
+      NRTThreadedNMFClient adaptor(p, hostCtx);
       adaptor.enqueue(p);
       report("process", adaptor.process());
       ProcessState st = kProcessing;

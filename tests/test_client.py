@@ -141,3 +141,36 @@ def test_client_resynthesis(driver, oracle, onp, tmp_path, ctx):
     for c in range(2):
         total = res[c * K:(c + 1) * K].sum(axis=0)
         assert np.abs(total[win:-win] - audio[win:-win, c]).max() < 0.02
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+def test_client_channels_over_two_device_contexts(driver, tmp_path, use_async, ctx):
+    """FluidContext::devices = {0, 0}: the three channels of a job run concurrently on two contexts (one host thread
+    each, channels dealt round-robin) -- the buffers must come out exactly as from the sequential single-context job
+    (same kernels, same seeds; nrt/NMFClient.hpp:233 channels share no state), resynthesis included"""
+    from conftest import ROOT as _r  # noqa: F401
+    import oracle_np as onp
+    frames, chans = 24000, 3
+    audio = np.stack([onp.synth_audio(frames, 700 + c) for c in range(chans)], axis=1)
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    win, hop, fft, K, iters, seed = 1024, 256, 1024, 4, 15, 42
+    outs = {}
+    for tag, env in (("one", {"CLIENT_RESYNTH": "1"}), ("two", {"CLIENT_RESYNTH": "1", "CLIENT_DEVICES": "0,0"})):
+        prefix = str(tmp_path / tag)
+        r = run(driver, "run", inp, frames, chans, win, hop, fft, K, iters, seed, 0, 0, use_async, 0, -1, 0, -1, prefix, env=env)
+        assert r["result"] == (OK, "")
+        outs[tag] = [read_buffer(prefix + s)[0] for s in ("_bases.bin", "_acts.bin", "_resynth.bin")]
+    for a, b in zip(outs["one"], outs["two"]):
+        assert a.shape == b.shape and np.array_equal(a, b)
+    assert outs["two"][0].shape == (K * chans, fft // 2 + 1)
+
+
+@pytest.mark.gpu
+def test_pool_from_a_cpp_host(driver, ctx):
+    """fluhip_pool_bufnmf_f32 called from C++ (tests/cpp/client_driver.cpp): 7 buffers over two contexts on device 0 give
+    the floats of the one-context run (the schedules differ by the number of buffers per launch: rounding only)"""
+    r = run(driver, "pool", 7, 30000)
+    assert r["pool_rc"][0] == 0 and r["pool_rc"][1] == "0"
+    assert r["pool_match"][0] == 1, r["pool_match"]

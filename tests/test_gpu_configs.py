@@ -153,6 +153,29 @@ def test_c5_device_resident_corpus(ctx, onp):
     assert np.array_equal(got, ref)
 
 
+def test_pool_two_contexts_shard_a_corpus(ctx, oracle, onp):
+    """fluhip_pool_*: the multi-device form behind the C ABI -- here two contexts on device 0, five buffers dealt 3 + 2 by
+    one host thread each, results written straight into the caller's arrays in corpus order; every buffer against the
+    oracle, progress in order, cancellation"""
+    import fluhip
+    n, win, fft, hop, K, iters = 30000, 1024, 1024, 256, 5, 12
+    audio = np.stack([onp.synth_audio(n, 3000 + b) for b in range(5)])
+    pool = fluhip.Pool([0, 0], ctx.lib)
+    assert pool.size() == 2 and pool.devices() == [0, 0]
+    seen = []
+    bases, acts, rc = pool.bufnmf(audio, win, fft, hop, K, iters, seed=42, progress=lambda it: seen.append(it) or True)
+    assert rc == 0 and seen == list(range(1, iters + 1))
+    for b in range(5):
+        rb, ra = oracle.bufnmf_channel(audio[b], win, fft, hop, K, iters, 42)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6
+    one = fluhip.Pool([0], ctx.lib)
+    b1, a1, _ = one.bufnmf(audio, win, fft, hop, K, iters, seed=42)
+    assert rel_err(b1, bases) < 1e-6 and rel_err(a1, acts) < 1e-6
+    _, _, rc = pool.bufnmf(audio, win, fft, hop, K, 400, seed=42, progress=lambda it: it < 3)
+    assert rc == fluhip.CANCELLED
+    pool.close(); one.close()
+
+
 def _bench(args, env=None):
     e = dict(os.environ)
     e.update(env or {})

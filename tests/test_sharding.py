@@ -36,6 +36,30 @@ def test_balanced_assignment_for_ragged_corpora():
     assert max(loads) - min(loads) <= max(costs)
 
 
+def test_c_abi_dealing_equals_the_python_one(fluhip_lib_path):
+    """fluhip_shard_range / fluhip_balanced_assignment (what a C++ host deals its corpus with) against sharding.py"""
+    import ctypes
+    import fluhip
+    import sharding
+    lib = fluhip.load_library(fluhip_lib_path)
+    b, e = ctypes.c_int64(), ctypes.c_int64()
+    for n in (0, 1, 7, 128, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                lib.fluhip_shard_range(n, world, r, ctypes.byref(b), ctypes.byref(e))
+                assert (b.value, e.value) == sharding.shard_range(n, world, r)
+    rs = np.random.RandomState(3)
+    for n, world in ((57, 8), (5, 2), (1, 4), (200, 3)):
+        costs = np.ascontiguousarray(rs.randint(1, 50, n).astype(np.float64))   # ties on purpose
+        out = (ctypes.c_int32 * n)()
+        assert lib.fluhip_balanced_assignment(costs.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n, world, out) == 0
+        parts = sharding.balanced_assignment(list(costs), world)
+        want = np.empty(n, dtype=np.int32)
+        for r, items in enumerate(parts):
+            want[items] = r
+        assert list(out) == list(want)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
