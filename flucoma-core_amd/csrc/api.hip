@@ -22,6 +22,7 @@
 #include <optional>
 #include <random>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
@@ -41,7 +42,7 @@ struct fluhip_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  std::map<std::pair<int, int>, double*> windows; // (win | fft << 16, type) -> device table
+  std::map<std::tuple<int64_t, int64_t, int>, double*> windows; // (win, fft, type) -> device table
   std::map<int, double*> twiddles;                // fft -> device table
   bool prof = false;
   std::vector<ProfRec> profRecs;
@@ -94,7 +95,7 @@ struct BlockPool
   static constexpr size_t kPoolCap = (size_t) 8 << 30;
   std::mutex m;
   std::multimap<size_t, void*> freeBlocks[16];
-  size_t cached = 0;
+  size_t cached[16] = {}; // per device
   static bool enabled()
   {
     static const bool on = [] { const char* e = std::getenv("FLUHIP_NO_POOL"); return !(e && std::atoi(e)); }();
@@ -108,22 +109,22 @@ struct BlockPool
     if (it == f.end() || it->first > 2 * n + ((size_t) 1 << 20)) return nullptr;
     void* p = it->second;
     *got = it->first;
-    cached -= it->first;
+    cached[dev & 15] -= it->first;
     f.erase(it);
     return p;
   }
   bool give(int dev, size_t n, void* p)
   {
     std::lock_guard<std::mutex> g(m);
-    if (cached + n > kPoolCap) return false;
+    if (cached[dev & 15] + n > kPoolCap) return false;
     freeBlocks[dev & 15].emplace(n, p);
-    cached += n;
+    cached[dev & 15] += n;
     return true;
   }
   void trim(int dev)
   {
     std::lock_guard<std::mutex> g(m);
-    for (auto& kv : freeBlocks[dev & 15]) { (void) hipFree(kv.second); cached -= kv.first; }
+    for (auto& kv : freeBlocks[dev & 15]) { (void) hipFree(kv.second); cached[dev & 15] -= kv.first; }
     freeBlocks[dev & 15].clear();
   }
 };
@@ -300,7 +301,7 @@ static bool make_window(int type, int64_t size, std::vector<double>& out)
 // is zero-padded at its tail, util/FFT.hpp:97-98)
 static int get_window(fluhip_ctx* ctx, int64_t win, int64_t fft, int type, const double** out)
 {
-  auto key = std::make_pair((int) win + (int) (fft << 16), type);
+  auto key = std::make_tuple(win, fft, type);
   auto it = ctx->windows.find(key);
   if (it == ctx->windows.end())
   {
@@ -502,6 +503,17 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   return FLUHIP_OK;
 }
 
+// launch-geometry limits of the factor-update paths, refused up front with a message instead of surfacing as an
+// "invalid configuration" launch error: the normalisation kernels put the padded rank in one workgroup (<= 1024
+// threads), and the any-rank path (rank above 128, kernels_nmf_wide.hip) puts frames / bins in gridDim.y (<= 65535)
+static int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K)
+{
+  if (round_up(K, 16) > 1024) return fail(ctx, "ranks above 1024 are not supported");
+  if (round_up(K, 16) > 128 && std::max(T, F) > 65535)
+    return fail(ctx, "ranks above 128 are limited to 65535 frames and bins");
+  return FLUHIP_OK;
+}
+
 static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t K)
 {
   if (n <= 0) return fail(ctx, "not enough frames");
@@ -512,7 +524,7 @@ static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int
     return fail(ctx, "fft sizes above 65536 are not supported");
   if (K < 1) return fail(ctx, "rank must be >= 1");
   if ((n + hop) / hop > 2000000000LL / 16) return fail(ctx, "too many frames");
-  return FLUHIP_OK;
+  return check_rank(ctx, (n + hop) / hop, fft / 2 + 1, K);
 }
 
 static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride)
@@ -758,9 +770,9 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
   }
 }
 
-// alg/NMF.hpp:154-181 loop + :175-176 callbacks.  Iterations are enqueued back to back; when a
-// progress callback is present the stream is drained every `chunk` iterations and the callback
-// is invoked once per completed iteration, in order, on the calling thread.
+// alg/NMF.hpp:154-181 loop + :175-176 callbacks.  Iterations are enqueued back to back; with a progress callback
+// every iteration is followed by an event and the callback is invoked once per completed iteration, in order, on
+// the calling thread, with a bounded run-ahead.
 static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
                                fluhip_progress_fn progress, void* user)
 {
@@ -771,21 +783,37 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
     HIPCHK(ctx, hipGetLastError());
     return FLUHIP_OK;
   }
-  int64_t done = 0, chunk = 1;
-  while (done < iters)
+  // One event per iteration; callbacks are delivered in order as the events complete, and the host never runs more
+  // than kLag iterations ahead of the last one it has reported: a cancel at iteration i stops the device after at
+  // most kLag - 1 further iterations (alg/NMF.hpp:175-176 stops at i exactly; the client above never looks at the
+  // factors of a cancelled job, clients/nrt/NMFClient.hpp:273-274).
+  constexpr int kLag = 8;
+  hipEvent_t ev[kLag];
+  for (int i = 0; i < kLag; i++) ev[i] = take_event(ctx);
+  auto give_back = [&] { for (int i = 0; i < kLag; i++) ctx->eventPool.push_back(ev[i]); };
+  int64_t reported = 0;
+  for (int64_t i = 0; i < iters; i++)
   {
-    const int64_t nthis = std::min(chunk, iters - done);
-    auto t0 = std::chrono::steady_clock::now();
-    for (int64_t i = 0; i < nthis; i++) enqueue_iteration(c, updateW, updateH);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    for (int64_t i = 0; i < nthis; i++)
-      if (!progress(done + i + 1, user)) return fail(ctx, "cancelled", FLUHIP_CANCELLED);
-    done += nthis;
-    // aim for ~4 ms between drains so the cancellation latency stays small
-    if (ms < 2.0 && chunk < 64) chunk *= 2;
-    else if (ms > 8.0 && chunk > 1) chunk /= 2;
+    enqueue_iteration(c, updateW, updateH);
+    if (hipEventRecord(ev[i % kLag], ctx->stream) != hipSuccess) { give_back(); return fail(ctx, "HIP error: hipEventRecord"); }
+    const int64_t enq = i + 1;
+    while (reported < enq)
+    {
+      hipEvent_t e = ev[reported % kLag];
+      const bool mustWait = enq - reported >= kLag || enq == iters;
+      hipError_t q = mustWait ? hipEventSynchronize(e) : hipEventQuery(e);
+      if (q == hipErrorNotReady) break;
+      if (q != hipSuccess) { give_back(); return fail(ctx, std::string("HIP error: ") + hipGetErrorString(q) + " in the iteration loop"); }
+      reported++;
+      if (!progress(reported, user))
+      {
+        (void) hipStreamSynchronize(ctx->stream);
+        give_back();
+        return fail(ctx, "cancelled", FLUHIP_CANCELLED);
+      }
+    }
   }
+  give_back();
   return FLUHIP_OK;
 }
 
@@ -860,6 +888,15 @@ int fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char
 }
 
 void* fluhip_ctx_stream(const fluhip_ctx* ctx) { return ctx ? (void*) ctx->stream : nullptr; }
+
+int fluhip_ctx_trim(fluhip_ctx* ctx)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  g_pool.trim(ctx->device);
+  return FLUHIP_OK;
+}
 
 int fluhip_ctx_synchronize(fluhip_ctx* ctx)
 {
@@ -1157,15 +1194,43 @@ int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stri
   return stft_common(ctx, audio, nullptr, n, stride, win, fft, hop, window_type, spec, mag, frames_out);
 }
 
-int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
-                           int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
-                           const double* W0, const double* H0, double* W1, double* H1,
-                           double* V1, fluhip_progress_fn progress, void* user)
+// ---- two-stride views at the algorithm boundary (data/FluidTensor_Support.hpp:260-420, util/FluidEigenMappings.hpp:35-225)
+namespace {
+inline bool view_empty(const fluhip_matrix_view* v) { return !v || !v->data || v->rows == 0 || v->cols == 0; }
+// contiguous row-major host copy of a view (small matrices: seeds)
+std::vector<double> view_gather(const fluhip_matrix_view& v)
+{
+  std::vector<double> out((size_t) (v.rows * v.cols));
+  for (int64_t r = 0; r < v.rows; r++)
+    for (int64_t c = 0; c < v.cols; c++) out[(size_t) (r * v.cols + c)] = v.data[r * v.row_stride + c * v.col_stride];
+  return out;
+}
+void view_scatter(const fluhip_matrix_view& v, const double* src)
+{
+  for (int64_t r = 0; r < v.rows; r++)
+    for (int64_t c = 0; c < v.cols; c++) v.data[r * v.row_stride + c * v.col_stride] = src[r * v.cols + c];
+}
+} // namespace
+
+int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, int64_t K, int64_t iters, int update_w,
+                                 int update_h, int64_t seed, const fluhip_matrix_view* W0v, const fluhip_matrix_view* H0v,
+                                 const fluhip_matrix_view* W1v, const fluhip_matrix_view* H1v, const fluhip_matrix_view* V1v,
+                                 fluhip_progress_fn progress, void* user)
 {
   if (!ctx) return FLUHIP_ERROR;
-  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
+  if (view_empty(Xv)) return fail(ctx, "bad input matrix");
+  const int64_t T = Xv->rows, F = Xv->cols;
   if (K < 1) return fail(ctx, "rank must be >= 1");
   if (iters < 0) return fail(ctx, "negative iteration count");
+  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
+  if ((Xv->col_stride == 1 && Xv->row_stride < F) || (Xv->row_stride == 1 && Xv->col_stride < T && Xv->col_stride != 1))
+    return fail(ctx, "bad input matrix");
+  // alg/NMF.hpp:109-110, 121-122 assert these shapes
+  if (!view_empty(W0v) && (W0v->rows != K || W0v->cols != F)) return fail(ctx, "W0 must be rank x bins");
+  if (!view_empty(H0v) && (H0v->rows != T || H0v->cols != K)) return fail(ctx, "H0 must be frames x rank");
+  if (!view_empty(W1v) && (W1v->rows != K || W1v->cols != F)) return fail(ctx, "W1 must be rank x bins");
+  if (!view_empty(H1v) && (H1v->rows != T || H1v->cols != K)) return fail(ctx, "H1 must be frames x rank");
+  if (!view_empty(V1v) && (V1v->rows != T || V1v->cols != F)) return fail(ctx, "V1 must be frames x bins");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   fluhip_corpus c;
@@ -1182,47 +1247,113 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
     HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
     if (int rc2 = plan_updates(ctx, &c)) return rc2;
   }
-  // alg/NMF.hpp:125  V = X^T (same bytes as the T x F row-major view)
-  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
-                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
-  launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T,
-                   (int) F, 1, s);
+  // alg/NMF.hpp:125  V = X^T.  A view with unit column stride is the T x F row-major image the frame-major copy wants;
+  // a view with unit ROW stride (FluidTensorView::transpose() of an F x T matrix) is byte for byte the bin-major copy:
+  // either goes up as one strided 2-D copy and the other layout is made on the device.  Anything else (both strides
+  // non-unit) is gathered on the host first.
+  std::vector<double> xtmp;
+  if (Xv->col_stride == 1 || T == 1)
+  {
+    HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), Xv->data, (size_t) Xv->row_stride * sizeof(double),
+                                 (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
+    launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T, (int) F, 1, s);
+  }
+  else if (Xv->row_stride == 1)
+  {
+    HIPCHK(ctx, hipMemcpy2DAsync(c.magT.p, (size_t) c.Tp * sizeof(double), Xv->data, (size_t) Xv->col_stride * sizeof(double),
+                                 (size_t) T * sizeof(double), (size_t) F, hipMemcpyHostToDevice, s));
+    launch_transpose(c.magT.as<double>(), c.Tp, c.Fp * c.Tp, c.mag.as<double>(), c.Fp, c.Tp * c.Fp, (int) F, (int) T, 1, s);
+  }
+  else
+  {
+    xtmp = view_gather(*Xv);
+    HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), xtmp.data(), (size_t) F * sizeof(double),
+                                 (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
+    launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T, (int) F, 1, s);
+  }
   c.haveMag = true;
+  // seeds are small (K x F, T x K): contiguous host images whatever their strides
+  std::vector<double> w0tmp, h0tmp;
   FactorInit fi;
-  fi.W0host = W0; fi.H0host = H0; fi.sharedW = fi.sharedH = true;
+  fi.sharedW = fi.sharedH = true;
+  if (!view_empty(W0v))
+  {
+    if (W0v->col_stride == 1 && W0v->row_stride == F) fi.W0host = W0v->data;
+    else { w0tmp = view_gather(*W0v); fi.W0host = w0tmp.data(); }
+  }
+  if (!view_empty(H0v))
+  {
+    if (H0v->col_stride == 1 && H0v->row_stride == K) fi.H0host = H0v->data;
+    else { h0tmp = view_gather(*H0v); fi.H0host = h0tmp.data(); }
+  }
   int rc = corpus_init_factors(&c, seed, nullptr, fi);
   if (rc) return rc;
   rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user);
   if (rc != FLUHIP_OK && rc != FLUHIP_CANCELLED) return rc;
   const bool cancelled = rc == FLUHIP_CANCELLED;
   // alg/NMF.hpp:127-133 outputs; :182 V = W*H only when the loop ran to completion
-  DevBuf dw, dh, dv;
-  if (W1)
+  DevBuf dw, dh, dv, dvt;
+  std::vector<double> w1tmp, h1tmp, v1tmp;
+  if (!view_empty(W1v))
   {
+    const bool direct = W1v->col_stride == 1 && W1v->row_stride == F;
+    if (!direct) w1tmp.resize((size_t) (K * F));
     HIPCHK(ctx, dw.alloc((size_t) K * F * sizeof(double), false, s));
     launch_gather_w_f64(c.Wf.as<double>(), 0, dw.as<double>(), 0, (int) F, (int) K, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(W1, dw.p, (size_t) K * F * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(direct ? W1v->data : w1tmp.data(), dw.p, (size_t) K * F * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  if (H1)
+  if (!view_empty(H1v))
   {
+    const bool direct = H1v->col_stride == 1 && H1v->row_stride == K;
+    if (!direct) h1tmp.resize((size_t) (T * K));
     HIPCHK(ctx, dh.alloc((size_t) T * K * sizeof(double), false, s));
     launch_gather_h_f64(c.H1.as<double>(), 0, dh.as<double>(), 0, (int) T, (int) K, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(H1, dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIPCHK(ctx, hipMemcpyAsync(direct ? H1v->data : h1tmp.data(), dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
   }
-  if (V1 && !cancelled)
+  if (!view_empty(V1v) && !cancelled)
   {
     HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
     launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F,
                 (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(V1, dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (V1v->col_stride == 1 || T == 1)
+      HIPCHK(ctx, hipMemcpy2DAsync(V1v->data, (size_t) V1v->row_stride * sizeof(double), dv.p, (size_t) F * sizeof(double),
+                                   (size_t) F * sizeof(double), (size_t) T, hipMemcpyDeviceToHost, s));
+    else if (V1v->row_stride == 1)
+    {
+      // a transposed view: the F x T image, made on the device
+      HIPCHK(ctx, dvt.alloc((size_t) F * T * sizeof(double), false, s));
+      launch_transpose(dv.as<double>(), F, 0, dvt.as<double>(), T, 0, (int) T, (int) F, 1, s);
+      HIPCHK(ctx, hipMemcpy2DAsync(V1v->data, (size_t) V1v->col_stride * sizeof(double), dvt.p, (size_t) T * sizeof(double),
+                                   (size_t) T * sizeof(double), (size_t) F, hipMemcpyDeviceToHost, s));
+    }
+    else
+    {
+      v1tmp.resize((size_t) (T * F));
+      HIPCHK(ctx, hipMemcpyAsync(v1tmp.data(), dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(s));
+  if (!w1tmp.empty()) view_scatter(*W1v, w1tmp.data());
+  if (!h1tmp.empty()) view_scatter(*H1v, h1tmp.data());
+  if (!v1tmp.empty()) view_scatter(*V1v, v1tmp.data());
   return cancelled ? FLUHIP_CANCELLED : FLUHIP_OK;
 }
 
-// alg/NMF.hpp:45-89 over every row of X: the H update with the dictionary fixed, from the processFrame
-// initial state (clamped x, clamped + row-normalised W, clamped un-normalised h).
+int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                           int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                           const double* W0, const double* H0, double* W1, double* H1,
+                           double* V1, fluhip_progress_fn progress, void* user)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
+  const fluhip_matrix_view xv{const_cast<double*>(X), T, F, ldx, 1};
+  const fluhip_matrix_view w0{const_cast<double*>(W0), K, F, F, 1}, h0{const_cast<double*>(H0), T, K, K, 1};
+  const fluhip_matrix_view w1{W1, K, F, F, 1}, h1{H1, T, K, K, 1}, v1{V1, T, F, F, 1};
+  return fluhip_nmf_process_views_f64(ctx, &xv, K, iters, update_w, update_h, seed, W0 ? &w0 : nullptr, H0 ? &h0 : nullptr,
+                                      W1 ? &w1 : nullptr, H1 ? &h1 : nullptr, V1 ? &v1 : nullptr, progress, user);
+}
+
 int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
                                   const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V)
 {
@@ -1230,6 +1361,7 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
   if (!W0 || K < 1) return fail(ctx, "bad dictionary");
   if (iters < 0) return fail(ctx, "negative iteration count");
+  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
   fluhip_corpus c;

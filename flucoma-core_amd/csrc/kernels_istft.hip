@@ -300,9 +300,11 @@ __global__ void polar_to_spec_kernel(const float* mag, const float* phase, int T
     double re = 0.0, im = 0.0;
     if (f < F && t < T)
     {
-      const double m = (double) mag[(int64_t) f * T + t], p = (double) phase[(int64_t) f * T + t];
-      re = m * cos(p); // std::polar(m, p), nrt/BufSTFTClient.hpp:248-250
-      im = m * sin(p);
+      // std::polar(m, p) on the buffers' float samples (nrt/BufSTFTClient.hpp:248-250): std::polar<float>, i.e.
+      // single-precision m cos p and m sin p, widened into the complex<double> frame afterwards
+      const float m = mag[(int64_t) f * T + t], p = phase[(int64_t) f * T + t];
+      re = (double) (m * cosf(p));
+      im = (double) (m * sinf(p));
     }
     tr[j][tx] = re;
     ti[j][tx] = im;

@@ -24,11 +24,24 @@ _ip = ctypes.POINTER(ctypes.c_int64)
 _vp = ctypes.c_void_p
 PROGRESS_FN = ctypes.CFUNCTYPE(ctypes.c_int, _i64, ctypes.c_void_p)
 
+
+class MatrixView(ctypes.Structure):
+    """fluhip_matrix_view: element (r, c) at data[r * row_stride + c * col_stride] (strides in doubles)"""
+    _fields_ = [("data", ctypes.POINTER(ctypes.c_double)), ("rows", _i64), ("cols", _i64), ("row_stride", _i64),
+                ("col_stride", _i64)]
+
+    @classmethod
+    def of(cls, a):
+        """view of a 2-D float64 numpy array with whatever strides it has (a.T, a[::2, 1:], ...)"""
+        assert a.dtype == np.float64 and a.ndim == 2 and all(st % 8 == 0 for st in a.strides)
+        return cls(ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_double)), a.shape[0], a.shape[1],
+                   a.strides[0] // 8, a.strides[1] // 8)
+
 EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
-    "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize",
+    "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize", "fluhip_ctx_trim",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
-    "fluhip_nmf_process_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
+    "fluhip_nmf_process_f64", "fluhip_nmf_process_views_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
     "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create",
@@ -68,6 +81,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_ctx_stream.argtypes = [_vp]
     L.fluhip_ctx_stream.restype = _vp
     L.fluhip_ctx_synchronize.argtypes = [_vp]
+    L.fluhip_ctx_trim.argtypes = [_vp]
     L.fluhip_fft_params.argtypes = [_i64, _i64, _i64, _ip, _ip, _ip, _ip]
     L.fluhip_stft_num_frames.argtypes = [_i64, _i64, _i64]
     L.fluhip_stft_num_frames.restype = _i64
@@ -75,6 +89,9 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_stft_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _dp, _dp, _ip]
     L.fluhip_nmf_process_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                          ctypes.c_int, _i64, _dp, _dp, _dp, _dp, _dp, PROGRESS_FN, _vp]
+    _mv = ctypes.POINTER(MatrixView)
+    L.fluhip_nmf_process_views_f64.argtypes = [_vp, _mv, _i64, _i64, ctypes.c_int, ctypes.c_int, _i64, _mv, _mv, _mv, _mv, _mv,
+                                               PROGRESS_FN, _vp]
     L.fluhip_nmf_process_frames_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _dp, _i64, _i64, _i64, _dp, _dp]
     _dbl = ctypes.c_double
     L.fluhip_nndsvd_f64.argtypes = [_vp, _dp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, ctypes.c_int, _i64, _dp, _dp, _ip]
@@ -220,6 +237,15 @@ class Context:
                                              _d(W1), _d(H1), _d(V1), cb, None)
         self._check(rc, allow=(OK, CANCELLED))
         return W1, H1, V1, rc
+
+    def nmf_process_views(self, X, K, iters, updateW=True, updateH=True, seed=42, W0=None, H0=None, W1=None, H1=None,
+                          V1=None, progress=None):
+        """NMF::process on numpy arrays used IN PLACE with their own strides (transposed views, sub-blocks)"""
+        ref = lambda a: ctypes.byref(MatrixView.of(a)) if a is not None else None  # noqa: E731
+        cb = _cb(progress)
+        rc = self.lib.fluhip_nmf_process_views_f64(self.h, ref(X), K, iters, int(updateW), int(updateH), seed, ref(W0),
+                                                   ref(H0), ref(W1), ref(H1), ref(V1), cb, None)
+        return self._check(rc, allow=(OK, CANCELLED))
 
     def nmf_process_frames(self, X, W0, iters, seed=42, want_v=True):
         """NMF::processFrame (alg/NMF.hpp:45-89) on every row of X [T,F] with the dictionary W0 [K,F]."""

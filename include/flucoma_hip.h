@@ -61,6 +61,8 @@ typedef int (*fluhip_progress_fn)(int64_t iteration, void* user);
 int         fluhip_abi_version(void);
 int         fluhip_device_count(void);                    /* 0 when no HIP device is visible */
 int         fluhip_ctx_create(int device, fluhip_ctx** out);
+/* Teardown order: destroy every corpus created on a context BEFORE the context (a corpus keeps using its context's
+ * stream until fluhip_corpus_destroy returns). */
 void        fluhip_ctx_destroy(fluhip_ctx* ctx);
 const char* fluhip_last_error(const fluhip_ctx* ctx);     /* never NULL */
 /* device name / gcnArchName into caller buffers (for bench reports) */
@@ -68,6 +70,10 @@ int         fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_l
                                    int arch_len, int* compute_units);
 /* raw HIP stream (hipStream_t) the context launches on -- for event timing by the caller */
 void*       fluhip_ctx_stream(const fluhip_ctx* ctx);
+/* Device buffers are recycled through a per-device cache of freed blocks (at most 8 GiB per device; a context's
+ * destruction empties its device's cache).  fluhip_ctx_trim hands the cached blocks of the context's device back to
+ * the driver now -- for hosts that share the GPU with other allocators (torch, RCCL). */
+int         fluhip_ctx_trim(fluhip_ctx* ctx);
 int         fluhip_ctx_synchronize(fluhip_ctx* ctx);
 
 /* ---- parameter arithmetic (integer, bit-exact) --------------------------------------- */
@@ -97,12 +103,30 @@ int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stri
  * + NMF::addProgressCallback  (algorithms/public/NMF.hpp:91-139, 144-183).
  * X: T x F with row stride ldx (doubles).  W0: K x F or NULL ("0x0 view").  H0: T x K or NULL.
  * W1: K x F, H1: T x K, V1: T x F or NULL.  seed < 0 => std::random_device like the reference.
- * On cancellation returns FLUHIP_CANCELLED; W1/H1 then hold the factors of the last completed
- * iteration batch and V1 is left unwritten. */
+ * progress is called once per completed iteration, in order; the device is never more than 8 iterations ahead of the last
+ * one reported.  On cancellation returns FLUHIP_CANCELLED; W1/H1 then hold the factors as they stand when the device has
+ * stopped -- at most 7 iterations after the one the callback refused (the reference stops at it exactly, NMF.hpp:175-176;
+ * its client discards the factors of a cancelled job, clients/nrt/NMFClient.hpp:273-274) -- and V1 is left unwritten. */
 int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
                            int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                            const double* W0, const double* H0, double* W1, double* H1,
                            double* V1, fluhip_progress_fn progress, void* user);
+
+/* The same with every matrix as a two-stride view, the shape FluidTensorView<double, 2> hands to asEigen
+ * (data/FluidTensor_Support.hpp:260-420 strides, :386-393 transpose(); util/FluidEigenMappings.hpp:35-225 maps them as
+ * Stride<Dynamic, Dynamic>): element (r, c) at data[r * row_stride + c * col_stride].  NULL, data == NULL or a zero
+ * extent is the reference's "0x0 view" (no seed / output not wanted).  Shapes as above (X T x F, W0 / W1 K x F,
+ * H0 / H1 T x K, V1 T x F).  Unit-column-stride views and their transposes (unit row stride) move as strided copies
+ * with no host-side repacking of X or V1; views with two non-unit strides are packed on the host. */
+typedef struct fluhip_matrix_view
+{
+  double* data;
+  int64_t rows, cols, row_stride, col_stride;
+} fluhip_matrix_view;
+int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* X, int64_t K, int64_t iters, int update_w,
+                                 int update_h, int64_t seed, const fluhip_matrix_view* W0, const fluhip_matrix_view* H0,
+                                 const fluhip_matrix_view* W1, const fluhip_matrix_view* H1, const fluhip_matrix_view* V1,
+                                 fluhip_progress_fn progress, void* user);
 
 /* Replaces NMF::processFrame(x, W0, out, nIterations, v, randomSeed, alloc) (algorithms/public/NMF.hpp:45-89)
  * applied to every row of X at once -- the per-frame activation solve that

@@ -77,6 +77,10 @@ struct MatrixView
   VectorView<T> row(index r) const { return {ptr + r * rstride, ncols, cstride}; }
   VectorView<T> col(index c) const { return {ptr + c * cstride, nrows, rstride}; }
   MatrixView    transpose() const { return {ptr, ncols, nrows, cstride, rstride}; } // data/FluidTensor_Support.hpp:386-393
+  // {data, rows, cols, row stride, col stride}: the field order of fluhip_matrix_view (include/flucoma_hip.h), so a
+  // MatrixView<double> -- transposed or not -- goes to fluhip_nmf_process_views_f64 as it is
+  template <typename V>
+  V as() const { return V{const_cast<std::remove_const_t<T>*>(ptr), nrows, ncols, rstride, cstride}; }
   T*            data() const { return ptr; }
 };
 

@@ -838,9 +838,10 @@ int64_t fo_bufstft_inverse(const float* mag, const float* phase, int64_t T, int6
   {
     for (int64_t f = 0; f < F; f++)
     {
-      /* :248-250 std::polar(m, p) on the float samples promoted to double */
-      const double m = (double) mag[f * T + t], ph = (double) phase[f * T + t];
-      double yr = m * cos(ph), yi = m * sin(ph);
+      /* :248-250 std::polar(m, p) with m, p the FLOAT samples of the buffers: std::polar<float> (m cosf(p), m sinf(p) in
+       * single precision), then widened into the complex<double> frame */
+      const float mf = mag[f * T + t], pf = phase[f * T + t];
+      double yr = (double) (mf * cosf(pf)), yi = (double) (mf * sinf(pf));
       if (f == 0 || f == F - 1) yi = 0; /* util/FFT.hpp:155-160 */
       re[f] = yr; im[f] = -yi;
       if (f > 0 && f < F - 1) { re[fft - f] = yr; im[fft - f] = yi; }

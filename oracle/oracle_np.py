@@ -409,11 +409,12 @@ def bufstft_forward(audio_f32, win, fft, hop, padding_mode=1):
 
 
 def bufstft_inverse(mag, phase, win, fft, hop, padding_mode=1):
-    mag = np.asarray(mag, dtype=np.float32).astype(np.float64)
-    phase = np.asarray(phase, dtype=np.float32).astype(np.float64)
+    mag = np.asarray(mag, dtype=np.float32)
+    phase = np.asarray(phase, dtype=np.float32)
     F, T = mag.shape
     pad = bufstft_padding(win, hop, padding_mode)
-    spec = (mag * np.exp(1j * phase)).T
+    # nrt/BufSTFTClient.hpp:248-250: std::polar on the float samples = single-precision m cos p, m sin p, widened after
+    spec = ((mag * np.cos(phase)).astype(np.float64) + 1j * (mag * np.sin(phase)).astype(np.float64)).T
     frames = np.fft.irfft(spec, n=fft, axis=1)[:, :win] * hann(win)[None, :]
     size = (T - 1) * hop + win
     acc, nrm = np.zeros(size), np.zeros(size)
