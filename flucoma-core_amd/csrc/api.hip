@@ -596,6 +596,11 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
   hipStream_t s = ctx->stream;
   const size_t FK = (size_t) c->F * c->K, TK = (size_t) c->T * c->K;
   const int B = (int) c->B;
+  // The draws run on the calling thread while the device is still busy with whatever was enqueued before (the STFT
+  // of this job); the host images stay alive to the single synchronisation at the end, so the two uploads and the
+  // scatter kernels queue up behind each other without a host round trip in between.
+  std::vector<double> hostW, hostH;
+  DevBuf stageH;
   // --- W ---
   if (fi.W0f32)
   {
@@ -603,11 +608,10 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     HIPCHK(ctx, hipMemcpyAsync(c->stage.p, fi.W0f32, (size_t) B * FK * sizeof(float), hipMemcpyHostToDevice, s));
     launch_scatter_factor_f32(c->stage.as<float>(), (int64_t) FK, c->Wf.as<double>(), c->Fp * c->Kp,
                               (int) c->F, (int) c->K, (int) c->Kp, B, s);
-    HIPCHK(ctx, hipStreamSynchronize(s));
   }
   else
   {
-    std::vector<double> host;
+    std::vector<double>& host = hostW;
     const double* src = fi.W0host;
     int nsrc = fi.W0host ? (fi.sharedW ? 1 : B) : 1;
     if (!src)
@@ -640,20 +644,18 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     // K x F row-major source (random: column-major F x K fill; seeded: W0 transposed, :102-112)
     launch_scatter_factor(c->stage.as<double>(), nsrc == 1 ? 0 : (int64_t) FK, c->Wf.as<double>(),
                           c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, s);
-    HIPCHK(ctx, hipStreamSynchronize(s)); // host vector goes out of scope
   }
   // --- H ---
   if (fi.H0f32)
   {
-    HIPCHK(ctx, c->stage.alloc((size_t) B * TK * sizeof(float), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, fi.H0f32, (size_t) B * TK * sizeof(float), hipMemcpyHostToDevice, s));
-    launch_scatter_factor_f32(c->stage.as<float>(), (int64_t) TK, c->H1.as<double>(), c->Tp * c->Kp,
+    HIPCHK(ctx, stageH.alloc((size_t) B * TK * sizeof(float), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(stageH.p, fi.H0f32, (size_t) B * TK * sizeof(float), hipMemcpyHostToDevice, s));
+    launch_scatter_factor_f32(stageH.as<float>(), (int64_t) TK, c->H1.as<double>(), c->Tp * c->Kp,
                               (int) c->T, (int) c->K, (int) c->Kp, B, s);
-    HIPCHK(ctx, hipStreamSynchronize(s));
   }
   else
   {
-    std::vector<double> host;
+    std::vector<double>& host = hostH;
     const double* src = fi.H0host;
     int nsrc = fi.H0host ? (fi.sharedH ? 1 : B) : 1;
     if (!src)
@@ -681,12 +683,11 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
         draw_uniform(seed, TK, host); // alg/NMF.hpp:116-117 (a fresh generator from the same seed)
       src = host.data();
     }
-    HIPCHK(ctx, c->stage.alloc((size_t) nsrc * TK * sizeof(double), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->stage.p, src, (size_t) nsrc * TK * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, stageH.alloc((size_t) nsrc * TK * sizeof(double), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(stageH.p, src, (size_t) nsrc * TK * sizeof(double), hipMemcpyHostToDevice, s));
     // T x K row-major source (random: column-major K x T fill; seeded: H0 transposed, :113-124)
-    launch_scatter_factor(c->stage.as<double>(), nsrc == 1 ? 0 : (int64_t) TK, c->H1.as<double>(),
+    launch_scatter_factor(stageH.as<double>(), nsrc == 1 ? 0 : (int64_t) TK, c->H1.as<double>(),
                           c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, false, s);
-    HIPCHK(ctx, hipStreamSynchronize(s));
   }
   // alg/NMF.hpp:150-153: clamp both to eps, normalise columns of W and rows of H (= columns of H1)
   if (!c->normScratch.p)
@@ -699,6 +700,7 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
   launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, false,
                  c->normScratch.as<double>(), s);
   HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipStreamSynchronize(s)); // the host images and the second staging buffer go out of scope
   c->haveFactors = true;
   return FLUHIP_OK;
 }

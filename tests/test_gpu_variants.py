@@ -1,0 +1,54 @@
+"""The factor-update kernel forms that production does not pick on its own (FLUHIP_NMF_KERNEL, read once per process, so
+each runs in a subprocess): the register-staged 4x4x4 kernel (4), the first 16x16x4 kernel (16) and the un-fused
+any-rank path (-1) -- the same shapes against the oracle, so the A/B switches of DESIGN section 6b stay trustworthy;
+plus the STFT forms (round-1 wave kernel + transposing copy, generic workgroup-per-frame kernel)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys
+import numpy as np
+ROOT = sys.argv[1]
+sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import fluhip, oracle_c, oracle_np
+from helpers import rel_err
+o = oracle_c.get("native")
+ctx = fluhip.Context(0)
+worst = 0.0
+for (T, F, K, iters) in ((200, 1025, 16, 12), (173, 1025, 32, 12), (97, 257, 48, 8), (64, 129, 64, 8), (33, 17, 1, 10), (300, 513, 3, 10)):
+    rs = np.random.RandomState(T * 7 + F)
+    X = np.abs(rs.standard_normal((T, 3)) @ rs.standard_normal((3, F))) + 0.01 * rs.uniform(0, 1, (T, F))
+    W1, H1, V1, rc = ctx.nmf_process(X, K, iters, True, True, 42)
+    rW, rH, rV, _ = o.nmf_process(X, K, iters, True, True, 42)
+    worst = max(worst, rel_err(W1, rW), rel_err(H1, rH), rel_err(V1, rV))
+# a corpus (batched schedule) and the single-buffer split schedule
+audio = np.stack([oracle_np.synth_audio(30000, 1000 + b) for b in range(9)])
+c = fluhip.Corpus(ctx, 9, 30000, 1024, 1024, 256, 8)
+c.set_audio(audio); c.stft(); c.nmf(10, seed=42)
+mag, W1, H1 = c.read_f64()
+for b in (0, 8):
+    _, rmag = o.stft_f32(audio[b], 1024, 1024, 256)
+    rW, rH, _, _ = o.nmf_process(rmag, 8, 10, True, True, 42)
+    worst = max(worst, rel_err(mag[b], rmag) * 1e3, rel_err(W1[b], rW), rel_err(H1[b], rH))
+print("plan", c.plan()["kernel"], "worst", worst)
+assert worst < 1e-9, worst
+'''
+
+
+@pytest.mark.parametrize("env", [{"FLUHIP_NMF_KERNEL": "4"}, {"FLUHIP_NMF_KERNEL": "16"}, {"FLUHIP_NMF_KERNEL": "-1"},
+                                 {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
+                                 {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_alternative_kernel_forms_against_the_oracle(env):
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=e)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    if "FLUHIP_NMF_KERNEL" in env and env["FLUHIP_NMF_KERNEL"] != "-1":
+        assert f"plan {env['FLUHIP_NMF_KERNEL']} " in p.stdout, p.stdout
