@@ -893,3 +893,19 @@ def test_feature_frame_positions_follow_fluidsource(ctx, onp, n, win, fft, hop):
             s = starts[k] if starts[k] is not None else start0 + k * hop
             covered = s < p < s + win          # i = p - s in 1 .. win-1: non-zero window sample
             assert bool(lit[k]) == covered, (p, k, s)
+
+
+@pytest.mark.parametrize("frame", [32, 64, 256, 1024, 8192])
+def test_reference_testbufferedprocess_cola_through_bufstft(ctx, frame):
+    """tests/clients/common/TestBufferedProcess.cpp:20-70 through the HIP path: the reference's step signal (a frame of
+    zeros, then ones), Hann-windowed frames at hop = frameSize / 2, transformed and resynthesised by BufSTFT forward ->
+    inverse.  Under COLA the input comes back (there to 1e-12 in doubles; here through float magnitude / phase buffers)."""
+    hop = frame // 2
+    n = min(128 * frame, 16 * frame + 4096)
+    x = np.zeros(n, dtype=np.float32)
+    x[frame:] = 1.0
+    mag, ph = ctx.bufstft_forward(x, frame, frame, hop, 1)
+    assert mag.shape == (frame // 2 + 1, 1 + (n + 2 * (frame // 2) - frame) // hop)
+    y = ctx.bufstft_inverse(mag, ph, frame, frame, hop, 1)
+    m = min(len(y), n)
+    assert np.abs(y[:m - frame] - x[:m - frame]).max() < 5e-6
