@@ -947,7 +947,7 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, WPS>();
-      if constexpr (M == 8 && (NG == 9 || NG == 8) && WPS == 1)
+      if constexpr (((M == 8 && (NG == 9 || NG == 8)) || (M == 4 && NG == 3)) && WPS == 1)
       {
         // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
         static const int instr = [] { const char* e = std::getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();

@@ -149,11 +149,12 @@ __device__ __forceinline__ int xpad(int i) { return i + (i >> 4); } // one 8-byt
 template <int R>
 __device__ __forceinline__ cx split_const(int r)
 {
-  // R = 8: sixteenth roots; R = 4: eighth roots
-  constexpr double c16[8] = {1.0, kC1, kC2, kS1, 0.0, -kS1, -kC2, -kC1};
-  constexpr double s16[8] = {0.0, kS1, kC2, kC1, 1.0, kC1, kC2, kS1};
-  const int q = (R == 8) ? r : 2 * r;
-  return cx{c16[q], -s16[q]};
+  // e^{-2 pi i r / (2 R)}: R = 16: thirty-second roots of unity; R = 8: every second one; R = 4: every fourth
+  constexpr double c32[16] = {1, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254523567, 0.70710678118654757274, 0.55557023301960228867, 0.38268343236508983729, 0.19509032201612833135, 0, -0.19509032201612819257, -0.38268343236508972627, -0.5555702330196019556, -0.70710678118654746172, -0.83146961230254534669, -0.92387953251128673848, -0.98078528040323043058};
+  constexpr double s32[16] = {0, 0.19509032201612824808, 0.38268343236508978178, 0.55557023301960217765, 0.70710678118654746172, 0.83146961230254523567, 0.92387953251128673848, 0.98078528040323043058, 1, 0.98078528040323043058, 0.92387953251128673848, 0.83146961230254545772, 0.70710678118654757274, 0.55557023301960217765, 0.3826834323650898928, 0.19509032201612860891};
+  static_assert(R == 16 || R == 8 || R == 4, "last-pass radix");
+  const int q = r * (16 / R);
+  return cx{c32[q], -s32[q]};
 }
 
 } // namespace
@@ -796,6 +797,11 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
   {
     // 8 frames per block: 224 registers, two wavefronts per SIMD (12 and 16 per workgroup spill and measured slower)
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
+  }
+  if (a.fft == 4096)
+  {
+    // BASELINE config 3: 32 points per lane (one wavefront per SIMD), 4 frames per block
+    return launch_block_t<16, 8, 16, 4, 1>(k, s);
   }
   if (a.fft == 1024)
   {

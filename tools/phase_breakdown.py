@@ -6,9 +6,15 @@ sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, o
 os.environ["FLUHIP_K5_INSTR"] = "1"
 import fluhip, oracle_np
 ctx = fluhip.Context(0)
-B, n = 128, 441000
-x = oracle_np.synth_audio(n, 1000)
-c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, 32)
+# default: the bench shard; `python tools/phase_breakdown.py c2` : the single 60 s buffer at rank 16 (split contraction)
+if len(sys.argv) > 1 and sys.argv[1] == "c2":
+    B, n, K = 1, 2646000, 16
+else:
+    B, n, K = 128, 441000, 32
+x = oracle_np.synth_audio(441000, 1000)
+x = np.tile(x, n // len(x) + 1)[:n]
+c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, K)
+print("plan", c.plan())
 c.set_audio(np.tile(x, (B, 1))); c.stft(); c.nmf(3, seed=42, updateH=False); ctx.synchronize()
 out = (ctypes.c_int64 * 32)()
 assert ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0
