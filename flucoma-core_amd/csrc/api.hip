@@ -391,7 +391,7 @@ static int choose_split4(int64_t B, int C, int R, int Kp)
   static const int forceS = [] { const char* e = std::getenv("FLUHIP_PLAN_SPLIT"); return e ? std::atoi(e) : 0; }();
   const int64_t nSteps = (R + 3) / 4;
   const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(64, nSteps / 12)); // >= 12 steps per wavefront
-  if (forceS > 0) return (int) std::min<int64_t>(forceS, std::max<int64_t>(1, nSteps / 2));
+  if (forceS > 0) return (int) std::min<int64_t>(std::min<int64_t>(forceS, 64), std::max<int64_t>(1, nSteps / 2)); // the finalize kernel sums at most 64 splits
   const int64_t waves = B * nmf_update4_waves_per_buffer(C, Kp, (int) B);
   if (waves >= 768) return 1;
   // one wavefront per SIMD (the kernel's register footprint allows no more): never exceed 1024 in
@@ -466,7 +466,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     }
     // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
     // finalize kernel when the contraction is split
-    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F)
+    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F, (int) c->Kp)
                                 : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
   }
   else

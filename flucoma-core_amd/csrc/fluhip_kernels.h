@@ -98,11 +98,11 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
 // alg/NMF.hpp:158-161 with (V, Mv, S) = (mag, H1, Wf) and :165-170 with (magT, Wf, H1).
 // split-contraction epilogue shared by the kernel forms: S <- S * (sum of the numerator partials) / max(sum of the
 // denominator partials, eps), with the deferred-normalisation arithmetic and (statPart) per-chunk column
-// statistics [B][update_finalize_parts(C)][2][Kp] when asked for
+// statistics [B][update_finalize_parts(C, Kp)][2][Kp] when asked for
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart, int C, int Kp,
                             int64_t Cp, int nsplit, int B, hipStream_t s, const double* nrm = nullptr,
                             int nrmMode = 0, double* statPart = nullptr);
-int update_finalize_parts(int C);
+int update_finalize_parts(int C, int Kp);
 void launch_nmf_update(const UpdateArgs& a, hipStream_t s);      // v_mfma_f64_16x16x4 form (A/B)
 int nmf_update_cols_per_wave(int Kp);
 void launch_nmf_update4(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b form

@@ -217,87 +217,102 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // LDS -- single-buffer problems have few rows and many splits, so the parallelism has to come from the splits.
 // With deferred normalisation (UpdateArgs::nrm) the step is the one of the un-split kernel's epilogue, and
 // for the W update the block leaves its column statistics (sum x^2, max) for wnorm_combine_kernel.
-constexpr int kFinRows = 16;
-constexpr int kFinSG = 4;
+// Latency shape: the kernel moves a few MB through a few hundred workgroups, so what it costs is the number of
+// DEPENDENT memory round trips, not bytes.  Every thread therefore issues all of its loads up front -- its share of
+// the split partials for kFinBatch rows at once, the old value of S, and (the first row group) the denominator
+// partials -- and only then starts adding; the first form walked its 16 rows in four dependent batches behind a
+// denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
+constexpr int kFinSG = 4;      // thread groups sharing the split partials of an element
+constexpr int kFinBatch = 4;   // rows per row group, all in flight together
+constexpr int kFinMaxPer = 16; // split partials per thread group (nsplit <= 64); the kernel is built for 1, 2, 4, 8 and 16
 
-__global__ void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
+static int fin_row_groups(int Kp) { int nrg = 256 / (Kp * kFinSG); return nrg < 1 ? 1 : nrg; }
+int update_finalize_rows(int Kp) { return kFinBatch * fin_row_groups(Kp); }
+int update_finalize_parts(int C, int Kp) { const int rows = update_finalize_rows(Kp); return (C + rows - 1) / rows; }
+
+template <int PER>
+__global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
                                            const double* dpart, int C, int Kp, int64_t Cp,
                                            int nsplit, const double* nrm, int nrmMode, double* statPart, int nch)
 {
-  extern __shared__ double sh[]; // [kFinSG][nrg][Kp] quarter sums; then [nrg][Kp] x 2 for the statistics
+  extern __shared__ double sh[]; // [kFinSG][nrg][kFinBatch][Kp] partial numerators, then [kFinSG][Kp] denominators; reused for the statistics
   const int chunk = blockIdx.x, buf = blockIdx.y;
   const int nrg = blockDim.x / (Kp * kFinSG);
   const int k = threadIdx.x % Kp, rg = (threadIdx.x / Kp) % nrg, sg = threadIdx.x / (Kp * nrg);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const int sb = sg * per, se = min(nsplit, sb + per);
-  // denominators: the same quarter-and-combine scheme (a plain loop would be nsplit dependent load latencies)
-  double den = 0.0, nk = 1.0;
-  if (rg == 0)
-  {
-    const double* dp = dpart + (int64_t) buf * nsplit * Kp + k;
-    int s = sb;
-    for (; s + 8 <= se; s += 8)
-    {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = dp[(int64_t) (s + u) * Kp];
-#pragma unroll
-      for (int u = 0; u < 8; u++) den += v[u];
-    }
-    for (; s < se; s++) den += dp[(int64_t) s * Kp];
-    sh[sg * Kp + k] = den;
-  }
-  __syncthreads();
-  if (sg == 0)
-  {
-    den = sh[k];
-#pragma unroll
-    for (int g = 1; g < kFinSG; g++) den += sh[g * Kp + k];
-    nk = nrmMode ? nrm[(int64_t) buf * Kp + k] : 1.0;
-    if (nrmMode == 2) den = den / nk;
-    den = fmax(den, kEpsilon);
-  }
-  __syncthreads();
+  const int rows = kFinBatch * nrg;
+  const int rbeg = chunk * rows, rend = min(rbeg + rows, C);
   const double* p0 = part + (int64_t) buf * nsplit * Cp * Kp;
   const int64_t sstride = Cp * Kp;
-  double ss = 0.0, mx = -INFINITY;
-  const int rbeg = chunk * kFinRows, rend = min(rbeg + kFinRows, C);
-  for (int r0 = rbeg; r0 < rend; r0 += nrg)
+  // ---- every load of this thread, issued before anything is consumed ---------------------------------------------
+  double pv[kFinBatch][PER];
+  double sold[kFinBatch];
+  double dv[PER];
+#pragma unroll
+  for (int i = 0; i < kFinBatch; i++)
   {
-    const int r = r0 + rg;
-    const int64_t idx = (int64_t) r * Kp + k;
+    const int r = rbeg + i * nrg + rg;
+    const int64_t idx = (int64_t) min(r, C - 1) * Kp + k;
+#pragma unroll
+    for (int u = 0; u < PER; u++) pv[i][u] = (u < per) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
+    sold[i] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
+  }
+  {
+    const double* dp = dpart + (int64_t) buf * nsplit * Kp + k;
+#pragma unroll
+    for (int u = 0; u < PER; u++) dv[u] = (rg == 0 && u < per) ? dp[(int64_t) min(sb + u, nsplit - 1) * Kp] : 0.0;
+  }
+  const double nk = (nrmMode && sg == 0) ? nrm[(int64_t) buf * Kp + k] : 1.0;
+  // ---- quarter sums in split order, combined in group order through LDS ----------------------------------------------------
+  double* shn = sh;                                   // [kFinSG][nrg][kFinBatch][Kp]
+  double* shd = sh + kFinSG * nrg * kFinBatch * Kp;   // [kFinSG][Kp]
+#pragma unroll
+  for (int i = 0; i < kFinBatch; i++)
+  {
     double num = 0.0;
-    if (r < rend)
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+      if (sb + u < se) num += pv[i][u];
+    shn[((sg * nrg + rg) * kFinBatch + i) * Kp + k] = num;
+  }
+  if (rg == 0)
+  {
+    double den = 0.0;
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+      if (sb + u < se) den += dv[u];
+    shd[sg * Kp + k] = den;
+  }
+  __syncthreads();
+  double ss = 0.0, mx = -INFINITY;
+  if (sg == 0)
+  {
+    double den = shd[k];
+#pragma unroll
+    for (int g = 1; g < kFinSG; g++) den += shd[g * Kp + k];
+    if (nrmMode == 2) den = den / nk;
+    den = fmax(den, kEpsilon);
+#pragma unroll
+    for (int i = 0; i < kFinBatch; i++)
     {
-      int s = sb;
-      for (; s + 8 <= se; s += 8)
+      const int r = rbeg + i * nrg + rg;
+      if (r < rend)
       {
-        double v[8];
+        double t = shn[(rg * kFinBatch + i) * Kp + k];
 #pragma unroll
-        for (int u = 0; u < 8; u++) v[u] = p0[(int64_t) (s + u) * sstride + idx];
-#pragma unroll
-        for (int u = 0; u < 8; u++) num += v[u];
+        for (int g = 1; g < kFinSG; g++) t += shn[((g * nrg + rg) * kFinBatch + i) * Kp + k];
+        double so = sold[i];
+        if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
+        const double x = (so * t) / den;
+        S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
+        ss += x * x;
+        mx = fmax(mx, x);
       }
-      for (; s < se; s++) num += p0[(int64_t) s * sstride + idx];
     }
-    sh[(sg * nrg + rg) * Kp + k] = num;
-    __syncthreads();
-    if (sg == 0 && r < rend)
-    {
-      double t = sh[rg * Kp + k];
-#pragma unroll
-      for (int g = 1; g < kFinSG; g++) t += sh[(g * nrg + rg) * Kp + k];
-      double* sp = S + (int64_t) buf * strideS + idx;
-      double so = *sp;
-      if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
-      const double x = (so * t) / den;
-      *sp = x;
-      ss += x * x;
-      mx = fmax(mx, x);
-    }
-    __syncthreads();
   }
   if (!statPart) return;
+  __syncthreads();
   if (sg == 0)
   {
     sh[rg * Kp + k] = ss;
@@ -318,18 +333,23 @@ __global__ void nmf_update_finalize_kernel(double* S, int64_t strideS, const dou
   }
 }
 
-int update_finalize_parts(int C) { return (C + kFinRows - 1) / kFinRows; }
-
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
                             int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s, const double* nrm,
                             int nrmMode, double* statPart)
 {
-  int nrg = 256 / Kp;
-  if (nrg < 1) nrg = 1;
-  const int nch = update_finalize_parts(C);
-  hipLaunchKernelGGL(nmf_update_finalize_kernel, dim3((unsigned) nch, (unsigned) B),
-                     dim3((unsigned) (kFinSG * nrg * Kp)), (size_t) kFinSG * nrg * Kp * sizeof(double), s, S, strideS,
-                     part, dpart, C, Kp, Cp, nsplit, nrm, nrmMode, statPart, nch);
+  const int nrg = fin_row_groups(Kp);
+  const int nch = update_finalize_parts(C, Kp);
+  const size_t shmem = ((size_t) kFinSG * nrg * kFinBatch * Kp + (size_t) kFinSG * Kp) * sizeof(double);
+  const int per = (nsplit + kFinSG - 1) / kFinSG;
+  const dim3 grid((unsigned) nch, (unsigned) B), block((unsigned) (kFinSG * nrg * Kp));
+#define FLUHIP_FIN(P) hipLaunchKernelGGL(nmf_update_finalize_kernel<P>, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, \
+                                         nsplit, nrm, nrmMode, statPart, nch)
+  if (per <= 1) FLUHIP_FIN(1);
+  else if (per <= 2) FLUHIP_FIN(2);
+  else if (per <= 4) FLUHIP_FIN(4);
+  else if (per <= 8) FLUHIP_FIN(8);
+  else FLUHIP_FIN(16);
+#undef FLUHIP_FIN
 }
 
 template <int NB, int CB, int MINW>
