@@ -71,16 +71,15 @@ namespace {
 __device__ __forceinline__ cx cmul2(cx a, cx b) { return cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cx mul_mi2(cx a) { return cx{a.im, -a.re}; } // a * (-i)
 
-// sqrt(x), x >= 0: v_rsq_f64 seed + two coupled Newton steps + residual correction (rounding error only)
+// sqrt(x), x >= 0: v_rsq_f64 seed y = (1 + e) / sqrt(x), |e| ~ 2^-23; one coupled Goldschmidt step leaves g = sqrt(x) (1 - 1.5 e^2)
+// (~2e-14) and h = 1 / (2 g) to the same order; the exact residual d = x - g^2 times h then squares that again: rounding
+// error only, in 9 FP64 operations (the wave kernel of round 1 ran a second Goldschmidt step first: 12).
 __device__ __forceinline__ double mag_sqrt2(double x)
 {
   x = fmax(x, 2.2250738585072014e-308);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
-  double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  r = __builtin_fma(-h, g, 0.5);
+  const double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
   const double d = __builtin_fma(-g, g, x);
@@ -548,6 +547,29 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   }
 }
 
+// ---- wavefront scan of doubles with DPP moves (no LDS crossbar): lanes a DPP source does not reach read 0 ----------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffff), CTRL, ROWMASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, ROWMASK, 0xf, false);
+  return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+// inclusive prefix sum over the 64 lanes, lane order
+__device__ __forceinline__ double wave_scan(double x)
+{
+  x += dpp_f64<0x111, 0xf>(x);   // row_shr:1
+  x += dpp_f64<0x112, 0xf>(x);   // row_shr:2
+  x += dpp_f64<0x114, 0xf>(x);   // row_shr:4
+  x += dpp_f64<0x118, 0xf>(x);   // row_shr:8
+  x += dpp_f64<0x142, 0xa>(x);   // row_bcast:15 into rows 1 and 3
+  x += dpp_f64<0x143, 0xc>(x);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// value of the lane below (0 for lane 0)
+__device__ __forceinline__ double wave_shr1(double x) { return dpp_f64<0x138, 0xf>(x); } // wave_shr:1
+
 // ---------------------------------------------------------------------------------------------------------------
 // Fused feature form (BASELINE config 5: STFT -> MelBands -> MFCC): the frame's magnitudes never leave the
 // wavefront's LDS buffer -- per frame the kernel reads hop 4 bytes of samples and writes nOut 4 bytes of features.
@@ -645,16 +667,10 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       pu[i] = su;
       pd[i] = sd;
     }
-    // inclusive scan of the lane totals, then shifted by one lane: what the lanes below contribute
-    double xu = su, xd = sd;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1)
-    {
-      const double tu = __shfl_up(xu, off), td = __shfl_up(xd, off);
-      if (lane >= off) { xu += tu; xd += td; }
-    }
-    double eu = __shfl_up(xu, 1), ed = __shfl_up(xd, 1);
-    if (lane == 0) { eu = 0.0; ed = 0.0; }
+    // inclusive scan of the lane totals over the wavefront (DPP: four shifts inside a row of 16, then the row totals
+    // broadcast upwards), then shifted by one lane: what the lanes below contribute
+    const double xu = wave_scan(su), xd = wave_scan(sd);
+    const double eu = wave_shr1(xu), ed = wave_shr1(xd);
 #pragma unroll
     for (int i = 0; i < CH; i++)
     {
@@ -671,7 +687,9 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       for (int off = 1; off < 64; off <<= 1) { bs += __shfl_xor(bs, off); en += __shfl_xor(en, off); }
       v = v * (en * scale2) / fmax(kEpsilon, bs);
     }
-    if (fa.logOutput) v = 20.0 * log10(fmax(v, kEpsilon));   // :95
+    // :95  20 log10(max(eps, band)).  The feature leaves as a float: the logarithm is taken in single precision (hardware
+    // log2; the band energy rounds to float with 6e-8 relative error = 5e-7 dB, below the float output's own resolution)
+    if (fa.logOutput) v = (double) (6.020599913279624f * __log2f((float) fmax(v, kEpsilon)));
     if (!fa.dct)
     {
       if (lane < fa.nBands) fa.out[((int64_t) b * fa.nOut + lane) * a.T + t] = (float) v;
