@@ -2,18 +2,18 @@
 //
 // The fused kernels (kernels_nmf5.hip) keep a wavefront's stationary rows in registers, which ends at Kp = 128.
 // Beyond that the update is done the way the reference writes it (alg/NMF.hpp:158-170), in three steps over a
-// materialised ratio matrix, with one plain tiled FP64 GEMM kernel:
+// materialised ratio matrix, with one LDS-tiled FP64 GEMM kernel on the matrix cores (v_mfma_f64_16x16x4):
 //   Q[r][c]  = sum_k Mv[r][k] S[c][k]            (GEMM, "NT")          R x C
 //   Q[r][c]  = V[r][c] / max(Q[r][c], eps)       (in place)
 //   N[c][k]  = sum_r Q[r][c] Mv[r][k]            (GEMM, "TN")          C x Kp
 //   S[c][k] <- S[c][k] N[c][k] / max(sum_r Mv[r][k], eps)
-// Rare in practice (FluCoMa ranks are a handful), so this path is correct and reasonably tiled, not tuned; it also
+// Rare in practice (FluCoMa ranks are a handful), so this path is correct and on the matrix cores, not tuned; it also
 // serves the tests as an independent second implementation of the same update.
 #include "fluhip_kernels.h"
 
 namespace fluhip {
 
-constexpr int TM = 64, TN = 64, TK = 16; // workgroup tile; 256 threads x (4 x 4) outputs
+constexpr int TM = 64, TN = 64, TK = 16; // workgroup tile; four wavefronts x (2 x 2) MFMA tiles of 16 x 16
 
 // C[m][n] = sum_k A(m,k) B(n,k)   with A(m,k) = A[m*lda + k] (TRANSA = 0) or A[k*lda + m] (TRANSA = 1),
 //                                       B(n,k) = B[n*ldb + k] (TRANSB = 0) or B[k*ldb + n] (TRANSB = 1)
@@ -26,12 +26,17 @@ __global__ __launch_bounds__(256) void dgemm_tile_kernel(const double* A, int64_
   const int b = blockIdx.z;
   A += (int64_t) b * strideA; B += (int64_t) b * strideB; C += (int64_t) b * strideC;
   const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4; // 16 x 16 threads, 4 x 4 outputs each
-  double acc[4][4];
+  // four wavefronts, a 32 x 32 quadrant each = 2 x 2 tiles of v_mfma_f64_16x16x4: A-operand lane l = (row l % 16, k l / 16),
+  // B-operand lane l = (k l / 16, column l % 16), result register e of lane l = (row l / 16 + 4 e, column l % 16)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+  const int lr = lane & 15, lk = lane >> 4;
+  typedef double d4 __attribute__((ext_vector_type(4)));
+  d4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = 0.0;
+    for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
   for (int k0 = 0; k0 < K; k0 += TK)
   {
     for (int e = threadIdx.x; e < TM * TK; e += 256)
@@ -50,28 +55,30 @@ __global__ __launch_bounds__(256) void dgemm_tile_kernel(const double* A, int64_
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < TK; k++)
+    for (int kk = 0; kk < TK; kk += 4)
     {
-      double a[4], bb[4];
+      double a[2], bb[2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) a[i] = As[k][ty * 4 + i];
+      for (int i = 0; i < 2; i++) a[i] = As[kk + lk][wm + 16 * i + lr];
 #pragma unroll
-      for (int j = 0; j < 4; j++) bb[j] = Bs[k][tx * 4 + j];
+      for (int j = 0; j < 2; j++) bb[j] = Bs[kk + lk][wn + 16 * j + lr];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = fma(a[i], bb[j], acc[i][j]);
+        for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < 2; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-    {
-      const int gm = m0 + ty * 4 + i, gn = n0 + tx * 4 + j;
-      if (gm < M && gn < N) C[(int64_t) gm * ldc + gn] = acc[i][j];
-    }
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+      {
+        const int gm = m0 + wm + 16 * i + lk + 4 * e, gn = n0 + wn + 16 * j + lr;
+        if (gm < M && gn < N) C[(int64_t) gm * ldc + gn] = acc[i][j][e];
+      }
 }
 
 __global__ void ratio_inplace_kernel(double* Q, int64_t ldq, int64_t strideQ, const double* V, int64_t ldv,
