@@ -78,7 +78,7 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                :
                : "s"(ldsAddr), "v"(voff), "s"(sbase)
-               : "memory");   // m0 is written; the compiler keeps nothing live in it around LDS-DMA code (gfx9 LDS ops do not use it)
+               : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_addr(const void* p)
 {
