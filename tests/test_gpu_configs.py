@@ -203,3 +203,13 @@ def test_bench_two_ranks_as_a_bare_command():
     # buffers per launch), which moves f64 sums by rounding only
     assert two["result_checksum"] == pytest.approx(one["result_checksum"], rel=1e-6)
     assert two["value"] > 0 and two["steps"] == 2
+
+
+def test_ctx_trim_returns_cached_blocks(ctx, onp):
+    """fluhip_ctx_trim: the per-device cache of freed device blocks is handed back to the driver on request (for hosts that
+    share the GPU with other allocators); the next call simply allocates again and gives the same result"""
+    x = onp.synth_audio(44100, 5)
+    a = ctx.bufnmf_channel(x, 1024, 1024, 256, 3, 5, 42)
+    assert ctx.lib.fluhip_ctx_trim(ctx.h) == 0
+    b = ctx.bufnmf_channel(x, 1024, 1024, 256, 3, 5, 42)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
