@@ -41,6 +41,7 @@ def test_stft_golden(ctx, golden, wfh):
     (20000, 8192, 8192, 2048),  # largest in-LDS size (twiddles from global memory)
     (60000, 16384, 16384, 4096), (70000, 20000, 32768, 8192), (140000, 65536, 65536, 16384),  # global-memory passes
     (3000, 256, 512, 64), (3000, 32, 2048, 8),
+    (12345, 1024, 1024, 333), (5001, 2048, 2048, 77), (30001, 4096, 4096, 999), (8191, 2048, 4096, 511),  # odd hops / lengths
 ])
 def test_stft_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
     x = onp.synth_audio(n, 1000 + n % 17)
@@ -549,6 +550,29 @@ def test_corpus_matches_per_buffer_oracle(ctx, oracle, onp):
         rb, ra = oracle.bufnmf_writeback(rW, rH)
         assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6
     c.close()
+
+
+@pytest.mark.parametrize("B,n,win,fft,hop,K", [(5, 22051, 2048, 2048, 333, 6),     # odd length (odd buffer bases), odd hop
+                                                (7, 9999, 1000, 1024, 250, 4),      # window shorter than the transform
+                                                (3, 40001, 4096, 4096, 1024, 8),    # config 3's transform, partial last block
+                                                (9, 3001, 1024, 1024, 512, 3),      # fewer frames than a block holds
+                                                (2, 100, 1024, 1024, 512, 2)])      # a single frame per buffer
+def test_corpus_block_stft_both_layouts(ctx, oracle, onp, B, n, win, fft, hop, K):
+    """The block STFT kernel writes V frame-major AND bin-major in one pass: the frame-major copy against the oracle's
+    spectrogram, the bin-major one through the H update that streams it (factors against the oracle), on shapes that
+    exercise its edges -- unaligned buffers, ragged last blocks, clamped gathers on every frame"""
+    import fluhip
+    audio = np.stack([onp.synth_audio(n, 4000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.set_audio(audio); c.stft(); c.nmf(6, seed=42)
+    mag, W1, H1 = c.read_f64()
+    c.close()
+    for b in sorted({0, B // 2, B - 1}):
+        _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
+        assert mag[b].shape == rmag.shape
+        assert rel_err(mag[b], rmag) < TOL_STFT
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, 6, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT
 
 
 def test_corpus_fast_path_partial_updates(ctx, oracle, onp):
