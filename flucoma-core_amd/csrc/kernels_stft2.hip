@@ -208,6 +208,8 @@ struct FftCore
     jB = LOCAL ? (lane == 0 ? NS3 / 2 : NS3 - lane) : 0;
     wA = tocx(twg[jA]);
     wB = LOCAL ? tocx(twg[jB]) : cx{0.0, 0.0};
+    wA = cx{0.5 * wA.re, 0.5 * wA.im};   // the split's 1/2 rides on its twiddle
+    wB = cx{0.5 * wB.re, 0.5 * wB.im};
     //   pass-1 outputs  (lane + 64 bb) R1 + r    pass-2 inputs   lane + 64 bb + r N/R2
     //   pass-2 outputs  (j - k) R2 + k + r NS2   pass-3 inputs   j + r NS3
     w1p = xb + (R1 == 16 ? 17 * lane : 8 * lane + (lane >> 1));
@@ -222,6 +224,7 @@ struct FftCore
     tw3pB = tw3 + jB;
   }
 
+  template <bool SPEC>
   __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
   {
   SCHED_FENCE();
@@ -350,17 +353,19 @@ struct FftCore
     for (int r = 0; r < R3; r++)
     {
       const int i = bb * R3 + r;
+      // X[k] = (Z[k] + conj Z[N-k]) / 2 - i / 2 e^{-2 pi i k / fft} (Z[k] - conj Z[N-k]); the halves ride on the twiddle
+      // (wj = e^{...} / 2) and on one multiplier of the sum
       const cx A = p3[i], Bc = partner(bb, r);
-      const double er = 0.5 * (A.re + Bc.re), ei = 0.5 * (A.im - Bc.im);
-      const double dr = 0.5 * (A.re - Bc.re), di = 0.5 * (A.im + Bc.im);
+      const double er = A.re + Bc.re, ei = A.im - Bc.im;
+      const double dr = A.re - Bc.re, di = A.im + Bc.im;
       const cx w = r == 0 ? wj : cmul2(wj, split_const<R3>(r));
-      const double xr = er + (w.re * di + w.im * dr);
-      double xi = ei - (w.re * dr - w.im * di);
+      const double xr = __builtin_fma(0.5, er, __builtin_fma(w.re, di, w.im * dr));
+      double xi = __builtin_fma(0.5, ei, __builtin_fma(w.im, di, -(w.re * dr)));
       const int k = j + r * NS3;
       if (k == 0) xi = 0.0;                     // DC is purely real (util/FFT.hpp:99-101)
       const double m = mag_sqrt2(xr * xr + xi * xi);
       xb[k] = m;                                // staged (the exchange buffer is idle now)
-      if (specRow) specRow[k] = d2{xr, xi};
+      if constexpr (SPEC) specRow[k] = d2{xr, xi};
       if (r & 1) SCHED_FENCE();                 // two bins' chains in flight, not sixteen
     }
   }
@@ -369,7 +374,7 @@ struct FftCore
     const cx z = p3[0];                         // Z[0]: Nyquist = Re - Im, purely real
     const double xr = z.re - z.im;
     xb[N] = fabs(xr);
-    if (specRow) specRow[N] = d2{xr, 0.0};
+    if constexpr (SPEC) specRow[N] = d2{xr, 0.0};
   }
   }
 };
@@ -443,7 +448,7 @@ __device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, 
   }
 }
 
-template <int R1, int R2, int R3, int NW, int WINLDS>
+template <int R1, int R2, int R3, int NW, int WINLDS, bool SPEC>
 __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 {
   constexpr int N = R1 * R2 * R3;  // complex points per frame = fft / 2
@@ -503,7 +508,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       cx pts[PPL];
       gather_points<R1, N>(a, b, t, lane, wsrc, pts);
       SCHED_FENCE();
-      core.run(pts, a.spec ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
+      core.template run<SPEC>(pts, SPEC ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
     }
     else if (a.magT)
     {
@@ -647,7 +652,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       cx pts[PPL];
       gather_points<R1, N>(a, b, t, lane, wl, pts);
       SCHED_FENCE();
-      core.run(pts, nullptr);
+      core.template run<false>(pts, nullptr);
     }
     SCHED_FENCE();
     // ---- band sums ------------------------------------------------------------------------------------------
@@ -783,7 +788,7 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
   k.blocksPerBuf = (k.T + NW - 1) / NW;
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
-  auto kern = stft_block_kernel<R1, R2, R3, NW, WINLDS>;
+  auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false>;   // the complex spectrum is kept for resynthesis / BufSTFT only
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
@@ -813,7 +818,8 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
   if (magT && (ldMagT % 2) != 0) return false;
   if (a.fft == 2048)
   {
-    // 8 frames per block: 224 registers, two wavefronts per SIMD (12 and 16 per workgroup spill and measured slower)
+    // 8 frames per block, two wavefronts per SIMD (143 registers without the spectrum output; 12 per workgroup fit too and
+    // measured the same: the phase is bound by its stores)
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
   }
   if (a.fft == 4096)

@@ -278,9 +278,9 @@ int  fluhip_balanced_assignment(const double* costs, int64_t n, int world, int32
 
 /* ---- live kernel timing (HIP events on the context stream) ----------------------------- */
 /* When enabled, every launch of the two dominant kernel classes is bracketed by hipEvents on
- * the stream it is launched on.  Classes: 0 = stft_r2c_mag, 1 = nmf_update (both factor
- * updates share one kernel), 2 = feature kernels, 3 = the small kernels between the factor
- * updates.  fluhip_prof_read synchronises and returns the launch count and the summed duration
+ * the stream it is launched on.  Classes: 0 = the STFT kernel (both magnitude layouts), 1 = nmf_update (both factor
+ * updates share one kernel; the split-contraction finalize counts with it), 2 = feature kernels, 3 = the small kernels
+ * between the factor updates, 4 = the transposing copy of shapes the block STFT kernel does not cover.  fluhip_prof_read synchronises and returns the launch count and the summed duration
  * since the last reset. */
 int fluhip_prof_enable(fluhip_ctx* ctx, int on);
 int fluhip_prof_reset(fluhip_ctx* ctx);
