@@ -358,6 +358,11 @@ struct fluhip_corpus
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
+  // frame-strip schedule of a single large buffer at rank <= 16 (kernels_nmf_strip.hip)
+  bool strip = false;
+  bool stripReady = false;     // the numerator partials of the next W update are in stripPart
+  bool stripNormFresh = false; // wnorm holds the column norms of the W' in memory
+  DevBuf stripPart;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
   {
@@ -417,7 +422,7 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
   hipStream_t s = ctx->stream;
   const size_t B = (size_t) c->B;
   const int ns = std::max(c->nsplitW, c->nsplitH);
-  if (ns > 1)
+  if (ns > 1 && !c->strip)
   {
     const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
     HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
@@ -463,6 +468,16 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       // worth it when the widest strip gets shorter, or when the launch needs fewer passes over the 1024 SIMDs
       const int64_t passes = (c->B * w + 1023) / 1024, passes1 = (c->B * w1 + 1023) / 1024;
       c->sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
+    }
+    // A buffer too small in columns to fill the chip on its own runs the frame-strip schedule when its rank allows:
+    // two launches per iteration instead of five and V read once (FLUHIP_STRIP=0 off, =1 wherever supported)
+    static const int stripEnv = [] { const char* e = std::getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
+    c->strip = c->lazy && stripEnv != 0 && nmf_strip_supported((int) c->F, (int) c->T, (int) c->Kp) &&
+               (stripEnv == 1 || (stripEnv == 2 && c->nsplitW > 1 && c->nsplitH > 1 && c->T >= 2048));
+    if (c->strip)
+    {
+      c->sideW = false;
+      HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), false, s));
     }
     // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
     // finalize kernel when the contraction is split
@@ -705,11 +720,48 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
   return FLUHIP_OK;
 }
 
-static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH)
+static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool last)
 {
   fluhip_ctx* ctx = c->ctx;
   hipStream_t s = ctx->stream;
   const int B = (int) c->B;
+  if (c->strip)
+  {
+    StripArgs a;
+    a.V = c->mag.as<double>(); a.strideV = c->Tp * c->Fp; a.ldv = c->Fp;
+    a.W = c->Wf.as<double>(); a.strideW = c->Fp * c->Kp;
+    a.H = c->H1.as<double>(); a.strideH = c->Tp * c->Kp;
+    a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
+    a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = B;
+    if (updateW)
+    {
+      // alg/NMF.hpp:158-161; :162 is implicit in the next staging of W'
+      if (!c->stripReady)
+      {
+        a.doH = 0; a.doW = 1; a.wPend = c->wPending ? 1 : 0;
+        ProfScope p(ctx, 1);
+        launch_nmf_strip(a, s);
+      }
+      {
+        a.wPend = c->wPending ? 1 : 0;
+        ProfScope p(ctx, 3);
+        launch_nmf_strip_reduce(a, s);
+      }
+      c->wPending = true;
+      c->stripReady = false;
+      c->stripNormFresh = false;
+    }
+    if (updateH)
+    {
+      // :165-170, and behind it the numerator of the next iteration's W update while the new H is at hand
+      a.doH = 1; a.doW = (updateW && !last) ? 1 : 0; a.wPend = c->wPending ? 1 : 0;
+      ProfScope p(ctx, 1);
+      launch_nmf_strip(a, s);
+      c->stripReady = a.doW != 0;
+      c->stripNormFresh = true;
+    }
+    return;
+  }
   if (updateW)
   {
     // alg/NMF.hpp:158-161
@@ -781,7 +833,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
   fluhip_ctx* ctx = c->ctx;
   if (!progress)
   {
-    for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH);
+    for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
     HIPCHK(ctx, hipGetLastError());
     return FLUHIP_OK;
   }
@@ -796,7 +848,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
   int64_t reported = 0;
   for (int64_t i = 0; i < iters; i++)
   {
-    enqueue_iteration(c, updateW, updateH);
+    enqueue_iteration(c, updateW, updateH, i + 1 == iters);
     if (hipEventRecord(ev[i % kLag], ctx->stream) != hipSuccess) { give_back(); return fail(ctx, "HIP error: hipEventRecord"); }
     const int64_t enq = i + 1;
     while (reported < enq)
@@ -823,6 +875,23 @@ static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool up
                           fluhip_progress_fn progress, void* user)
 {
   const int rc = corpus_iterate_loop(c, iters, updateW, updateH, progress, user);
+  if (c->strip)
+  {
+    c->stripReady = false; // H may change before the next call
+    if (c->wPending && !c->stripNormFresh)
+    {
+      // the last launch was a reduce: one workgroup per buffer recomputes the column norms of W'
+      StripArgs a;
+      a.V = c->mag.as<double>(); a.strideV = c->Tp * c->Fp; a.ldv = c->Fp;
+      a.W = c->Wf.as<double>(); a.strideW = c->Fp * c->Kp;
+      a.H = c->H1.as<double>(); a.strideH = c->Tp * c->Kp;
+      a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
+      a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = (int) c->B;
+      a.doH = a.doW = 0; a.wPend = 1;
+      launch_nmf_strip(a, c->ctx->stream);
+      c->stripNormFresh = true;
+    }
+  }
   if (c->wPending)
   {
     // leave the deferred form on every exit (also a cancelled run hands back W, alg/NMF.hpp:175-176)
@@ -2124,7 +2193,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
   out8[4] = c->sideW ? 1 : 0;
   out8[5] = c->stripsW;
   out8[6] = c->Kp;
-  out8[7] = 0;
+  out8[7] = c->strip ? 1 : 0;
   return FLUHIP_OK;
 }
 
@@ -2134,6 +2203,14 @@ int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
 {
   if (!c || !out32 || !c->dpart.p) return FLUHIP_ERROR;
   HIPCHK(c->ctx, hipStreamSynchronize(c->ctx->stream));
+  if (c->strip)
+  {
+    // FLUHIP_STRIP_INSTR: the 16 words behind the partials (kernels_nmf_strip.hip STRIP_STAMP)
+    std::memset(out32, 0, 32 * sizeof(int64_t));
+    const int64_t off = nmf_strip_part_doubles((int) c->F, (int) c->T, (int) c->B) - 16;
+    HIPCHK(c->ctx, hipMemcpy(out32, c->stripPart.as<double>() + off, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return FLUHIP_OK;
+  }
   HIPCHK(c->ctx, hipMemcpy(out32, c->dpart.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
   return FLUHIP_OK;
 }

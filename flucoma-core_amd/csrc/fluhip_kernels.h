@@ -144,6 +144,29 @@ void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double
 void launch_fill_ones(double* p, int64_t n, hipStream_t s);
 int nmf_update5_strips(int C, int Kp, int B); // wavefronts per buffer launch_nmf_update5 uses (nsplit == 1)
 
+// Strip schedule of one large buffer at rank <= 16 (kernels_nmf_strip.hip): a workgroup owns a strip of frames, does
+// their H update (alg/NMF.hpp:165-170) against the W it staged (normalised while staging when wPend) and, behind it,
+// the strip's share of the next W update's numerator (:158-160); the reduce launch forms W' (:161, un-normalised).
+struct StripArgs
+{
+  const double* V;  // mag [B][Tp][ldv]
+  int64_t strideV, ldv;
+  double* W;        // [B][Fp][16]
+  int64_t strideW;
+  double* H;        // [B][Tp][16]
+  int64_t strideH;
+  double* part;     // nmf_strip_part_doubles() of workspace
+  double* nrm;      // [B][16]: written by the strip launch (the column norms it divided by, 1 when !wPend)
+  int F, T, K, B;
+  int doH, doW;     // both 0: only nrm is produced
+  int wPend;        // W in memory is the un-normalised W' of the last reduce launch
+};
+bool nmf_strip_supported(int F, int T, int Kp);
+int nmf_strip_workgroups(int T);
+int64_t nmf_strip_part_doubles(int F, int T, int B);
+void launch_nmf_strip(const StripArgs& a, hipStream_t s);
+void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s);
+
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,
                            int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s);

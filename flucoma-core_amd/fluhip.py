@@ -445,7 +445,7 @@ class Corpus:
     def plan(self):
         out = (ctypes.c_int64 * 8)()
         self.ctx._check(self.ctx.lib.fluhip_corpus_plan(self.h, out))
-        keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank")
+        keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank", "strip")
         return dict(zip(keys, [int(v) for v in out]))
 
     def read_f64(self, mag=True, factors=True):
