@@ -362,6 +362,8 @@ struct fluhip_corpus
   bool strip = false;
   bool stripReady = false;     // the numerator partials of the next W update are in stripPart
   bool stripNormFresh = false; // wnorm holds the column norms of the W' in memory
+  bool stripStatsValid = false; // the column-statistics records of generation stripGen describe the W in memory
+  int stripGen = 0;
   DevBuf stripPart;
   bool haveMag = false, haveFactors = false;
   int64_t device_bytes() const
@@ -469,11 +471,13 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       const int64_t passes = (c->B * w + 1023) / 1024, passes1 = (c->B * w1 + 1023) / 1024;
       c->sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
     }
-    // A buffer too small in columns to fill the chip on its own runs the frame-strip schedule when its rank allows:
-    // two launches per iteration instead of five and V read once (FLUHIP_STRIP=0 off, =1 wherever supported)
+    // A single buffer of rank <= 16 runs the frame-strip schedule while one round of workgroups covers it (at most 6 frame
+    // quads per CU: 71 s at hop 512): two launches per iteration instead of five and V read once.  Longer buffers and
+    // batches stay with the split / batched kernels, which win there (tools/strip_vs_split.py).  FLUHIP_STRIP=0 off,
+    // =1 wherever the kernel supports the shape.
     static const int stripEnv = [] { const char* e = std::getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
     c->strip = c->lazy && stripEnv != 0 && nmf_strip_supported((int) c->F, (int) c->T, (int) c->Kp) &&
-               (stripEnv == 1 || (stripEnv == 2 && c->nsplitW > 1 && c->nsplitH > 1 && c->T >= 2048));
+               (stripEnv == 1 || (c->B == 1 && nmf_strip_workgroups((int) c->T) <= 256));
     if (c->strip)
     {
       c->sideW = false;
@@ -717,6 +721,7 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(s)); // the host images and the second staging buffer go out of scope
   c->haveFactors = true;
+  c->stripStatsValid = false;
   return FLUHIP_OK;
 }
 
@@ -733,19 +738,28 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.H = c->H1.as<double>(); a.strideH = c->Tp * c->Kp;
     a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
     a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = B;
+    a.doH = a.doW = 0; a.wPend = c->wPending ? 1 : 0;
+    if (!c->stripStatsValid)
+    {
+      // W was written by something else (initialisation, the normalisation at the end of the last call)
+      a.statGen = c->stripGen;
+      launch_nmf_strip_wstats(a, s);
+      c->stripStatsValid = true;
+    }
     if (updateW)
     {
       // alg/NMF.hpp:158-161; :162 is implicit in the next staging of W'
       if (!c->stripReady)
       {
-        a.doH = 0; a.doW = 1; a.wPend = c->wPending ? 1 : 0;
+        a.doH = 0; a.doW = 1; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
         ProfScope p(ctx, 1);
         launch_nmf_strip(a, s);
       }
       {
-        a.wPend = c->wPending ? 1 : 0;
+        a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
         ProfScope p(ctx, 3);
         launch_nmf_strip_reduce(a, s);
+        c->stripGen ^= 1;
       }
       c->wPending = true;
       c->stripReady = false;
@@ -754,7 +768,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     if (updateH)
     {
       // :165-170, and behind it the numerator of the next iteration's W update while the new H is at hand
-      a.doH = 1; a.doW = (updateW && !last) ? 1 : 0; a.wPend = c->wPending ? 1 : 0;
+      a.doH = 1; a.doW = (updateW && !last) ? 1 : 0; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
       ProfScope p(ctx, 1);
       launch_nmf_strip(a, s);
       c->stripReady = a.doW != 0;
@@ -887,10 +901,11 @@ static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool up
       a.H = c->H1.as<double>(); a.strideH = c->Tp * c->Kp;
       a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
       a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = (int) c->B;
-      a.doH = a.doW = 0; a.wPend = 1;
+      a.doH = a.doW = 0; a.wPend = 1; a.statGen = c->stripGen;
       launch_nmf_strip(a, c->ctx->stream);
       c->stripNormFresh = true;
     }
+    if (c->wPending) c->stripStatsValid = false; // the normalisation below rewrites W
   }
   if (c->wPending)
   {
@@ -2205,10 +2220,10 @@ int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
   HIPCHK(c->ctx, hipStreamSynchronize(c->ctx->stream));
   if (c->strip)
   {
-    // FLUHIP_STRIP_INSTR: the 16 words behind the partials (kernels_nmf_strip.hip STRIP_STAMP)
+    // FLUHIP_STRIP_INSTR: the 32 words behind the partials (kernels_nmf_strip.hip STRIP_STAMP)
     std::memset(out32, 0, 32 * sizeof(int64_t));
-    const int64_t off = nmf_strip_part_doubles((int) c->F, (int) c->T, (int) c->B) - 16;
-    HIPCHK(c->ctx, hipMemcpy(out32, c->stripPart.as<double>() + off, 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    const int64_t off = nmf_strip_part_doubles((int) c->F, (int) c->T, (int) c->B) - 32;
+    HIPCHK(c->ctx, hipMemcpy(out32, c->stripPart.as<double>() + off, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return FLUHIP_OK;
   }
   HIPCHK(c->ctx, hipMemcpy(out32, c->dpart.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));

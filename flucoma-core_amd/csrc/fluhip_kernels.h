@@ -156,7 +156,9 @@ struct StripArgs
   double* H;        // [B][Tp][16]
   int64_t strideH;
   double* part;     // nmf_strip_part_doubles() of workspace
-  double* nrm;      // [B][16]: written by the strip launch (the column norms it divided by, 1 when !wPend)
+  double* nrm;      // [B][16]: written by the strip launch (the column norms it worked with, 1 when !wPend)
+  int statGen;      // which of the two generations of column-statistics records describes the W in memory: written by
+                    // launch_nmf_strip_wstats (same generation) or by the reduce launch (into the other one)
   int F, T, K, B;
   int doH, doW;     // both 0: only nrm is produced
   int wPend;        // W in memory is the un-normalised W' of the last reduce launch
@@ -166,6 +168,7 @@ int nmf_strip_workgroups(int T);
 int64_t nmf_strip_part_doubles(int F, int T, int B);
 void launch_nmf_strip(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s);
+void launch_nmf_strip_wstats(const StripArgs& a, hipStream_t s);
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,

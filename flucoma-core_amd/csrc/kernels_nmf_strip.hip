@@ -4,13 +4,14 @@
 // (kernels_nmf5.hip), which then splits both contractions and needs a finalize launch after each: five launches per
 // iteration and V streamed twice.  Here a workgroup owns a strip of frames t (whole columns of V, all bins f):
 //
-//   strip kernel   the normalised W (F x 16 doubles, <= 135 KB) is staged in the LDS once per launch.  With it the H
+//   strip kernel   every wavefront keeps the rows of W it works on (F x 16 doubles altogether, <= 135 KB) in the LDS.  With them the H
 //                  update of the strip's frames is LOCAL (the contraction runs over f, which the workgroup holds
 //                  completely: ref alg/NMF.hpp:165-170), and right behind it -- with the new H still in registers --
 //                  the strip's share of the NEXT W update's numerator, sum_t V/(W H) H^T over the strip's frames
 //                  (alg/NMF.hpp:158-161), which goes out as one partial per workgroup.
-//   reduce kernel  adds the partials in fixed order, W' <- W * num / max(den, eps) (the column normalisation of
-//                  :162 stays deferred: the next strip launch normalises W while staging it).
+//   reduce kernel  adds the partials in fixed order, W' <- W * num / max(den, eps), and leaves the column statistics
+//                  of W' (sum x^2, sum x, max) as per-workgroup records: the normalisation of :162 stays deferred,
+//                  every later use works with (W', norms) -- Q = W' (H / nrm), results divided by nrm.
 //
 // One iteration = strip + reduce; V is read once per iteration (the second phase re-reads the strip from the L2).
 // Everything is deterministic (fixed summation orders, no atomics): same-seed runs are bit-identical like the
@@ -37,7 +38,9 @@ namespace strip {
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kNQ = 6;    // frame quads of a workgroup's strip
-constexpr int kEarly = 0; // bin pairs per wavefront whose V is requested before W is staged
+constexpr int kAhead = 3; // bin pairs of V a wavefront keeps in flight (first touch of V: HBM latency x bandwidth)
+constexpr bool kWriteThrough = true;
+constexpr int kStatW = 12; // doubles per statistics record: [sum x^2, sum x, max x][4 columns]
 
 struct StripK
 {
@@ -48,13 +51,15 @@ struct StripK
   int64_t strideW;
   double* H;
   int64_t strideH;
-  double* part;
-  int64_t strideP;
-  int psz; // doubles per workgroup partial: nPairs * 512 numerators + 16 denominators
+  double* part;     // [B][nBlk / 4][nWG][4][64] numerator partials: a strip workgroup writes 2 KB runs (the four column
+                    // blocks of one bin step), the four reduce workgroups of a step share one nWG x 2 KB region
+  double* dpart;    // [B][nWG][16] denominator partials
+  const double* statIn; // [B][nBlk][kStatW] column statistics of the W in memory
+  double* statOut;      // reduce / wstats: the statistics of the W they leave behind
   double* nrm;
-  int F, T, K, nPairs, nq, nWG;
+  int F, T, K, nPairs, nBlk, nq, nWG;
   int doH, doW, wPend;
-  long long* dbg; // FLUHIP_STRIP_INSTR: shader-clock stamps of workgroup 0 (tools/phase_breakdown.py strip)
+  long long* dbg; // FLUHIP_STRIP_INSTR: shader-clock stamps of workgroup 0 (tools/strip_timing.py)
 };
 
 // v / d for d > 0, v >= 0 in the normal range (kernels_nmf5.hip fdiv_pos)
@@ -68,14 +73,14 @@ __device__ __forceinline__ double qdiv(double v, double d)
   return __builtin_fma(res, yv, r);
 }
 
-// LDS image of W: byte offset of row f, 16-byte chunk c.  Element k = 4 m + j lives in chunk 2 j + (m >> 1), half m & 1:
-// a lane's four m of one j are 32 contiguous bytes.  Two rows share a 256-byte line; the chunk position is XOR-ed with
-// row bits so that both operand read patterns (16 rows x one chunk; 4 rows x 4 chunks) touch 16 different 16-byte
-// bank groups.
+// LDS image of W (each wavefront keeps the bin pairs it works on): byte offset of row f, 16-byte chunk c = columns
+// (2 c, 2 c + 1), inside the pair's 4 KB.  Two rows share a 256-byte line; the chunk position is XOR-ed with row bits so
+// that both operand read patterns (16 rows x one chunk pair; 4 rows x 4 chunk pairs) touch 16 different 16-byte bank
+// groups.
 __device__ __forceinline__ int wl_off(int f, int c)
 {
   const int g = ((((c >> 1) ^ ((f >> 1) & 3)) << 2) | ((((f & 1) << 1) | (c & 1)) ^ ((f >> 3) & 3)));
-  return (f >> 1) * 256 + g * 16;
+  return ((f >> 1) & 15) * 256 + g * 16;
 }
 
 template <int CTRL>
@@ -87,6 +92,27 @@ __device__ __forceinline__ double dppmov(double v)
   return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
 }
 
+// R[q] = V[q] / max(Q[q], eps) for the kNQ tiles of one step, stage by stage: left to the scheduler the seven dependent
+// operations of one quotient run back to back (register pressure), each waiting for the one before it
+#define STRIP_QUOT(R, V, Q)                                                                                   \
+  {                                                                                                           \
+    double d_[NQ], y_[NQ], e_[NQ];                                                                         \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) d_[q] = fmax(Q[q], kEpsilon);                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) y_[q] = __builtin_amdgcn_rcp(d_[q]);                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) e_[q] = __builtin_fma(-d_[q], y_[q], 1.0);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) y_[q] = __builtin_fma(y_[q], e_[q], y_[q]);               \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) e_[q] = V[q] * y_[q];                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) d_[q] = __builtin_fma(-d_[q], e_[q], V[q]);               \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) R[q] = __builtin_fma(d_[q], y_[q], e_[q]);                \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+
 #define MFMA44(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 #define STRIP_STAMP(i)                                                                          \
@@ -94,175 +120,190 @@ __device__ __forceinline__ double dppmov(double v)
   {                                                                                              \
     if (g == 0 && tid == 0)                                                                      \
     {                                                                                            \
-      a.dbg[2 * (i)] = (long long) __builtin_readcyclecounter();                                 \
-      a.dbg[2 * (i) + 1] = (long long) wall_clock64();                                           \
+      a.dbg[(i)] = (long long) __builtin_readcyclecounter();                                     \
+      if ((i) == 0 || (i) == 5) a.dbg[16 + (i)] = (long long) wall_clock64();                    \
     }                                                                                            \
   }
 
-template <int NPW, bool INSTR>
+// Column statistics of W from the records the last reduce (or wstats) launch left: record r = (jp * 2 + e) * 4 + m holds
+// columns k = 4 x + m, x = 0..3.  Every consumer adds them in the same order, so every workgroup of every launch sees
+// the same norms bit for bit.  256 threads; sc = [3][16][16] doubles of scratch; out: nrmL[16], csL[16].
+struct StripStat
+{
+  double s2, s1, mx;
+};
+struct StripStatRaw
+{
+  double v2[5], v1[5], vm[5];
+};
+// first half: this thread's share of the records (plain loads; a caller with other loads to issue puts them behind
+// these -- vmcnt retires in order)
+__device__ __forceinline__ StripStatRaw strip_column_stats_load(const double* stat, int nBlk, int tid)
+{
+  const int k = tid & 15, part = tid >> 4;
+  const int m = k & 3, xx = k >> 2;
+  // nBlk <= 288 (36 bin pairs): at most 5 records per thread, requested together, nothing consumed here
+  StripStatRaw w;
+#pragma unroll
+  for (int u = 0; u < 5; u++)
+  {
+    const int blkIdx = 4 * (part + 16 * u) + m;
+    const double* r = stat + (int64_t) min(blkIdx, nBlk - 1) * kStatW;
+    w.v2[u] = r[xx];
+    w.v1[u] = r[4 + xx];
+    w.vm[u] = r[8 + xx];
+  }
+  return w;
+}
+__device__ __forceinline__ StripStat strip_column_stats_sum(const StripStatRaw& w, int nBlk, int tid)
+{
+  const int k = tid & 15, part = tid >> 4;
+  const int m = k & 3;
+  StripStat st{0.0, 0.0, 0.0};
+#pragma unroll
+  for (int u = 0; u < 5; u++)
+    if (4 * (part + 16 * u) + m < nBlk)
+    {
+      st.s2 += w.v2[u];
+      st.s1 += w.v1[u];
+      st.mx = fmax(st.mx, w.vm[u]);
+    }
+  return st;
+}
+__device__ __forceinline__ void strip_column_stats(const StripStat& st, int K, int wPend, double* sc, double* nrmL, double* csL,
+                                                   int tid)
+{
+  {
+    // the four parts a wavefront holds per column (lane bits 4, 5), then the four wavefronts, in fixed order
+    double s2 = st.s2, s1 = st.s1, mx = st.mx;
+#pragma unroll
+    for (int sh = 16; sh < 64; sh <<= 1)
+    {
+      s2 += __shfl_xor(s2, sh);
+      s1 += __shfl_xor(s1, sh);
+      mx = fmax(mx, __shfl_xor(mx, sh));
+    }
+    if ((tid & 63) < 16)
+    {
+      const int w = tid >> 6, k = tid & 15;
+      sc[w * 16 + k] = s2;
+      sc[64 + w * 16 + k] = s1;
+      sc[128 + w * 16 + k] = mx;
+    }
+  }
+  __syncthreads();
+  double S2 = 0, S1 = 0;
+  if (tid < 16)
+  {
+    S2 = ((sc[tid] + sc[16 + tid]) + sc[32 + tid]) + sc[48 + tid];
+    S1 = ((sc[64 + tid] + sc[80 + tid]) + sc[96 + tid]) + sc[112 + tid];
+    csL[tid] = fmax(fmax(sc[128 + tid], sc[144 + tid]), fmax(sc[160 + tid], sc[176 + tid])); // parked for the matrix-wide maximum
+  }
+  __syncthreads();
+  double gmax = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) gmax = fmax(gmax, csL[k]);
+  __syncthreads();
+  if (tid < 16)
+  {
+    // alg/NMF.hpp:162 "if (W.maxCoeff() > epsilon) W.colwise().normalize()"; padded columns keep a divisor of one
+    nrmL[tid] = (wPend && tid < K && gmax > kEpsilon) ? sqrt(S2) : 1.0;
+    csL[tid] = S1;
+  }
+  __syncthreads();
+}
+
+template <int NPW, int NQ, bool INSTR>
 __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6); // scalar: everything per bin pair is SALU arithmetic
   const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
   const int g = blockIdx.x, b = blockIdx.y;
   const int wlBytes = a.nPairs * 4096;
-  unsigned char* wl = smem;
-  double* red = reinterpret_cast<double*>(smem + wlBytes); // [4][kNQ][4][16]; the staging statistics before that
-  double* hn = red + 4 * kNQ * 4 * 16;                     // [kNQ * 4][16] the strip's new H
-  double* nrmL = hn + kNQ * 64;                            // [16]
-  double* denL = nrmL + 16;                                // [16] max(sum_f W[f][k], eps)
+  unsigned char* wl = smem;                                 // pair jp at jp * 4096, written and read by wavefront jp & 3
+  double* red = reinterpret_cast<double*>(smem + wlBytes);  // [4][kNQ][4][16]; the statistics scratch before that
+  double* hn = red + 4 * kNQ * 4 * 16;                      // [kNQ * 4][16] the strip's new H
+  double* nrmL = hn + kNQ * 64;                             // [16] column norms of W' (1 when W is normalised)
+  double* csL = nrmL + 16;                                  // [16] column sums of W'
+  unsigned char* zeroPage = reinterpret_cast<unsigned char*>(csL + 16); // 4 KB
 
   const double* Vb = a.V + (int64_t) b * a.strideV;
-  double* Wg = a.W + (int64_t) b * a.strideW;
+  const double* Wg = a.W + (int64_t) b * a.strideW;
   double* Hg = a.H + (int64_t) b * a.strideH;
   STRIP_STAMP(0)
 
   const int qBeg = (int) ((int64_t) g * a.nq / a.nWG), qEnd = (int) ((int64_t) (g + 1) * a.nq / a.nWG);
   const int jpLast = a.nPairs - 1;
-
-  // V of the strip, all of it, in the H-phase view: lane (x, blk, y) holds bins 32 jp + 8 blk + 2 y + {0, 1} of frame
-  // t0 + 4 q + x.  Issued right behind the loads of W (vmcnt retires in order: W must not queue behind the strip) and
-  // pair-major, so that the first pairs' tiles can start while the rest of the strip is still streaming in from HBM;
-  // out-of-range quads / pairs re-read a valid address and meet zero factors.
-  const int nql = min(kNQ, qEnd - qBeg);
+  const int nql = min(NQ, qEnd - qBeg);
   const int t0 = 4 * qBeg;
-  d2 vh[NPW][kNQ];
-  double Hs[kNQ][4];
 
-  // ---- stage W: W' / sqrt(sum W'^2) per column when the memory copy is un-normalised (alg/NMF.hpp:162) ------------
-  {
-    constexpr int NST = 4 * NPW; // row groups of 32
-    const int cp = tid & 7, rr = tid >> 3;
-    const int j0 = (2 * cp) & 3, mh = cp >> 2, ml = (cp >> 1) & 1;
-    const int c0 = 2 * j0 + mh, c1 = 2 * (j0 + 1) + mh;
-    d2 v[NST];
+  // The strip's tiles of V stay in registers from their first use to their last: lane (x, blk, y) holds bins
+  // 32 jp + 8 blk + 2 y + {0, 1} of frame t0 + 4 q + x.  Requests go out kAhead pairs ahead of their use: all at once
+  // they only queue (the memory pipe takes what the HBM share of a CU lets through), and what stands in the queue
+  // ahead of W's rows delays the first tile.  Out-of-range quads / pairs re-read a valid address and meet zero factors.
+  d2 vh[NPW][NQ];
+  // No load below sits behind a branch: the wait-count pass takes the path with the fewest requests at every join, and a
+  // pessimistic vmcnt turns "kAhead pairs in flight" into "wait for everything".  A wavefront that has fewer pairs than
+  // NPW (the pairs are dealt round-robin) repeats the last pair's addresses and works against a page of zeros instead.
+  const double* vstrip = Vb + (int64_t) t0 * a.ldv; // uniform; the lane part fits 32 bits
+  unsigned vofs[NQ];
 #pragma unroll
-    for (int i = 0; i < NST; i++)
-    {
-      // no branches and no consumers here: every load goes out before the first is waited for
-      v[i] = *reinterpret_cast<const d2*>(Wg + (int64_t) min(rr + 32 * i, a.F - 1) * 16 + 2 * cp);
-    }
-    // the strip's rows of H in the B-operand arrangement of the H phase: H[4 m + y][t0 + 4 q + x]
-#pragma unroll
-    for (int q = 0; q < kNQ; q++)
-#pragma unroll
-      for (int m = 0; m < 4; m++) Hs[q][m] = Hg[(int64_t) (t0 + 4 * min(q, nql - 1) + x) * 16 + 4 * m + y];
-    __builtin_amdgcn_sched_barrier(0); // (left alone the scheduler serialises these loads to save registers)
-    // the first pairs of the strip go out with W (both fit the registers while W is being staged), the rest behind it
-#pragma unroll
-    for (int p = 0; p < kEarly && p < NPW; p++)
-#pragma unroll
-      for (int q = 0; q < kNQ; q++)
-        vh[p][q] = *reinterpret_cast<const d2*>(Vb + (int64_t) (t0 + 4 * min(q, nql - 1) + x) * a.ldv + 8 * blk + 2 * y +
-                                                32 * min(wv + 4 * p, jpLast));
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int i = 0; i < NST; i++)
-      if (rr + 32 * i >= a.F) v[i] = d2{0.0, 0.0};
-    double s2a = 0, s2b = 0, mxa = 0, mxb = 0, csa = 0, csb = 0;
-#pragma unroll
-    for (int i = 0; i < NST; i++)
-    {
-      s2a += v[i][0] * v[i][0];
-      s2b += v[i][1] * v[i][1];
-      mxa = fmax(mxa, v[i][0]);
-      mxb = fmax(mxb, v[i][1]);
-      csa += v[i][0];
-      csb += v[i][1];
-    }
-    // the eight lanes of a wavefront that share a column pair (lane bits 3..5), then the four wavefronts
-#pragma unroll
-    for (int sh = 8; sh < 64; sh <<= 1)
-    {
-      s2a += __shfl_xor(s2a, sh);
-      s2b += __shfl_xor(s2b, sh);
-      mxa = fmax(mxa, __shfl_xor(mxa, sh));
-      mxb = fmax(mxb, __shfl_xor(mxb, sh));
-      csa += __shfl_xor(csa, sh);
-      csb += __shfl_xor(csb, sh);
-    }
-    STRIP_STAMP(1)
-    double* st2 = red;       // [4][16]
-    double* stm = red + 64;  // [4][16]
-    double* stc = red + 128; // [4][16]
-    double* gm = red + 192;  // [16]
-    if (lane < 8)
-    {
-      st2[wv * 16 + 2 * cp] = s2a;
-      st2[wv * 16 + 2 * cp + 1] = s2b;
-      stm[wv * 16 + 2 * cp] = mxa;
-      stm[wv * 16 + 2 * cp + 1] = mxb;
-      stc[wv * 16 + 2 * cp] = csa;
-      stc[wv * 16 + 2 * cp + 1] = csb;
-    }
-    __syncthreads();
-    if (tid < 16) gm[tid] = fmax(fmax(stm[tid], stm[16 + tid]), fmax(stm[32 + tid], stm[48 + tid]));
-    __syncthreads();
-    double gmax = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) gmax = fmax(gmax, gm[k]);
-    if (tid < 16)
-    {
-      const double S2 = ((st2[tid] + st2[16 + tid]) + st2[32 + tid]) + st2[48 + tid];
-      const double CS = ((stc[tid] + stc[16 + tid]) + stc[32 + tid]) + stc[48 + tid];
-      // :162 "if (W.maxCoeff() > epsilon) W.colwise().normalize()"; padded columns keep a divisor of one
-      nrmL[tid] = (a.wPend && tid < a.K && gmax > kEpsilon) ? sqrt(S2) : 1.0;
-      denL[tid] = fmax(CS, kEpsilon);
-    }
-    __syncthreads();
-    STRIP_STAMP(2)
-    if (a.wPend)
-    {
-      const double na = nrmL[2 * cp], nb = nrmL[2 * cp + 1];
-      const double ia = 1.0 / na, ib = 1.0 / nb;
-      csa = 0;
-      csb = 0;
-#pragma unroll
-      for (int i = 0; i < NST; i++)
-      {
-        // x / n with the reciprocal shared: quotient estimate + one residual correction
-        const double ra = v[i][0] * ia, rb = v[i][1] * ib;
-        v[i][0] = __builtin_fma(__builtin_fma(-na, ra, v[i][0]), ia, ra);
-        v[i][1] = __builtin_fma(__builtin_fma(-nb, rb, v[i][1]), ib, rb);
-        csa += v[i][0];
-        csb += v[i][1];
-      }
-#pragma unroll
-      for (int sh = 8; sh < 64; sh <<= 1)
-      {
-        csa += __shfl_xor(csa, sh);
-        csb += __shfl_xor(csb, sh);
-      }
-      if (lane < 8)
-      {
-        stc[wv * 16 + 2 * cp] = csa;
-        stc[wv * 16 + 2 * cp + 1] = csb;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NST; i++)
-      if (i < a.nPairs)
-      {
-        const int r = rr + 32 * i;
-        *reinterpret_cast<double*>(wl + wl_off(r, c0) + ml * 8) = v[i][0];
-        *reinterpret_cast<double*>(wl + wl_off(r, c1) + ml * 8) = v[i][1];
-      }
-    __syncthreads();
-    if (a.wPend && tid < 16) denL[tid] = fmax(((stc[tid] + stc[16 + tid]) + stc[32 + tid]) + stc[48 + tid], kEpsilon);
-    if (g == 0 && tid < 16) a.nrm[(int64_t) b * 16 + tid] = nrmL[tid];
-    __syncthreads();
+  for (int q = 0; q < NQ; q++) vofs[q] = (unsigned) ((4 * min(q, nql - 1) + x) * a.ldv + 8 * blk + 2 * y);
+#define STRIP_LOAD_V(P)                                                                                       \
+  {                                                                                                           \
+    const double* vp_ = vstrip + 32 * min(wv + 4 * (P), jpLast);                                              \
+    _Pragma("unroll") for (int q = 0; q < NQ; q++) vh[P][q] = *reinterpret_cast<const d2*>(vp_ + vofs[q]);   \
   }
-  if (!a.doH && !a.doW) return;
-#pragma unroll
-  for (int p = kEarly; p < NPW; p++)
-#pragma unroll
-    for (int q = 0; q < kNQ; q++)
-      vh[p][q] = *reinterpret_cast<const d2*>(Vb + (int64_t) (t0 + 4 * min(q, nql - 1) + x) * a.ldv + 8 * blk + 2 * y +
-                                              32 * min(wv + 4 * p, jpLast));
-  STRIP_STAMP(3)
 
-  // per-lane LDS offsets of the two operand read patterns, [e][half]
+  // A wavefront stages the rows of its own pairs: memory chunk n = lane + 64 i of the pair (row n >> 3, chunk n & 7)
+  const unsigned wsrcLane = (unsigned) ((lane >> 3) * 128 + (lane & 7) * 16);
+  unsigned wdst[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) wdst[i] = (unsigned) wl_off(8 * i + (lane >> 3), lane & 7);
+#define STRIP_LOAD_W(DST, P)                                                                                  \
+  {                                                                                                           \
+    const unsigned char* wp_ = reinterpret_cast<const unsigned char*>(Wg) + min(wv + 4 * (P), jpLast) * 4096; \
+    _Pragma("unroll") for (int i = 0; i < 4; i++)                                                             \
+      DST[i] = *reinterpret_cast<const d2*>(wp_ + i * 1024 + wsrcLane);                                       \
+  }
+#define STRIP_STORE_W(SRC, P)                                                                                 \
+  if (wv + 4 * (P) <= jpLast)                                                                                 \
+  {                                                                                                           \
+    unsigned char* wq_ = wl + (wv + 4 * (P)) * 4096;                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; i++) *reinterpret_cast<d2*>(wq_ + wdst[i]) = SRC[i];             \
+  }
+  // LDS base of a pair's operand rows: the page of zeros for a pair this wavefront does not have
+#define STRIP_PAIR_BASE(P) ((wv + 4 * (P) <= jpLast) ? wl + (wv + 4 * (P)) * 4096 : zeroPage)
+  d2 wt[2][4];
+  d2 Hsv[NQ][2];
+  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk, tid);
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    STRIP_LOAD_W(wt[0], 0)
+    STRIP_LOAD_W(wt[1], 1)
+    // the strip's rows of H in the B-operand arrangement of the H phase: H[4 y + m][t0 + 4 q + x]
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+    {
+      const double* hp = Hg + (int64_t) (t0 + 4 * min(q, nql - 1) + x) * 16 + 4 * y;
+      Hsv[q][0] = *reinterpret_cast<const d2*>(hp);
+      Hsv[q][1] = *reinterpret_cast<const d2*>(hp + 2);
+    }
+#pragma unroll
+    for (int p = 0; p < kAhead && p < NPW; p++) STRIP_LOAD_V(p)
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  *reinterpret_cast<d2*>(zeroPage + tid * 16) = d2{0.0, 0.0};
+
+  strip_column_stats(strip_column_stats_sum(straw, a.nBlk, tid), a.K, a.wPend, red, nrmL, csL, tid);
+  if (g == 0 && tid < 16) a.nrm[(int64_t) b * 16 + tid] = nrmL[tid];
+  if (!a.doH && !a.doW) return;
+  STRIP_STAMP(1)
+
+  // per-lane LDS offsets of the two operand read patterns, [e][half]: A rows by x with columns 4 y + m, B rows by y with
+  // columns 4 x + m
   int offA[2][2], offB[2][2];
 #pragma unroll
   for (int e = 0; e < 2; e++)
@@ -270,87 +311,105 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
     for (int h = 0; h < 2; h++)
     {
       const int gl = ((x ^ y) << 2) | (((e << 1) | h) ^ blk);
-      offA[e][h] = (4 * blk + x) * 256 + gl * 16; // rows by x, j = y
-      offB[e][h] = (4 * blk + y) * 256 + gl * 16; // rows by y, j = x
+      offA[e][h] = (4 * blk + x) * 256 + gl * 16;
+      offB[e][h] = (4 * blk + y) * 256 + gl * 16;
     }
+  double rn[4]; // 1 / norm of the columns 4 y + m this lane feeds into the first product
+#pragma unroll
+  for (int m = 0; m < 4; m++) rn[m] = 1.0 / nrmL[4 * y + m];
 
   double wdenAcc = 0.0;
-  // one pass: the launcher sizes the grid so that no workgroup has more than kNQ quads
   if (a.doH)
   {
-    // ---- H phase: the strip's frames against every bin -------------------------------------------------------------
-    double out[kNQ][4];
+    // ---- H phase: the strip's frames against every bin (alg/NMF.hpp:165-170).  W stays as it is in memory,
+    // W' = W diag(nrm): Q = W' (H / nrm), and the numerator and the column sums are divided by nrm at the end.
+    double Hs[NQ][4], out[NQ][4];
 #pragma unroll
-    for (int q = 0; q < kNQ; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
       for (int m = 0; m < 4; m++)
       {
-        if (q >= nql) Hs[q][m] = 0.0;
+        Hs[q][m] = q < nql ? Hsv[q][m >> 1][m & 1] * rn[m] : 0.0;
         out[q][m] = 0.0;
       }
     d2 wa[2][2], wb[2][2]; // operand rows of the current pair, [e][half]; the next pair's are read a pair ahead
-    {
-      const unsigned char* wj = wl + min(wv, jpLast) * 4096;
+    STRIP_STORE_W(wt[0], 0)
 #pragma unroll
-      for (int e = 0; e < 2; e++)
+    for (int e = 0; e < 2; e++)
 #pragma unroll
-        for (int h = 0; h < 2; h++)
-        {
-          wa[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
-          wb[e][h] = *reinterpret_cast<const d2*>(wj + offB[e][h]);
-        }
-    }
+      for (int h = 0; h < 2; h++)
+      {
+        wa[e][h] = *reinterpret_cast<const d2*>(STRIP_PAIR_BASE(0) + offA[e][h]);
+        wb[e][h] = *reinterpret_cast<const d2*>(STRIP_PAIR_BASE(0) + offB[e][h]);
+      }
 #pragma unroll
     for (int p = 0; p < NPW; p++)
     {
-      const int jp = wv + 4 * p;
       __builtin_amdgcn_sched_barrier(0); // keep a pair's tiles inside the pair (register pressure)
-      if (jp < a.nPairs)
       {
-        d2 na[2][2], nb[2][2];
+        // next pair's rows into the LDS, the pair after that requested, V kAhead pairs ahead; the next pair's operand
+        // rows replace this pair's as soon as the product that reads them has been issued
+        const bool more = p + 1 < NPW;
+        const unsigned char* wj = STRIP_PAIR_BASE(p + 1);
+        if (more)
         {
-          const unsigned char* wj = wl + min(jp + 4, jpLast) * 4096;
+          STRIP_STORE_W(wt[(p + 1) & 1], p + 1)
+          if (p + 2 < NPW) STRIP_LOAD_W(wt[p & 1], p + 2)
+          if (p + kAhead < NPW) STRIP_LOAD_V(p + kAhead)
+        }
+        if (p == 2) { STRIP_STAMP(6) }
+        double Q[2][NQ];
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+#pragma unroll
+          for (int q = 0; q < NQ; q++) Q[e][q] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
 #pragma unroll
           for (int e = 0; e < 2; e++)
 #pragma unroll
-            for (int h = 0; h < 2; h++)
-            {
-              na[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
-              nb[e][h] = *reinterpret_cast<const d2*>(wj + offB[e][h]);
-            }
+            for (int q = 0; q < NQ; q++) Q[e][q] = MFMA44(wa[e][m >> 1][m & 1], Hs[q][m], Q[e][q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 2) { STRIP_STAMP(7) }
+        if (more)
+        {
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) wa[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
         }
+        double R[2][NQ];
 #pragma unroll
         for (int e = 0; e < 2; e++)
         {
-          double Q[kNQ];
+          double vv[NQ];
 #pragma unroll
-          for (int q = 0; q < kNQ; q++) Q[q] = 0.0;
-#pragma unroll
-          for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int q = 0; q < kNQ; q++) Q[q] = MFMA44(wa[e][m >> 1][m & 1], Hs[q][m], Q[q]);
-          double R[kNQ];
-#pragma unroll
-          for (int q = 0; q < kNQ; q++) R[q] = qdiv(vh[p][q][e], fmax(Q[q], kEpsilon));
-#pragma unroll
-          for (int q = 0; q < kNQ; q++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) out[q][m] = MFMA44(R[q], wb[e][m >> 1][m & 1], out[q][m]);
+          for (int q = 0; q < NQ; q++) vv[q] = vh[p][q][e];
+          STRIP_QUOT(R[e], vv, Q[e])
         }
+        if (p == 2) { STRIP_STAMP(8) }
 #pragma unroll
         for (int e = 0; e < 2; e++)
 #pragma unroll
-          for (int h = 0; h < 2; h++)
-          {
-            wa[e][h] = na[e][h];
-            wb[e][h] = nb[e][h];
-          }
+          for (int q = 0; q < NQ; q++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) out[q][m] = MFMA44(R[e][q], wb[e][m >> 1][m & 1], out[q][m]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 2) { STRIP_STAMP(9) }
+        if (more)
+        {
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) wb[e][h] = *reinterpret_cast<const d2*>(wj + offB[e][h]);
+        }
       }
     }
-    STRIP_STAMP(4)
-    // blocks of a wavefront (bins), then the four wavefronts, in fixed order
+    STRIP_STAMP(2)
+    // blocks of a wavefront (bins), then the four wavefronts, in fixed order; lane (x, y) of block 0 holds frame y,
+    // column 4 x + m
 #pragma unroll
-    for (int q = 0; q < kNQ; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
       for (int m = 0; m < 4; m++)
       {
@@ -360,16 +419,17 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         if (blk == 0) red[((wv * kNQ + q) * 4 + m) * 16 + x + 4 * y] = v;
       }
     __syncthreads();
-    for (int o = tid; o < kNQ * 64; o += 256)
+    for (int o = tid; o < NQ * 64; o += 256)
     {
       const int q = o >> 6, rem = o & 63, yy = rem >> 4, k = rem & 15;
       double hv = 0.0;
       if (q < nql)
       {
-        const int ix = (q * 4 + (k >> 2)) * 16 + (k & 3) + 4 * yy;
+        const int ix = (q * 4 + (k & 3)) * 16 + (k >> 2) + 4 * yy;
         const double s = ((red[ix] + red[kNQ * 64 + ix]) + red[2 * kNQ * 64 + ix]) + red[3 * kNQ * 64 + ix];
         double* hp = Hg + (int64_t) t0 * 16 + o;
-        hv = *hp * s / denL[k]; // :170  H * (W^T (V / V2)) / max(W^T 1, eps)
+        // :170  H * (W^T (V / V2)) / max(W^T 1, eps) with W = W' / nrm
+        hv = *hp * (s / nrmL[k]) / fmax(csL[k] / nrmL[k], kEpsilon);
         *hp = hv;
       }
       hn[o] = hv;
@@ -377,54 +437,51 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   }
   else
   {
-    for (int o = tid; o < kNQ * 64; o += 256) hn[o] = (o >> 6) < nql ? Hg[(int64_t) t0 * 16 + o] : 0.0;
+    // no H phase in this launch: its side jobs -- the rows of W into the LDS, the strip's V -- happen here
+#pragma unroll
+    for (int p = 0; p < NPW; p++)
+    {
+      if (p >= 2) STRIP_LOAD_W(wt[p & 1], p)
+      STRIP_STORE_W(wt[p & 1], p)
+      if (p >= kAhead) STRIP_LOAD_V(p)
+    }
+    for (int o = tid; o < NQ * 64; o += 256) hn[o] = (o >> 6) < nql ? Hg[(int64_t) t0 * 16 + o] : 0.0;
   }
   __syncthreads();
-  STRIP_STAMP(5)
+  STRIP_STAMP(3)
   if (a.doW)
   {
     if (tid < 16)
       for (int t = 0; t < 4 * nql; t++) wdenAcc += hn[t * 16 + tid]; // :160 row sums of H, this strip's share
-    // ---- W phase: the strip's share of the next W update's numerator.  The tiles are the ones the H phase used, seen
-    // transposed: lane (x, blk, y) needs bins 32 jp + 8 blk + 2 x + {0, 1} of frame t0 + 4 q + y, which lane (y, blk, x)
-    // holds -- one lane permutation per 32-bit half instead of a second read of V.
-    double Ha[kNQ][4], Hb[kNQ][4];
+    // ---- W phase: the strip's share of the next W update's numerator (alg/NMF.hpp:158-160).  The tiles are the ones
+    // the H phase used, seen transposed: lane (x, blk, y) needs bins 32 jp + 8 blk + 2 x + {0, 1} of frame
+    // t0 + 4 q + y, which lane (y, blk, x) holds -- one lane permutation per 32-bit half instead of a second read of V.
+    double Ha[NQ][4], Hb[NQ][4];
 #pragma unroll
-    for (int q = 0; q < kNQ; q++)
+    for (int q = 0; q < NQ; q++)
 #pragma unroll
       for (int m = 0; m < 4; m++)
       {
-        Ha[q][m] = hn[(4 * q + x) * 16 + 4 * m + y];
-        Hb[q][m] = hn[(4 * q + y) * 16 + 4 * m + x];
+        Ha[q][m] = hn[(4 * q + x) * 16 + 4 * y + m] * rn[m]; // first product: (H / nrm)[4 y + m][frame x]
+        Hb[q][m] = hn[(4 * q + y) * 16 + 4 * x + m];         // second product: H[4 x + m][frame y]
       }
     const int srcLane4 = 4 * (y + 4 * blk + 16 * x);
-    double* P = a.part + (int64_t) b * a.strideP + (int64_t) g * a.psz;
+    double* P = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + lane;
     d2 wa[2][2];
-    {
-      const unsigned char* wj = wl + min(wv, jpLast) * 4096;
 #pragma unroll
-      for (int e = 0; e < 2; e++)
+    for (int e = 0; e < 2; e++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) wa[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
-    }
+      for (int h = 0; h < 2; h++) wa[e][h] = *reinterpret_cast<const d2*>(STRIP_PAIR_BASE(0) + offA[e][h]);
 #pragma unroll
     for (int p = 0; p < NPW; p++)
     {
       const int jp = wv + 4 * p;
       __builtin_amdgcn_sched_barrier(0);
-      if (jp < a.nPairs)
       {
-        d2 na[2][2];
-        {
-          const unsigned char* wj = wl + min(jp + 4, jpLast) * 4096;
+        if (p == 2) { STRIP_STAMP(10) }
+        double vt[2][NQ];
 #pragma unroll
-          for (int e = 0; e < 2; e++)
-#pragma unroll
-            for (int h = 0; h < 2; h++) na[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
-        }
-        double vt[2][kNQ];
-#pragma unroll
-        for (int q = 0; q < kNQ; q++)
+        for (int q = 0; q < NQ; q++)
 #pragma unroll
           for (int e = 0; e < 2; e++)
           {
@@ -433,77 +490,147 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
             const int hi = __builtin_amdgcn_ds_bpermute(srcLane4, (int) (bits >> 32));
             vt[e][q] = __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
           }
+        double Q[2][NQ];
 #pragma unroll
         for (int e = 0; e < 2; e++)
+#pragma unroll
+          for (int q = 0; q < NQ; q++) Q[e][q] = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++)
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int q = 0; q < NQ; q++) Q[e][q] = MFMA44(Ha[q][m], wa[e][m >> 1][m & 1], Q[e][q]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 2) { STRIP_STAMP(11) }
+        if (p + 1 < NPW)
         {
-          double Q[kNQ];
+          const unsigned char* wj = STRIP_PAIR_BASE(p + 1);
 #pragma unroll
-          for (int q = 0; q < kNQ; q++) Q[q] = 0.0;
+          for (int e = 0; e < 2; e++)
 #pragma unroll
-          for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int q = 0; q < kNQ; q++) Q[q] = MFMA44(Ha[q][m], wa[e][m >> 1][m & 1], Q[q]);
-          double R[kNQ];
-#pragma unroll
-          for (int q = 0; q < kNQ; q++) R[q] = qdiv(vt[e][q], fmax(Q[q], kEpsilon));
-          double num[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int q = 0; q < kNQ; q++)
-#pragma unroll
-            for (int m = 0; m < 4; m++) num[m] = MFMA44(R[q], Hb[q][m], num[m]);
-          // complete as soon as the pair's last quad is in: out it goes (a kilobyte per store instruction)
-#pragma unroll
-          for (int m = 0; m < 4; m++) P[((jp * 2 + e) * 4 + m) * 64 + lane] = num[m];
+            for (int h = 0; h < 2; h++) wa[e][h] = *reinterpret_cast<const d2*>(wj + offA[e][h]);
         }
+        double R[2][NQ];
+#pragma unroll
+        for (int e = 0; e < 2; e++) STRIP_QUOT(R[e], vt[e], Q[e])
+        if (p == 2) { STRIP_STAMP(12) }
+        double num[2][4];
 #pragma unroll
         for (int e = 0; e < 2; e++)
 #pragma unroll
-          for (int h = 0; h < 2; h++) wa[e][h] = na[e][h];
+          for (int m = 0; m < 4; m++) num[e][m] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int m = 0; m < 4; m++) num[e][m] = MFMA44(R[e][q], Hb[q][m], num[e][m]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (p == 2) { STRIP_STAMP(13) }
+        // complete as soon as the pair's last quad is in: out it goes (512 contiguous bytes per store instruction)
+        if (jp <= jpLast)
+        {
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+            {
+              // write-through (sc0 sc1): the partials leave the L2 while the phase runs instead of at the end of the
+              // launch, where 35 MB of dirty lines would stand between this kernel and the reduce launch
+              double* dst = P + ((int64_t) (jp * 2 + e) * a.nWG * 4 + m) * 64;
+              if (kWriteThrough) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(num[e][m]) : "memory");
+              else *dst = num[e][m];
+            }
+        }
+        if (p == 2) { STRIP_STAMP(14) }
       }
     }
-    STRIP_STAMP(6)
-    if (tid < 16) P[a.nPairs * 512 + tid] = wdenAcc;
+    STRIP_STAMP(4)
+    if (tid < 16) a.dpart[((int64_t) b * a.nWG + g) * 16 + tid] = wdenAcc;
   }
-  STRIP_STAMP(7)
+  STRIP_STAMP(5)
 }
 
-// W'[f][k] <- W[f][k] * (sum of the numerator partials) / max(sum of the denominator partials, eps)   (alg/NMF.hpp:161)
-// Element idx of a partial = ((jp * 2 + e) * 4 + m) * 64 + lane  <->  f = 32 jp + 8 blk + 2 y + e, k = 4 m + x.
-constexpr int kRedWaves = 8, kRedU = 32;
+// Element `lane` of block r = (jp * 2 + e) * 4 + m  <->  f = 32 jp + 8 blk + 2 y + e, k = 4 x + m.
+// Column statistics of the 64 values a wavefront holds (one block): [sum x^2, sum x, max x] of the four columns,
+// 16 rows each, added over lane bits 2..5 in fixed order.
+__device__ __forceinline__ void strip_block_stats(double v, double* rec, int lane)
+{
+  double s2 = v * v, s1 = v, mx = v;
+#pragma unroll
+  for (int sh = 4; sh < 64; sh <<= 1)
+  {
+    s2 += __shfl_xor(s2, sh);
+    s1 += __shfl_xor(s1, sh);
+    mx = fmax(mx, __shfl_xor(mx, sh));
+  }
+  if (lane < 4)
+  {
+    rec[lane] = s2;
+    rec[4 + lane] = s1;
+    rec[8 + lane] = mx;
+  }
+}
+
+// W'[f][k] <- (W'[f][k] / nrm[k]) * (sum of the numerator partials) / max(sum of the denominator partials, eps)
+// (alg/NMF.hpp:161; the division by nrm is :162 of the previous iteration), and the statistics of the new W'.
+// One workgroup per column block r (64 values), eight wavefronts taking every eighth strip.  Tried and slower on this
+// part: 32 loads in flight per thread (13.4 us against 11.0), sixteen wavefronts per workgroup (15.1), one workgroup per
+// bin step reading its strips' 2 KB runs as contiguous streams (23.9: a quarter of the CUs cannot pull the 35 MB).
+constexpr int kRedWaves = 8, kRedU = 16;
 __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK a)
 {
   __shared__ double red[kRedWaves][64];
-  __shared__ double dred[32][16];
-  __shared__ double den[16];
+  __shared__ double sc[768];
+  __shared__ double nrmL[16], csL[16], den[16];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int b = blockIdx.y;
-  const int idx = blockIdx.x * 64 + lane;
-  const double* P = a.part + (int64_t) b * a.strideP;
+  const int b = blockIdx.y, r = blockIdx.x;
+  const double* P = a.part + (((int64_t) b * a.nBlk + (r & ~3)) * a.nWG + (r & 3)) * 64 + lane;
+  // every request of the launch goes out before the first sum (no load behind a branch, nothing consumed in between):
+  // the statistics records, the denominator partials, the numerator partials
+  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk, tid & 255);
+  const int dk = tid & 15, dgrp = tid >> 4; // 32 groups
+  const double* D = a.dpart + (int64_t) b * a.nWG * 16 + dk;
+  double dv[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++) dv[u] = D[(int64_t) min(dgrp + 32 * u, a.nWG - 1) * 16];
+  // the old value of the element this thread will write (first wavefront), requested now rather than after the barriers
+  const int ex = lane & 3, eblk = (lane >> 2) & 3, ey = lane >> 4;
+  const int em = r & 3, ee = (r >> 2) & 1, ejp = r >> 3;
+  const int ef = 32 * ejp + 8 * eblk + 2 * ey + ee, ek = 4 * ex + em;
+  double* wp = a.W + (int64_t) b * a.strideW + (int64_t) min(ef, a.F - 1) * 16 + ek;
+  const double wold = *wp;
+  double v[kRedU];
+#pragma unroll
+  for (int u = 0; u < kRedU; u++) v[u] = P[(int64_t) min(wv + kRedWaves * u, a.nWG - 1) * 256];
+  __builtin_amdgcn_sched_barrier(0);
+  double dsum = 0.0;
+#pragma unroll
+  for (int u = 0; u < 8; u++) dsum += dgrp + 32 * u < a.nWG ? dv[u] : 0.0;
+  for (int p = dgrp + 256; p < a.nWG; p += 32) dsum += D[(int64_t) p * 16]; // more than 256 strips: long buffers
   double s = 0.0;
-  for (int p0 = wv; p0 < a.nWG; p0 += kRedWaves * kRedU)
+#pragma unroll
+  for (int u = 0; u < kRedU; u++) s += wv + kRedWaves * u < a.nWG ? v[u] : 0.0;
+  for (int p0 = wv + kRedWaves * kRedU; p0 < a.nWG; p0 += kRedWaves * kRedU)
   {
-    double v[kRedU];
 #pragma unroll
-    for (int u = 0; u < kRedU; u++)
-    {
-      const int p = p0 + kRedWaves * u;
-      v[u] = p < a.nWG ? P[(int64_t) p * a.psz + idx] : 0.0;
-    }
+    for (int u = 0; u < kRedU; u++) v[u] = P[(int64_t) min(p0 + kRedWaves * u, a.nWG - 1) * 256];
 #pragma unroll
-    for (int u = 0; u < kRedU; u++) s += v[u];
+    for (int u = 0; u < kRedU; u++) s += p0 + kRedWaves * u < a.nWG ? v[u] : 0.0;
   }
   red[wv][lane] = s;
+  if (tid < 256) strip_column_stats(strip_column_stats_sum(straw, a.nBlk, tid), a.K, a.wPend, sc, nrmL, csL, tid);
+  else
   {
-    const int k = tid & 15, grp = tid >> 4; // 32 groups
-    double d = 0.0;
-    for (int p = grp; p < a.nWG; p += 32) d += P[(int64_t) p * a.psz + a.nPairs * 512 + k];
-    dred[grp][k] = d;
+    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); // the barriers inside strip_column_stats
   }
+  sc[(tid >> 4) * 16 + (tid & 15)] = dsum;
   __syncthreads();
   if (tid < 16)
   {
     double d = 0.0;
-    for (int i = 0; i < 32; i++) d += dred[i][tid];
+    for (int i = 0; i < 32; i++) d += sc[i * 16 + tid];
     den[tid] = fmax(d, kEpsilon);
   }
   __syncthreads();
@@ -512,17 +639,26 @@ __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK
     double tot = red[0][lane];
 #pragma unroll
     for (int w = 1; w < kRedWaves; w++) tot += red[w][lane];
-    const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
-    const int m = (idx >> 6) & 3, e = (idx >> 8) & 1, jp = idx >> 9;
-    const int f = 32 * jp + 8 * blk + 2 * y + e, k = 4 * m + x;
-    if (f < a.F && k < a.K)
+    double wnew = 0.0;
+    if (ef < a.F && ek < a.K)
     {
-      double* wp = a.W + (int64_t) b * a.strideW + (int64_t) f * 16 + k;
-      double w = *wp;
-      if (a.wPend) w = w / a.nrm[(int64_t) b * 16 + k];
-      *wp = w * tot / den[k];
+      wnew = (wold / nrmL[ek]) * tot / den[ek];
+      *wp = wnew;
     }
+    strip_block_stats(wnew, a.statOut + ((int64_t) b * a.nBlk + r) * kStatW, lane);
   }
+}
+
+// statistics records of a W that something else wrote (factor initialisation)
+__global__ __launch_bounds__(64) void nmf_strip_wstats_kernel(StripK a)
+{
+  const int lane = threadIdx.x, b = blockIdx.y, r = blockIdx.x;
+  const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
+  const int m = r & 3, e = (r >> 2) & 1, jp = r >> 3;
+  const int f = 32 * jp + 8 * blk + 2 * y + e, k = 4 * x + m;
+  double v = 0.0;
+  if (f < a.F && k < a.K) v = a.W[(int64_t) b * a.strideW + (int64_t) f * 16 + k];
+  strip_block_stats(v, a.statOut + ((int64_t) b * a.nBlk + r) * kStatW, lane);
 }
 
 int strip_pairs(int F) { return (F + 31) / 32; }
@@ -531,15 +667,17 @@ int strip_pairs(int F) { return (F + 31) / 32; }
 using namespace strip;
 
 bool nmf_strip_supported(int F, int T, int Kp) { return Kp == 16 && F >= 1 && strip_pairs(F) <= 36 && T >= 1; }
-// one pass of at most kNQ frame quads per workgroup: 256 workgroups (one per CU) while that holds, more for longer buffers
+// at most kNQ frame quads per workgroup: 256 workgroups (one per CU) while that holds, more for longer buffers
 int nmf_strip_workgroups(int T)
 {
   const int64_t nq = (T + 3) / 4;
   return (int) std::max<int64_t>(std::min<int64_t>(256, nq), (nq + kNQ - 1) / kNQ);
 }
+// workspace: numerator partials, denominator partials, two generations of statistics records, 16 words of stamps
 int64_t nmf_strip_part_doubles(int F, int T, int B)
 {
-  return (int64_t) B * nmf_strip_workgroups(T) * (strip_pairs(F) * 512 + 16) + 16;
+  const int64_t nBlk = strip_pairs(F) * 8, nWG = nmf_strip_workgroups(T);
+  return (int64_t) B * (nBlk * nWG * 64 + nWG * 16 + 2 * nBlk * kStatW) + 32;
 }
 
 static StripK make_k(const StripArgs& s)
@@ -548,48 +686,73 @@ static StripK make_k(const StripArgs& s)
   k.V = s.V; k.strideV = s.strideV; k.ldv = (int) s.ldv;
   k.W = s.W; k.strideW = s.strideW;
   k.H = s.H; k.strideH = s.strideH;
-  k.part = s.part;
   k.nPairs = strip_pairs(s.F);
-  k.psz = k.nPairs * 512 + 16;
+  k.nBlk = k.nPairs * 8;
   k.nWG = nmf_strip_workgroups(s.T);
-  k.strideP = (int64_t) k.nWG * k.psz;
+  k.part = s.part;
+  k.dpart = k.part + (int64_t) s.B * k.nBlk * k.nWG * 64;
+  double* stat0 = k.dpart + (int64_t) s.B * k.nWG * 16;
+  double* stat1 = stat0 + (int64_t) s.B * k.nBlk * kStatW;
+  k.statIn = s.statGen ? stat1 : stat0;
+  k.statOut = s.statGen ? stat0 : stat1;
   k.nrm = s.nrm;
   k.F = s.F; k.T = s.T; k.K = s.K;
   k.nq = (s.T + 3) / 4;
   k.doH = s.doH; k.doW = s.doW; k.wPend = s.wPend;
-  // the stamps live behind the partials (nmf_strip_part_doubles leaves 16 doubles for them)
-  k.dbg = reinterpret_cast<long long*>(s.part + (int64_t) s.B * k.strideP);
+  k.dbg = reinterpret_cast<long long*>(stat1 + (int64_t) s.B * k.nBlk * kStatW);
   return k;
 }
 
-template <int NPW, bool INSTR = false>
+template <int NPW, int NQ, bool INSTR = false>
 static void launch_strip_t(const StripK& k, int B, hipStream_t s)
 {
-  const size_t shmem = (size_t) k.nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double);
-  auto kern = nmf_strip_kernel<NPW, INSTR>;
+  const size_t shmem = (size_t) k.nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double) + 4096;
+  auto kern = nmf_strip_kernel<NPW, NQ, INSTR>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
   const unsigned grid = (k.doH || k.doW) ? (unsigned) k.nWG : 1u;
   hipLaunchKernelGGL(kern, dim3(grid, (unsigned) B), dim3(256), shmem, s, k);
+}
+
+template <int NPW>
+static void launch_strip_q(const StripK& k, int B, hipStream_t s)
+{
+  // widest strip of the launch, in frame quads: the tile loops are built for 2, 4 or 6
+  const int widest = (k.nq + k.nWG - 1) / k.nWG;
+  if (widest <= 2) launch_strip_t<NPW, 2>(k, B, s);
+  else if (widest <= 4) launch_strip_t<NPW, 4>(k, B, s);
+  else
+  {
+    if constexpr (NPW == 9)
+    {
+      static const int instr = [] { const char* e = std::getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
+      if (instr && k.doH && k.doW) { launch_strip_t<9, kNQ, true>(k, B, s); return; }
+    }
+    launch_strip_t<NPW, kNQ>(k, B, s);
+  }
 }
 
 void launch_nmf_strip(const StripArgs& a, hipStream_t s)
 {
   const StripK k = make_k(a);
   const int npw = (k.nPairs + 3) / 4;
-  if (npw <= 3) launch_strip_t<3>(k, a.B, s);
-  else if (npw <= 5) launch_strip_t<5>(k, a.B, s);
-  else
-  {
-    static const int instr = [] { const char* e = std::getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
-    if (instr && k.doH && k.doW) launch_strip_t<9, true>(k, a.B, s);
-    else launch_strip_t<9>(k, a.B, s);
-  }
+  if (npw <= 3) launch_strip_q<3>(k, a.B, s);
+  else if (npw <= 5) launch_strip_q<5>(k, a.B, s);
+  else launch_strip_q<9>(k, a.B, s);
 }
 
+// reads the records of generation statGen, leaves those of the new W' in the other generation
 void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s)
 {
   const StripK k = make_k(a);
-  hipLaunchKernelGGL(nmf_strip_reduce_kernel, dim3((unsigned) (k.nPairs * 8), (unsigned) a.B), dim3(64 * kRedWaves), 0, s, k);
+  hipLaunchKernelGGL(nmf_strip_reduce_kernel, dim3((unsigned) k.nBlk, (unsigned) a.B), dim3(64 * kRedWaves), 0, s, k);
+}
+
+// writes the records of generation statGen from the W in memory
+void launch_nmf_strip_wstats(const StripArgs& a, hipStream_t s)
+{
+  StripK k = make_k(a);
+  k.statOut = const_cast<double*>(k.statIn);
+  hipLaunchKernelGGL(nmf_strip_wstats_kernel, dim3((unsigned) k.nBlk, (unsigned) a.B), dim3(64), 0, s, k);
 }
 
 } // namespace fluhip

@@ -85,7 +85,7 @@ def test_strip_schedule_against_the_oracle():
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
 
 
-def _disabled_test_strip_schedule_is_what_config_2_gets():
+def test_strip_schedule_is_what_config_2_gets():
     sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
     import fluhip
     ctx = fluhip.Context(0)

@@ -30,9 +30,14 @@ t0 = time.perf_counter(); c.nmf(200, seed=42); ctx.synchronize()
 print(f"200 iterations, no events: {(time.perf_counter() - t0) / 200 * 1e6:7.2f} us per iteration")
 out = (ctypes.c_int64 * 32)()
 if ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0 and out[0]:
-    names = ["W loaded, column stats", "norms (3 barriers)", "normalise, LDS image", "H phase loop", "H reduce + combine", "W phase loop", "tail"]
-    cyc = [out[2 * i] for i in range(8)]; rt = [out[2 * i + 1] for i in range(8)]
+    names = ["prologue (stats, first loads)", "H phase loop", "H reduce + combine", "W phase loop", "tail"]
+    cyc = [out[i] for i in range(16)]
+    us = (out[16 + 5] - out[16]) / 100.0
+    ghz = (cyc[5] - cyc[0]) / us / 1e3
     for i, nme in enumerate(names):
-        dc, dt = cyc[i + 1] - cyc[i], (rt[i + 1] - rt[i]) / 100.0
-        print(f"  {nme:24s} {dc:8d} cycles  {dt:7.2f} us" + (f"  ({dc / dt / 1e3:5.2f} GHz)" if dt > 0 else ""))
-    print(f"  workgroup 0 total      {cyc[7] - cyc[0]:8d} cycles  {(rt[7] - rt[0]) / 100.0:7.2f} us")
+        dc = cyc[i + 1] - cyc[i]
+        print(f"  {nme:30s} {dc:8d} cycles  {dc / ghz / 1e3:7.2f} us")
+    print(f"  workgroup 0 total              {cyc[5] - cyc[0]:8d} cycles  {us:7.2f} us  ({ghz:5.2f} GHz)")
+    print("  H phase, third pair of wavefront 0: first product", cyc[7] - cyc[6], " quotients", cyc[8] - cyc[7], " second product", cyc[9] - cyc[8])
+    print("  W phase, third pair of wavefront 0: lane permutation", cyc[11] - cyc[10], "(with the first product)  quotients", cyc[12] - cyc[11],
+          " second product", cyc[13] - cyc[12], " stores", cyc[14] - cyc[13])
