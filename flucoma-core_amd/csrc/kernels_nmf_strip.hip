@@ -38,9 +38,13 @@ namespace strip {
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kNQ = 6;    // frame quads of a workgroup's strip
-constexpr int kAhead = 3; // bin pairs of V a wavefront keeps in flight (first touch of V: HBM latency x bandwidth)
+constexpr int kAhead = 1; // bin pairs of V a wavefront requests ahead of their use.  The H phase is bound by the arrival of V
+                          // (a CU gets ~17 GB/s of this stream), and requests beyond what the memory pipe takes block the
+                          // issue of everything behind them: 3 pairs ahead cost 1.3 us more in the prologue and gain
+                          // nothing in the loop, 5 pairs 3 us.
+constexpr int kEarly = 1; // ... of which are requested before the column norms are known
 constexpr bool kWriteThrough = true;
-constexpr int kStatW = 12; // doubles per statistics record: [sum x^2, sum x, max x][4 columns]
+constexpr int kStatW = 12; // statistics: 12 doubles per column block (3 kinds x 4 columns), stored [kind][column][bin step]
 
 struct StripK
 {
@@ -57,7 +61,7 @@ struct StripK
   const double* statIn; // [B][nBlk][kStatW] column statistics of the W in memory
   double* statOut;      // reduce / wstats: the statistics of the W they leave behind
   double* nrm;
-  int F, T, K, nPairs, nBlk, nq, nWG;
+  int F, T, K, nPairs, nBlk, nq, nWG, qBase, qRem;
   int doH, doW, wPend;
   long long* dbg; // FLUHIP_STRIP_INSTR: shader-clock stamps of workgroup 0 (tools/strip_timing.py)
 };
@@ -125,90 +129,70 @@ __device__ __forceinline__ double dppmov(double v)
     }                                                                                            \
   }
 
-// Column statistics of W from the records the last reduce (or wstats) launch left: record r = (jp * 2 + e) * 4 + m holds
-// columns k = 4 x + m, x = 0..3.  Every consumer adds them in the same order, so every workgroup of every launch sees
-// the same norms bit for bit.  256 threads; sc = [3][16][16] doubles of scratch; out: nrmL[16], csL[16].
-struct StripStat
-{
-  double s2, s1, mx;
-};
+// Column statistics of W from the records the last reduce (or wstats) launch left, stat[kind][column k][step i] with
+// kind = sum x^2, sum x, max x and step i = jp * 2 + e (16 bins of the column each).  Every consumer adds them in the
+// same order, so every workgroup of every launch sees the same norms bit for bit.  Thread (k = tid >> 4, j = tid & 15)
+// takes steps j, j + 16, ...: 16 lanes read 128 contiguous bytes.  First 256 threads of a workgroup.
 struct StripStatRaw
 {
   double v2[5], v1[5], vm[5];
 };
-// first half: this thread's share of the records (plain loads; a caller with other loads to issue puts them behind
-// these -- vmcnt retires in order)
-__device__ __forceinline__ StripStatRaw strip_column_stats_load(const double* stat, int nBlk, int tid)
+// first half: the requests only (a caller with other loads to issue puts them behind these -- vmcnt retires in order --
+// and consumes nothing in between)
+__device__ __forceinline__ StripStatRaw strip_column_stats_load(const double* stat, int nStep, int tid)
 {
-  const int k = tid & 15, part = tid >> 4;
-  const int m = k & 3, xx = k >> 2;
-  // nBlk <= 288 (36 bin pairs): at most 5 records per thread, requested together, nothing consumed here
-  StripStatRaw w;
+  const int k = tid >> 4, j = tid & 15;
+  StripStatRaw w; // nStep <= 72 (36 bin pairs): at most 5 steps per thread
 #pragma unroll
   for (int u = 0; u < 5; u++)
   {
-    const int blkIdx = 4 * (part + 16 * u) + m;
-    const double* r = stat + (int64_t) min(blkIdx, nBlk - 1) * kStatW;
-    w.v2[u] = r[xx];
-    w.v1[u] = r[4 + xx];
-    w.vm[u] = r[8 + xx];
+    const int i = min(j + 16 * u, nStep - 1);
+    w.v2[u] = stat[(int64_t) k * nStep + i];
+    w.v1[u] = stat[(int64_t) (16 + k) * nStep + i];
+    w.vm[u] = stat[(int64_t) (32 + k) * nStep + i];
   }
   return w;
 }
-__device__ __forceinline__ StripStat strip_column_stats_sum(const StripStatRaw& w, int nBlk, int tid)
+// second half: two barriers; out: nrmL[16] (1 when W is normalised), csL[16] column sums; sc = 48 doubles of scratch
+__device__ __forceinline__ void strip_column_stats(const StripStatRaw& w, int nStep, int K, int wPend, double* sc, double* nrmL,
+                                                   double* csL, int tid, bool active)
 {
-  const int k = tid & 15, part = tid >> 4;
-  const int m = k & 3;
-  StripStat st{0.0, 0.0, 0.0};
-#pragma unroll
-  for (int u = 0; u < 5; u++)
-    if (4 * (part + 16 * u) + m < nBlk)
-    {
-      st.s2 += w.v2[u];
-      st.s1 += w.v1[u];
-      st.mx = fmax(st.mx, w.vm[u]);
-    }
-  return st;
-}
-__device__ __forceinline__ void strip_column_stats(const StripStat& st, int K, int wPend, double* sc, double* nrmL, double* csL,
-                                                   int tid)
-{
+  if (active)
   {
-    // the four parts a wavefront holds per column (lane bits 4, 5), then the four wavefronts, in fixed order
-    double s2 = st.s2, s1 = st.s1, mx = st.mx;
+    const int k = tid >> 4, j = tid & 15;
+    double s2 = 0.0, s1 = 0.0, mx = 0.0;
 #pragma unroll
-    for (int sh = 16; sh < 64; sh <<= 1)
+    for (int u = 0; u < 5; u++)
+      if (j + 16 * u < nStep)
+      {
+        s2 += w.v2[u];
+        s1 += w.v1[u];
+        mx = fmax(mx, w.vm[u]);
+      }
+    // the 16 lanes of a column: xor butterfly (the same tree in every lane)
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1)
     {
       s2 += __shfl_xor(s2, sh);
       s1 += __shfl_xor(s1, sh);
       mx = fmax(mx, __shfl_xor(mx, sh));
     }
-    if ((tid & 63) < 16)
+    if (j == 0)
     {
-      const int w = tid >> 6, k = tid & 15;
-      sc[w * 16 + k] = s2;
-      sc[64 + w * 16 + k] = s1;
-      sc[128 + w * 16 + k] = mx;
+      sc[k] = s2;
+      sc[16 + k] = s1;
+      sc[32 + k] = mx;
     }
   }
   __syncthreads();
-  double S2 = 0, S1 = 0;
-  if (tid < 16)
+  if (active && tid < 16)
   {
-    S2 = ((sc[tid] + sc[16 + tid]) + sc[32 + tid]) + sc[48 + tid];
-    S1 = ((sc[64 + tid] + sc[80 + tid]) + sc[96 + tid]) + sc[112 + tid];
-    csL[tid] = fmax(fmax(sc[128 + tid], sc[144 + tid]), fmax(sc[160 + tid], sc[176 + tid])); // parked for the matrix-wide maximum
-  }
-  __syncthreads();
-  double gmax = 0;
+    double gmax = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; k++) gmax = fmax(gmax, csL[k]);
-  __syncthreads();
-  if (tid < 16)
-  {
+    for (int k = 0; k < 16; k++) gmax = fmax(gmax, sc[32 + k]);
     // alg/NMF.hpp:162 "if (W.maxCoeff() > epsilon) W.colwise().normalize()"; padded columns keep a divisor of one
-    nrmL[tid] = (wPend && tid < K && gmax > kEpsilon) ? sqrt(S2) : 1.0;
-    csL[tid] = S1;
+    nrmL[tid] = (wPend && tid < K && gmax > kEpsilon) ? sqrt(sc[tid]) : 1.0;
+    csL[tid] = sc[16 + tid];
   }
   __syncthreads();
 }
@@ -234,15 +218,17 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   double* Hg = a.H + (int64_t) b * a.strideH;
   STRIP_STAMP(0)
 
-  const int qBeg = (int) ((int64_t) g * a.nq / a.nWG), qEnd = (int) ((int64_t) (g + 1) * a.nq / a.nWG);
+  // quads dealt evenly (host-side quotient and remainder: a 64-bit division here is 300 instructions of cold code)
+  const int qBeg = g * a.qBase + min(g, a.qRem), qEnd = qBeg + a.qBase + (g < a.qRem ? 1 : 0);
   const int jpLast = a.nPairs - 1;
   const int nql = min(NQ, qEnd - qBeg);
   const int t0 = 4 * qBeg;
 
-  // The strip's tiles of V stay in registers from their first use to their last: lane (x, blk, y) holds bins
-  // 32 jp + 8 blk + 2 y + {0, 1} of frame t0 + 4 q + x.  Requests go out kAhead pairs ahead of their use: all at once
-  // they only queue (the memory pipe takes what the HBM share of a CU lets through), and what stands in the queue
-  // ahead of W's rows delays the first tile.  Out-of-range quads / pairs re-read a valid address and meet zero factors.
+  // The strip's tiles of V stay in registers from their first use to their last, in the arrangement the W phase works
+  // with: lane (x, blk, y) holds bins 32 jp + 8 blk + 2 x + {0, 1} of frame t0 + 4 q + y -- sixteen consecutive lanes read
+  // 256 contiguous bytes of a frame (the H phase's arrangement, frames on x, made every four lanes a separate request:
+  // 285 cycles of address processing per load instruction); the H phase takes its view through a lane permutation.
+  // Out-of-range quads / pairs re-read a valid address and meet zero factors.
   d2 vh[NPW][NQ];
   // No load below sits behind a branch: the wait-count pass takes the path with the fewest requests at every join, and a
   // pessimistic vmcnt turns "kAhead pairs in flight" into "wait for everything".  A wavefront that has fewer pairs than
@@ -250,7 +236,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   const double* vstrip = Vb + (int64_t) t0 * a.ldv; // uniform; the lane part fits 32 bits
   unsigned vofs[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; q++) vofs[q] = (unsigned) ((4 * min(q, nql - 1) + x) * a.ldv + 8 * blk + 2 * y);
+  for (int q = 0; q < NQ; q++) vofs[q] = (unsigned) ((4 * min(q, nql - 1) + y) * a.ldv + 8 * blk + 2 * x);
 #define STRIP_LOAD_V(P)                                                                                       \
   {                                                                                                           \
     const double* vp_ = vstrip + 32 * min(wv + 4 * (P), jpLast);                                              \
@@ -278,11 +264,15 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 #define STRIP_PAIR_BASE(P) ((wv + 4 * (P) <= jpLast) ? wl + (wv + 4 * (P)) * 4096 : zeroPage)
   d2 wt[2][4];
   d2 Hsv[NQ][2];
-  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk, tid);
+  STRIP_STAMP(10)
+  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, tid);
   __builtin_amdgcn_sched_barrier(0);
+  STRIP_STAMP(11)
   {
     STRIP_LOAD_W(wt[0], 0)
     STRIP_LOAD_W(wt[1], 1)
+    __builtin_amdgcn_sched_barrier(0);
+    STRIP_STAMP(12)
     // the strip's rows of H in the B-operand arrangement of the H phase: H[4 y + m][t0 + 4 q + x]
 #pragma unroll
     for (int q = 0; q < NQ; q++)
@@ -291,15 +281,25 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
       Hsv[q][0] = *reinterpret_cast<const d2*>(hp);
       Hsv[q][1] = *reinterpret_cast<const d2*>(hp + 2);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    STRIP_STAMP(13)
 #pragma unroll
-    for (int p = 0; p < kAhead && p < NPW; p++) STRIP_LOAD_V(p)
+    for (int p = 0; p < kEarly && p < NPW; p++) STRIP_LOAD_V(p)
   }
+  // the strip's old H once more, one value per thread of the combine step (o = tid, tid + 256)
+  double hold[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) hold[i] = Hg[(int64_t) t0 * 16 + min(tid + 256 * i, nql * 64 - 1)];
   __builtin_amdgcn_sched_barrier(0);
+  STRIP_STAMP(9)
   *reinterpret_cast<d2*>(zeroPage + tid * 16) = d2{0.0, 0.0};
 
-  strip_column_stats(strip_column_stats_sum(straw, a.nBlk, tid), a.K, a.wPend, red, nrmL, csL, tid);
+  strip_column_stats(straw, a.nBlk / 4, a.K, a.wPend, red, nrmL, csL, tid, true);
+  STRIP_STAMP(15)
   if (g == 0 && tid < 16) a.nrm[(int64_t) b * 16 + tid] = nrmL[tid];
   if (!a.doH && !a.doW) return;
+#pragma unroll
+  for (int p = kEarly; p < kAhead && p < NPW; p++) STRIP_LOAD_V(p)
   STRIP_STAMP(1)
 
   // per-lane LDS offsets of the two operand read patterns, [e][half]: A rows by x with columns 4 y + m, B rows by y with
@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   for (int m = 0; m < 4; m++) rn[m] = 1.0 / nrmL[4 * y + m];
 
   double wdenAcc = 0.0;
+  const int srcLane4 = 4 * (y + 4 * blk + 16 * x);
   if (a.doH)
   {
     // ---- H phase: the strip's frames against every bin (alg/NMF.hpp:165-170).  W stays as it is in memory,
@@ -358,6 +359,18 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
           if (p + kAhead < NPW) STRIP_LOAD_V(p + kAhead)
         }
         if (p == 2) { STRIP_STAMP(6) }
+        // this phase sees the tiles transposed: lane (x, blk, y) needs what lane (y, blk, x) holds
+        double vt[2][NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++)
+#pragma unroll
+          for (int e = 0; e < 2; e++)
+          {
+            const long long bits = __double_as_longlong(vh[p][q][e]);
+            const int lo = __builtin_amdgcn_ds_bpermute(srcLane4, (int) (bits & 0xffffffff));
+            const int hi = __builtin_amdgcn_ds_bpermute(srcLane4, (int) (bits >> 32));
+            vt[e][q] = __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+          }
         double Q[2][NQ];
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -380,13 +393,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         }
         double R[2][NQ];
 #pragma unroll
-        for (int e = 0; e < 2; e++)
-        {
-          double vv[NQ];
-#pragma unroll
-          for (int q = 0; q < NQ; q++) vv[q] = vh[p][q][e];
-          STRIP_QUOT(R[e], vv, Q[e])
-        }
+        for (int e = 0; e < 2; e++) STRIP_QUOT(R[e], vt[e], Q[e])
         if (p == 2) { STRIP_STAMP(8) }
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 #pragma unroll
             for (int m = 0; m < 4; m++) out[q][m] = MFMA44(R[e][q], wb[e][m >> 1][m & 1], out[q][m]);
         __builtin_amdgcn_sched_barrier(0);
-        if (p == 2) { STRIP_STAMP(9) }
+        if (p == 2) { STRIP_STAMP(14) }
         if (more)
         {
 #pragma unroll
@@ -419,20 +426,24 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         if (blk == 0) red[((wv * kNQ + q) * 4 + m) * 16 + x + 4 * y] = v;
       }
     __syncthreads();
-    for (int o = tid; o < NQ * 64; o += 256)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
     {
-      const int q = o >> 6, rem = o & 63, yy = rem >> 4, k = rem & 15;
-      double hv = 0.0;
-      if (q < nql)
+      const int o = tid + 256 * i;
+      if (o < NQ * 64)
       {
-        const int ix = (q * 4 + (k & 3)) * 16 + (k >> 2) + 4 * yy;
-        const double s = ((red[ix] + red[kNQ * 64 + ix]) + red[2 * kNQ * 64 + ix]) + red[3 * kNQ * 64 + ix];
-        double* hp = Hg + (int64_t) t0 * 16 + o;
-        // :170  H * (W^T (V / V2)) / max(W^T 1, eps) with W = W' / nrm
-        hv = *hp * (s / nrmL[k]) / fmax(csL[k] / nrmL[k], kEpsilon);
-        *hp = hv;
+        const int q = o >> 6, rem = o & 63, yy = rem >> 4, k = rem & 15;
+        double hv = 0.0;
+        if (q < nql)
+        {
+          const int ix = (q * 4 + (k & 3)) * 16 + (k >> 2) + 4 * yy;
+          const double s = ((red[ix] + red[kNQ * 64 + ix]) + red[2 * kNQ * 64 + ix]) + red[3 * kNQ * 64 + ix];
+          // :170  H * (W^T (V / V2)) / max(W^T 1, eps) with W = W' / nrm
+          hv = hold[i] * (s / nrmL[k]) / fmax(csL[k] / nrmL[k], kEpsilon);
+          Hg[(int64_t) t0 * 16 + o] = hv;
+        }
+        hn[o] = hv;
       }
-      hn[o] = hv;
     }
   }
   else
@@ -445,7 +456,9 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
       STRIP_STORE_W(wt[p & 1], p)
       if (p >= kAhead) STRIP_LOAD_V(p)
     }
-    for (int o = tid; o < NQ * 64; o += 256) hn[o] = (o >> 6) < nql ? Hg[(int64_t) t0 * 16 + o] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+      if (tid + 256 * i < NQ * 64) hn[tid + 256 * i] = ((tid + 256 * i) >> 6) < nql ? hold[i] : 0.0;
   }
   __syncthreads();
   STRIP_STAMP(3)
@@ -453,9 +466,8 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   {
     if (tid < 16)
       for (int t = 0; t < 4 * nql; t++) wdenAcc += hn[t * 16 + tid]; // :160 row sums of H, this strip's share
-    // ---- W phase: the strip's share of the next W update's numerator (alg/NMF.hpp:158-160).  The tiles are the ones
-    // the H phase used, seen transposed: lane (x, blk, y) needs bins 32 jp + 8 blk + 2 x + {0, 1} of frame
-    // t0 + 4 q + y, which lane (y, blk, x) holds -- one lane permutation per 32-bit half instead of a second read of V.
+    // ---- W phase: the strip's share of the next W update's numerator (alg/NMF.hpp:158-160), on the tiles the H phase
+    // used (no second read of V).
     double Ha[NQ][4], Hb[NQ][4];
 #pragma unroll
     for (int q = 0; q < NQ; q++)
@@ -465,7 +477,6 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         Ha[q][m] = hn[(4 * q + x) * 16 + 4 * y + m] * rn[m]; // first product: (H / nrm)[4 y + m][frame x]
         Hb[q][m] = hn[(4 * q + y) * 16 + 4 * x + m];         // second product: H[4 x + m][frame y]
       }
-    const int srcLane4 = 4 * (y + 4 * blk + 16 * x);
     double* P = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + lane;
     d2 wa[2][2];
 #pragma unroll
@@ -478,18 +489,11 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
       const int jp = wv + 4 * p;
       __builtin_amdgcn_sched_barrier(0);
       {
-        if (p == 2) { STRIP_STAMP(10) }
         double vt[2][NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++)
 #pragma unroll
-          for (int e = 0; e < 2; e++)
-          {
-            const long long bits = __double_as_longlong(vh[p][q][e]);
-            const int lo = __builtin_amdgcn_ds_bpermute(srcLane4, (int) (bits & 0xffffffff));
-            const int hi = __builtin_amdgcn_ds_bpermute(srcLane4, (int) (bits >> 32));
-            vt[e][q] = __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
-          }
+          for (int e = 0; e < 2; e++) vt[e][q] = vh[p][q][e];
         double Q[2][NQ];
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -502,7 +506,6 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 #pragma unroll
             for (int q = 0; q < NQ; q++) Q[e][q] = MFMA44(Ha[q][m], wa[e][m >> 1][m & 1], Q[e][q]);
         __builtin_amdgcn_sched_barrier(0);
-        if (p == 2) { STRIP_STAMP(11) }
         if (p + 1 < NPW)
         {
           const unsigned char* wj = STRIP_PAIR_BASE(p + 1);
@@ -514,7 +517,6 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         double R[2][NQ];
 #pragma unroll
         for (int e = 0; e < 2; e++) STRIP_QUOT(R[e], vt[e], Q[e])
-        if (p == 2) { STRIP_STAMP(12) }
         double num[2][4];
 #pragma unroll
         for (int e = 0; e < 2; e++)
@@ -527,7 +529,6 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 #pragma unroll
             for (int m = 0; m < 4; m++) num[e][m] = MFMA44(R[e][q], Hb[q][m], num[e][m]);
         __builtin_amdgcn_sched_barrier(0);
-        if (p == 2) { STRIP_STAMP(13) }
         // complete as soon as the pair's last quad is in: out it goes (512 contiguous bytes per store instruction)
         if (jp <= jpLast)
         {
@@ -543,7 +544,6 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
               else *dst = num[e][m];
             }
         }
-        if (p == 2) { STRIP_STAMP(14) }
       }
     }
     STRIP_STAMP(4)
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 // Element `lane` of block r = (jp * 2 + e) * 4 + m  <->  f = 32 jp + 8 blk + 2 y + e, k = 4 x + m.
 // Column statistics of the 64 values a wavefront holds (one block): [sum x^2, sum x, max x] of the four columns,
 // 16 rows each, added over lane bits 2..5 in fixed order.
-__device__ __forceinline__ void strip_block_stats(double v, double* rec, int lane)
+__device__ __forceinline__ void strip_block_stats(double v, double* stat, int nStep, int r, int lane)
 {
   double s2 = v * v, s1 = v, mx = v;
 #pragma unroll
@@ -567,9 +567,10 @@ __device__ __forceinline__ void strip_block_stats(double v, double* rec, int lan
   }
   if (lane < 4)
   {
-    rec[lane] = s2;
-    rec[4 + lane] = s1;
-    rec[8 + lane] = mx;
+    const int k = 4 * lane + (r & 3), i = r >> 2; // stat[kind][k][step]
+    stat[(int64_t) k * nStep + i] = s2;
+    stat[(int64_t) (16 + k) * nStep + i] = s1;
+    stat[(int64_t) (32 + k) * nStep + i] = mx;
   }
 }
 
@@ -589,7 +590,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK
   const double* P = a.part + (((int64_t) b * a.nBlk + (r & ~3)) * a.nWG + (r & 3)) * 64 + lane;
   // every request of the launch goes out before the first sum (no load behind a branch, nothing consumed in between):
   // the statistics records, the denominator partials, the numerator partials
-  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk, tid & 255);
+  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, tid & 255);
   const int dk = tid & 15, dgrp = tid >> 4; // 32 groups
   const double* D = a.dpart + (int64_t) b * a.nWG * 16 + dk;
   double dv[8];
@@ -620,11 +621,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK
     for (int u = 0; u < kRedU; u++) s += p0 + kRedWaves * u < a.nWG ? v[u] : 0.0;
   }
   red[wv][lane] = s;
-  if (tid < 256) strip_column_stats(strip_column_stats_sum(straw, a.nBlk, tid), a.K, a.wPend, sc, nrmL, csL, tid);
-  else
-  {
-    __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); // the barriers inside strip_column_stats
-  }
+  strip_column_stats(straw, a.nBlk / 4, a.K, a.wPend, sc, nrmL, csL, tid, tid < 256);
   sc[(tid >> 4) * 16 + (tid & 15)] = dsum;
   __syncthreads();
   if (tid < 16)
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK
       wnew = (wold / nrmL[ek]) * tot / den[ek];
       *wp = wnew;
     }
-    strip_block_stats(wnew, a.statOut + ((int64_t) b * a.nBlk + r) * kStatW, lane);
+    strip_block_stats(wnew, a.statOut + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, r, lane);
   }
 }
 
@@ -658,7 +655,7 @@ __global__ __launch_bounds__(64) void nmf_strip_wstats_kernel(StripK a)
   const int f = 32 * jp + 8 * blk + 2 * y + e, k = 4 * x + m;
   double v = 0.0;
   if (f < a.F && k < a.K) v = a.W[(int64_t) b * a.strideW + (int64_t) f * 16 + k];
-  strip_block_stats(v, a.statOut + ((int64_t) b * a.nBlk + r) * kStatW, lane);
+  strip_block_stats(v, a.statOut + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, r, lane);
 }
 
 int strip_pairs(int F) { return (F + 31) / 32; }
@@ -698,6 +695,8 @@ static StripK make_k(const StripArgs& s)
   k.nrm = s.nrm;
   k.F = s.F; k.T = s.T; k.K = s.K;
   k.nq = (s.T + 3) / 4;
+  k.qBase = k.nq / k.nWG;
+  k.qRem = k.nq % k.nWG;
   k.doH = s.doH; k.doW = s.doW; k.wPend = s.wPend;
   k.dbg = reinterpret_cast<long long*>(stat1 + (int64_t) s.B * k.nBlk * kStatW);
   return k;

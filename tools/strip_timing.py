@@ -38,6 +38,7 @@ if ctx.lib.fluhip_corpus_debug_words(c.h, out) == 0 and out[0]:
         dc = cyc[i + 1] - cyc[i]
         print(f"  {nme:30s} {dc:8d} cycles  {dc / ghz / 1e3:7.2f} us")
     print(f"  workgroup 0 total              {cyc[5] - cyc[0]:8d} cycles  {us:7.2f} us  ({ghz:5.2f} GHz)")
-    print("  H phase, third pair of wavefront 0: first product", cyc[7] - cyc[6], " quotients", cyc[8] - cyc[7], " second product", cyc[9] - cyc[8])
-    print("  W phase, third pair of wavefront 0: lane permutation", cyc[11] - cyc[10], "(with the first product)  quotients", cyc[12] - cyc[11],
-          " second product", cyc[13] - cyc[12], " stores", cyc[14] - cyc[13])
+    print("  prologue detail: to the first request", cyc[10] - cyc[0], " statistics requests", cyc[11] - cyc[10], " rows of W", cyc[12] - cyc[11],
+          " H", cyc[13] - cyc[12], " V + rest", cyc[9] - cyc[13], " | column norms known", cyc[15] - cyc[9], " then to the first tile", cyc[1] - cyc[15])
+    print("  H phase, third pair of wavefront 0: lane permutation + first product", cyc[7] - cyc[6], " quotients", cyc[8] - cyc[7],
+          " second product", cyc[14] - cyc[8])
