@@ -477,7 +477,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // =1 wherever the kernel supports the shape.
     static const int stripEnv = [] { const char* e = std::getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
     c->strip = c->lazy && stripEnv != 0 && nmf_strip_supported((int) c->F, (int) c->T, (int) c->Kp) &&
-               (stripEnv == 1 || (c->B == 1 && nmf_strip_workgroups((int) c->T) <= 256));
+               (stripEnv == 1 || (c->B == 1 && nmf_strip_workgroups((int) c->T) <= 512));
     if (c->strip)
     {
       c->sideW = false;
