@@ -247,7 +247,9 @@ int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1
  * bug reports; no effect on results beyond summation order): out8 = { kernel form (5 = 4x4x4 MFMA + LDS-DMA,
  * 4 = 4x4x4 register-staged, 16 = 16x16x4), contraction splits of the W update, of the H update,
  * deferred column normalisation of W (alg/NMF.hpp:162 applied on load) 0/1, Nyquist bin as a side column 0/1,
- * wavefronts per buffer of the W update, padded rank, 0 }. */
+ * wavefronts per buffer of the W update, padded rank, frame-strip schedule 0/1 (a single buffer of rank <= 16: the H
+ * update local to a strip of frames, the W update's numerator as per-workgroup partials + a reduce launch; the split
+ * counts before it then describe the schedule it replaces) }. */
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
