@@ -54,6 +54,16 @@ struct Upd5Args
   double* statPart;
 };
 
+// The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
+// Relative error <= ~1.4e-14 per quotient; the device factors stay where they were against the oracle (1e-14 after 200
+// iterations, tools/parity_levels.py: the difference is dominated by the summation orders).  -DFLUHIP_QUOTIENT_CORRECTION=1
+// adds the residual correction (error ~2^-96 before the final rounding: IEEE division for all practical purposes) at 2 of 7
+// FP64 operations per element: 93 of the 2 470 cycles of a 4-row step, 3 % of the job.
+#ifndef FLUHIP_QUOTIENT_CORRECTION
+#define FLUHIP_QUOTIENT_CORRECTION 0
+#endif
+constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
+
 // v / d for d > 0, v >= 0 in the normal range: v_rcp_f64 -> one Newton step -> quotient -> residual correction
 // (error ~2^-96 before the final rounding; exact when d == 1)
 __device__ __forceinline__ double fdiv_pos(double v, double d)
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     }
   };
   // V / max(Q, eps), stage by stage across the NG independent quotients:
-  // v_rcp_f64 (~24 bits) -> one Newton step -> quotient -> residual correction (error ~2^-96)
+  // v_rcp_f64 (~23 bits) -> one Newton step -> quotient [-> residual correction, kQuotientCorrection]
   auto ratio_phase = [&](const double (&v)[NG], const double (&q)[NG], double (&ratio)[NG]) {
     double d[NG], yv[NG];
 #pragma unroll
@@ -343,10 +353,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int g = 0; g < NG; g++) yv[g] = __builtin_fma(yv[g], ratio[g], yv[g]);
 #pragma unroll
     for (int g = 0; g < NG; g++) ratio[g] = v[g] * yv[g];
+    if constexpr (kQuotientCorrection)
+    {
 #pragma unroll
-    for (int g = 0; g < NG; g++) d[g] = __builtin_fma(-d[g], ratio[g], v[g]);
+      for (int g = 0; g < NG; g++) d[g] = __builtin_fma(-d[g], ratio[g], v[g]);
 #pragma unroll
-    for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(d[g], yv[g], ratio[g]);
+      for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(d[g], yv[g], ratio[g]);
+    }
   };
   auto out_phase = [&](const double (&ratio)[NG], const double (&mb)[M]) {
 #pragma unroll

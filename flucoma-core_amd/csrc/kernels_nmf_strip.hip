@@ -44,6 +44,11 @@ constexpr int kAhead = 1; // bin pairs of V a wavefront requests ahead of their 
                           // nothing in the loop, 5 pairs 3 us.
 constexpr int kEarly = 1; // ... of which are requested before the column norms are known
 constexpr bool kWriteThrough = true;
+// quotients of the tile loops without / with the residual correction: see kernels_nmf5.hip (same switch)
+#ifndef FLUHIP_QUOTIENT_CORRECTION
+#define FLUHIP_QUOTIENT_CORRECTION 0
+#endif
+constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
 constexpr int kStatW = 12; // statistics: 12 doubles per column block (3 kinds x 4 columns), stored [kind][column][bin step]
 
 struct StripK
@@ -109,11 +114,18 @@ __device__ __forceinline__ double dppmov(double v)
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     _Pragma("unroll") for (int q = 0; q < NQ; q++) y_[q] = __builtin_fma(y_[q], e_[q], y_[q]);               \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
-    _Pragma("unroll") for (int q = 0; q < NQ; q++) e_[q] = V[q] * y_[q];                                     \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    _Pragma("unroll") for (int q = 0; q < NQ; q++) d_[q] = __builtin_fma(-d_[q], e_[q], V[q]);               \
-    __builtin_amdgcn_sched_barrier(0);                                                                        \
-    _Pragma("unroll") for (int q = 0; q < NQ; q++) R[q] = __builtin_fma(d_[q], y_[q], e_[q]);                \
+    if constexpr (kQuotientCorrection)                                                                        \
+    {                                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < NQ; q++) e_[q] = V[q] * y_[q];                                   \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int q = 0; q < NQ; q++) d_[q] = __builtin_fma(-d_[q], e_[q], V[q]);             \
+      __builtin_amdgcn_sched_barrier(0);                                                                      \
+      _Pragma("unroll") for (int q = 0; q < NQ; q++) R[q] = __builtin_fma(d_[q], y_[q], e_[q]);              \
+    }                                                                                                         \
+    else                                                                                                      \
+    {                                                                                                         \
+      _Pragma("unroll") for (int q = 0; q < NQ; q++) R[q] = V[q] * y_[q];                                    \
+    }                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
   }
 
