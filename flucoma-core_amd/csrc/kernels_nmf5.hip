@@ -63,6 +63,10 @@ struct Upd5Args
 #define FLUHIP_QUOTIENT_CORRECTION 0
 #endif
 constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
+#ifndef FLUHIP_SHARED_RECIPROCAL
+#define FLUHIP_SHARED_RECIPROCAL 1
+#endif
+constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
 
 // v / d for d > 0, v >= 0 in the normal range: v_rcp_f64 -> one Newton step -> quotient -> residual correction
 // (error ~2^-96 before the final rounding; exact when d == 1)
@@ -345,12 +349,39 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     double d[NG], yv[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) d[g] = q[g] > kEpsilon ? q[g] : kEpsilon;
+    if constexpr (kQuotientCorrection || !kSharedReciprocal)
+    {
 #pragma unroll
-    for (int g = 0; g < NG; g++) yv[g] = __builtin_amdgcn_rcp(d[g]);
+      for (int g = 0; g < NG; g++) yv[g] = __builtin_amdgcn_rcp(d[g]);
 #pragma unroll
-    for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(-d[g], yv[g], 1.0);
+      for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(-d[g], yv[g], 1.0);
 #pragma unroll
-    for (int g = 0; g < NG; g++) yv[g] = __builtin_fma(yv[g], ratio[g], yv[g]);
+      for (int g = 0; g < NG; g++) yv[g] = __builtin_fma(yv[g], ratio[g], yv[g]);
+    }
+    else
+    {
+      // one reciprocal per TWO quotients: r = 1 / (a b) refined once, 1 / a = r b, 1 / b = r a (v_rcp_f64 is a quarter-rate
+      // instruction; a b stays far inside the range: eps^2 .. max(Q)^2)
+      constexpr int NP = NG / 2;
+      double pr[NP > 0 ? NP : 1], rr[NP > 0 ? NP : 1], ee[NP > 0 ? NP : 1];
+#pragma unroll
+      for (int h = 0; h < NP; h++) pr[h] = d[2 * h] * d[2 * h + 1];
+#pragma unroll
+      for (int h = 0; h < NP; h++) rr[h] = __builtin_amdgcn_rcp(pr[h]);
+      if constexpr (NG & 1) yv[NG - 1] = __builtin_amdgcn_rcp(d[NG - 1]);
+#pragma unroll
+      for (int h = 0; h < NP; h++) ee[h] = __builtin_fma(-pr[h], rr[h], 1.0);
+      if constexpr (NG & 1) ratio[NG - 1] = __builtin_fma(-d[NG - 1], yv[NG - 1], 1.0);
+#pragma unroll
+      for (int h = 0; h < NP; h++) rr[h] = __builtin_fma(rr[h], ee[h], rr[h]);
+      if constexpr (NG & 1) yv[NG - 1] = __builtin_fma(yv[NG - 1], ratio[NG - 1], yv[NG - 1]);
+#pragma unroll
+      for (int h = 0; h < NP; h++)
+      {
+        yv[2 * h] = rr[h] * d[2 * h + 1];
+        yv[2 * h + 1] = rr[h] * d[2 * h];
+      }
+    }
 #pragma unroll
     for (int g = 0; g < NG; g++) ratio[g] = v[g] * yv[g];
     if constexpr (kQuotientCorrection)
