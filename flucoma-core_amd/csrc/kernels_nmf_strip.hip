@@ -71,17 +71,6 @@ struct StripK
   long long* dbg; // FLUHIP_STRIP_INSTR: shader-clock stamps of workgroup 0 (tools/strip_timing.py)
 };
 
-// v / d for d > 0, v >= 0 in the normal range (kernels_nmf5.hip fdiv_pos)
-__device__ __forceinline__ double qdiv(double v, double d)
-{
-  double yv = __builtin_amdgcn_rcp(d);
-  const double e = __builtin_fma(-d, yv, 1.0);
-  yv = __builtin_fma(yv, e, yv);
-  const double r = v * yv;
-  const double res = __builtin_fma(-d, r, v);
-  return __builtin_fma(res, yv, r);
-}
-
 // LDS image of W (each wavefront keeps the bin pairs it works on): byte offset of row f, 16-byte chunk c = columns
 // (2 c, 2 c + 1), inside the pair's 4 KB.  Two rows share a 256-byte line; the chunk position is XOR-ed with row bits so
 // that both operand read patterns (16 rows x one chunk pair; 4 rows x 4 chunk pairs) touch 16 different 16-byte bank
