@@ -175,4 +175,121 @@ int fluhip_pool_bufnmf_f32(fluhip_pool* p, const float* audio, int64_t count, in
   return rc;
 }
 
+// Ragged corpus: buffers of different lengths.  Dealt by the greedy longest-processing-time rule over cost = frames (the
+// work of a buffer is ~ T F K, F and K being common); on its device every run of equal-length buffers becomes one
+// corpus (the batched kernels), the rest run one by one (the single-buffer schedules).
+int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, const int64_t* n, int64_t count, int64_t win,
+                                  int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                                  const int64_t* seeds, float* const* bases, float* const* acts, fluhip_progress_fn progress,
+                                  void* user)
+{
+  if (!p) return FLUHIP_ERROR;
+  p->err.clear();
+  if (!audio || !n || count < 1) { p->err = "null / empty corpus"; return FLUHIP_ERROR; }
+  for (int64_t i = 0; i < count; i++)
+    if (!audio[i] || n[i] < 1) { p->err = "buffer " + std::to_string(i) + ": null or empty"; return FLUHIP_ERROR; }
+  const int world = (int) p->ctx.size();
+  const int64_t F = fft / 2 + 1;
+  std::vector<double> cost((size_t) count);
+  for (int64_t i = 0; i < count; i++) cost[(size_t) i] = (double) fluhip_stft_num_frames(n[i], win, hop);
+  std::vector<int32_t> owner((size_t) count);
+  if (fluhip_balanced_assignment(cost.data(), count, world, owner.data()) != FLUHIP_OK) return FLUHIP_ERROR;
+
+  std::atomic<int64_t> buffersDone{0};
+  std::atomic<bool> cancel{false};
+  std::vector<int> rcs((size_t) world, FLUHIP_OK);
+  std::vector<std::string> errs((size_t) world);
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; r++)
+  {
+    std::vector<int64_t> mine;
+    for (int64_t i = 0; i < count; i++)
+      if (owner[(size_t) i] == r) mine.push_back(i);
+    if (mine.empty()) continue;
+    // equal lengths next to each other, longest first; ties in corpus order (deterministic grouping)
+    std::stable_sort(mine.begin(), mine.end(), [&](int64_t a, int64_t b) { return n[a] > n[b]; });
+    th.emplace_back([=, &rcs, &errs, &buffersDone, &cancel] {
+      fluhip_ctx* ctx = p->ctx[(size_t) r];
+      std::vector<float> packed, gb, ga;
+      std::vector<int64_t> gseeds;
+      for (size_t i0 = 0; i0 < mine.size() && rcs[(size_t) r] == FLUHIP_OK && !cancel.load(std::memory_order_acquire);)
+      {
+        size_t i1 = i0;
+        while (i1 < mine.size() && n[mine[i1]] == n[mine[i0]] && i1 - i0 < 65535) i1++;
+        const int64_t nb = (int64_t) (i1 - i0), len = n[mine[i0]];
+        const int64_t T = fluhip_stft_num_frames(len, win, hop);
+        const float* src = audio[mine[i0]];
+        if (nb > 1)
+        {
+          packed.resize((size_t) nb * (size_t) len);
+          for (int64_t j = 0; j < nb; j++)
+            std::copy(audio[mine[i0 + (size_t) j]], audio[mine[i0 + (size_t) j]] + len, packed.begin() + (size_t) j * (size_t) len);
+          src = packed.data();
+        }
+        if (seeds)
+        {
+          gseeds.resize((size_t) nb);
+          for (int64_t j = 0; j < nb; j++) gseeds[(size_t) j] = seeds[mine[i0 + (size_t) j]];
+        }
+        fluhip_corpus* c = nullptr;
+        int rc = fluhip_corpus_create(ctx, nb, len, win, fft, hop, K, &c);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, src);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(c);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? gseeds.data() : nullptr, nullptr, nullptr);
+        if (rc == FLUHIP_OK)
+        {
+          float* bdst = nullptr;
+          float* adst = nullptr;
+          if (nb == 1) { bdst = bases ? bases[mine[i0]] : nullptr; adst = acts ? acts[mine[i0]] : nullptr; }
+          else
+          {
+            if (bases) { gb.resize((size_t) (nb * K * F)); bdst = gb.data(); }
+            if (acts) { ga.resize((size_t) (nb * K * T)); adst = ga.data(); }
+          }
+          rc = fluhip_corpus_writeback_host(c, bdst, adst);
+          if (rc == FLUHIP_OK && nb > 1)
+            for (int64_t j = 0; j < nb; j++)
+            {
+              const int64_t g = mine[i0 + (size_t) j];
+              if (bases && bases[g]) std::copy(gb.begin() + (size_t) (j * K * F), gb.begin() + (size_t) ((j + 1) * K * F), bases[g]);
+              if (acts && acts[g]) std::copy(ga.begin() + (size_t) (j * K * T), ga.begin() + (size_t) ((j + 1) * K * T), acts[g]);
+            }
+        }
+        if (rc != FLUHIP_OK) { rcs[(size_t) r] = rc; errs[(size_t) r] = fluhip_last_error(ctx); }
+        if (c) fluhip_corpus_destroy(c);
+        buffersDone.fetch_add(nb, std::memory_order_release);
+        i0 = i1;
+      }
+    });
+  }
+  // progress = buffers finished so far (1 .. count), from the calling thread; a refusal stops every device after the group it
+  // is working on
+  if (progress)
+  {
+    int64_t reported = 0;
+    for (;;)
+    {
+      const int64_t d = buffersDone.load(std::memory_order_acquire);
+      bool stop = false;
+      for (; reported < d && !stop; reported++)
+        if (!progress(reported + 1, user)) { cancel.store(true, std::memory_order_release); stop = true; }
+      if (stop || reported >= count) break;
+      bool failed = false;
+      for (int r = 0; r < world; r++) failed = failed || rcs[(size_t) r] != FLUHIP_OK;
+      if (failed) break;
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  for (auto& t : th) t.join();
+  int rc = FLUHIP_OK;
+  for (int r = 0; r < world; r++)
+    if (rcs[(size_t) r] != FLUHIP_OK && rc == FLUHIP_OK)
+    {
+      rc = rcs[(size_t) r];
+      p->err = "device " + std::to_string(p->device[(size_t) r]) + ": " + errs[(size_t) r];
+    }
+  if (rc == FLUHIP_OK && cancel.load()) { rc = FLUHIP_CANCELLED; p->err = "cancelled"; }
+  return rc;
+}
+
 } // extern "C"

@@ -52,7 +52,7 @@ EXPORTS = [
     "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
-    "fluhip_pool_bufnmf_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
+    "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
 ]
 
 
@@ -136,6 +136,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_pool_last_error.restype = ctypes.c_char_p
     L.fluhip_pool_bufnmf_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int,
                                          _i64, _ip, _fp, _fp, PROGRESS_FN, _vp]
+    L.fluhip_pool_bufnmf_ragged_f32.argtypes = [_vp, ctypes.POINTER(_fp), _ip, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
+                                                ctypes.c_int, _i64, _ip, ctypes.POINTER(_fp), ctypes.POINTER(_fp), PROGRESS_FN, _vp]
     L.fluhip_shard_range.argtypes = [_i64, ctypes.c_int, ctypes.c_int, _ip, _ip]
     L.fluhip_shard_range.restype = None
     L.fluhip_balanced_assignment.argtypes = [_dp, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32)]
@@ -499,6 +501,27 @@ class Pool:
         rc = self.lib.fluhip_pool_bufnmf_f32(self.h, _f(audio), count, n, win, fft, hop, K, iters, int(updateW), int(updateH),
                                              seed, sarr.ctypes.data_as(_ip) if sarr is not None else None, _f(bases), _f(acts),
                                              cb, None)
+        if rc not in (OK, CANCELLED):
+            raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
+        return bases, acts, rc
+
+    def bufnmf_ragged(self, audios, win, fft, hop, K, iters, seed=42, updateW=True, updateH=True, seeds=None, progress=None):
+        """buffers of different lengths: lists of per-buffer bases [K,F] and activations [K,T_i]"""
+        audios = [np.ascontiguousarray(a, dtype=np.float32) for a in audios]
+        count = len(audios)
+        F = fft // 2 + 1
+        Ts = [int(self.lib.fluhip_stft_num_frames(a.shape[0], win, hop)) for a in audios]
+        bases = [np.empty((K, F), dtype=np.float32) for _ in range(count)]
+        acts = [np.empty((K, T), dtype=np.float32) for T in Ts]
+        fpp = ctypes.POINTER(ctypes.c_float)
+        ap = (fpp * count)(*[a.ctypes.data_as(fpp) for a in audios])
+        bp = (fpp * count)(*[b.ctypes.data_as(fpp) for b in bases])
+        cp = (fpp * count)(*[c.ctypes.data_as(fpp) for c in acts])
+        lens = (ctypes.c_int64 * count)(*[a.shape[0] for a in audios])
+        sarr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)
+        cb = _cb(progress)
+        rc = self.lib.fluhip_pool_bufnmf_ragged_f32(self.h, ap, lens, count, win, fft, hop, K, iters, int(updateW), int(updateH),
+                                                    seed, sarr.ctypes.data_as(_ip) if sarr is not None else None, bp, cp, cb, None)
         if rc not in (OK, CANCELLED):
             raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
         return bases, acts, rc

@@ -272,6 +272,16 @@ const char* fluhip_pool_last_error(const fluhip_pool* pool);
 int fluhip_pool_bufnmf_f32(fluhip_pool* pool, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
                            int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                            const int64_t* seeds, float* bases, float* acts, fluhip_progress_fn progress, void* user);
+/* The same over buffers of DIFFERENT lengths (a folder of sound files): audio[i] = n[i] host floats; bases[i] receives
+ * K x F, acts[i] K x T_i floats with T_i = fluhip_stft_num_frames(n[i], win, hop) (either array, or single entries, may be
+ * NULL).  Buffers are dealt by fluhip_balanced_assignment over their frame counts; on its device every run of
+ * equal-length buffers is processed as one corpus, the others one by one.  progress (may be NULL) is called on the
+ * calling thread with the number of buffers finished so far, 1..count in order; returning 0 stops every device after
+ * the group it is working on (FLUHIP_CANCELLED; the outputs of unfinished buffers are not written). */
+int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* pool, const float* const* audio, const int64_t* n, int64_t count, int64_t win,
+                                  int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                                  const int64_t* seeds, float* const* bases, float* const* acts, fluhip_progress_fn progress,
+                                  void* user);
 /* the dealing itself (integer arithmetic, also used by the multi-process launcher): contiguous blocks [begin, end) of
  * n_items over `world` ranks; and the greedy longest-processing-time deal for ragged corpora (cost ~ T F K per buffer,
  * ties to the lower index / rank): rank_of_item[i] = rank of item i */

@@ -176,6 +176,34 @@ def test_pool_two_contexts_shard_a_corpus(ctx, oracle, onp):
     pool.close(); one.close()
 
 
+def test_pool_ragged_corpus(ctx, oracle, onp):
+    """fluhip_pool_bufnmf_ragged_f32: buffers of different lengths (a folder of sound files) over two contexts on device 0 --
+    dealt by frame count, runs of equal length as one corpus (the batched kernels), the rest one by one (the single-buffer
+    schedules); every buffer against the oracle, per-buffer seeds, progress = buffers finished, cancellation"""
+    import fluhip
+    win, fft, hop, K, iters = 1024, 1024, 256, 5, 10
+    lens = [30000, 22050, 30000, 5000, 22050, 30000, 12345, 257]
+    audios = [onp.synth_audio(n, 4000 + i) for i, n in enumerate(lens)]
+    pool = fluhip.Pool([0, 0], ctx.lib)
+    seen = []
+    bases, acts, rc = pool.bufnmf_ragged(audios, win, fft, hop, K, iters, seed=42, progress=lambda d: seen.append(d) or True)
+    assert rc == 0 and seen == list(range(1, len(lens) + 1)), seen
+    for i, a in enumerate(audios):
+        rb, ra = oracle.bufnmf_channel(a, win, fft, hop, K, iters, 42)
+        assert bases[i].shape == rb.shape and acts[i].shape == ra.shape
+        assert rel_err(bases[i], rb) < 1e-6 and rel_err(acts[i], ra) < 1e-6, i
+    seeds = [7, 7, 8, 9, 10, 11, 12, 13]
+    bases, acts, rc = pool.bufnmf_ragged(audios, win, fft, hop, K, iters, seeds=seeds)
+    for i in (0, 2, 7):
+        rb, ra = oracle.bufnmf_channel(audios[i], win, fft, hop, K, iters, seeds[i])
+        assert rel_err(bases[i], rb) < 1e-6 and rel_err(acts[i], ra) < 1e-6, i
+    _, _, rc = pool.bufnmf_ragged(audios, win, fft, hop, K, iters, progress=lambda d: d < 2)
+    assert rc == fluhip.CANCELLED
+    with pytest.raises(fluhip.FluhipError):
+        pool.bufnmf_ragged([np.zeros(0, dtype=np.float32)], win, fft, hop, K, iters)
+    pool.close()
+
+
 def _bench(args, env=None):
     e = dict(os.environ)
     e.update(env or {})
