@@ -224,7 +224,7 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
 constexpr int kFinSG = 4;      // thread groups sharing the split partials of an element
 constexpr int kFinBatch = 4;   // rows per row group, all in flight together
-constexpr int kFinMaxPer = 16; // split partials per thread group (nsplit <= 64); the kernel is built for 1, 2, 4, 8 and 16
+// (split partials per thread group: nsplit <= 64, the kernel is built for 1, 2, 4, 8 and 16)
 
 static int fin_row_groups(int Kp) { int nrg = 256 / (Kp * kFinSG); return nrg < 1 ? 1 : nrg; }
 int update_finalize_rows(int Kp) { return kFinBatch * fin_row_groups(Kp); }

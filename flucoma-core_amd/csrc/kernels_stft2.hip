@@ -142,8 +142,6 @@ __device__ __forceinline__ void bfr<16>(cx (&v)[16])
   }
 }
 
-__device__ __forceinline__ int xpad(int i) { return i + (i >> 4); } // one 8-byte slot of padding per 16
-
 // cos / sin of 2 pi r / (2 R) for the split's constant factor e^{-2 pi i r / (2 R)}
 template <int R>
 __device__ __forceinline__ cx split_const(int r)
@@ -300,7 +298,6 @@ struct FftCore
 #pragma unroll
   for (int bb = 0; bb < NB3; bb++)
   {
-    const int j = LOCAL ? (bb == 0 ? jA : jB) : lane + 64 * bb;
     cx v[R3];
     v[0] = p3[bb * R3];
 #pragma unroll
@@ -456,7 +453,6 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   constexpr int NB1 = N / (64 * R1), NB2 = N / (64 * R2), NB3 = N / (64 * R3);
   static_assert(NB1 >= 1 && NB2 >= 1 && (NB3 == 1 || NB3 == 2), "tiling");
   constexpr int NS2 = R1, NS3 = R1 * R2;
-  constexpr bool LOCAL = NB3 == 2;            // both bins of a split pair in one lane
   constexpr int BUFD = N + N / 16 + 2;        // doubles per wavefront (the + 2 staggers the wavefronts' buffers over the banks)
   constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -480,7 +476,6 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 
   FftCore<R1, R2, R3> core;
   core.init(xb, tw2, twg, lane);
-  const int halfWin = a.win / 2;
   const int nthreads = 64 * NW;
 
   // blocks are dealt so that workgroups on one XCD (blockIdx & 7) take neighbouring blocks of a buffer: their
