@@ -73,6 +73,18 @@ for b in (0, 4):
     e = max(rel_err(W1[b], rW), rel_err(H1[b], rH))
     print("corpus", b, e)
     worst = max(worst, e)
+# ... and at fft 2048 (nine bin pairs per wavefront), three buffers, seeds per buffer
+audio = np.stack([oracle_np.synth_audio(40000, 2000 + b) for b in range(3)])
+c = fluhip.Corpus(ctx, 3, 40000, 2048, 2048, 512, 16)
+assert c.plan()["strip"] == 1, c.plan()
+c.set_audio(audio); c.stft(); c.nmf(6, seeds=[5, 6, 5])
+mag, W1, H1 = c.read_f64()
+for b in range(3):
+    _, rmag = o.stft_f32(audio[b], 2048, 2048, 512)
+    rW, rH, _, _ = o.nmf_process(rmag, 16, 6, True, True, [5, 6, 5][b])
+    e = max(rel_err(W1[b], rW), rel_err(H1[b], rH))
+    print("corpus fft 2048", b, e)
+    worst = max(worst, e)
 print("worst", worst)
 assert worst < 1e-9, worst
 '''
