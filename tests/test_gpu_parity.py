@@ -230,6 +230,17 @@ def test_nmf_zero_columns_and_rows(ctx, oracle):
     assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
 
 
+def test_nmf_all_zero_input(ctx, oracle):
+    """digital silence: V == 0 everywhere -- the factors collapse to zero after one iteration and stay finite (every
+    denominator is clamped at eps, alg/NMF.hpp:158-170), on the frame-strip schedule (rank 3) and the split one (rank 32)"""
+    X = np.zeros((70, 129))
+    for K in (3, 32):
+        W1, H1, V1, _ = ctx.nmf_process(X, K, 6, True, True, 42)
+        rW, rH, rV, _ = oracle.nmf_process(X, K, 6, True, True, 42)
+        assert np.isfinite(W1).all() and np.isfinite(H1).all() and np.isfinite(V1).all()
+        assert np.array_equal(W1, rW) and np.array_equal(H1, rH)
+
+
 def test_nmf_progress_and_cancel(ctx):
     import fluhip
     X = np.abs(np.random.RandomState(1).standard_normal((64, 33)))
