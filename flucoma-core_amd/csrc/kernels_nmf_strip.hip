@@ -38,10 +38,10 @@ namespace strip {
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kNQ = 6;    // frame quads of a workgroup's strip
-constexpr int kAhead = 1; // bin pairs of V a wavefront requests ahead of their use.  The H phase is bound by the arrival of V
-                          // (a CU gets ~17 GB/s of this stream), and requests beyond what the memory pipe takes block the
-                          // issue of everything behind them: 3 pairs ahead cost 1.3 us more in the prologue and gain
-                          // nothing in the loop, 5 pairs 3 us.
+constexpr int kAhead = 1; // bin pairs of V a wavefront requests ahead of their use.  Requests beyond what the memory pipe takes
+                          // block the issue of everything behind them: 3 pairs ahead cost 1.3 us more in the prologue and
+                          // gain nothing in the loop (which is bound by its instruction stream, not by the arrival of V:
+                          // profiles/r02/strip_notes.md), 5 pairs 3 us.
 constexpr int kEarly = 1; // ... of which are requested before the column norms are known
 constexpr bool kWriteThrough = true;
 // quotients of the tile loops without / with the residual correction: see kernels_nmf5.hip (same switch)
