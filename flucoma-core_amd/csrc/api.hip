@@ -1281,6 +1281,7 @@ int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stri
 }
 
 // ---- two-stride views at the algorithm boundary (data/FluidTensor_Support.hpp:260-420, util/FluidEigenMappings.hpp:35-225)
+} // extern "C" (the helpers below are C++)
 namespace {
 inline bool view_empty(const fluhip_matrix_view* v) { return !v || !v->data || v->rows == 0 || v->cols == 0; }
 // contiguous row-major host copy of a view (small matrices: seeds)
@@ -1297,6 +1298,7 @@ void view_scatter(const fluhip_matrix_view& v, const double* src)
     for (int64_t c = 0; c < v.cols; c++) v.data[r * v.row_stride + c * v.col_stride] = src[r * v.cols + c];
 }
 } // namespace
+extern "C" {
 
 int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, int64_t K, int64_t iters, int update_w,
                                  int update_h, int64_t seed, const fluhip_matrix_view* W0v, const fluhip_matrix_view* H0v,
