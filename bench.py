@@ -36,6 +36,7 @@ import numpy as np  # noqa: E402
 # tools/mfma_f64_probe (profiles/).
 PEAK_HBM_GBS = 8000.0
 PEAK_FP64_MFMA_TFLOPS = 78.6
+PEAK_MHZ = 2400.0   # the clock the datasheet peak is quoted at (MI355X_MICROARCH.md "Max clock")
 
 WORKLOAD = dict(buffers_per_gpu=128, seconds=10.0, sr=44100, win=2048, fft=2048, hop=512, rank=32,
                 iters=200, seed=42)
@@ -52,6 +53,9 @@ def parse():
     ap.add_argument("--rank", type=int, default=WORKLOAD["rank"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget")
+    ap.add_argument("--prof-in-timed-region", action="store_true",
+                    help="bracket every update launch by HIP events inside the timed steps (the round-1/2 behaviour) "
+                         "instead of in one extra step right behind them")
     return ap.parse_args()
 
 
@@ -179,8 +183,19 @@ def main():
         local = local % ndev
     assert local < ndev, f"rank {rank}: LOCAL_RANK {local} but only {ndev} GPUs visible"
     torch.cuda.set_device(local)
-    if world > 1:
+    # FLUHIP_BENCH_BACKEND set explicitly at N = 1: a ONE-rank process group, so that the collective code of the N > 1
+    # job (RCCL all-gather of the device-resident results, MAX all-reduce of the step time) executes on a 1-GPU box
+    # exactly as written -- there is no `world > 1` short cut on that path
+    use_dist = world > 1 or "FLUHIP_BENCH_BACKEND" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -211,13 +226,13 @@ def main():
         corpus.nmf(iters, seed=wl["seed"])
         corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
         ctx.synchronize()
-        if world > 1:  # the one collective of the path: final dictionary/activation gather (RCCL)
+        if use_dist:  # the one collective of the path: final dictionary/activation gather (RCCL)
             src_b, src_a = (bases, acts) if backend == "nccl" else (bases.cpu(), acts.cpu())
             gathered["bases"] = sharding.gather_results(src_b, dist, world)
             gathered["acts"] = sharding.gather_results(src_a, dist, world)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -225,20 +240,36 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    ctx.prof_enable(True)
-    ctx.prof_reset()
+    # The timed steps run as a user's job would: no HIP events between the launches.  The per-kernel durations of the
+    # roofline come from ONE more step of the same loop right behind them, every launch of the dominant kernel classes
+    # bracketed by events on the stream it is launched on (--prof-in-timed-region puts the events back into the timed
+    # steps).  The shader-cycle stamps of the update kernel cost nothing measurable and cover both.
+    if args.prof_in_timed_region:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+    corpus.update_clocks(reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if not args.prof_in_timed_region:
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        t1 = time.perf_counter()
+        step()
+        fence()
+        profiled_step_ms = (time.perf_counter() - t1) * 1e3
+    else:
+        profiled_step_ms = None
     n_upd, ms_upd = ctx.prof_read(1)
     n_stft, ms_stft = ctx.prof_read(0)
     n_mid, ms_mid = ctx.prof_read(3)
     ctx.prof_enable(False)
+    clocks = corpus.update_clocks()
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max = float(tmax.item())
 
@@ -257,8 +288,8 @@ def main():
     # total number of buffers (tests/test_gpu_parity.py compares --gpus 2 against --gpus 1)
     a_host = acts.cpu().numpy()
     finite = bool(np.isfinite(a_host).all())
-    all_b = gathered["bases"] if world > 1 else bases
-    all_a = gathered["acts"] if world > 1 else acts
+    all_b = gathered["bases"] if use_dist else bases
+    all_a = gathered["acts"] if use_dist else acts
     wts = torch.arange(1, all_b.shape[0] + 1, dtype=torch.float64, device=all_b.device)
     checksum = float((wts * (all_b.double().sum(dim=(1, 2)) + all_a.double().sum(dim=(1, 2)))).sum().item())
 
@@ -285,6 +316,13 @@ def main():
                     break
             except (OSError, KeyError, ValueError):
                 pass
+        # shader cycles per launch and the clock the part sustained while it ran them (s_memtime / s_memrealtime stamps of
+        # one wavefront per launch, fluhip_corpus_update_clocks): a kernel change moves cycles_per_launch whatever the box;
+        # frac_at_sustained_clock prices the same achieved rate against the peak at THAT clock instead of 2.4 GHz
+        cyc = [c["cycles_per_launch"] for c in clocks.values() if c["cycles_per_launch"]]
+        mhz = [c["sustained_mhz"] for c in clocks.values() if c["sustained_mhz"]]
+        cycles_per_launch = sum(cyc) / len(cyc) if cyc else None
+        sustained_mhz = sum(mhz) / len(mhz) if mhz else None
         stft_ms = ms_stft / max(n_stft, 1)
         stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
         out = {
@@ -304,6 +342,13 @@ def main():
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_from_profile": traffic_src,
                          "launches": int(n_upd), "avg_launch_ms": avg_ms,
+                         "events": "in the timed steps" if args.prof_in_timed_region else "one extra step right behind the timed ones",
+                         "profiled_step_ms": profiled_step_ms,
+                         "shader_cycles_per_launch": cycles_per_launch, "sustained_mhz": sustained_mhz,
+                         "datasheet_mhz": PEAK_MHZ,
+                         "frac_at_sustained_clock": (ach_tflops / (PEAK_FP64_MFMA_TFLOPS * sustained_mhz / PEAK_MHZ)
+                                                     if sustained_mhz else None),
+                         "clock_stamps": clocks,
                          "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                       "frac": ach_gbs / PEAK_HBM_GBS}},
@@ -319,7 +364,9 @@ def main():
             "device": {"name": name, "arch": arch, "compute_units": cus,
                        "corpus_device_bytes": corpus.device_bytes()},
             "result_finite": finite, "result_checksum": checksum, "total_buffers": world * B,
-            "backend": "single process" if world == 1 else ("rccl" if backend == "nccl" else backend + " (ranks share devices)"),
+            "backend": ("single process" if not use_dist else
+                        ("rccl" if backend == "nccl" else backend + " (ranks share devices)") +
+                        (" (one-rank group: the collectives of the N > 1 job executed on one GPU)" if world == 1 else "")),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(audio[0], wl, args.cpu_seconds, bases[0].cpu().numpy(), a_host[0])
@@ -327,7 +374,7 @@ def main():
             out["cpu_baseline"]["gpu_speedup_per_buffer_job"] = (
                 out["cpu_baseline"]["bufnmf_wall_s_200iter_est"] * (iters / WORKLOAD["iters"]) / gpu_job_s)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     corpus.close()

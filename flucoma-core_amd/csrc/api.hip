@@ -358,6 +358,7 @@ struct fluhip_corpus
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
+  DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's
   // frame-strip schedule of a single large buffer at rank <= 16 (kernels_nmf_strip.hip)
   bool strip = false;
   bool stripReady = false;     // the numerator partials of the next W update are in stripPart
@@ -366,6 +367,8 @@ struct fluhip_corpus
   int stripGen = 0;
   DevBuf stripPart;
   bool haveMag = false, haveFactors = false;
+  // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats
+  std::vector<float> seedW32, seedH32;
   int64_t device_bytes() const
   {
     return (int64_t) (audioOwn.bytes + mag.bytes + magT.bytes + Wf.bytes + H1.bytes + spec.bytes +
@@ -495,6 +498,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
   }
   if (int rc = alloc_update_scratch(ctx, c)) return rc;
+  HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
   if (c->lazy)
   {
     HIPCHK(ctx, c->wnorm.alloc(B * c->Kp * sizeof(double), false, s));
@@ -786,6 +790,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
+    a.clk = c->clk.as<long long>();
     if (c->lazy)
     {
       // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
@@ -828,6 +833,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.R = (int) c->F; a.C = (int) c->T; a.B = B; a.Kp = (int) c->Kp;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
+    a.clk = c->clk.as<long long>() + 4;
     if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
@@ -1085,9 +1091,22 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
   if (iters < 0) return fail(ctx, "negative iteration count");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   FactorInit fi;
+  if (!c->seedW32.empty()) fi.W0f32 = c->seedW32.data(); // nrt/NMFClient.hpp:246-258 -> alg/NMF.hpp:102-112
+  if (!c->seedH32.empty()) fi.H0f32 = c->seedH32.data(); // :113-124
   int rc = corpus_init_factors(c, seed, seeds, fi);
   if (rc) return rc;
   return corpus_iterate(c, iters, update_w != 0, update_h != 0, progress, user);
+}
+
+int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
+{
+  if (!c) return FLUHIP_ERROR;
+  const size_t nw = (size_t) c->B * c->K * c->F, nh = (size_t) c->B * c->K * c->T;
+  if (bases_seed) c->seedW32.assign(bases_seed, bases_seed + nw);
+  else std::vector<float>().swap(c->seedW32);
+  if (acts_seed) c->seedH32.assign(acts_seed, acts_seed + nh);
+  else std::vector<float>().swap(c->seedH32);
+  return FLUHIP_OK;
 }
 
 int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev)
@@ -2229,6 +2248,17 @@ int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
     return FLUHIP_OK;
   }
   HIPCHK(c->ctx, hipMemcpy(out32, c->dpart.p, 32 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset)
+{
+  if (!c || !c->clk.p) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (out8) HIPCHK(ctx, hipMemcpy(out8, c->clk.p, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(ctx, hipMemset(c->clk.p, 0, 8 * sizeof(int64_t)));
   return FLUHIP_OK;
 }
 

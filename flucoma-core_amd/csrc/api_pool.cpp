@@ -94,8 +94,8 @@ struct Worker
 {
   std::atomic<int64_t> done{0};
   std::atomic<bool>* cancel = nullptr;
-  int rc = FLUHIP_OK;
-  std::string err;
+  std::atomic<int> rc{FLUHIP_OK};
+  std::string err; // written before rc is stored (release), read after rc is seen (acquire) or after the join
 };
 int worker_progress(int64_t it, void* u)
 {
@@ -105,15 +105,14 @@ int worker_progress(int64_t it, void* u)
 }
 } // namespace
 
-int fluhip_pool_bufnmf_f32(fluhip_pool* p, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
-                           int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
-                           const int64_t* seeds, float* bases, float* acts, fluhip_progress_fn progress, void* user)
+int fluhip_pool_bufnmf_job_f32(fluhip_pool* p, const fluhip_bufnmf_job* job, fluhip_progress_fn progress, void* user)
 {
   if (!p) return FLUHIP_ERROR;
   p->err.clear();
-  if (!audio || count < 1 || n < 1) { p->err = "null / empty corpus"; return FLUHIP_ERROR; }
+  if (!job || !job->audio || job->count < 1 || job->n < 1) { p->err = "null / empty corpus"; return FLUHIP_ERROR; }
+  const fluhip_bufnmf_job j = *job;
   const int world = (int) p->ctx.size();
-  const int64_t F = fft / 2 + 1, T = fluhip_stft_num_frames(n, win, hop);
+  const int64_t F = j.fft / 2 + 1, T = fluhip_stft_num_frames(j.n, j.win, j.hop);
   std::vector<Worker> ws((size_t) world);
   std::atomic<bool> cancel{false};
   std::vector<std::thread> th;
@@ -121,58 +120,88 @@ int fluhip_pool_bufnmf_f32(fluhip_pool* p, const float* audio, int64_t count, in
   for (int r = 0; r < world; r++)
   {
     int64_t b0, b1;
-    fluhip_shard_range(count, world, r, &b0, &b1);
-    if (b1 <= b0) { ws[(size_t) r].done.store(iters); continue; }
+    fluhip_shard_range(j.count, world, r, &b0, &b1);
+    if (b1 <= b0) { ws[(size_t) r].done.store(j.iters); continue; }
     active.push_back(r);
     ws[(size_t) r].cancel = &cancel;
     th.emplace_back([=, &ws] {
       Worker& w = ws[(size_t) r];
       fluhip_ctx* ctx = p->ctx[(size_t) r];
       // a corpus handle holds at most 65535 buffers: larger shares go in slices
-      for (int64_t s0 = b0; s0 < b1 && w.rc == FLUHIP_OK; s0 += 65535)
+      for (int64_t s0 = b0; s0 < b1 && w.rc.load() == FLUHIP_OK && !w.cancel->load(std::memory_order_acquire); s0 += 65535)
       {
         const int64_t nb = std::min<int64_t>(65535, b1 - s0);
         fluhip_corpus* c = nullptr;
-        int rc = fluhip_corpus_create(ctx, nb, n, win, fft, hop, K, &c);
-        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, audio + s0 * n);
+        int rc = fluhip_corpus_create(ctx, nb, j.n, j.win, j.fft, j.hop, j.K, &c);
+        if (rc == FLUHIP_OK && j.resynth) rc = fluhip_corpus_keep_spectrum(c, 1);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, j.audio + s0 * j.n);
         if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(c);
+        if (rc == FLUHIP_OK && (j.bases_seed || j.acts_seed)) // clients/nrt/NMFClient.hpp:246-258
+          rc = fluhip_corpus_set_factors(c, j.bases_seed ? j.bases_seed + s0 * j.K * F : nullptr,
+                                         j.acts_seed ? j.acts_seed + s0 * j.K * T : nullptr);
         if (rc == FLUHIP_OK)
-          rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? seeds + s0 : nullptr,
+          rc = fluhip_corpus_nmf(c, j.iters, j.update_w, j.update_h, j.seed, j.seeds ? j.seeds + s0 : nullptr,
                                  progress ? worker_progress : nullptr, progress ? &w : nullptr);
         if (rc == FLUHIP_OK)
-          rc = fluhip_corpus_writeback_host(c, bases ? bases + s0 * K * F : nullptr, acts ? acts + s0 * K * T : nullptr);
-        if (rc != FLUHIP_OK) { w.rc = rc; w.err = fluhip_last_error(ctx); }
+          rc = fluhip_corpus_writeback_host(c, j.bases ? j.bases + s0 * j.K * F : nullptr, j.acts ? j.acts + s0 * j.K * T : nullptr);
+        if (rc == FLUHIP_OK && j.resynth) rc = fluhip_corpus_resynth_host(c, j.resynth + s0 * j.K * j.n); // :302-334
+        if (rc != FLUHIP_OK)
+        {
+          w.err = fluhip_last_error(ctx);
+          w.rc.store(rc, std::memory_order_release);
+          if (rc != FLUHIP_CANCELLED) w.cancel->store(true, std::memory_order_release); // a failed share stops the others
+        }
         if (c) fluhip_corpus_destroy(c);
       }
-      w.done.store(iters, std::memory_order_release);
+      if (w.rc.load() == FLUHIP_OK) w.done.store(j.iters, std::memory_order_release);
     });
   }
-  // progress of the whole job = the slowest device; reported in order from the calling thread (alg/NMF.hpp:175-176)
+  // progress of the whole job = the slowest device; reported in order from the calling thread (alg/NMF.hpp:175-176).  A share
+  // that failed reports nothing further: the job ends with its error instead of counting up to `iters`.
   int64_t reported = 0;
   if (progress)
   {
     bool running = true;
     while (running)
     {
-      int64_t m = iters;
-      for (int r : active) m = std::min(m, ws[(size_t) r].done.load(std::memory_order_acquire));
-      for (; reported < m; reported++)
+      int64_t m = j.iters;
+      bool failed = false;
+      for (int r : active)
+      {
+        m = std::min(m, ws[(size_t) r].done.load(std::memory_order_acquire));
+        failed = failed || ws[(size_t) r].rc.load(std::memory_order_acquire) != FLUHIP_OK;
+      }
+      for (; reported < m && !failed; reported++)
         if (!cancel.load() && !progress(reported + 1, user)) cancel.store(true, std::memory_order_release);
-      running = reported < iters && !cancel.load();
+      running = reported < j.iters && !cancel.load() && !failed;
       if (running) std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
   }
   for (auto& t : th) t.join();
   int rc = FLUHIP_OK;
   for (int r : active)
-    if (ws[(size_t) r].rc != FLUHIP_OK && rc != FLUHIP_ERROR)
+  {
+    const int wrc = ws[(size_t) r].rc.load();
+    if (wrc != FLUHIP_OK && rc != FLUHIP_ERROR)
     {
-      rc = ws[(size_t) r].rc;
+      rc = wrc;
       if (rc == FLUHIP_ERROR) p->err = "device " + std::to_string(p->device[(size_t) r]) + ": " + ws[(size_t) r].err;
     }
+  }
   if (rc == FLUHIP_OK && cancel.load()) rc = FLUHIP_CANCELLED;
   if (rc == FLUHIP_CANCELLED && p->err.empty()) p->err = "cancelled";
   return rc;
+}
+
+int fluhip_pool_bufnmf_f32(fluhip_pool* p, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                           int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                           const int64_t* seeds, float* bases, float* acts, fluhip_progress_fn progress, void* user)
+{
+  fluhip_bufnmf_job j{};
+  j.count = count; j.n = n; j.win = win; j.fft = fft; j.hop = hop; j.K = K; j.iters = iters;
+  j.update_w = update_w; j.update_h = update_h; j.seed = seed; j.seeds = seeds;
+  j.audio = audio; j.bases = bases; j.acts = acts;
+  return fluhip_pool_bufnmf_job_f32(p, &j, progress, user);
 }
 
 // Ragged corpus: buffers of different lengths.  Dealt by the greedy longest-processing-time rule over cost = frames (the
@@ -197,7 +226,8 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
 
   std::atomic<int64_t> buffersDone{0};
   std::atomic<bool> cancel{false};
-  std::vector<int> rcs((size_t) world, FLUHIP_OK);
+  std::vector<std::atomic<int>> rcs((size_t) world); // polled by the calling thread while the workers run
+  for (auto& x : rcs) x.store(FLUHIP_OK);
   std::vector<std::string> errs((size_t) world);
   std::vector<std::thread> th;
   for (int r = 0; r < world; r++)
@@ -212,7 +242,7 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
       fluhip_ctx* ctx = p->ctx[(size_t) r];
       std::vector<float> packed, gb, ga;
       std::vector<int64_t> gseeds;
-      for (size_t i0 = 0; i0 < mine.size() && rcs[(size_t) r] == FLUHIP_OK && !cancel.load(std::memory_order_acquire);)
+      for (size_t i0 = 0; i0 < mine.size() && rcs[(size_t) r].load() == FLUHIP_OK && !cancel.load(std::memory_order_acquire);)
       {
         size_t i1 = i0;
         while (i1 < mine.size() && n[mine[i1]] == n[mine[i0]] && i1 - i0 < 65535) i1++;
@@ -255,7 +285,7 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
               if (acts && acts[g]) std::copy(ga.begin() + (size_t) (j * K * T), ga.begin() + (size_t) ((j + 1) * K * T), acts[g]);
             }
         }
-        if (rc != FLUHIP_OK) { rcs[(size_t) r] = rc; errs[(size_t) r] = fluhip_last_error(ctx); }
+        if (rc != FLUHIP_OK) { errs[(size_t) r] = fluhip_last_error(ctx); rcs[(size_t) r].store(rc, std::memory_order_release); }
         if (c) fluhip_corpus_destroy(c);
         buffersDone.fetch_add(nb, std::memory_order_release);
         i0 = i1;
@@ -275,7 +305,7 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
         if (!progress(reported + 1, user)) { cancel.store(true, std::memory_order_release); stop = true; }
       if (stop || reported >= count) break;
       bool failed = false;
-      for (int r = 0; r < world; r++) failed = failed || rcs[(size_t) r] != FLUHIP_OK;
+      for (int r = 0; r < world; r++) failed = failed || rcs[(size_t) r].load(std::memory_order_acquire) != FLUHIP_OK;
       if (failed) break;
       std::this_thread::sleep_for(std::chrono::microseconds(200));
     }
@@ -283,9 +313,9 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
   for (auto& t : th) t.join();
   int rc = FLUHIP_OK;
   for (int r = 0; r < world; r++)
-    if (rcs[(size_t) r] != FLUHIP_OK && rc == FLUHIP_OK)
+    if (rcs[(size_t) r].load() != FLUHIP_OK && rc == FLUHIP_OK)
     {
-      rc = rcs[(size_t) r];
+      rc = rcs[(size_t) r].load();
       p->err = "device " + std::to_string(p->device[(size_t) r]) + ": " + errs[(size_t) r];
     }
   if (rc == FLUHIP_OK && cancel.load()) { rc = FLUHIP_CANCELLED; p->err = "cancelled"; }

@@ -86,6 +86,8 @@ struct UpdateArgs
   // rank 65..128: workspace of colsum_scratch_doubles() for the column sums of Mv (see launch_colsum); also
   // needs dpart of at least B * nsplit * Kp doubles
   double* colsumScratch = nullptr;
+  // kernels_nmf5.hip: {launches, shader cycles, 100 MHz ticks} of one wavefront per launch, accumulated (or null)
+  long long* clk = nullptr;
 };
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine

@@ -52,6 +52,7 @@ struct Upd5Args
   const double* nrm;
   int nrmMode;
   double* statPart;
+  long long* clk; // {launches, shader cycles, 100 MHz ticks} of wavefront 0 of workgroup 0, accumulated per launch (or null)
 };
 
 // The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
@@ -145,6 +146,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   if (buf >= a.B) return;
   long long tEntry = 0;
   if constexpr (INSTR) tEntry = (long long) __builtin_amdgcn_s_memrealtime();
+  // box-invariant cost of a launch: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of one wavefront that
+  // lives as long as the launch does (one wavefront per SIMD, one round); their ratio is the clock the part sustained
+  long long clkC0 = 0, clkR0 = 0;
+  const bool stamp = a.clk != nullptr && blockIdx.x == 0;
+  if (stamp)
+  {
+    clkC0 = (long long) __builtin_readcyclecounter();
+    clkR0 = (long long) __builtin_amdgcn_s_memrealtime();
+  }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int WPB = 4 * WPS; // wavefronts per workgroup
@@ -928,6 +938,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       for (int m = 0; m < M; m++) dp[m] = dsum[m];
     }
   }
+  if (stamp && threadIdx.x == 0)
+  {
+    __builtin_amdgcn_s_waitcnt(0); // the results have left
+    const long long c1 = (long long) __builtin_readcyclecounter(), r1 = (long long) __builtin_amdgcn_s_memrealtime();
+    a.clk[0] += 1;
+    a.clk[1] += c1 - clkC0;
+    a.clk[2] += r1 - clkR0;
+  }
   if constexpr (INSTR)
   {
     __builtin_amdgcn_s_waitcnt(0);
@@ -955,6 +973,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   // split contraction: the stationary rows are normalised on load all the same; the rest of the deferred form
   // (epilogue arithmetic, statistics) is the finalize kernel's
   k.nrm = a.nrm; k.nrmMode = a.nrmMode; k.statPart = a.nsplit > 1 ? nullptr : a.statPart;
+  k.clk = a.clk;
   k.xcdMap = a.B >= 8 ? 1 : 0;
   const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);

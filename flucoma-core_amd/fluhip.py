@@ -37,6 +37,13 @@ class MatrixView(ctypes.Structure):
         return cls(ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_double)), a.shape[0], a.shape[1],
                    a.strides[0] // 8, a.strides[1] // 8)
 
+class BufNMFJob(ctypes.Structure):
+    """fluhip_bufnmf_job"""
+    _fields_ = [("count", _i64), ("n", _i64), ("win", _i64), ("fft", _i64), ("hop", _i64), ("K", _i64), ("iters", _i64),
+                ("update_w", ctypes.c_int), ("update_h", ctypes.c_int), ("seed", _i64), ("seeds", _ip),
+                ("audio", _fp), ("bases_seed", _fp), ("acts_seed", _fp), ("bases", _fp), ("acts", _fp), ("resynth", _fp)]
+
+
 EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize", "fluhip_ctx_trim",
@@ -47,12 +54,12 @@ EXPORTS = [
     "fluhip_corpus_create",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
-    "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_writeback_dev",
+    "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
     "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
     "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
-    "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words",
+    "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
-    "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
+    "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
 ]
 
 
@@ -116,6 +123,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_set_audio_dev.argtypes = [_vp, _vp]
     L.fluhip_corpus_stft.argtypes = [_vp]
     L.fluhip_corpus_nmf.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_int, _i64, _ip, PROGRESS_FN, _vp]
+    L.fluhip_corpus_set_factors.argtypes = [_vp, _fp, _fp]
     L.fluhip_corpus_writeback_dev.argtypes = [_vp, _vp, _vp]
     L.fluhip_corpus_writeback_host.argtypes = [_vp, _fp, _fp]
     L.fluhip_corpus_read_f64.argtypes = [_vp, _dp, _dp, _dp]
@@ -127,6 +135,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
     L.fluhip_corpus_debug_words.argtypes = [_vp, _ip]
+    L.fluhip_corpus_update_clocks.argtypes = [_vp, _ip, ctypes.c_int]
     L.fluhip_pool_create.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(_vp)]
     L.fluhip_pool_destroy.argtypes = [_vp]
     L.fluhip_pool_destroy.restype = None
@@ -136,6 +145,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_pool_last_error.restype = ctypes.c_char_p
     L.fluhip_pool_bufnmf_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int,
                                          _i64, _ip, _fp, _fp, PROGRESS_FN, _vp]
+    L.fluhip_pool_bufnmf_job_f32.argtypes = [_vp, ctypes.POINTER(BufNMFJob), PROGRESS_FN, _vp]
     L.fluhip_pool_bufnmf_ragged_f32.argtypes = [_vp, ctypes.POINTER(_fp), _ip, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int,
                                                 ctypes.c_int, _i64, _ip, ctypes.POINTER(_fp), ctypes.POINTER(_fp), PROGRESS_FN, _vp]
     L.fluhip_shard_range.argtypes = [_i64, ctypes.c_int, ctypes.c_int, _ip, _ip]
@@ -425,6 +435,14 @@ class Corpus:
         rc = self.ctx.lib.fluhip_corpus_nmf(self.h, iters, int(updateW), int(updateH), seed, sp, cb, None)
         return self.ctx._check(rc, allow=(OK, CANCELLED))
 
+    def set_factors(self, bases_seed=None, acts_seed=None):
+        """Seed / Fixed factors for the following nmf() calls: [count, K, F] / [count, K, T] floats, or None for random draws"""
+        bs = None if bases_seed is None else np.ascontiguousarray(bases_seed, dtype=np.float32)
+        hs = None if acts_seed is None else np.ascontiguousarray(acts_seed, dtype=np.float32)
+        assert bs is None or bs.shape == (self.count, self.K, self.F)
+        assert hs is None or hs.shape == (self.count, self.K, self.T)
+        self.ctx._check(self.ctx.lib.fluhip_corpus_set_factors(self.h, _f(bs), _f(hs)))
+
     def writeback_dev(self, bases_ptr: int | None, acts_ptr: int | None):
         self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_dev(
             self.h, _vp(bases_ptr) if bases_ptr else None, _vp(acts_ptr) if acts_ptr else None))
@@ -449,6 +467,19 @@ class Corpus:
         self.ctx._check(self.ctx.lib.fluhip_corpus_plan(self.h, out))
         keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank", "strip")
         return dict(zip(keys, [int(v) for v in out]))
+
+    def update_clocks(self, reset=False):
+        """per factor update: launches, shader cycles and 100 MHz ticks of one wavefront per launch, summed since the last reset;
+        derived: cycles per launch and the clock the part sustained (fluhip_corpus_update_clocks)"""
+        out = (ctypes.c_int64 * 8)()
+        self.ctx._check(self.ctx.lib.fluhip_corpus_update_clocks(self.h, out, int(reset)))
+        res = {}
+        for name, o in (("w", 0), ("h", 4)):
+            n, cyc, ticks = int(out[o]), int(out[o + 1]), int(out[o + 2])
+            res[name] = {"launches": n, "shader_cycles": cyc, "ticks_100mhz": ticks,
+                         "cycles_per_launch": cyc / n if n else None,
+                         "sustained_mhz": 100.0 * cyc / ticks if ticks else None}
+        return res
 
     def read_f64(self, mag=True, factors=True):
         m = np.empty((self.count, self.T, self.F)) if mag else None
@@ -504,6 +535,26 @@ class Pool:
         if rc not in (OK, CANCELLED):
             raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
         return bases, acts, rc
+
+    def bufnmf_job(self, audio, win, fft, hop, K, iters, seed=42, updateW=True, updateH=True, seeds=None, bases_seed=None,
+                   acts_seed=None, resynth=False, progress=None):
+        """fluhip_pool_bufnmf_job_f32: the batched form with Seed / Fixed factors and the resynthesis output"""
+        audio = np.ascontiguousarray(audio, dtype=np.float32)
+        count, n = audio.shape
+        F, T = fft // 2 + 1, int(self.lib.fluhip_stft_num_frames(n, win, hop))
+        bases = np.empty((count, K, F), dtype=np.float32)
+        acts = np.empty((count, K, T), dtype=np.float32)
+        res = np.empty((count, K, n), dtype=np.float32) if resynth else None
+        sarr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)
+        bs = None if bases_seed is None else np.ascontiguousarray(bases_seed, dtype=np.float32)
+        hs = None if acts_seed is None else np.ascontiguousarray(acts_seed, dtype=np.float32)
+        job = BufNMFJob(count, n, win, fft, hop, K, iters, int(updateW), int(updateH), seed,
+                        sarr.ctypes.data_as(_ip) if sarr is not None else None, _f(audio), _f(bs), _f(hs), _f(bases), _f(acts),
+                        _f(res))
+        rc = self.lib.fluhip_pool_bufnmf_job_f32(self.h, ctypes.byref(job), _cb(progress), None)
+        if rc not in (OK, CANCELLED):
+            raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
+        return bases, acts, res, rc
 
     def bufnmf_ragged(self, audios, win, fft, hop, K, iters, seed=42, updateW=True, updateH=True, seeds=None, progress=None):
         """buffers of different lengths: lists of per-buffer bases [K,F] and activations [K,T_i]"""

@@ -35,8 +35,10 @@ def gather_results(local, dist_module, world: int):
     dictionaries / activations in global buffer order (rank-major == contiguous-block order).
     `local` is [B_local, ...]; returns [world * B_local, ...]."""
     import torch
-    if world == 1:
+    if world == 1 and not (dist_module is not None and dist_module.is_initialized()):
         return local
+    # with an initialised process group the collective runs for ANY world size, also a one-rank group: bench.py with
+    # FLUHIP_BENCH_BACKEND set and the 1-GPU RCCL test execute exactly what the N > 1 job executes
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist_module.all_gather_into_tensor(out, local.contiguous())
     return out

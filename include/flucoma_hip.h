@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLUHIP_ABI_VERSION 2
+#define FLUHIP_ABI_VERSION 3
 
 /* clients/common/Result.hpp:24  enum class Status { kOk, kWarning, kError, kCancelled } */
 enum fluhip_status
@@ -231,6 +231,13 @@ int fluhip_corpus_stft(fluhip_corpus* c);
  * given (progress is then reported per iteration across the whole batch). */
 int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
                       const int64_t* seeds, fluhip_progress_fn progress, void* user);
+/* Seed / Fixed factors of the batched form: basesMode / actMode of clients/nrt/NMFClient.hpp:246-258 as they reach
+ * NMF::process (alg/NMF.hpp:102-124: a given W0 / H0 replaces the random draw; clamping and normalisation :150-153 run
+ * either way).  bases_seed: count x K x F floats or NULL; acts_seed: count x K x T floats or NULL -- channel-major per
+ * buffer like BufferAdaptor::samps(component), the layout of fluhip_bufnmf_channel_f32's seeds.  The arrays are copied;
+ * they apply to every later fluhip_corpus_nmf of this corpus until replaced (NULL: back to random draws from the seed).
+ * Seed mode = seeds + update flag 1, Fixed mode = seeds + update flag 0 (fluhip_corpus_nmf's update_w / update_h). */
+int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed);
 /* write-back (clients/nrt/NMFClient.hpp:277-300) into device or host float arrays:
  * bases: count x K x F, acts: count x K x T.  Either may be NULL. */
 int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev);
@@ -272,6 +279,24 @@ const char* fluhip_pool_last_error(const fluhip_pool* pool);
 int fluhip_pool_bufnmf_f32(fluhip_pool* pool, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
                            int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                            const int64_t* seeds, float* bases, float* acts, fluhip_progress_fn progress, void* user);
+/* The whole BufNMF parameter set of the batched form in one description: Seed / Fixed factors (basesMode / actMode,
+ * clients/nrt/NMFClient.hpp:63-67, 246-258) and the resynthesis output (resynthMode 1, :302-334) on top of what
+ * fluhip_pool_bufnmf_f32 takes.  Zero-initialise, then fill in what the job uses. */
+typedef struct fluhip_bufnmf_job
+{
+  int64_t count, n;                  /* equal-length mono buffers, samples each */
+  int64_t win, fft, hop, K, iters;
+  int     update_w, update_h;        /* 0 together with the matching seed array = Fixed mode */
+  int64_t seed;                      /* randomSeed for every buffer ... */
+  const int64_t* seeds;              /* ... or `count` seeds (NULL: `seed`) */
+  const float* audio;                /* count x n */
+  const float* bases_seed;           /* count x K x F or NULL */
+  const float* acts_seed;            /* count x K x T or NULL */
+  float* bases;                      /* count x K x F or NULL */
+  float* acts;                       /* count x K x T or NULL */
+  float* resynth;                    /* count x K x n or NULL */
+} fluhip_bufnmf_job;
+int fluhip_pool_bufnmf_job_f32(fluhip_pool* pool, const fluhip_bufnmf_job* job, fluhip_progress_fn progress, void* user);
 /* The same over buffers of DIFFERENT lengths (a folder of sound files): audio[i] = n[i] host floats; bases[i] receives
  * K x F, acts[i] K x T_i floats with T_i = fluhip_stft_num_frames(n[i], win, hop) (either array, or single entries, may be
  * NULL).  Buffers are dealt by fluhip_balanced_assignment over their frame counts; on its device every run of
@@ -297,6 +322,12 @@ int  fluhip_balanced_assignment(const double* costs, int64_t n, int world, int32
 int fluhip_prof_enable(fluhip_ctx* ctx, int on);
 int fluhip_prof_reset(fluhip_ctx* ctx);
 int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms);
+/* Box-invariant cost of the factor-update launches of a corpus (kernels_nmf5.hip): one wavefront per launch -- it lives as
+ * long as the launch does -- adds its shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) to a device record.
+ * out8 = { W update: launches, shader cycles, 100 MHz ticks, 0;  H update: the same four }.  cycles / launches is what a
+ * kernel change moves whatever clock the box sustains; cycles / ticks * 100 MHz is that sustained clock.  Zero counts when
+ * the corpus runs a schedule without the stamps (frame-strip schedule, A/B kernel forms).  reset != 0 clears the record. */
+int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset);
 /* Kernel-developer diagnostic: with FLUHIP_K5_INSTR=1 in the environment the factor-update kernel of the
  * c4-shaped schedules runs an instrumented build that leaves cycle counters and a timeline of one wavefront in the
  * corpus' scratch; this copies the first 32 words out (tools/phase_breakdown.py decodes them).  Without the

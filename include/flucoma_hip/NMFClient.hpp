@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -284,10 +285,124 @@ public:
         {
           BufferAdaptor::Access resynth(P.resynth.get());
           for (index j = 0; j < rank; ++j)
+          {
             resynth.samps(i * rank + j) <<= VectorView<const float>(outRC[ci].data() + j * nFrames, nFrames);
+            // the 3 steps per component of :321-332 are part of `total`: reported here, so that progress reaches 1
+            for (int step = 0; step < 3; ++step)
+            {
+              shared.count += 1;
+              if (c.task() && !c.task()->processUpdate(shared.count, shared.total)) return {S::kCancelled, ""};
+            }
+          }
         }
       }
       return {S::kOk, ""};
+    }
+
+    // ---- one device, several channels: ONE corpus on the batched kernels ----------------------------------------------
+    // The channels of a buffer are equal-shape independent jobs by construction (:233; a fresh algorithm::NMF per
+    // channel, :260), i.e. exactly what the corpus entry points batch: one STFT launch, every factor-update launch over
+    // all channels, Seed / Fixed factors through fluhip_corpus_set_factors.  Same floats per channel as the sequential
+    // loop below up to the summation order of the schedule the batch gets.  Progress: an iteration of the batch is one
+    // iteration of every channel, so it counts nChannels of the progressTotal * nChannels steps (the arithmetic of
+    // :261-267 summed over the channel loop).  FLUHIP_CLIENT_SEQUENTIAL=1 keeps the channel-by-channel loop (A/B, tests);
+    // a corpus that does not fit the device falls back to it as well.
+    if (nChannels > 1 && !sequentialForced())
+    {
+      const size_t nc = static_cast<size_t>(nChannels);
+      std::vector<float> audioAll(nc * static_cast<size_t>(nFrames));
+      std::vector<float> seedWAll, seedHAll;
+      if (seedFilters) seedWAll.resize(nc * static_cast<size_t>(rank * nBins));
+      if (seedEnvelopes) seedHAll.resize(nc * static_cast<size_t>(rank * nWindows));
+      for (index i = 0; i < nChannels; ++i)
+      {
+        VectorView<float>(audioAll.data() + i * nFrames, nFrames) <<= source.samps(P.startFrame, nFrames, P.startChan + i);
+        for (index j = 0; j < rank; ++j)
+        {
+          if (seedFilters)
+            VectorView<float>(seedWAll.data() + (i * rank + j) * nBins, nBins) <<=
+                VectorView<const float>(BufferAdaptor::Access(P.bases.get()).samps(i * rank + j));
+          if (seedEnvelopes)
+            VectorView<float>(seedHAll.data() + (i * rank + j) * nWindows, nWindows) <<=
+                VectorView<const float>(BufferAdaptor::Access(P.activations.get()).samps(i * rank + j));
+        }
+      }
+      fluhip_corpus* cor = nullptr;
+      if (fluhip_corpus_create(mCtx, nChannels, nFrames, fftParams.winSize(), fftParams.fftSize(), hop, rank, &cor) == FLUHIP_OK)
+      {
+        struct Guard
+        {
+          fluhip_corpus* c;
+          ~Guard() { fluhip_corpus_destroy(c); }
+        } guard{cor};
+        if (c.task() && !c.task()->iterationUpdate(0.0, 1.0)) return {S::kCancelled, ""};
+        const bool wantResynth = shouldResynth && hasResynth;
+        int        rc = FLUHIP_OK;
+        if (wantResynth) rc = fluhip_corpus_keep_spectrum(cor, 1);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(cor, audioAll.data());
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(cor);                                            // :240-242, all channels
+        if (rc == FLUHIP_OK)
+          rc = fluhip_corpus_set_factors(cor, seedFilters ? seedWAll.data() : nullptr, seedEnvelopes ? seedHAll.data() : nullptr);
+        struct BatchProg
+        {
+          FluidContext* c;
+          double        count, total, perIteration;
+        } prog{&c, 0.0, progressTotal * static_cast<double>(nChannels), static_cast<double>(nChannels)};
+        auto cb = [](int64_t, void* u) -> int {
+          auto* p = static_cast<BatchProg*>(u);
+          p->count += p->perIteration;
+          return p->c->task() ? (p->c->task()->processUpdate(p->count, p->total) ? 1 : 0) : 1;
+        };
+        // a negative seed means a fresh std::random_device draw per NMF object (:260, util/EigenRandom.hpp:87): one per channel
+        std::vector<int64_t> perChannelSeeds;
+        if (P.seed < 0) perChannelSeeds.assign(nc, -1);
+        if (rc == FLUHIP_OK)
+          rc = fluhip_corpus_nmf(cor, needsAnalysis ? P.iterations : 0, !fixFilters, !fixEnvelopes, P.seed,
+                                 perChannelSeeds.empty() ? nullptr : perChannelSeeds.data(), cb, &prog);      // :268-271
+        if (rc == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""};        // :273-274
+        std::vector<float> outWAll, outHAll, outRAll;
+        if (hasFilters && !fixFilters) outWAll.resize(nc * static_cast<size_t>(rank * nBins));
+        if (hasEnvelopes && !fixEnvelopes) outHAll.resize(nc * static_cast<size_t>(rank * nWindows));
+        if (rc == FLUHIP_OK)
+          rc = fluhip_corpus_writeback_host(cor, outWAll.empty() ? nullptr : outWAll.data(),
+                                            outHAll.empty() ? nullptr : outHAll.data());                    // :277-300
+        if (rc == FLUHIP_OK && wantResynth)
+        {
+          outRAll.resize(nc * static_cast<size_t>(rank * nFrames));
+          rc = fluhip_corpus_resynth_host(cor, outRAll.data());                                              // :302-334
+        }
+        if (rc != FLUHIP_OK) return {S::kError, "BufNMF: ", fluhip_last_error(mCtx)};
+        for (index i = 0; i < nChannels; ++i) // buffer writes in channel order, as the reference's loop leaves them
+        {
+          if (!outWAll.empty())
+          {
+            BufferAdaptor::Access filters(P.bases.get());
+            for (index j = 0; j < rank; ++j)
+              filters.samps(i * rank + j) <<= VectorView<const float>(outWAll.data() + (i * rank + j) * nBins, nBins);
+          }
+          if (!outHAll.empty())
+          {
+            BufferAdaptor::Access envelopes(P.activations.get());
+            for (index j = 0; j < rank; ++j)
+              envelopes.samps(i * rank + j) <<= VectorView<const float>(outHAll.data() + (i * rank + j) * nWindows, nWindows);
+          }
+          if (wantResynth)
+          {
+            BufferAdaptor::Access resynth(P.resynth.get());
+            for (index j = 0; j < rank; ++j)
+            {
+              resynth.samps(i * rank + j) <<= VectorView<const float>(outRAll.data() + (i * rank + j) * nFrames, nFrames);
+              for (int step = 0; step < 3; ++step)
+              {
+                prog.count += 1;
+                if (c.task() && !c.task()->processUpdate(prog.count, prog.total)) return {S::kCancelled, ""};
+              }
+            }
+          }
+        }
+        return {S::kOk, ""};
+      }
+      // the corpus could not be created (device memory): the channel-by-channel loop below needs one channel at a time
     }
 
     for (index i = 0; i < nChannels; ++i)
@@ -347,6 +462,11 @@ public:
   }
 
 private:
+  static bool sequentialForced()
+  {
+    const char* e = std::getenv("FLUHIP_CLIENT_SEQUENTIAL");
+    return e && std::atoi(e) != 0;
+  }
   NMFParams*  mParams;
   fluhip_ctx* mCtx{nullptr};
   int         mDevice{-1};

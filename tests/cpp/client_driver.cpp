@@ -241,10 +241,20 @@ int main(int argc, char** argv)
     Result r;
     if (!async)
     {
+      // CLIENT_REPEAT=n: the same job n times on one client (the first pays for the context and the code objects);
+      // elapsed_ms is the last one's wall time around process()
+      const int repeat = std::getenv("CLIENT_REPEAT") ? std::max(1, std::atoi(std::getenv("CLIENT_REPEAT"))) : 1;
       NRTThreadedNMFClient adaptor(p, hostCtx);
       adaptor.setSynchronous(true);
-      adaptor.enqueue(p);
-      r = adaptor.process();
+      double ms = 0;
+      for (int rep = 0; rep < repeat; ++rep)
+      {
+        adaptor.enqueue(p);
+        const auto t0 = std::chrono::steady_clock::now();
+        r = adaptor.process();
+        ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      }
+      std::printf("elapsed_ms|1|%.3f\n", ms);
     }
     else
     {

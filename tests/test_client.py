@@ -168,6 +168,54 @@ def test_client_channels_over_two_device_contexts(driver, tmp_path, use_async, c
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("bases_mode,act_mode", [(0, 0), (1, 0), (2, 1)])
+def test_client_eight_channels_run_as_one_corpus(driver, oracle, onp, tmp_path, ctx, bases_mode, act_mode):
+    """the channel loop of nrt/NMFClient.hpp:233 on the batched kernels.  An 8-channel x 10 s rank-32
+    job through NRTThreadedNMFClient: random start, seeded bases, fixed bases + seeded activations -- channels against the
+    per-channel oracle, the whole result against the channel-by-channel loop (FLUHIP_CLIENT_SEQUENTIAL=1), and the wall
+    time of the batched job at most a quarter of the sequential one's."""
+    frames, chans = 441000, 8
+    win, hop, fft, K, iters, seed = 2048, 512, 2048, 32, 200, 42
+    F, T = fft // 2 + 1, frames // hop + 1
+    audio = np.stack([onp.synth_audio(frames, 800 + c) for c in range(chans)], axis=1)   # frames x chans
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    extra = []
+    rs = np.random.RandomState(3)
+    seedW = rs.uniform(0.05, 1, (chans * K, F)).astype(np.float32)
+    seedH = rs.uniform(0.05, 1, (chans * K, T)).astype(np.float32)
+    if bases_mode or act_mode:
+        seedW.tofile(tmp_path / "sw.f32"); seedH.tofile(tmp_path / "sh.f32")
+        extra = [tmp_path / "sw.f32", tmp_path / "sh.f32"]
+    outs, ms = {}, {}
+    for tag, env in (("batched", {"CLIENT_REPEAT": "2"}), ("sequential", {"CLIENT_REPEAT": "2", "FLUHIP_CLIENT_SEQUENTIAL": "1"})):
+        prefix = str(tmp_path / tag)
+        r = run(driver, "run", inp, frames, chans, win, hop, fft, K, iters, seed, bases_mode, act_mode, 0, 0, -1, 0, -1, prefix,
+                *extra, env=env)
+        assert r["result"] == (OK, "")
+        outs[tag] = [read_buffer(prefix + s)[0] for s in ("_bases.bin", "_acts.bin")]
+        ms[tag] = float(r["elapsed_ms"][1])
+    for a, b in zip(outs["batched"], outs["sequential"]):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-6           # schedules differ (summation order), floats agree
+    bases, acts = outs["batched"]
+    assert bases.shape == (K * chans, F) and acts.shape == (K * chans, T)
+    for c in (0, 5, 7):
+        x = np.ascontiguousarray(audio[:, c])
+        _, mag = oracle.stft_f32(x, win, fft, hop)
+        W0 = seedW[c * K:(c + 1) * K].astype(np.float64) if bases_mode else None
+        H0 = np.ascontiguousarray(seedH[c * K:(c + 1) * K].T.astype(np.float64)) if act_mode else None
+        rW, rH, _, _ = oracle.nmf_process(mag, K, iters, bases_mode != 2, act_mode != 2, seed, W0=W0, H0=H0)
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        if bases_mode != 2:
+            assert rel_err(bases[c * K:(c + 1) * K], rb) < 1e-6, c
+        else:
+            assert np.array_equal(bases[c * K:(c + 1) * K], seedW[c * K:(c + 1) * K])   # fixed bases are not written back
+        assert rel_err(acts[c * K:(c + 1) * K], ra) < 1e-6, c
+    print(f"8-channel job: batched {ms['batched']:.1f} ms, channel by channel {ms['sequential']:.1f} ms")
+    assert ms["batched"] <= 0.25 * ms["sequential"], ms
+
+
+@pytest.mark.gpu
 def test_pool_from_a_cpp_host(driver, ctx):
     """fluhip_pool_bufnmf_f32 called from C++ (tests/cpp/client_driver.cpp): 7 buffers over two contexts on device 0 give
     the floats of the one-context run (the schedules differ by the number of buffers per launch: rounding only)"""

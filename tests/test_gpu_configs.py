@@ -176,6 +176,34 @@ def test_pool_two_contexts_shard_a_corpus(ctx, oracle, onp):
     pool.close(); one.close()
 
 
+def test_pool_job_with_seeds_fixed_bases_and_resynthesis(ctx, oracle, onp):
+    """fluhip_pool_bufnmf_job_f32: the batched form with everything the BufNMF parameter set has -- Seed / Fixed factors
+    (basesMode / actMode) and the resynthesis output -- over two contexts on device 0 (shares 3 + 2): fixed bases with
+    seeded activations against the oracle per buffer, resynthesis against the single-channel entry point"""
+    import fluhip
+    n, win, fft, hop, K, iters = 20000, 1024, 1024, 256, 4, 10
+    B = 5
+    audio = np.stack([onp.synth_audio(n, 3300 + b) for b in range(B)])
+    F, T = fft // 2 + 1, (n + hop) // hop
+    rs = np.random.RandomState(5)
+    sW = rs.uniform(0.05, 1.0, (B, K, F)).astype(np.float32)
+    sH = rs.uniform(0.05, 1.0, (B, K, T)).astype(np.float32)
+    pool = fluhip.Pool([0, 0], ctx.lib)
+    bases, acts, res, rc = pool.bufnmf_job(audio, win, fft, hop, K, iters, seed=42, updateW=False, bases_seed=sW, acts_seed=sH,
+                                           resynth=True)
+    assert rc == 0
+    for b in range(B):
+        _, mag = oracle.stft_f32(audio[b], win, fft, hop)
+        rW, rH, _, _ = oracle.nmf_process(mag, K, iters, False, True, 42, W0=sW[b].astype(np.float64),
+                                          H0=np.ascontiguousarray(sH[b].T.astype(np.float64)))
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6, b
+        _, _, r1, _ = ctx.bufnmf_channel(audio[b], win, fft, hop, K, iters, 42, updateW=False, bases_seed=sW[b],
+                                         acts_seed=sH[b], resynth=True)
+        assert rel_err(res[b], r1) < 1e-6
+    pool.close()
+
+
 def test_pool_ragged_corpus(ctx, oracle, onp):
     """fluhip_pool_bufnmf_ragged_f32: buffers of different lengths (a folder of sound files) over two contexts on device 0 --
     dealt by frame count, runs of equal length as one corpus (the batched kernels), the rest one by one (the single-buffer
@@ -231,6 +259,78 @@ def test_bench_two_ranks_as_a_bare_command():
     # buffers per launch), which moves f64 sums by rounding only
     assert two["result_checksum"] == pytest.approx(one["result_checksum"], rel=1e-6)
     assert two["value"] > 0 and two["steps"] == 2
+
+
+def test_bench_one_rank_rccl_group_executes_the_collectives():
+    """RCCL on the box that is there: FLUHIP_BENCH_BACKEND=nccl at N = 1 builds a ONE-rank `nccl`
+    process group and runs the N > 1 job's collective code as written -- all_gather_into_tensor of the device-resident
+    dictionaries / activations inside every step, the MAX all-reduce of the step time on a device tensor, the barriers --
+    with no `world > 1` short cut.  Same floats as the plain single-process run."""
+    common = ["--gpus", "1", "--buffers", "4", "--steps", "2", "--warmup", "1", "--iters", "3", "--no-cpu-baseline"]
+    grp = _bench(common, env={"FLUHIP_BENCH_BACKEND": "nccl"})
+    one = _bench(common)
+    assert grp["backend"].startswith("rccl") and "one-rank group" in grp["backend"] and one["backend"] == "single process"
+    assert grp["n_gpus"] == 1 and grp["result_finite"]
+    assert grp["result_checksum"] == one["result_checksum"]          # same kernels, same schedule: bit-equal floats
+    # the box-invariant fields of the roofline (shader cycles per launch, sustained clock) are there and sane
+    r = grp["roofline"]
+    assert r["shader_cycles_per_launch"] > 0 and 500 < r["sustained_mhz"] < 2600
+    assert r["clock_stamps"]["w"]["launches"] == r["clock_stamps"]["h"]["launches"] == 3 * 3   # 2 timed + 1 profiled step
+
+
+def _rccl_worker(q, root):
+    import socket
+    sys.path.insert(0, os.path.join(root, "flucoma-core_amd"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    import torch
+    import torch.distributed as dist
+    import sharding
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    loc_b = torch.arange(3 * 5 * 7, dtype=torch.float32, device="cuda").reshape(3, 5, 7)
+    gb = sharding.gather_results(loc_b, dist, 1)            # all_gather_into_tensor over RCCL, device tensors
+    t = torch.tensor([1.25], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put((gb.data_ptr() != loc_b.data_ptr(), bool(torch.equal(gb, loc_b)), float(t.item()), dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_rccl_gather_on_one_gpu():
+    """sharding.gather_results + the MAX all-reduce exactly as bench.py issues them, on a 1-rank nccl (= RCCL) group: librccl
+    loads, a communicator is built on the box's GPU and both collectives run on device tensors."""
+    import torch.multiprocessing as mp
+    mctx = mp.get_context("spawn")
+    q = mctx.Queue()
+    p = mctx.Process(target=_rccl_worker, args=(q, ROOT))
+    p.start()
+    fresh, same, t, backend = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert fresh and same and t == 1.25 and backend == "nccl"
+
+
+def test_update_clock_stamps(ctx, onp):
+    """fluhip_corpus_update_clocks: one wavefront per update launch adds its shader cycles and 100 MHz ticks; the counts
+    follow the launches, the implied clock is a plausible shader clock, reset clears"""
+    import fluhip
+    n, win, fft, hop, K, iters = 44100, 2048, 2048, 512, 32, 6
+    audio = np.stack([onp.synth_audio(n, 6000 + b) for b in range(16)])
+    c = fluhip.Corpus(ctx, 16, n, win, fft, hop, K)
+    c.set_audio(audio); c.stft()
+    c.update_clocks(reset=True)
+    c.nmf(iters, seed=42)
+    k = c.update_clocks(reset=True)
+    assert k["w"]["launches"] == iters and k["h"]["launches"] == iters
+    for side in ("w", "h"):
+        assert k[side]["cycles_per_launch"] > 1000 and 500 < k[side]["sustained_mhz"] < 2600
+    z = c.update_clocks()
+    assert z["w"]["launches"] == 0 and z["h"]["shader_cycles"] == 0
+    c.close()
 
 
 def test_ctx_trim_returns_cached_blocks(ctx, onp):

@@ -686,6 +686,44 @@ def test_corpus_per_buffer_seeds(ctx, oracle, onp):
     c.close()
 
 
+@pytest.mark.parametrize("uw,uh", [(True, True), (False, True), (True, False), (False, False)])
+def test_corpus_seeded_and_fixed_factors(ctx, oracle, onp, uw, uh):
+    """fluhip_corpus_set_factors: basesMode / actMode Seed and Fixed (nrt/NMFClient.hpp:246-258 -> alg/NMF.hpp:102-124) on
+    the batched form -- per-buffer seeds for W and H, every update combination incl. both fixed (0 iterations of work:
+    clamp + normalise only, :150-153), every buffer against the oracle; and clearing the seeds goes back to random draws"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 5, 16000, 1024, 1024, 256, 6, 12
+    audio = np.stack([onp.synth_audio(n, 7000 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    rs = np.random.RandomState(11)
+    sW = rs.uniform(0.05, 1.0, (B, K, c.F)).astype(np.float32)
+    sH = rs.uniform(0.05, 1.0, (B, K, c.T)).astype(np.float32)
+    c.set_audio(audio); c.stft()
+    mag = c.read_f64(factors=False)[0]
+    c.set_factors(sW, sH)
+    c.nmf(iters, seed=42, updateW=uw, updateH=uh)
+    _, W1, H1 = c.read_f64(mag=False)
+    bases, acts = c.writeback()
+    for b in range(B):
+        rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, uw, uh, 42, W0=sW[b].astype(np.float64),
+                                          H0=np.ascontiguousarray(sH[b].T.astype(np.float64)))
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, b
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6
+    # only W seeded, H random from the seed; then no seeds at all
+    c.set_factors(sW, None)
+    c.nmf(iters, seed=5063, updateW=uw, updateH=uh)
+    _, W1, H1 = c.read_f64(mag=False)
+    rW, rH, _, _ = oracle.nmf_process(mag[3], K, iters, uw, uh, 5063, W0=sW[3].astype(np.float64))
+    assert rel_err(W1[3], rW) < TOL_FACTORS_TIGHT and rel_err(H1[3], rH) < TOL_FACTORS_TIGHT
+    c.set_factors(None, None)
+    c.nmf(iters, seed=5063, updateW=uw, updateH=uh)
+    _, W1, H1 = c.read_f64(mag=False)
+    rW, rH, _, _ = oracle.nmf_process(mag[1], K, iters, uw, uh, 5063)
+    assert rel_err(W1[1], rW) < TOL_FACTORS_TIGHT and rel_err(H1[1], rH) < TOL_FACTORS_TIGHT
+    c.close()
+
+
 @pytest.mark.parametrize("name,n,win,fft,hop,K,iters", [("c2", 2646000, 2048, 2048, 512, 16, 60),
                                                        ("c3", 26460000, 4096, 4096, 1024, 128, 12)])
 def test_single_buffer_full_size_properties(ctx, onp, name, n, win, fft, hop, K, iters):
