@@ -1358,14 +1358,16 @@ int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, 
   // a view with unit ROW stride (FluidTensorView::transpose() of an F x T matrix) is byte for byte the bin-major copy:
   // either goes up as one strided 2-D copy and the other layout is made on the device.  Anything else (both strides
   // non-unit) is gathered on the host first.
+  // (a one-row view with a non-unit column stride is NOT a contiguous row: the frame-major path needs unit column stride
+  //  or a single column; such a view is byte for byte a bin-major image of one frame and takes the second path)
   std::vector<double> xtmp;
-  if (Xv->col_stride == 1 || T == 1)
+  if (Xv->col_stride == 1 || F == 1)
   {
     HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), Xv->data, (size_t) Xv->row_stride * sizeof(double),
                                  (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
     launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T, (int) F, 1, s);
   }
-  else if (Xv->row_stride == 1)
+  else if (Xv->row_stride == 1 || T == 1)
   {
     HIPCHK(ctx, hipMemcpy2DAsync(c.magT.p, (size_t) c.Tp * sizeof(double), Xv->data, (size_t) Xv->col_stride * sizeof(double),
                                  (size_t) T * sizeof(double), (size_t) F, hipMemcpyHostToDevice, s));
@@ -1422,10 +1424,10 @@ int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, 
     HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
     launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F,
                 (int) c.Kp, 1, s);
-    if (V1v->col_stride == 1 || T == 1)
+    if (V1v->col_stride == 1 || F == 1)
       HIPCHK(ctx, hipMemcpy2DAsync(V1v->data, (size_t) V1v->row_stride * sizeof(double), dv.p, (size_t) F * sizeof(double),
                                    (size_t) F * sizeof(double), (size_t) T, hipMemcpyDeviceToHost, s));
-    else if (V1v->row_stride == 1)
+    else if (V1v->row_stride == 1 || T == 1)
     {
       // a transposed view: the F x T image, made on the device
       HIPCHK(ctx, dvt.alloc((size_t) F * T * sizeof(double), false, s));

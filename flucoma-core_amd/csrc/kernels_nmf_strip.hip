@@ -664,7 +664,16 @@ int strip_pairs(int F) { return (F + 31) / 32; }
 } // namespace strip
 using namespace strip;
 
-bool nmf_strip_supported(int F, int T, int Kp) { return Kp == 16 && F >= 1 && strip_pairs(F) <= 36 && T >= 1; }
+// LDS of a strip workgroup: the W image (4 KiB per bin pair), the H / partial staging and a page of zeros
+static size_t strip_shmem(int nPairs)
+{
+  return (size_t) nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double) + 4096;
+}
+// the W image of all bin pairs must fit the 160 KiB of a CU next to the staging: 35 pairs, F <= 1120
+bool nmf_strip_supported(int F, int T, int Kp)
+{
+  return Kp == 16 && F >= 1 && T >= 1 && strip_pairs(F) <= 36 && strip_shmem(strip_pairs(F)) <= (size_t) 160 * 1024;
+}
 // at most kNQ frame quads per workgroup: 256 workgroups (one per CU) while that holds, more for longer buffers
 int nmf_strip_workgroups(int T)
 {
@@ -706,7 +715,7 @@ static StripK make_k(const StripArgs& s)
 template <int NPW, int NQ, bool INSTR = false>
 static void launch_strip_t(const StripK& k, int B, hipStream_t s)
 {
-  const size_t shmem = (size_t) k.nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double) + 4096;
+  const size_t shmem = strip_shmem(k.nPairs); // <= 160 KiB: nmf_strip_supported() is what the planner asks
   auto kern = nmf_strip_kernel<NPW, NQ, INSTR>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
   const unsigned grid = (k.doH || k.doW) ? (unsigned) k.nWG : 1u;

@@ -196,6 +196,21 @@ def test_nmf_two_stride_views(ctx, oracle):
     assert ctx.nmf_process_views(Xs, K, iters, seed=7, W1=W1b, H1=H1b) == 0
     rW, rH, _, _ = oracle.nmf_process(np.ascontiguousarray(Xs), K, iters, True, True, 7)
     assert rel_err(W1b, rW) < TOL_FACTORS_TIGHT and rel_err(H1b, rH) < TOL_FACTORS_TIGHT
+    # a ONE-ROW view with a non-unit column stride (a[:, ::2] of a 1 x 2F matrix) is not a contiguous row: X must be
+    # gathered with its stride and V1 scattered with it, leaving the elements in between alone
+    row = np.abs(rs.standard_normal((1, 2 * F))) + 0.01
+    W1c = np.zeros((K, F)); H1c = np.zeros((1, K)); V1c = np.full((1, 2 * F), -1.0)
+    assert ctx.nmf_process_views(row[:, ::2], K, iters, seed=7, W1=W1c, H1=H1c, V1=V1c[:, ::2]) == 0
+    rW, rH, rV, _ = oracle.nmf_process(np.ascontiguousarray(row[:, ::2]), K, iters, True, True, 7)
+    assert rel_err(W1c, rW) < TOL_FACTORS_TIGHT and rel_err(H1c, rH) < TOL_FACTORS_TIGHT
+    assert rel_err(V1c[:, ::2], rV) < TOL_FACTORS_TIGHT and (V1c[:, 1::2] == -1.0).all()
+    # and the mirror image: a one-COLUMN view (a single bin) with a non-unit row stride
+    col = np.abs(rs.standard_normal((2 * T, 3))) + 0.01
+    W1d = np.zeros((2, 1)); H1d = np.zeros((T, 2)); V1d = np.full((2 * T, 3), -1.0)
+    assert ctx.nmf_process_views(col[::2, 1:2], 2, iters, seed=7, W1=W1d, H1=H1d, V1=V1d[::2, 1:2]) == 0
+    rW, rH, rV, _ = oracle.nmf_process(np.ascontiguousarray(col[::2, 1:2]), 2, iters, True, True, 7)
+    assert rel_err(W1d, rW) < TOL_FACTORS_TIGHT and rel_err(H1d, rH) < TOL_FACTORS_TIGHT
+    assert rel_err(V1d[::2, 1:2], rV) < TOL_FACTORS_TIGHT and (V1d[1::2] == -1.0).all() and (V1d[:, 0] == -1.0).all()
     # shape checks of alg/NMF.hpp:109-110, 121-122
     import fluhip
     with pytest.raises(fluhip.FluhipError):

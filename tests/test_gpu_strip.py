@@ -26,7 +26,10 @@ def data(T, F):
     rs = np.random.RandomState(T * 7 + F)
     return np.abs(rs.standard_normal((T, 3)) @ rs.standard_normal((3, F))) + 0.01 * rs.uniform(0, 1, (T, F))
 for (T, F, K, iters) in ((200, 1025, 16, 12), (33, 17, 1, 10), (300, 513, 3, 10), (1000, 257, 16, 7), (2601, 513, 9, 5),
-                         (7003, 129, 16, 4), (5, 33, 2, 3), (1031, 1025, 13, 6)):
+                         (7003, 129, 16, 4), (5, 33, 2, 3), (1031, 1025, 13, 6),
+                         # 35 bin pairs is the most whose W image fits the LDS (F <= 1120); 36 pairs (ADVICE r02: the launch
+                         # failed there) must fall back to the split schedule also with the strip schedule forced
+                         (150, 1120, 16, 5), (150, 1121, 16, 5), (150, 1152, 9, 5)):
     X = data(T, F)
     W1, H1, V1, rc = ctx.nmf_process(X, K, iters, True, True, 42)
     rW, rH, rV, _ = o.nmf_process(X, K, iters, True, True, 42)
