@@ -369,6 +369,20 @@ struct fluhip_corpus
   bool haveMag = false, haveFactors = false;
   // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats
   std::vector<float> seedW32, seedH32;
+  // ragged corpus (fluhip_corpus_create_ragged): buffers of different lengths in ONE set of launches.  n / T are those of
+  // the longest buffer (the strides of every array); frames past a buffer's own count are zero padding that stays zero.
+  // The factor updates run kernels_nmf5.hip in work-list mode: one WaveDesc per wavefront, dealt by work.
+  bool ragged = false;
+  std::vector<int64_t> nOf; // samples per buffer
+  std::vector<int> tOf;     // frames per buffer
+  DevBuf nTab, tTab;        // the same on the device
+  struct WorkList
+  {
+    DevBuf list, splitTab;
+    int wgs = 0, ng = 0, partial = 0, maxSplit = 1;
+    int64_t nPartials = 0;
+    int statParts = 0; // column-statistics parts per buffer (W update)
+  } listW, listH;
   int64_t device_bytes() const
   {
     return (int64_t) (audioOwn.bytes + mag.bytes + magT.bytes + Wf.bytes + H1.bytes + spec.bytes +
@@ -508,6 +522,214 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
   return FLUHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// ragged corpora: work lists of the two factor updates
+// ---------------------------------------------------------------------------------------
+namespace {
+struct WaveUnit
+{
+  int buf, split, nsplit, s0, s1; // a (buffer, contraction range) pair: `waves` wavefronts, one per strip
+  int64_t work;
+};
+
+// wavefronts -> workgroups of 4, dealt over the 8 XCDs (workgroup i runs on XCD i & 7): the units are taken longest
+// first (the hardware hands the next workgroup to whichever CU frees up), all wavefronts of a unit to one XCD
+void pack_list(const std::vector<std::vector<WaveDesc>>& units, std::vector<WaveDesc>& out, int* wgs)
+{
+  std::vector<std::vector<WaveDesc>> q(8);
+  std::vector<size_t> load(8, 0);
+  for (const auto& u : units)
+  {
+    size_t best = 0;
+    for (size_t x = 1; x < 8; x++)
+      if (load[x] < load[best]) best = x;
+    q[best].insert(q[best].end(), u.begin(), u.end());
+    load[best] += u.size();
+  }
+  size_t slots = 0;
+  for (auto& v : q) slots = std::max(slots, (v.size() + 3) / 4);
+  out.assign(slots * 8 * 4, WaveDesc{0, 0, 0, 0, 0, -1, 0, -1});
+  for (size_t x = 0; x < 8; x++)
+    for (size_t i = 0; i < q[x].size(); i++) out[((i / 4) * 8 + x) * 4 + (i % 4)] = q[x][i];
+  *wgs = (int) (slots * 8);
+}
+} // namespace
+
+static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  const int B = (int) c->B, Kp = (int) c->Kp, F = (int) c->F;
+  const int maxNG = nmf_update5_max_groups(Kp);
+  c->lazy = true; c->strip = false; c->nsplitW = c->nsplitH = 1;
+  // ---- W update: strips over the bins (the same for every buffer), the contraction over a buffer's own frames ------------
+  {
+    std::vector<int> steps((size_t) B);
+    for (int b = 0; b < B; b++) steps[(size_t) b] = (c->tOf[(size_t) b] + 3) / 4;
+    // the Nyquist bin as a side column when that makes the strips even (fluhip_kernels.h SideColumn) and nothing is split
+    auto strips_for = [&](int C) { const int G = (C + 15) / 16; return (G + maxNG - 1) / maxNG; };
+    int wW = strips_for(F);
+    int64_t waves0 = (int64_t) B * wW;
+    // split the contractions when one round of wavefronts (1024 SIMDs) would stay part empty: S steps per wavefront
+    int S = 0;
+    if (waves0 < 1536)
+    {
+      const int64_t target = waves0 <= 1024 ? 1024 : 2048;
+      for (S = 12;; S++)
+      {
+        int64_t w = 0;
+        bool capped = false;
+        for (int b = 0; b < B; b++)
+        {
+          const int ns = (steps[(size_t) b] + S - 1) / S;
+          if (ns > 64) capped = true;
+          w += (int64_t) wW * ns;
+        }
+        if (w <= target && !capped) break;
+      }
+      bool any = false;
+      for (int b = 0; b < B; b++) any = any || steps[(size_t) b] > S;
+      if (!any) S = 0;
+    }
+    c->sideW = S == 0 && nmf_side_column_supported((int) c->T, F, Kp) && strips_for(F - 1) <= wW &&
+               (((F - 1 + 15) / 16 + strips_for(F - 1) - 1) / strips_for(F - 1) < ((F + 15) / 16 + wW - 1) / wW);
+    static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    if (sideOff) c->sideW = false;
+    const int C = F - (c->sideW ? 1 : 0);
+    const int G = (C + 15) / 16;
+    wW = strips_for(C);
+    const int ngW = (G + wW - 1) / wW;
+    std::vector<WaveUnit> units;
+    std::vector<int> splitTab((size_t) B * 2);
+    int64_t pbase = 0;
+    int maxSplit = 1;
+    for (int b = 0; b < B; b++)
+    {
+      const int ns = S > 0 ? std::max(1, (steps[(size_t) b] + S - 1) / S) : 1;
+      const int per = (steps[(size_t) b] + ns - 1) / ns;
+      splitTab[(size_t) b * 2] = (int) pbase;
+      splitTab[(size_t) b * 2 + 1] = ns;
+      maxSplit = std::max(maxSplit, ns);
+      for (int j = 0; j < ns; j++)
+      {
+        const int s0 = j * per, s1 = std::min(steps[(size_t) b], s0 + per);
+        units.push_back(WaveUnit{b, j, ns, s0, std::max(s0, s1), (int64_t) (s1 - s0)});
+      }
+      pbase += ns;
+    }
+    std::stable_sort(units.begin(), units.end(), [](const WaveUnit& a, const WaveUnit& b) { return a.work > b.work; });
+    std::vector<std::vector<WaveDesc>> packed;
+    for (const auto& u : units)
+    {
+      std::vector<WaveDesc> ws;
+      const int base = G / wW, rem = G % wW;
+      int g0 = 0;
+      for (int st = 0; st < wW; st++)
+      {
+        const int ng = base + (st < rem ? 1 : 0);
+        WaveDesc d;
+        d.buf = u.buf; d.g0 = g0; d.ng = ng; d.s0 = u.s0; d.s1 = u.s1;
+        d.partIdx = S > 0 ? splitTab[(size_t) u.buf * 2] + u.split : -1;
+        d.statIdx = u.buf * wW + st;
+        d.dIdx = (S > 0 && st == 0) ? d.partIdx : -1;
+        if (ng > 0) ws.push_back(d);
+        g0 += ng;
+      }
+      packed.push_back(std::move(ws));
+    }
+    std::vector<WaveDesc> list;
+    pack_list(packed, list, &c->listW.wgs);
+    c->listW.ng = ngW; c->listW.partial = S > 0 ? 1 : 0; c->listW.maxSplit = maxSplit; c->listW.nPartials = S > 0 ? pbase : 0;
+    c->listW.statParts = S > 0 ? update_finalize_parts(C, Kp) : wW;
+    c->stripsW = c->listW.statParts;
+    c->nsplitW = maxSplit;
+    HIPCHK(ctx, c->listW.list.alloc(list.size() * sizeof(WaveDesc), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->listW.list.p, list.data(), list.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, c->listW.splitTab.alloc(splitTab.size() * sizeof(int), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->listW.splitTab.p, splitTab.data(), splitTab.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s)); // the host images go out of scope
+  }
+  // ---- H update: strips over a buffer's own frames, the contraction over the bins (the same for every buffer) ------------
+  {
+    std::vector<int> groups((size_t) B);
+    for (int b = 0; b < B; b++) groups[(size_t) b] = (c->tOf[(size_t) b] + 15) / 16;
+    // the strip width that wastes the fewest MFMA slots over the whole corpus (a wavefront runs its widest form)
+    int NG = maxNG;
+    double bestEff = -1.0;
+    for (int cand = maxNG; cand >= std::max(1, maxNG - 3); cand--)
+    {
+      int64_t used = 0, slots = 0;
+      for (int b = 0; b < B; b++)
+      {
+        const int w = (groups[(size_t) b] + cand - 1) / cand;
+        used += groups[(size_t) b];
+        slots += (int64_t) w * ((groups[(size_t) b] + w - 1) / std::max(w, 1));
+      }
+      const double eff = slots ? (double) used / (double) slots : 0.0;
+      if (eff > bestEff + 1e-9) { bestEff = eff; NG = cand; }
+    }
+    int64_t waves0 = 0;
+    int ngH = 1;
+    for (int b = 0; b < B; b++)
+    {
+      const int w = (groups[(size_t) b] + NG - 1) / NG;
+      waves0 += w;
+      ngH = std::max(ngH, (groups[(size_t) b] + w - 1) / std::max(w, 1));
+    }
+    const int steps = (F + 3) / 4;
+    int ns = 1;
+    if (waves0 < 768) ns = (int) std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024 / std::max<int64_t>(waves0, 1), steps / 12), 64));
+    const int per = (steps + ns - 1) / ns;
+    std::vector<int> order((size_t) B);
+    for (int b = 0; b < B; b++) order[(size_t) b] = b;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[(size_t) a] > groups[(size_t) b]; });
+    std::vector<std::vector<WaveDesc>> packed;
+    std::vector<int> splitTab((size_t) B * 2);
+    for (int b = 0; b < B; b++) { splitTab[(size_t) b * 2] = b * ns; splitTab[(size_t) b * 2 + 1] = ns; }
+    for (int b : order)
+    {
+      const int G = groups[(size_t) b];
+      const int w = (G + NG - 1) / NG;
+      for (int j = 0; j < ns; j++)
+      {
+        std::vector<WaveDesc> ws;
+        const int base = G / w, rem = G % w;
+        int g0 = 0;
+        for (int st = 0; st < w; st++)
+        {
+          const int ng = base + (st < rem ? 1 : 0);
+          WaveDesc d;
+          d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = j * per; d.s1 = std::max(d.s0, std::min(steps, d.s0 + per));
+          d.partIdx = ns > 1 ? b * ns + j : -1;
+          d.statIdx = 0;
+          d.dIdx = (ns > 1 && st == 0) ? d.partIdx : -1;
+          if (ng > 0) ws.push_back(d);
+          g0 += ng;
+        }
+        packed.push_back(std::move(ws));
+      }
+    }
+    std::vector<WaveDesc> list;
+    pack_list(packed, list, &c->listH.wgs);
+    c->listH.ng = ngH; c->listH.partial = ns > 1 ? 1 : 0; c->listH.maxSplit = ns; c->listH.nPartials = ns > 1 ? (int64_t) B * ns : 0;
+    c->nsplitH = ns;
+    HIPCHK(ctx, c->listH.list.alloc(list.size() * sizeof(WaveDesc), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->listH.list.p, list.data(), list.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, c->listH.splitTab.alloc(splitTab.size() * sizeof(int), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->listH.splitTab.p, splitTab.data(), splitTab.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipStreamSynchronize(s));
+  }
+  // workspaces
+  const int64_t nPart = std::max(c->listW.nPartials, c->listH.nPartials);
+  const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
+  if (nPart > 0) HIPCHK(ctx, c->part.alloc((size_t) nPart * Cp * Kp * sizeof(double), true, s));
+  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, (size_t) std::max<int64_t>(nPart, B) * Kp * sizeof(double)), true, s));
+  HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
+  HIPCHK(ctx, c->wnorm.alloc((size_t) B * Kp * sizeof(double), false, s));
+  launch_fill_ones(c->wnorm.as<double>(), (int64_t) B * Kp, s);
+  HIPCHK(ctx, c->wscratch.alloc((size_t) wnorm_scratch_doubles(Kp, B, c->stripsW) * sizeof(double), true, s));
+  return FLUHIP_OK;
+}
+
 static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
@@ -522,6 +744,14 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->hmax.alloc(B * sizeof(double), true, s));
+  if (c->ragged)
+  {
+    HIPCHK(ctx, c->nTab.alloc(B * sizeof(int64_t), false, s));
+    HIPCHK(ctx, c->tTab.alloc(B * sizeof(int), false, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->nTab.p, c->nOf.data(), B * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(ctx, hipMemcpyAsync(c->tTab.p, c->tOf.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
+    return plan_ragged(ctx, c);
+  }
   if (int rc = plan_updates(ctx, c)) return rc;
   return FLUHIP_OK;
 }
@@ -568,6 +798,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
   a.mag = c->mag.as<double>(); a.magStride = c->Tp * c->Fp; a.ldMag = c->Fp;
   a.spec = c->keepSpec ? c->spec.as<double>() : nullptr; a.specStride = c->T * c->F * 2;
   a.frameOffset = 0;
+  a.nTab = c->ragged ? c->nTab.as<int64_t>() : nullptr;
   a.bigScratch = big_fft_scratch(ctx, c->win, c->fft, c->B * c->T);
   if (stft_needs_scratch(c->win, c->fft) && !a.bigScratch) return FLUHIP_ERROR;
   // V is kept in both layouts (frame-major for the W update, bin-major for the H update).  The block form of K1
@@ -577,6 +808,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
     ProfScope p(ctx, 0);
     if (!stft_needs_scratch(c->win, c->fft))
       both = launch_stft_block(a, c->magT.as<double>(), c->Fp * c->Tp, c->Tp, ctx->stream);
+    if (!both && c->ragged) return fail(ctx, "ragged corpora need an STFT shape with a block form (fft 1024 / 2048 / 4096, even window)");
     if (!both) launch_stft(a, ctx->stream);
   }
   if (!both)
@@ -710,7 +942,8 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     HIPCHK(ctx, hipMemcpyAsync(stageH.p, src, (size_t) nsrc * TK * sizeof(double), hipMemcpyHostToDevice, s));
     // T x K row-major source (random: column-major K x T fill; seeded: H0 transposed, :113-124)
     launch_scatter_factor(stageH.as<double>(), nsrc == 1 ? 0 : (int64_t) TK, c->H1.as<double>(),
-                          c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, false, s);
+                          c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, false, s,
+                          c->ragged ? c->tTab.as<int>() : nullptr); // (K x T_b column-major = the first T_b K draws)
   }
   // alg/NMF.hpp:150-153: clamp both to eps, normalise columns of W and rows of H (= columns of H1)
   if (!c->normScratch.p)
@@ -719,7 +952,7 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     HIPCHK(ctx, c->normScratch.alloc(nd * sizeof(double), false, s));
   }
   launch_colnorm(c->H1.as<double>(), c->Tp * c->Kp, (int) c->T, (int) c->K, (int) c->Kp, B, true, false,
-                 c->normScratch.as<double>(), s);
+                 c->normScratch.as<double>(), s, c->ragged ? c->tTab.as<int>() : nullptr);
   launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, true, false,
                  c->normScratch.as<double>(), s);
   HIPCHK(ctx, hipGetLastError());
@@ -791,6 +1024,10 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>();
+    if (c->ragged)
+    {
+      a.list = c->listW.list.as<WaveDesc>(); a.listWGs = c->listW.wgs; a.listNG = c->listW.ng; a.listPartial = c->listW.partial;
+    }
     if (c->lazy)
     {
       // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
@@ -800,6 +1037,9 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       {
         ProfScope p(ctx, 1);
         launch_nmf_update5(a, s);
+        if (c->ragged && c->listW.partial)
+          launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listW.maxSplit, a.B, s, a.nrm, a.nrmMode,
+                                 a.statPart, c->listW.splitTab.as<int>());
       }
       ProfScope p(ctx, 3);
       SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
@@ -837,6 +1077,15 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
+    if (c->ragged)
+    {
+      a.list = c->listH.list.as<WaveDesc>(); a.listWGs = c->listH.wgs; a.listNG = c->listH.ng; a.listPartial = c->listH.partial;
+      launch_nmf_update5(a, s);
+      if (c->listH.partial)
+        launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listH.maxSplit, a.B, s, a.nrm, a.nrmMode,
+                               nullptr, c->listH.splitTab.as<int>());
+    }
+    else
     if (uv == 5) launch_nmf_update5(a, s);
     else if (uv == 4) launch_nmf_update4(a, s);
     else if (uv == 0) launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
@@ -1042,6 +1291,91 @@ int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win,
   return FLUHIP_OK;
 }
 
+int fluhip_corpus_create_ragged(fluhip_ctx* ctx, int64_t count, const int64_t* n, int64_t win, int64_t fft, int64_t hop,
+                                int64_t K, fluhip_corpus** out)
+{
+  if (!ctx || !out) return FLUHIP_ERROR;
+  *out = nullptr;
+  if (!n || count < 1) return fail(ctx, "corpus must hold at least one buffer");
+  if (count > 65535) return fail(ctx, "a corpus holds at most 65535 buffers (split larger corpora into several)");
+  int64_t nmax = 0;
+  for (int64_t i = 0; i < count; i++)
+  {
+    if (n[i] < 1) return fail(ctx, "buffer " + std::to_string(i) + ": not enough frames");
+    nmax = std::max(nmax, n[i]);
+  }
+  int rc = check_shape(ctx, nmax, win, fft, hop, K);
+  if (rc) return rc;
+  // one set of launches over buffers of different lengths needs the work-list form of the factor-update kernel (padded
+  // rank 16 / 32 / 64 / 128) and the block form of the STFT (it takes per-buffer lengths)
+  if (update_variant((int) round_up(K, 16)) != 5) return fail(ctx, "ragged corpora support ranks up to 128");
+  if (!(fft == 1024 || fft == 2048 || fft == 4096) || (win % 2) != 0 || win > fft)
+    return fail(ctx, "ragged corpora need an STFT shape with a block form (fft 1024 / 2048 / 4096, even window)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::unique_ptr<fluhip_corpus> c(new fluhip_corpus);
+  c->ctx = ctx; c->B = count; c->n = nmax; c->win = win; c->fft = fft; c->hop = hop; c->K = K;
+  c->ragged = true;
+  c->nOf.assign(n, n + count);
+  c->tOf.resize((size_t) count);
+  for (int64_t i = 0; i < count; i++) c->tOf[(size_t) i] = (int) ((n[i] + hop) / hop); // alg/STFT.hpp:98-99 per buffer
+  rc = corpus_alloc(ctx, c.get());
+  if (rc) return rc;
+  *out = c.release();
+  return FLUHIP_OK;
+}
+
+int64_t fluhip_corpus_frames_of(const fluhip_corpus* c, int64_t i)
+{
+  if (!c || i < 0 || i >= c->B) return 0;
+  return c->ragged ? c->tOf[(size_t) i] : c->T;
+}
+
+int fluhip_corpus_set_audio_ragged_host(fluhip_corpus* c, const float* const* audio)
+{
+  if (!c || !audio) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  if (!c->ragged) return fail(ctx, "not a ragged corpus");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t) c->B * c->n * sizeof(float);
+  if (c->audioOwn.bytes < bytes) HIPCHK(ctx, c->audioOwn.alloc(bytes, false, ctx->stream));
+  // every buffer at its slot of the longest buffer's stride; the kernel never reads past a buffer's own length
+  for (int64_t i = 0; i < c->B; i++)
+  {
+    if (!audio[i]) return fail(ctx, "buffer " + std::to_string(i) + ": null audio");
+    HIPCHK(ctx, hipMemcpyAsync(c->audioOwn.as<float>() + i * c->n, audio[i], (size_t) c->nOf[(size_t) i] * sizeof(float),
+                               hipMemcpyHostToDevice, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  c->audioDev = c->audioOwn.as<float>();
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_writeback_ragged_host(fluhip_corpus* c, float* const* bases, float* const* acts)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf db, da;
+  const size_t nb = (size_t) c->B * c->K * c->F * sizeof(float), na = (size_t) c->B * c->K * c->T * sizeof(float);
+  if (bases) HIPCHK(ctx, db.alloc(nb, false, ctx->stream));
+  if (acts) HIPCHK(ctx, da.alloc(na, false, ctx->stream));
+  int rc = fluhip_corpus_writeback_dev(c, bases ? db.as<float>() : nullptr, acts ? da.as<float>() : nullptr);
+  if (rc) return rc;
+  for (int64_t i = 0; i < c->B; i++)
+  {
+    const int64_t Ti = fluhip_corpus_frames_of(c, i);
+    if (bases && bases[i])
+      HIPCHK(ctx, hipMemcpyAsync(bases[i], db.as<float>() + i * c->K * c->F, (size_t) c->K * c->F * sizeof(float),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    if (acts && acts[i]) // K rows of the buffer's own T_i frames out of rows of the longest buffer's length
+      HIPCHK(ctx, hipMemcpy2DAsync(acts[i], (size_t) Ti * sizeof(float), da.as<float>() + i * c->K * c->T,
+                                   (size_t) c->T * sizeof(float), (size_t) Ti * sizeof(float), (size_t) c->K,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
 void fluhip_corpus_destroy(fluhip_corpus* c)
 {
   if (!c) return;
@@ -1101,6 +1435,7 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
 int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
 {
   if (!c) return FLUHIP_ERROR;
+  if (c->ragged && acts_seed) return fail(c->ctx, "activation seeds of a ragged corpus are not supported (bases are)");
   const size_t nw = (size_t) c->B * c->K * c->F, nh = (size_t) c->B * c->K * c->T;
   if (bases_seed) c->seedW32.assign(bases_seed, bases_seed + nw);
   else std::vector<float>().swap(c->seedW32);
@@ -1141,6 +1476,7 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   if (!c || !out_dev) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
   if (!c->haveFactors) return fail(ctx, "corpus has no factors: call fluhip_corpus_nmf first");
+  if (c->ragged) return fail(ctx, "resynthesis of a ragged corpus is not supported: run its buffers as equal-length groups");
   if (!c->keepSpec || !c->spec.p)
     return fail(ctx, "resynthesis needs the complex spectrogram: fluhip_corpus_keep_spectrum(c, 1) before fluhip_corpus_stft");
   HIPCHK(ctx, hipSetDevice(ctx->device));

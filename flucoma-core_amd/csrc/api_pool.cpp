@@ -205,8 +205,85 @@ int fluhip_pool_bufnmf_f32(fluhip_pool* p, const float* audio, int64_t count, in
 }
 
 // Ragged corpus: buffers of different lengths.  Dealt by the greedy longest-processing-time rule over cost = frames (the
-// work of a buffer is ~ T F K, F and K being common); on its device every run of equal-length buffers becomes one
-// corpus (the batched kernels), the rest run one by one (the single-buffer schedules).
+// work of a buffer is ~ T F K, F and K being common); every device runs ITS buffers as one ragged corpus
+// (fluhip_corpus_create_ragged: one STFT launch, one set of factor-update launches per iteration, the work dealt per
+// wavefront by each buffer's own length).  Shapes the ragged form does not cover (ranks above 128, fft sizes without a
+// block STFT) fall back to runs of equal length as equal-length corpora.
+namespace {
+// the fallback: runs of equal length as one corpus each, the others one by one
+int ragged_by_groups(fluhip_ctx* ctx, const std::vector<int64_t>& mine, const float* const* audio, const int64_t* n, int64_t win,
+                     int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
+                     const int64_t* seeds, float* const* bases, float* const* acts, std::atomic<int64_t>& buffersDone,
+                     std::atomic<bool>& cancel, std::string& err)
+{
+  const int64_t F = fft / 2 + 1;
+  std::vector<float> packed, gb, ga;
+  std::vector<int64_t> gseeds;
+  for (size_t i0 = 0; i0 < mine.size() && !cancel.load(std::memory_order_acquire);)
+  {
+    size_t i1 = i0;
+    while (i1 < mine.size() && n[mine[i1]] == n[mine[i0]] && i1 - i0 < 65535) i1++;
+    const int64_t nb = (int64_t) (i1 - i0), len = n[mine[i0]];
+    const int64_t T = fluhip_stft_num_frames(len, win, hop);
+    const float* src = audio[mine[i0]];
+    if (nb > 1)
+    {
+      packed.resize((size_t) nb * (size_t) len);
+      for (int64_t j = 0; j < nb; j++)
+        std::copy(audio[mine[i0 + (size_t) j]], audio[mine[i0 + (size_t) j]] + len, packed.begin() + (size_t) j * (size_t) len);
+      src = packed.data();
+    }
+    if (seeds)
+    {
+      gseeds.resize((size_t) nb);
+      for (int64_t j = 0; j < nb; j++) gseeds[(size_t) j] = seeds[mine[i0 + (size_t) j]];
+    }
+    fluhip_corpus* c = nullptr;
+    int rc = fluhip_corpus_create(ctx, nb, len, win, fft, hop, K, &c);
+    if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, src);
+    if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(c);
+    if (rc == FLUHIP_OK) rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? gseeds.data() : nullptr, nullptr, nullptr);
+    if (rc == FLUHIP_OK)
+    {
+      float* bdst = nullptr;
+      float* adst = nullptr;
+      if (nb == 1) { bdst = bases ? bases[mine[i0]] : nullptr; adst = acts ? acts[mine[i0]] : nullptr; }
+      else
+      {
+        if (bases) { gb.resize((size_t) (nb * K * F)); bdst = gb.data(); }
+        if (acts) { ga.resize((size_t) (nb * K * T)); adst = ga.data(); }
+      }
+      rc = fluhip_corpus_writeback_host(c, bdst, adst);
+      if (rc == FLUHIP_OK && nb > 1)
+        for (int64_t j = 0; j < nb; j++)
+        {
+          const int64_t g = mine[i0 + (size_t) j];
+          if (bases && bases[g]) std::copy(gb.begin() + (size_t) (j * K * F), gb.begin() + (size_t) ((j + 1) * K * F), bases[g]);
+          if (acts && acts[g]) std::copy(ga.begin() + (size_t) (j * K * T), ga.begin() + (size_t) ((j + 1) * K * T), acts[g]);
+        }
+    }
+    if (rc != FLUHIP_OK) err = fluhip_last_error(ctx);
+    if (c) fluhip_corpus_destroy(c);
+    if (rc != FLUHIP_OK) return rc;
+    buffersDone.fetch_add(nb, std::memory_order_release);
+    i0 = i1;
+  }
+  return FLUHIP_OK;
+}
+
+struct RaggedWorker
+{
+  std::atomic<int64_t> done{0}; // iterations completed by this device's corpus
+  std::atomic<bool>* cancel = nullptr;
+};
+int ragged_progress(int64_t it, void* u)
+{
+  RaggedWorker* w = static_cast<RaggedWorker*>(u);
+  w->done.store(it, std::memory_order_release);
+  return w->cancel->load(std::memory_order_acquire) ? 0 : 1;
+}
+} // namespace
+
 int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, const int64_t* n, int64_t count, int64_t win,
                                   int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                                   const int64_t* seeds, float* const* bases, float* const* acts, fluhip_progress_fn progress,
@@ -218,7 +295,6 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
   for (int64_t i = 0; i < count; i++)
     if (!audio[i] || n[i] < 1) { p->err = "buffer " + std::to_string(i) + ": null or empty"; return FLUHIP_ERROR; }
   const int world = (int) p->ctx.size();
-  const int64_t F = fft / 2 + 1;
   std::vector<double> cost((size_t) count);
   for (int64_t i = 0; i < count; i++) cost[(size_t) i] = (double) fluhip_stft_num_frames(n[i], win, hop);
   std::vector<int32_t> owner((size_t) count);
@@ -236,64 +312,49 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
     for (int64_t i = 0; i < count; i++)
       if (owner[(size_t) i] == r) mine.push_back(i);
     if (mine.empty()) continue;
-    // equal lengths next to each other, longest first; ties in corpus order (deterministic grouping)
+    // longest first; ties in corpus order (deterministic)
     std::stable_sort(mine.begin(), mine.end(), [&](int64_t a, int64_t b) { return n[a] > n[b]; });
     th.emplace_back([=, &rcs, &errs, &buffersDone, &cancel] {
       fluhip_ctx* ctx = p->ctx[(size_t) r];
-      std::vector<float> packed, gb, ga;
-      std::vector<int64_t> gseeds;
-      for (size_t i0 = 0; i0 < mine.size() && rcs[(size_t) r].load() == FLUHIP_OK && !cancel.load(std::memory_order_acquire);)
+      int rc = FLUHIP_OK;
+      // ---- the whole share as ONE ragged corpus (slices of 65535 buffers) ---------------------------------------
+      bool fallback = false;
+      for (size_t i0 = 0; i0 < mine.size() && rc == FLUHIP_OK && !fallback && !cancel.load(std::memory_order_acquire); i0 += 65535)
       {
-        size_t i1 = i0;
-        while (i1 < mine.size() && n[mine[i1]] == n[mine[i0]] && i1 - i0 < 65535) i1++;
-        const int64_t nb = (int64_t) (i1 - i0), len = n[mine[i0]];
-        const int64_t T = fluhip_stft_num_frames(len, win, hop);
-        const float* src = audio[mine[i0]];
-        if (nb > 1)
+        const size_t nb = std::min<size_t>(65535, mine.size() - i0);
+        std::vector<int64_t> lens(nb), sd;
+        std::vector<const float*> ap(nb);
+        std::vector<float*> bp(nb, nullptr), cp(nb, nullptr);
+        for (size_t j = 0; j < nb; j++)
         {
-          packed.resize((size_t) nb * (size_t) len);
-          for (int64_t j = 0; j < nb; j++)
-            std::copy(audio[mine[i0 + (size_t) j]], audio[mine[i0 + (size_t) j]] + len, packed.begin() + (size_t) j * (size_t) len);
-          src = packed.data();
+          const int64_t g = mine[i0 + j];
+          lens[j] = n[g]; ap[j] = audio[g];
+          if (bases) bp[j] = bases[g];
+          if (acts) cp[j] = acts[g];
         }
-        if (seeds)
-        {
-          gseeds.resize((size_t) nb);
-          for (int64_t j = 0; j < nb; j++) gseeds[(size_t) j] = seeds[mine[i0 + (size_t) j]];
-        }
+        if (seeds) { sd.resize(nb); for (size_t j = 0; j < nb; j++) sd[j] = seeds[mine[i0 + j]]; }
         fluhip_corpus* c = nullptr;
-        int rc = fluhip_corpus_create(ctx, nb, len, win, fft, hop, K, &c);
-        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, src);
+        rc = fluhip_corpus_create_ragged(ctx, (int64_t) nb, lens.data(), win, fft, hop, K, &c);
+        if (rc != FLUHIP_OK && i0 == 0) { fallback = true; rc = FLUHIP_OK; break; } // a shape the ragged form does not cover
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_ragged_host(c, ap.data());
         if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(c);
-        if (rc == FLUHIP_OK) rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? gseeds.data() : nullptr, nullptr, nullptr);
+        RaggedWorker w;
+        w.cancel = &cancel;
         if (rc == FLUHIP_OK)
-        {
-          float* bdst = nullptr;
-          float* adst = nullptr;
-          if (nb == 1) { bdst = bases ? bases[mine[i0]] : nullptr; adst = acts ? acts[mine[i0]] : nullptr; }
-          else
-          {
-            if (bases) { gb.resize((size_t) (nb * K * F)); bdst = gb.data(); }
-            if (acts) { ga.resize((size_t) (nb * K * T)); adst = ga.data(); }
-          }
-          rc = fluhip_corpus_writeback_host(c, bdst, adst);
-          if (rc == FLUHIP_OK && nb > 1)
-            for (int64_t j = 0; j < nb; j++)
-            {
-              const int64_t g = mine[i0 + (size_t) j];
-              if (bases && bases[g]) std::copy(gb.begin() + (size_t) (j * K * F), gb.begin() + (size_t) ((j + 1) * K * F), bases[g]);
-              if (acts && acts[g]) std::copy(ga.begin() + (size_t) (j * K * T), ga.begin() + (size_t) ((j + 1) * K * T), acts[g]);
-            }
-        }
-        if (rc != FLUHIP_OK) { errs[(size_t) r] = fluhip_last_error(ctx); rcs[(size_t) r].store(rc, std::memory_order_release); }
+          rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? sd.data() : nullptr, ragged_progress, &w);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_writeback_ragged_host(c, bases ? bp.data() : nullptr, acts ? cp.data() : nullptr);
+        if (rc != FLUHIP_OK) errs[(size_t) r] = fluhip_last_error(ctx);
         if (c) fluhip_corpus_destroy(c);
-        buffersDone.fetch_add(nb, std::memory_order_release);
-        i0 = i1;
+        if (rc == FLUHIP_OK) buffersDone.fetch_add((int64_t) nb, std::memory_order_release);
       }
+      if (fallback)
+        rc = ragged_by_groups(ctx, mine, audio, n, win, fft, hop, K, iters, update_w, update_h, seed, seeds, bases, acts,
+                              buffersDone, cancel, errs[(size_t) r]);
+      if (rc != FLUHIP_OK && rc != FLUHIP_CANCELLED) rcs[(size_t) r].store(rc, std::memory_order_release);
     });
   }
-  // progress = buffers finished so far (1 .. count), from the calling thread; a refusal stops every device after the group it
-  // is working on
+  // progress = buffers finished so far (1 .. count), from the calling thread; a refusal stops every device (at its next
+  // iteration in the ragged form, after the group it is working on in the fallback)
   if (progress)
   {
     int64_t reported = 0;

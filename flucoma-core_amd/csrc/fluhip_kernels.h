@@ -43,6 +43,9 @@ struct StftArgs
   double* bigScratch = nullptr; // big_fft_scratch_bytes() of workspace, needed when stft_needs_scratch(win, fft)
   int frameOffset;      // extra sample offset of frame 0 (0 for STFT::process; the buffered feature
                         // clients start (win/hop)*hop - win earlier when hop does not divide win)
+  // ragged corpora (block form only): samples of every buffer (device, [B]); n / T are then those of the longest one
+  // and frames past a buffer's own (n_b + hop) / hop are left zero
+  const int64_t* nTab = nullptr;
 };
 
 void launch_stft(const StftArgs& a, hipStream_t s);
@@ -59,6 +62,17 @@ double* launch_big_fft_passes(double* bufA, double* bufB, int nc, int fft, const
 // out[b][c][r] = in[b][r][c]; in [R][ldin], out [C][ldout] (valid R x C)
 void launch_transpose(const double* in, int64_t ldin, int64_t strideIn, double* out,
                       int64_t ldout, int64_t strideOut, int R, int C, int B, hipStream_t s);
+
+// One wavefront's share of a factor update in work-list mode (ragged corpora: buffers of different lengths in one
+// launch).  Column groups [g0, g0 + ng) of buffer `buf`, contraction steps [s0, s1) (4 rows each); partIdx >= 0: the
+// accumulators leave as partial `partIdx` of a split contraction ([Cp][Kp] doubles each) for the finalize launch,
+// dIdx >= 0: this wavefront also stores the column sums of its steps as denominator partial `dIdx`; partIdx < 0: the
+// wavefront covers the whole contraction and writes the result and (W update) its column statistics as part `statIdx`.
+// ng == 0: an idle slot of the last workgroup.
+struct WaveDesc
+{
+  int buf, g0, ng, s0, s1, partIdx, statIdx, dIdx;
+};
 
 struct UpdateArgs
 {
@@ -88,6 +102,10 @@ struct UpdateArgs
   double* colsumScratch = nullptr;
   // kernels_nmf5.hip: {launches, shader cycles, 100 MHz ticks} of one wavefront per launch, accumulated (or null)
   long long* clk = nullptr;
+  // kernels_nmf5.hip work-list mode: listWGs workgroups of 4 wavefronts, list[4 * listWGs]; listNG = the widest strip;
+  // listPartial: the list's wavefronts write split partials (the caller finalizes)
+  const WaveDesc* list = nullptr;
+  int listWGs = 0, listNG = 0, listPartial = 0;
 };
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine
@@ -103,7 +121,9 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
 // statistics [B][update_finalize_parts(C, Kp)][2][Kp] when asked for
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart, int C, int Kp,
                             int64_t Cp, int nsplit, int B, hipStream_t s, const double* nrm = nullptr,
-                            int nrmMode = 0, double* statPart = nullptr);
+                            int nrmMode = 0, double* statPart = nullptr, const int* splitTab = nullptr);
+// splitTab (device, [B][2] ints, work-list mode): first partial and number of partials of every buffer; `nsplit` is
+// then the largest count
 int update_finalize_parts(int C, int Kp);
 void launch_nmf_update(const UpdateArgs& a, hipStream_t s);      // v_mfma_f64_16x16x4 form (A/B)
 int nmf_update_cols_per_wave(int Kp);
@@ -118,8 +138,9 @@ bool nmf_update5_supported(int Kp);
 
 // per column k < K of S [C][Kp]: optional clamp to eps, then (if !checkMax or max(S) > eps)
 // divide the column by its L2 norm.  alg/NMF.hpp:150-153 (init) and :162 (after W update).
+// rowsTab (device, [B] ints; ragged corpora): the valid rows of every buffer -- the clamp touches only those
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s);
+                    bool checkMax, double* scratch, hipStream_t s, const int* rowsTab = nullptr);
 int colnorm_scratch_doubles(int C, int Kp, int B);
 
 // ---- deferred normalisation of W (UpdateArgs::nrm) ------------------------------------------------
@@ -145,6 +166,7 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);
 void launch_fill_ones(double* p, int64_t n, hipStream_t s);
 int nmf_update5_strips(int C, int Kp, int B); // wavefronts per buffer launch_nmf_update5 uses (nsplit == 1)
+int nmf_update5_max_groups(int Kp);           // widest strip (16-column groups) a wavefront can hold at this rank
 
 // Strip schedule of one large buffer at rank <= 16 (kernels_nmf_strip.hip): a workgroup owns a strip of frames, does
 // their H update (alg/NMF.hpp:165-170) against the W it staged (normalised while staging when wPend) and, behind it,
@@ -173,8 +195,9 @@ void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_wstats(const StripArgs& a, hipStream_t s);
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
+// rowsTab (device, [B] ints; ragged corpora): only rows < rowsTab[b] of buffer b are written
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,
-                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s);
+                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s, const int* rowsTab = nullptr);
 // f32 seed variant: src[b][k][rows] floats (BufferAdaptor channel-major)
 void launch_scatter_factor_f32(const float* src, int64_t strideSrc, double* dst,
                                int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s);

@@ -233,17 +233,25 @@ int update_finalize_parts(int C, int Kp) { const int rows = update_finalize_rows
 template <int PER>
 __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
                                            const double* dpart, int C, int Kp, int64_t Cp,
-                                           int nsplit, const double* nrm, int nrmMode, double* statPart, int nch)
+                                           int nsplit, const double* nrm, int nrmMode, double* statPart, int nch,
+                                           const int* splitTab)
 {
   extern __shared__ double sh[]; // [kFinSG][nrg][kFinBatch][Kp] partial numerators, then [kFinSG][Kp] denominators; reused for the statistics
   const int chunk = blockIdx.x, buf = blockIdx.y;
+  // work-list mode (ragged corpora): buffer b owns the partials [splitTab[2 b], splitTab[2 b] + splitTab[2 b + 1])
+  int64_t pbase = (int64_t) buf * nsplit;
+  if (splitTab)
+  {
+    pbase = splitTab[2 * buf];
+    nsplit = splitTab[2 * buf + 1];
+  }
   const int nrg = blockDim.x / (Kp * kFinSG);
   const int k = threadIdx.x % Kp, rg = (threadIdx.x / Kp) % nrg, sg = threadIdx.x / (Kp * nrg);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const int sb = sg * per, se = min(nsplit, sb + per);
   const int rows = kFinBatch * nrg;
   const int rbeg = chunk * rows, rend = min(rbeg + rows, C);
-  const double* p0 = part + (int64_t) buf * nsplit * Cp * Kp;
+  const double* p0 = part + pbase * Cp * Kp;
   const int64_t sstride = Cp * Kp;
   // ---- every load of this thread, issued before anything is consumed ---------------------------------------------
   double pv[kFinBatch][PER];
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
     sold[i] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
   }
   {
-    const double* dp = dpart + (int64_t) buf * nsplit * Kp + k;
+    const double* dp = dpart + pbase * Kp + k;
 #pragma unroll
     for (int u = 0; u < PER; u++) dv[u] = (rg == 0 && u < per) ? dp[(int64_t) min(sb + u, nsplit - 1) * Kp] : 0.0;
   }
@@ -335,7 +343,7 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
 
 void launch_update_finalize(double* S, int64_t strideS, const double* part, const double* dpart,
                             int C, int Kp, int64_t Cp, int nsplit, int B, hipStream_t s, const double* nrm,
-                            int nrmMode, double* statPart)
+                            int nrmMode, double* statPart, const int* splitTab)
 {
   const int nrg = fin_row_groups(Kp);
   const int nch = update_finalize_parts(C, Kp);
@@ -343,7 +351,7 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const dim3 grid((unsigned) nch, (unsigned) B), block((unsigned) (kFinSG * nrg * Kp));
 #define FLUHIP_FIN(P) hipLaunchKernelGGL(nmf_update_finalize_kernel<P>, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, \
-                                         nsplit, nrm, nrmMode, statPart, nch)
+                                         nsplit, nrm, nrmMode, statPart, nch, splitTab)
   if (per <= 1) FLUHIP_FIN(1);
   else if (per <= 2) FLUHIP_FIN(2);
   else if (per <= 4) FLUHIP_FIN(4);
@@ -399,10 +407,11 @@ void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
 // ---------------------------------------------------------------------------------------
 
 __global__ void colstats_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp, int clampEps,
-                                double* part, int nch)
+                                double* part, int nch, const int* rowsTab)
 {
   extern __shared__ double sh[]; // [nrg][Kp] sums then [nrg][Kp] maxima
   const int chunk = blockIdx.x, b = blockIdx.y;
+  if (rowsTab) C = rowsTab[b]; // ragged corpora: the buffer's own row count (rows beyond it are padding and stay zero)
   double* S = Sbase + (int64_t) b * strideS;
   const int nrg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
@@ -482,7 +491,7 @@ __global__ void colscale_kernel(double* Sbase, int64_t strideS, int C, int K, in
 int colnorm_scratch_doubles(int C, int Kp, int B) { return ((C + kNormRows - 1) / kNormRows) * 2 * Kp * B; }
 
 void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, bool clampEps,
-                    bool checkMax, double* scratch, hipStream_t s)
+                    bool checkMax, double* scratch, hipStream_t s, const int* rowsTab)
 {
   int nrg = 256 / Kp;
   if (nrg < 1) nrg = 1;
@@ -490,7 +499,7 @@ void launch_colnorm(double* S, int64_t strideS, int C, int K, int Kp, int B, boo
   const int nch = (C + kNormRows - 1) / kNormRows;
   dim3 grid((unsigned) nch, (unsigned) B);
   hipLaunchKernelGGL(colstats_kernel, grid, dim3((unsigned) threads), (size_t) 2 * nrg * Kp * sizeof(double), s, S,
-                     strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch);
+                     strideS, C, K, Kp, clampEps ? 1 : 0, scratch, nch, rowsTab);
   // very long factors (c3: 404 chunks x rank 128) do not fit the partials in LDS: combine from global there
   const bool stage = (size_t) (nch + 1) * 2 * Kp * sizeof(double) <= 48 * 1024;
   const size_t shScale = (size_t) ((stage ? nch : 0) + 1) * 2 * Kp * sizeof(double);
@@ -803,7 +812,7 @@ void launch_fill_ones(double* p, int64_t n, hipStream_t s)
 // layout plumbing (all tiny next to the updates)
 // ---------------------------------------------------------------------------------------
 __global__ void scatter_factor_kernel(const double* src, int64_t strideSrc, double* dst,
-                                      int64_t strideDst, int rows, int K, int Kp, int kMajor)
+                                      int64_t strideDst, int rows, int K, int Kp, int kMajor, const int* rowsTab)
 {
   const int b = blockIdx.y;
   const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -811,16 +820,17 @@ __global__ void scatter_factor_kernel(const double* src, int64_t strideSrc, doub
   int row, k;
   if (kMajor) { k = (int) (idx / rows); row = (int) (idx % rows); }
   else { row = (int) (idx / K); k = (int) (idx % K); }
+  if (rowsTab && row >= rowsTab[b]) return; // ragged corpora: rows past the buffer's own count are padding and stay zero
   dst[(int64_t) b * strideDst + (int64_t) row * Kp + k] = src[(int64_t) b * strideSrc + idx];
 }
 
 void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, int64_t strideDst,
-                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s)
+                           int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s, const int* rowsTab)
 {
   const int64_t total = (int64_t) rows * K;
   dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
   hipLaunchKernelGGL(scatter_factor_kernel, g, dim3(256), 0, s, src, strideSrc, dst, strideDst,
-                     rows, K, Kp, srcIsKMajor ? 1 : 0);
+                     rows, K, Kp, srcIsKMajor ? 1 : 0, rowsTab);
 }
 
 __global__ void scatter_factor_f32_kernel(const float* src, int64_t strideSrc, double* dst,

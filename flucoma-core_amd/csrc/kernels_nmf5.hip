@@ -53,6 +53,9 @@ struct Upd5Args
   int nrmMode;
   double* statPart;
   long long* clk; // {launches, shader cycles, 100 MHz ticks} of wavefront 0 of workgroup 0, accumulated per launch (or null)
+  // work-list mode (ragged corpora, fluhip_kernels.h WaveDesc): wavefront w of workgroup i takes list[4 i + w]; the uniform
+  // mapping above (wavesPerBuf, nsplit, stepsPerSplit, xcdMap) is then unused
+  const WaveDesc* list;
 };
 
 // The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
@@ -112,7 +115,7 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
   }
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
@@ -128,6 +131,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 
   int id = blockIdx.x;
   int buf, wg, split;
+  // work-list mode is a separate instantiation (LIST): the uniform form below keeps its statement order -- and with it its
+  // register allocation, which sits at the limit of the file -- exactly as it was
+  [[maybe_unused]] const WaveDesc* wd = nullptr;
+  if constexpr (LIST != 0)
+  {
+    wd = a.list + ((int64_t) id * 4 * WPS + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+    buf = __builtin_amdgcn_readfirstlane(wd->buf);
+    wg = 0; split = 0;
+  }
+  else
+  {
   if (a.xcdMap)
   {
     const int xcd = id & 7;
@@ -144,6 +158,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     buf = id / (a.nsplit * a.wgPerBuf);
   }
   if (buf >= a.B) return;
+  }
   long long tEntry = 0;
   if constexpr (INSTR) tEntry = (long long) __builtin_amdgcn_s_memrealtime();
   // box-invariant cost of a launch: shader cycles (s_memtime) and 100 MHz ticks (s_memrealtime) of one wavefront that
@@ -159,12 +174,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int WPB = 4 * WPS; // wavefronts per workgroup
   const int strip = wg * WPB + wave;
+  int g0 = 0, ng = 0;
+  if constexpr (LIST != 0)
+  {
+    g0 = __builtin_amdgcn_readfirstlane(wd->g0);
+    ng = __builtin_amdgcn_readfirstlane(wd->ng);
+  }
+  else
+  {
   if (strip >= a.wavesPerBuf) return;
   // Column groups are dealt out as evenly as possible.  With two wavefronts per SIMD (WPS == 2)
   // wavefronts w and w+4 of a workgroup share a SIMD, so the "one extra group" strips are spread
   // over distinct SIMD pairs first: the per-SIMD load stays within one group of the mean.
   const int base = a.nGroups / a.wavesPerBuf, rem = a.nGroups % a.wavesPerBuf;
-  int g0 = 0, ng = 0;
   {
     const int nPairs = (a.wavesPerBuf + WPS - 1) / WPS;
     int acc0 = 0;
@@ -178,6 +200,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       if (st == strip) { g0 = acc0; ng = cnt; }
       acc0 += cnt;
     }
+  }
   }
   if (ng <= 0) return;
 
@@ -217,8 +240,17 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     moffs[j] = (unsigned) ((row * KP + c * 2) * 8);    // slot pos of row `row` holds chunk c
   }
 
-  const int s0 = split * a.stepsPerSplit;
-  const int s1 = min(s0 + a.stepsPerSplit, a.nSteps);
+  int s0, s1;
+  if constexpr (LIST != 0)
+  {
+    s0 = __builtin_amdgcn_readfirstlane(wd->s0);
+    s1 = __builtin_amdgcn_readfirstlane(wd->s1);
+  }
+  else
+  {
+    s0 = split * a.stepsPerSplit;
+    s1 = min(s0 + a.stepsPerSplit, a.nSteps);
+  }
   const int sLast = s1 - 1;
 
   auto issue_stage = [&](int st) {
@@ -787,6 +819,15 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     }
   }
 
+  // where the results go: split partials (a finalize launch forms the result) or the result itself + column statistics
+  [[maybe_unused]] int lPart = -1, lStat = 0, lD = -1;
+  if constexpr (LIST != 0)
+  {
+    lPart = __builtin_amdgcn_readfirstlane(wd->partIdx);
+    lStat = __builtin_amdgcn_readfirstlane(wd->statIdx);
+    lD = __builtin_amdgcn_readfirstlane(wd->dIdx);
+  }
+  auto whole = [&]() -> bool { if constexpr (LIST != 0) return lPart < 0; else return a.nsplit == 1; };
   if constexpr (DS)
   {
 #pragma unroll
@@ -798,14 +839,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       dsum[m] = d;
     }
   }
-  else if (a.nsplit == 1)
+  else if (whole())
   {
     // DS == 0: the column sums of Mv were taken by launch_colsum into slot (buf, split 0) of dpart (the wide
     // ranks have no registers to spare for M accumulators every wavefront would hold identically)
     load_vec5<M>(dsum, a.dpart + (int64_t) buf * KP + M * x);
   }
 
-  if (a.nsplit == 1)
+  if (whole())
   {
     double nrE[M], ss[M], mx[M];
     if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
@@ -911,7 +952,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       }
       if (lane < 4)
       {
-        double* sp = a.statPart + ((int64_t) buf * a.wavesPerBuf + strip) * 2 * KP + M * x;
+        double* sp = a.statPart + (LIST ? (int64_t) lStat : ((int64_t) buf * a.wavesPerBuf + strip)) * 2 * KP + M * x;
 #pragma unroll
         for (int m = 0; m < M; m++) { sp[m] = ss[m]; sp[KP + m] = mx[m]; }
       }
@@ -919,7 +960,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   }
   else
   {
-    double* part = a.part + ((int64_t) buf * a.nsplit + split) * a.Cp * KP;
+    double* part = a.part + (LIST ? (int64_t) lPart : ((int64_t) buf * a.nsplit + split)) * a.Cp * KP;
 #pragma unroll
     for (int g = 0; g < NG; g++)
     {
@@ -931,9 +972,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         for (int m = 0; m < M; m++) pp[m] = acc[g][m];
       }
     }
-    if (DS && strip == 0 && blk == 0 && y == 0)
+    if (DS && (LIST ? lD >= 0 : strip == 0) && blk == 0 && y == 0)
     {
-      double* dp = a.dpart + ((int64_t) buf * a.nsplit + split) * KP + M * x;
+      double* dp = a.dpart + (LIST ? (int64_t) lD : ((int64_t) buf * a.nsplit + split)) * KP + M * x;
 #pragma unroll
       for (int m = 0; m < M; m++) dp[m] = dsum[m];
     }
@@ -955,6 +996,29 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 }
 
 
+// work-list mode: the LIST instantiation of the same kernel, one workgroup per four descriptors
+template <int M, int NG, int NS, int MODE>
+static void launch5_list(const UpdateArgs& a, hipStream_t s)
+{
+  Upd5Args k{};
+  k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
+  k.Mv = a.Mv; k.strideM = a.strideM;
+  k.S = a.S; k.strideS = a.strideS;
+  k.R = a.R; k.C = a.C; k.B = a.B;
+  k.nGroups = (a.C + 15) / 16;
+  k.wavesPerBuf = 1; k.wgPerBuf = 1; k.nSteps = (a.R + 3) / 4; k.nsplit = 1; k.stepsPerSplit = k.nSteps;
+  k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
+  k.nrm = a.nrm; k.nrmMode = a.nrmMode; k.statPart = a.listPartial ? nullptr : a.statPart;
+  k.clk = a.clk; k.xcdMap = 0; k.list = a.list;
+  constexpr int KP = 4 * M, SPR = KP / 2;
+  constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
+  constexpr size_t shmem = (size_t) 4 * NS * (NJV + NJM) * 1024;
+  auto kern = nmf_update5_kernel<M, NG, NS, 1, 0, MODE, 1, 1>;
+  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int) shmem);
+  hipLaunchKernelGGL(kern, dim3((unsigned) a.listWGs), dim3(256), shmem, s, k);
+}
+
 template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
@@ -975,6 +1039,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   k.nrm = a.nrm; k.nrmMode = a.nrmMode; k.statPart = a.nsplit > 1 ? nullptr : a.statPart;
   k.clk = a.clk;
   k.xcdMap = a.B >= 8 ? 1 : 0;
+  k.list = nullptr;
   const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
   constexpr int KP = 4 * M, SPR = KP / 2;
@@ -1048,6 +1113,25 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
   }
 }
 
+// the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
+// sets up to rank 32, refilled in place at rank 64, grouped at rank 128 (the in-place form has no room for the column sums
+// there, and the pre-pass that replaces them deals its slots per equal-length buffer)
+template <int M, int NG>
+static void launch5_list_ng(const UpdateArgs& a, int ng, hipStream_t s)
+{
+  if constexpr (NG == 1) launch5_list<M, 1, ring_depth<M, 1, 1>(), 0>(a, s);
+  else
+  {
+    if (ng >= NG)
+    {
+      constexpr int NS = ring_depth<M, NG, 1>();
+      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M == 32 ? 0 : (M == 16 ? 2 : 1)) : 0;
+      launch5_list<M, NG, NS, MODE>(a, s);
+    }
+    else launch5_list_ng<M, NG - 1>(a, ng, s);
+  }
+}
+
 bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
 static int k5_wps()
 {
@@ -1055,6 +1139,7 @@ static int k5_wps()
   static const int wps = [] { const char* e = std::getenv("FLUHIP_K5_WPS"); return e ? std::atoi(e) : 1; }();
   return wps;
 }
+int nmf_update5_max_groups(int Kp) { return Kp <= 32 ? 9 : (Kp <= 64 ? 4 : 2); }
 int nmf_update5_strips(int C, int Kp, int B)
 {
   const int G = (C + 15) / 16;
@@ -1067,6 +1152,20 @@ int nmf_update5_strips(int C, int Kp, int B)
 // keeps at least one group
 void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
+  if (a.list)
+  {
+    // work-list mode: one wavefront per SIMD, the widest strip of the list picks the instantiation; the column sums
+    // always ride in the kernel (no pre-pass: its per-buffer slots are dealt differently here)
+    switch (a.Kp / 4)
+    {
+    case 4: launch5_list_ng<4, 9>(a, a.listNG, s); break;
+    case 8: launch5_list_ng<8, 9>(a, a.listNG, s); break;
+    case 16: launch5_list_ng<16, 4>(a, a.listNG, s); break;
+    case 32: launch5_list_ng<32, 2>(a, a.listNG, s); break;
+    default: break;
+    }
+    return;
+  }
   const int G = (a.C + 15) / 16;
   const int w = nmf_update5_strips(a.C, a.Kp, a.B);
   const bool two = w != nmf_update4_waves_per_buffer(a.C, a.Kp, a.B);

@@ -59,6 +59,7 @@ struct StftBArgs
   int frameOffset;
   int blocksPerBuf;
   int64_t totalBlocks;
+  const int64_t* nTab;    // ragged corpora: samples of every buffer (n is then the longest), or nullptr
 };
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -379,7 +380,8 @@ struct FftCore
 // gather + window of frame t of buffer b: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 (alg/STFT.hpp:94-105;
 // clients/nrt/NMFClient.hpp:240 float -> double); zero outside [0, n)
 template <int R1, int N>
-__device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, int lane, const d2* wsrc, cx (&pts)[N / 64])
+__device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, int lane, const d2* wsrc, cx (&pts)[N / 64],
+                                              int64_t nSamples)
 {
   constexpr int NB1 = N / (64 * R1);
   const int64_t s0 = (int64_t) t * a.hop - a.win / 2 + a.frameOffset;
@@ -387,7 +389,7 @@ __device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, 
   // sample positions are 32-bit offsets from the frame's first sample (a wave-uniform 64-bit base); only frames
   // that stick out of the buffer (or an odd base) take the clamped path
   const int lo = s0 < 0 ? (int) (-s0 < 2 * N ? -s0 : 2 * N) : 0;                 // first valid offset
-  const int64_t room = a.n - s0;
+  const int64_t room = nSamples - s0;
   const int hi = room < 2 * N ? (int) (room > 0 ? room : 0) : 2 * N;             // one past the last valid offset
   if (a.audio)
   {
@@ -496,12 +498,15 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     if ((L >> 3) >= chunk) break;
     if (!decode(L, b, t0)) continue;
     const int t = t0 + wave;
-    const bool active = t < a.T;
+    // ragged corpora: the buffer's own length decides its frame count (alg/STFT.hpp:98-99); frames past it are padding
+    const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
+    const int Tb = a.nTab ? (int) ((nSamples + a.hop) / a.hop) : a.T;
+    const bool active = t < Tb;
 
     if (active)
     {
       cx pts[PPL];
-      gather_points<R1, N>(a, b, t, lane, wsrc, pts);
+      gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
       SCHED_FENCE();
       core.template run<SPEC>(pts, SPEC ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
     }
@@ -645,7 +650,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     if (t >= a.T) continue;
     {
       cx pts[PPL];
-      gather_points<R1, N>(a, b, t, lane, wl, pts);
+      gather_points<R1, N>(a, b, t, lane, wl, pts, a.n);
       SCHED_FENCE();
       core.template run<false>(pts, nullptr);
     }
@@ -761,6 +766,7 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
   k.window = a.window; k.twiddle = a.twiddle;
   k.mag = nullptr; k.magStride = 0; k.ldMag = 0; k.magT = nullptr; k.magTStride = 0; k.ldMagT = 0;
   k.spec = nullptr; k.specStride = 0; k.frameOffset = a.frameOffset; k.blocksPerBuf = 0; k.totalBlocks = 0;
+  k.nTab = nullptr;
   FeatFusedArgs fa;
   fa.up = up; fa.dn = dn; fa.slot = slot; fa.dct = f.dct;
   fa.nBands = f.nBands; fa.nDct = f.nDct; fa.startCoeff = f.startCoeff; fa.nOut = f.nOut;
@@ -810,6 +816,7 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
   k.spec = a.spec; k.specStride = a.specStride;
   k.frameOffset = a.frameOffset;
   k.blocksPerBuf = 0; k.totalBlocks = 0;
+  k.nTab = a.nTab;
   if (magT && (ldMagT % 2) != 0) return false;
   if (a.fft == 2048)
   {

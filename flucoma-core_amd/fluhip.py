@@ -51,7 +51,8 @@ EXPORTS = [
     "fluhip_nmf_process_f64", "fluhip_nmf_process_views_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
     "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
-    "fluhip_corpus_create",
+    "fluhip_corpus_create", "fluhip_corpus_create_ragged", "fluhip_corpus_frames_of", "fluhip_corpus_set_audio_ragged_host",
+    "fluhip_corpus_writeback_ragged_host",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
@@ -114,6 +115,11 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_bufstft_forward_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _fp, _ip]
     L.fluhip_bufstft_inverse_f32.argtypes = [_vp, _fp, _fp, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _ip]
     L.fluhip_corpus_create.argtypes = [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
+    L.fluhip_corpus_create_ragged.argtypes = [_vp, _i64, _ip, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
+    L.fluhip_corpus_frames_of.argtypes = [_vp, _i64]
+    L.fluhip_corpus_frames_of.restype = _i64
+    L.fluhip_corpus_set_audio_ragged_host.argtypes = [_vp, ctypes.POINTER(_fp)]
+    L.fluhip_corpus_writeback_ragged_host.argtypes = [_vp, ctypes.POINTER(_fp), ctypes.POINTER(_fp)]
     L.fluhip_corpus_destroy.argtypes = [_vp]
     L.fluhip_corpus_destroy.restype = None
     for f in ("fluhip_corpus_frames", "fluhip_corpus_bins", "fluhip_corpus_device_bytes"):
@@ -487,6 +493,40 @@ class Corpus:
         H1 = np.empty((self.count, self.T, self.K)) if factors else None
         self.ctx._check(self.ctx.lib.fluhip_corpus_read_f64(self.h, _d(m), _d(W1), _d(H1)))
         return m, W1, H1
+
+
+class RaggedCorpus(Corpus):
+    """fluhip_corpus_create_ragged: mono buffers of DIFFERENT lengths as one device-resident batch.  T / n are those of the
+    longest buffer (the shapes read_f64 returns; frames past a buffer's own are zero); Ts holds every buffer's own frames."""
+
+    def __init__(self, ctx: Context, lens, win, fft, hop, K):
+        self.ctx = ctx
+        self.lens = [int(x) for x in lens]
+        self.count, self.n, self.win, self.fft, self.hop, self.K = len(self.lens), max(self.lens), win, fft, hop, K
+        arr = (ctypes.c_int64 * self.count)(*self.lens)
+        h = _vp()
+        ctx._check(ctx.lib.fluhip_corpus_create_ragged(ctx.h, self.count, arr, win, fft, hop, K, ctypes.byref(h)))
+        self.h = h
+        if not hasattr(ctx, "_corpora"):
+            ctx._corpora = []
+        ctx._corpora.append(weakref.ref(self))
+        self.T = int(ctx.lib.fluhip_corpus_frames(h))
+        self.F = int(ctx.lib.fluhip_corpus_bins(h))
+        self.Ts = [int(ctx.lib.fluhip_corpus_frames_of(h, i)) for i in range(self.count)]
+
+    def set_audio(self, audios):
+        audios = [np.ascontiguousarray(a, dtype=np.float32) for a in audios]
+        assert [a.shape[0] for a in audios] == self.lens
+        ap = (_fp * self.count)(*[a.ctypes.data_as(_fp) for a in audios])
+        self.ctx._check(self.ctx.lib.fluhip_corpus_set_audio_ragged_host(self.h, ap))
+
+    def writeback(self):
+        bases = [np.empty((self.K, self.F), dtype=np.float32) for _ in range(self.count)]
+        acts = [np.empty((self.K, T), dtype=np.float32) for T in self.Ts]
+        bp = (_fp * self.count)(*[b.ctypes.data_as(_fp) for b in bases])
+        cp = (_fp * self.count)(*[c.ctypes.data_as(_fp) for c in acts])
+        self.ctx._check(self.ctx.lib.fluhip_corpus_writeback_ragged_host(self.h, bp, cp))
+        return bases, acts
 
 
 class Pool:

@@ -244,6 +244,22 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
  * they apply to every later fluhip_corpus_nmf of this corpus until replaced (NULL: back to random draws from the seed).
  * Seed mode = seeds + update flag 1, Fixed mode = seeds + update flag 0 (fluhip_corpus_nmf's update_w / update_h). */
 int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed);
+/* RAGGED corpus: `count` mono buffers of DIFFERENT lengths n[i] (a folder of sound files) as one device-resident batch --
+ * one STFT launch and one set of factor-update launches per iteration over all of them, the work dealt per wavefront
+ * by each buffer's own frame count T_i = (n[i] + hop) / hop (long contractions are split, the strips of the H update
+ * follow the buffer's frames).  Every buffer is the same independent BufNMF job as in an equal-length corpus
+ * (clients/nrt/NMFClient.hpp:233 loop body).  Supported: ranks up to 128, fft 1024 / 2048 / 4096 with an even window
+ * (FLUHIP_ERROR with a message otherwise: run such buffers as equal-length groups).  The other corpus entry points work
+ * on a ragged corpus with T = the longest buffer's frame count: fluhip_corpus_stft, fluhip_corpus_nmf (seed / seeds),
+ * fluhip_corpus_set_factors (bases only), fluhip_corpus_read_f64 (frames past a buffer's own are zero),
+ * fluhip_corpus_plan. */
+int fluhip_corpus_create_ragged(fluhip_ctx* ctx, int64_t count, const int64_t* n, int64_t win, int64_t fft, int64_t hop,
+                                int64_t K, fluhip_corpus** out);
+int64_t fluhip_corpus_frames_of(const fluhip_corpus* c, int64_t i);   /* T_i (T for an equal-length corpus) */
+/* audio[i]: n[i] host floats */
+int fluhip_corpus_set_audio_ragged_host(fluhip_corpus* c, const float* const* audio);
+/* bases[i]: K x F floats, acts[i]: K x T_i floats (either array, or single entries, may be NULL) */
+int fluhip_corpus_writeback_ragged_host(fluhip_corpus* c, float* const* bases, float* const* acts);
 /* write-back (clients/nrt/NMFClient.hpp:277-300) into device or host float arrays:
  * bases: count x K x F, acts: count x K x T.  Either may be NULL. */
 int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev);

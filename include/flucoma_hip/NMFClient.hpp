@@ -314,9 +314,27 @@ public:
       std::vector<float> seedWAll, seedHAll;
       if (seedFilters) seedWAll.resize(nc * static_cast<size_t>(rank * nBins));
       if (seedEnvelopes) seedHAll.resize(nc * static_cast<size_t>(rank * nWindows));
+      {
+        // :240 for every channel.  The channels of a host buffer are usually interleaved (MemoryBufferAdaptor: frames x
+        // channels), so a channel at a time would pull the whole buffer through the cache once per channel: the frames go
+        // in blocks that stay cached across the channel views instead.
+        std::vector<VectorView<const float>> chan;
+        for (index i = 0; i < nChannels; ++i) chan.push_back(source.samps(P.startFrame, nFrames, P.startChan + i));
+        constexpr index kBlock = 4096;
+        for (index t0 = 0; t0 < nFrames; t0 += kBlock)
+        {
+          const index nb = std::min<index>(kBlock, nFrames - t0);
+          for (index i = 0; i < nChannels; ++i)
+          {
+            const float* src = chan[static_cast<size_t>(i)].data() + t0 * chan[static_cast<size_t>(i)].stride;
+            const index  st = chan[static_cast<size_t>(i)].stride;
+            float*       dst = audioAll.data() + i * nFrames + t0;
+            for (index t = 0; t < nb; ++t) dst[t] = src[t * st];
+          }
+        }
+      }
       for (index i = 0; i < nChannels; ++i)
       {
-        VectorView<float>(audioAll.data() + i * nFrames, nFrames) <<= source.samps(P.startFrame, nFrames, P.startChan + i);
         for (index j = 0; j < rank; ++j)
         {
           if (seedFilters)

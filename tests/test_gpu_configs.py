@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from helpers import TOL_FACTORS_TIGHT, TOL_STFT, rel_err
+from helpers import TOL_FACTORS_TIGHT, TOL_STFT, rel_err  # noqa: F401
 from test_client import OK, read_buffer, run
 
 pytestmark = pytest.mark.gpu
@@ -230,6 +230,51 @@ def test_pool_ragged_corpus(ctx, oracle, onp):
     with pytest.raises(fluhip.FluhipError):
         pool.bufnmf_ragged([np.zeros(0, dtype=np.float32)], win, fft, hop, K, iters)
     pool.close()
+
+
+def test_ragged_corpus_64_buffers_of_40_lengths_at_equal_length_speed(ctx, oracle, onp):
+    """a folder of different-length files on the batched schedule.  64 buffers of 40 distinct lengths
+    (4 .. 16 s, rank 32, fft 2048) as ONE ragged corpus: a sample of the buffers against the oracle, and the iterations at
+    >= 1 / 1.2 of the buffer-iterations/s of an equal-length corpus with the same number of buffers and total frames."""
+    import time
+    import fluhip
+    win, fft, hop, K = 2048, 2048, 512, 32
+    rs = np.random.RandomState(7)
+    distinct = sorted(int(x) for x in rs.randint(4 * 44100, 16 * 44100, 40))
+    lens = [distinct[i % 40] for i in range(64)]
+    rs.shuffle(lens)
+    assert len(set(lens)) == 40
+    base = [onp.synth_audio(16 * 44100, 5000 + i) for i in range(8)]
+    audios = [base[i % 8][:n] for i, n in enumerate(lens)]
+    c = fluhip.RaggedCorpus(ctx, lens, win, fft, hop, K)
+    c.set_audio(audios); c.stft()
+    iters = 6
+    c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    for b in (0, 13, 40, 63, int(np.argmin(lens)), int(np.argmax(lens))):
+        T = c.Ts[b]
+        _, rmag = oracle.stft_f32(audios[b], win, fft, hop)
+        assert rel_err(mag[b, :T], rmag) < TOL_STFT
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b, :T], rH) < TOL_FACTORS_TIGHT, b
+    del mag, W1, H1
+
+    def rate(corpus, n_it=60):
+        corpus.nmf(10, seed=42); ctx.synchronize()
+        t0 = time.perf_counter(); corpus.nmf(0, seed=42); ctx.synchronize(); t_fixed = time.perf_counter() - t0
+        t0 = time.perf_counter(); corpus.nmf(n_it, seed=42); ctx.synchronize()
+        return (time.perf_counter() - t0 - t_fixed) / n_it
+    t_ragged = rate(c)
+    plan_r = c.plan()
+    c.close()
+    n_eq = int(sum(lens) / len(lens))
+    u = fluhip.Corpus(ctx, 64, n_eq, win, fft, hop, K)
+    u.set_audio(np.stack([base[i % 8][:n_eq] for i in range(64)])); u.stft()
+    t_equal = rate(u)
+    plan_u = u.plan()
+    u.close()
+    print(f"64 buffers, 40 lengths: ragged {t_ragged * 1e6:.0f} us / iteration {plan_r}, equal-length twin {t_equal * 1e6:.0f} us {plan_u}")
+    assert t_ragged <= 1.2 * t_equal, (t_ragged, t_equal)
 
 
 def _bench(args, env=None):

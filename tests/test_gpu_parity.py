@@ -701,6 +701,70 @@ def test_corpus_per_buffer_seeds(ctx, oracle, onp):
     c.close()
 
 
+def _check_ragged(ctx, oracle, onp, lens, win, fft, hop, K, iters, check, seeds=None, seedW=None, uw=True):
+    import fluhip
+    audios = [onp.synth_audio(n, 9000 + i) for i, n in enumerate(lens)]
+    c = fluhip.RaggedCorpus(ctx, lens, win, fft, hop, K)
+    assert c.Ts == [(n + hop) // hop for n in lens] and c.T == max(c.Ts)
+    c.set_audio(audios); c.stft()
+    if seedW is not None:
+        c.set_factors(seedW, None)
+    c.nmf(iters, seed=42, seeds=seeds, updateW=uw)
+    mag, W1, H1 = c.read_f64()
+    bases, acts = c.writeback()
+    plan = c.plan()
+    c.close()
+    for b in check:
+        T = (lens[b] + hop) // hop
+        _, rmag = oracle.stft_f32(audios[b], win, fft, hop)
+        assert rel_err(mag[b, :T], rmag) < TOL_STFT, b
+        assert not mag[b, T:].any() and not H1[b, T:].any(), b             # padding frames are zero and stay zero
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, True, 42 if seeds is None else seeds[b],
+                                          W0=None if seedW is None else seedW[b].astype(np.float64))
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b, :T], rH) < TOL_FACTORS_TIGHT, b
+        rb, ra = oracle.bufnmf_writeback(rW, rH)
+        assert bases[b].shape == rb.shape and acts[b].shape == ra.shape
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6, b
+    return plan
+
+
+def test_ragged_corpus_few_buffers_split_contractions(ctx, oracle, onp):
+    """fluhip_corpus_create_ragged, the small-corpus regime: a handful of buffers of very different lengths (one frame to 12 s)
+    in one set of launches -- the W update's contractions split by each buffer's own length (work-list mode + the finalize's
+    per-buffer split table), the H update's strips following each buffer's frames; every buffer against the oracle"""
+    lens = [529200, 100, 44100, 200001, 88200, 3000, 352800, 257, 61234]
+    plan = _check_ragged(ctx, oracle, onp, lens, 2048, 2048, 512, 32, 8, range(len(lens)))
+    assert plan["kernel"] == 5 and plan["split_w"] > 1, plan
+    # per-buffer seeds, a rank that is not a multiple of 16, another transform size, seeded and fixed bases
+    lens = [30000, 22050, 30000, 5000, 22050, 30000, 12345, 257]
+    _check_ragged(ctx, oracle, onp, lens, 1024, 1024, 256, 5, 10, range(len(lens)), seeds=[7, 7, 8, 9, 10, 11, 12, 13])
+    rs = np.random.RandomState(2)
+    sW = rs.uniform(0.05, 1.0, (len(lens), 5, 513)).astype(np.float32)
+    _check_ragged(ctx, oracle, onp, lens, 1024, 1024, 256, 5, 10, (0, 3, 7), seedW=sW)
+    _check_ragged(ctx, oracle, onp, lens, 1024, 1024, 256, 5, 10, (1, 6), seedW=sW, uw=False)
+    _check_ragged(ctx, oracle, onp, [40000, 9000, 70001], 4096, 4096, 1024, 70, 4, range(3))   # padded rank 128, fft 4096
+
+
+def test_ragged_corpus_many_buffers_whole_contractions(ctx, oracle, onp):
+    """the large-corpus regime: enough buffers that every (buffer, strip) wavefront keeps its whole contraction -- no
+    split, results and column statistics straight from the update kernel, the Nyquist side column -- with lengths from
+    0.1 s to 3 s dealt longest first"""
+    rs = np.random.RandomState(4)
+    lens = [int(x) for x in rs.randint(4410, 132300, 260)]
+    lens[17] = 132300; lens[200] = 300
+    plan = _check_ragged(ctx, oracle, onp, lens, 2048, 2048, 512, 32, 6, (0, 17, 99, 200, 259))
+    assert plan["split_w"] == 1 and plan["split_h"] == 1 and plan["side_column"] == 1, plan
+
+
+def test_ragged_corpus_rejects_what_it_does_not_cover(ctx):
+    import fluhip
+    for args in (([1000, 2000], 1024, 1024, 256, 200),      # rank above 128
+                 ([1000, 2000], 512, 512, 128, 4),          # no block STFT for fft 512
+                 ([1000, 0], 1024, 1024, 256, 4)):          # an empty buffer
+        with pytest.raises(fluhip.FluhipError):
+            fluhip.RaggedCorpus(ctx, *args)
+
+
 @pytest.mark.parametrize("uw,uh", [(True, True), (False, True), (True, False), (False, False)])
 def test_corpus_seeded_and_fixed_factors(ctx, oracle, onp, uw, uh):
     """fluhip_corpus_set_factors: basesMode / actMode Seed and Fixed (nrt/NMFClient.hpp:246-258 -> alg/NMF.hpp:102-124) on
