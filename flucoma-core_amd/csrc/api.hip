@@ -526,35 +526,60 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
 // ragged corpora: work lists of the two factor updates
 // ---------------------------------------------------------------------------------------
 namespace {
-struct WaveUnit
+// up to four wavefronts that share a strip and split its contraction (WaveDesc::grp); they stay together in one workgroup
+struct WaveGroup
 {
-  int buf, split, nsplit, s0, s1; // a (buffer, contraction range) pair: `waves` wavefronts, one per strip
-  int64_t work;
+  std::vector<WaveDesc> waves; // waves[0] is the leader; grp holds (rank << 4 | size << 8) until the packing
+  int64_t work;                // what the group takes: its longest member
+  int buf;
 };
 
-// wavefronts -> workgroups of 4, dealt over the 8 XCDs (workgroup i runs on XCD i & 7): the units are taken longest
-// first (the hardware hands the next workgroup to whichever CU frees up), all wavefronts of a unit to one XCD
-void pack_list(const std::vector<std::vector<WaveDesc>>& units, std::vector<WaveDesc>& out, int* wgs)
+// groups -> workgroups of 4 wavefronts: longest first (the hardware hands the next workgroup to whichever CU frees up),
+// first fit (a later, shorter group fills the slots an earlier workgroup has left).  Workgroup i runs on XCD i & 7 and a
+// launch of up to 256 workgroups is ONE round only if every XCD gets at most 32 of them, so the workgroups are numbered
+// in list order -- 8 consecutive ones on 8 different XCDs -- rather than by buffer.
+void pack_groups(std::vector<WaveGroup>& groups, std::vector<WaveDesc>& out, int* wgs)
 {
-  std::vector<std::vector<WaveDesc>> q(8);
-  std::vector<size_t> load(8, 0);
-  for (const auto& u : units)
+  std::stable_sort(groups.begin(), groups.end(), [](const WaveGroup& a, const WaveGroup& b) { return a.work > b.work; });
+  std::vector<std::vector<WaveDesc>> q; // workgroups of up to 4 descriptors
+  size_t firstOpen = 0;
+  for (const auto& g : groups)
   {
-    size_t best = 0;
-    for (size_t x = 1; x < 8; x++)
-      if (load[x] < load[best]) best = x;
-    q[best].insert(q[best].end(), u.begin(), u.end());
-    load[best] += u.size();
+    bool placed = false;
+    while (firstOpen < q.size() && q[firstOpen].size() >= 4) firstOpen++;
+    for (size_t i = firstOpen; i < q.size(); i++)
+      if (q[i].size() + g.waves.size() <= 4) { q[i].insert(q[i].end(), g.waves.begin(), g.waves.end()); placed = true; break; }
+    if (!placed) q.push_back(g.waves);
   }
-  size_t slots = 0;
-  for (auto& v : q) slots = std::max(slots, (v.size() + 3) / 4);
-  out.assign(slots * 8 * 4, WaveDesc{0, 0, 0, 0, 0, -1, 0, -1});
-  for (size_t x = 0; x < 8; x++)
-    for (size_t i = 0; i < q[x].size(); i++) out[((i / 4) * 8 + x) * 4 + (i % 4)] = q[x][i];
-  *wgs = (int) (slots * 8);
+  out.assign(q.size() * 4, WaveDesc{0, 0, 0, 0, 0, -1, 0, -1, 0, 0, 0, 0});
+  for (size_t i = 0; i < q.size(); i++)
+  {
+    auto& wgp = q[i];
+    bool barrier = false;
+    for (const auto& d : wgp) barrier = barrier || ((d.grp >> 8) & 15) > 1;
+    size_t leaderAt = 0; // the leader's wavefront index is known only now
+    for (size_t w = 0; w < wgp.size(); w++)
+    {
+      WaveDesc d = wgp[w];
+      const int rank = (d.grp >> 4) & 15, size = (d.grp >> 8) & 15;
+      if (rank == 0) leaderAt = w;
+      d.grp = (int) leaderAt | (rank << 4) | (size << 8) | (barrier ? (1 << 16) : 0);
+      out[i * 4 + w] = d;
+    }
+  }
+  *wgs = (int) q.size();
+}
+
+int upload_list(fluhip_ctx* ctx, DevBuf& dst, const void* src, size_t bytes)
+{
+  HIPCHK(ctx, dst.alloc(bytes, false, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // the host image may go out of scope
+  return FLUHIP_OK;
 }
 } // namespace
 
+// Work lists of the two factor updates over buffers with their own frame counts tOf[b] (a ragged corpus).
 static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
@@ -565,158 +590,203 @@ static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
   {
     std::vector<int> steps((size_t) B);
     for (int b = 0; b < B; b++) steps[(size_t) b] = (c->tOf[(size_t) b] + 3) / 4;
-    // the Nyquist bin as a side column when that makes the strips even (fluhip_kernels.h SideColumn) and nothing is split
+    // the Nyquist bin as a side column when that makes the strips narrower (fluhip_kernels.h SideColumn): a wavefront
+    // runs the loop of the widest strip of the launch, so 65 column groups over 8 strips cost every strip a ninth group
     auto strips_for = [&](int C) { const int G = (C + 15) / 16; return (G + maxNG - 1) / maxNG; };
-    int wW = strips_for(F);
-    int64_t waves0 = (int64_t) B * wW;
-    // split the contractions when one round of wavefronts (1024 SIMDs) would stay part empty: S steps per wavefront
-    int S = 0;
-    if (waves0 < 1536)
-    {
-      const int64_t target = waves0 <= 1024 ? 1024 : 2048;
-      for (S = 12;; S++)
-      {
-        int64_t w = 0;
-        bool capped = false;
-        for (int b = 0; b < B; b++)
-        {
-          const int ns = (steps[(size_t) b] + S - 1) / S;
-          if (ns > 64) capped = true;
-          w += (int64_t) wW * ns;
-        }
-        if (w <= target && !capped) break;
-      }
-      bool any = false;
-      for (int b = 0; b < B; b++) any = any || steps[(size_t) b] > S;
-      if (!any) S = 0;
-    }
-    c->sideW = S == 0 && nmf_side_column_supported((int) c->T, F, Kp) && strips_for(F - 1) <= wW &&
-               (((F - 1 + 15) / 16 + strips_for(F - 1) - 1) / strips_for(F - 1) < ((F + 15) / 16 + wW - 1) / wW);
+    auto widest = [&](int C) { const int G = (C + 15) / 16, w = strips_for(C); return (G + w - 1) / w; };
     static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
-    if (sideOff) c->sideW = false;
+    c->sideW = !sideOff && nmf_side_column_supported((int) c->T, F, Kp) &&
+               (strips_for(F - 1) < strips_for(F) || (strips_for(F - 1) == strips_for(F) && widest(F - 1) < widest(F)));
     const int C = F - (c->sideW ? 1 : 0);
     const int G = (C + 15) / 16;
-    wW = strips_for(C);
+    const int wW = strips_for(C);
     const int ngW = (G + wW - 1) / wW;
-    std::vector<WaveUnit> units;
+    // Contractions are cut into pieces when one round of wavefronts (1024 SIMDs) would stay part empty: the wavefront
+    // budget of one round (two when the whole contractions already need more than one) goes to whichever buffer has the
+    // longest pieces, until pieces are down to 12 steps -- the longest piece is what the launch takes.
+    const int64_t waves0 = (int64_t) B * wW;
+    // (FLUHIP_RG_*: schedule overrides for A/B measurements, tools/ragged_timing.py)
+    auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    const int gmax = std::min(envInt("FLUHIP_RG_GMAX", 4), nmf_update5_groups_fit(Kp, ngW) ? 4 : 1);
+    std::vector<int> nsOf((size_t) B, 1);
+    std::vector<WaveDesc> list;
     std::vector<int> splitTab((size_t) B * 2);
+    bool anyPartial = false;
     int64_t pbase = 0;
     int maxSplit = 1;
-    for (int b = 0; b < B; b++)
+    // One workgroup (4 wavefronts) per CU: a launch of up to 256 workgroups is one round.  The budget is lowered until the
+    // packed list -- groups of 3 leave a slot empty unless a single fills it -- is back within the rounds it was meant for.
+    const int64_t wgs0 = (waves0 + 3) / 4;
+    const int64_t roundsWanted = wgs0 <= 384 ? std::max<int64_t>(1, (wgs0 + 255) / 256) : 0; // 0: many rounds, no splitting
+    for (int64_t budgetWaves = envInt("FLUHIP_RG_WBUDGET", (int) (1024 * std::max<int64_t>(roundsWanted, 1)));; budgetWaves -= 32)
     {
-      const int ns = S > 0 ? std::max(1, (steps[(size_t) b] + S - 1) / S) : 1;
-      const int per = (steps[(size_t) b] + ns - 1) / ns;
-      splitTab[(size_t) b * 2] = (int) pbase;
-      splitTab[(size_t) b * 2 + 1] = ns;
-      maxSplit = std::max(maxSplit, ns);
-      for (int j = 0; j < ns; j++)
+      std::fill(nsOf.begin(), nsOf.end(), 1);
+      if (roundsWanted > 0 && budgetWaves > waves0)
       {
-        const int s0 = j * per, s1 = std::min(steps[(size_t) b], s0 + per);
-        units.push_back(WaveUnit{b, j, ns, s0, std::max(s0, s1), (int64_t) (s1 - s0)});
+        const int64_t budget = budgetWaves / wW;
+        auto piece = [&](int b) { return (steps[(size_t) b] + nsOf[(size_t) b] - 1) / nsOf[(size_t) b]; };
+        std::vector<std::pair<int, int>> heap; // (piece, buffer)
+        for (int b = 0; b < B; b++) heap.emplace_back(piece(b), b);
+        std::make_heap(heap.begin(), heap.end());
+        for (int64_t units = B; units < budget; units++)
+        {
+          std::pop_heap(heap.begin(), heap.end());
+          const int b = heap.back().second;
+          if (heap.back().first <= 12 || nsOf[(size_t) b] >= 64) break; // the longest piece cannot get shorter
+          nsOf[(size_t) b]++;
+          heap.back() = std::make_pair(piece(b), b);
+          std::push_heap(heap.begin(), heap.end());
+        }
       }
-      pbase += ns;
-    }
-    std::stable_sort(units.begin(), units.end(), [](const WaveUnit& a, const WaveUnit& b) { return a.work > b.work; });
-    std::vector<std::vector<WaveDesc>> packed;
-    for (const auto& u : units)
-    {
-      std::vector<WaveDesc> ws;
-      const int base = G / wW, rem = G % wW;
-      int g0 = 0;
-      for (int st = 0; st < wW; st++)
+      // the pieces of one strip go to up to four wavefronts of one workgroup (added up through the LDS: WaveDesc::grp);
+      // only what is left beyond four becomes partials in memory for the finalize launch
+      anyPartial = false;
+      for (int b = 0; b < B; b++) anyPartial = anyPartial || nsOf[(size_t) b] > gmax;
+      std::vector<WaveGroup> groups;
+      pbase = 0;
+      maxSplit = 1;
+      for (int b = 0; b < B; b++)
       {
-        const int ng = base + (st < rem ? 1 : 0);
-        WaveDesc d;
-        d.buf = u.buf; d.g0 = g0; d.ng = ng; d.s0 = u.s0; d.s1 = u.s1;
-        d.partIdx = S > 0 ? splitTab[(size_t) u.buf * 2] + u.split : -1;
-        d.statIdx = u.buf * wW + st;
-        d.dIdx = (S > 0 && st == 0) ? d.partIdx : -1;
-        if (ng > 0) ws.push_back(d);
-        g0 += ng;
+        const int ns = nsOf[(size_t) b];
+        const int per = (steps[(size_t) b] + ns - 1) / ns;
+        const int np = (ns + gmax - 1) / gmax; // partials in memory
+        splitTab[(size_t) b * 2] = (int) pbase;
+        splitTab[(size_t) b * 2 + 1] = np;
+        maxSplit = std::max(maxSplit, np);
+        int piece = 0;
+        for (int q = 0; q < np; q++)
+        {
+          const int size = ns / np + (q < ns % np ? 1 : 0);
+          const int base = G / wW, rem = G % wW;
+          int g0 = 0;
+          for (int st = 0; st < wW; st++)
+          {
+            const int ng = base + (st < rem ? 1 : 0);
+            WaveGroup grp;
+            grp.buf = b; grp.work = 0;
+            for (int r = 0; r < size; r++)
+            {
+              const int s0 = (piece + r) * per, s1 = std::min(steps[(size_t) b], s0 + per);
+              WaveDesc d{};
+              d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = s0; d.s1 = std::max(s0, s1);
+              d.partIdx = (anyPartial && r == 0) ? (int) pbase + q : -1;
+              d.statIdx = b * wW + st;
+              d.dIdx = (anyPartial && st == 0 && r == 0) ? d.partIdx : -1;
+              d.grp = (r << 4) | (size << 8);
+              grp.work = std::max<int64_t>(grp.work, d.s1 - d.s0);
+              grp.waves.push_back(d);
+            }
+            if (ng > 0) groups.push_back(std::move(grp));
+            g0 += ng;
+          }
+          piece += size;
+        }
+        pbase += np;
       }
-      packed.push_back(std::move(ws));
+      pack_groups(groups, list, &c->listW.wgs);
+      if (roundsWanted == 0 || c->listW.wgs <= 256 * roundsWanted || budgetWaves <= waves0) break;
     }
-    std::vector<WaveDesc> list;
-    pack_list(packed, list, &c->listW.wgs);
-    c->listW.ng = ngW; c->listW.partial = S > 0 ? 1 : 0; c->listW.maxSplit = maxSplit; c->listW.nPartials = S > 0 ? pbase : 0;
-    c->listW.statParts = S > 0 ? update_finalize_parts(C, Kp) : wW;
+    c->listW.ng = ngW; c->listW.partial = anyPartial ? 1 : 0; c->listW.maxSplit = maxSplit;
+    c->listW.nPartials = anyPartial ? pbase : 0;
+    c->listW.statParts = anyPartial ? update_finalize_parts(C, Kp) : wW;
     c->stripsW = c->listW.statParts;
-    c->nsplitW = maxSplit;
-    HIPCHK(ctx, c->listW.list.alloc(list.size() * sizeof(WaveDesc), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->listW.list.p, list.data(), list.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, c->listW.splitTab.alloc(splitTab.size() * sizeof(int), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->listW.splitTab.p, splitTab.data(), splitTab.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipStreamSynchronize(s)); // the host images go out of scope
+    c->nsplitW = 1;
+    for (int b = 0; b < B; b++) c->nsplitW = std::max(c->nsplitW, nsOf[(size_t) b]);
+    if (int rc = upload_list(ctx, c->listW.list, list.data(), list.size() * sizeof(WaveDesc))) return rc;
+    if (int rc = upload_list(ctx, c->listW.splitTab, splitTab.data(), splitTab.size() * sizeof(int))) return rc;
   }
   // ---- H update: strips over a buffer's own frames, the contraction over the bins (the same for every buffer) ------------
   {
-    std::vector<int> groups((size_t) B);
-    for (int b = 0; b < B; b++) groups[(size_t) b] = (c->tOf[(size_t) b] + 15) / 16;
-    // the strip width that wastes the fewest MFMA slots over the whole corpus (a wavefront runs its widest form)
-    int NG = maxNG;
-    double bestEff = -1.0;
-    for (int cand = maxNG; cand >= std::max(1, maxNG - 3); cand--)
+    std::vector<int> groupsOf((size_t) B);
+    for (int b = 0; b < B; b++) groupsOf[(size_t) b] = (c->tOf[(size_t) b] + 15) / 16;
+    // Strip width NG, pieces of the bin contraction that share a workgroup (gsz: added up through the LDS) and partials in
+    // memory (ns: a finalize launch) by a small cost model in shader cycles, fitted to tools/ragged_sweep.sh
+    // (profiles/r03/ragged_sweep.txt): a wavefront runs the loop of the launch's widest strip at ~325 cycles per column group
+    // and 4-row step (8 groups: 2600, 4 groups: 1300 -- width costs nothing per group), a round of up to 256 workgroups
+    // pays ~40 k cycles of prologue, epilogue and launch, a finalize launch ~60 k.
+    const int steps = (F + 3) / 4;
+    int NG = maxNG, gsz = 1, ns = 1;
+    double bestCost = 1e300;
+    for (int cand = maxNG; cand >= 1; cand--)
     {
-      int64_t used = 0, slots = 0;
+      int64_t strips = 0;
+      int widestStrip = 1;
       for (int b = 0; b < B; b++)
       {
-        const int w = (groups[(size_t) b] + cand - 1) / cand;
-        used += groups[(size_t) b];
-        slots += (int64_t) w * ((groups[(size_t) b] + w - 1) / std::max(w, 1));
+        const int w = (groupsOf[(size_t) b] + cand - 1) / cand;
+        strips += w;
+        widestStrip = std::max(widestStrip, (groupsOf[(size_t) b] + w - 1) / std::max(w, 1));
       }
-      const double eff = slots ? (double) used / (double) slots : 0.0;
-      if (eff > bestEff + 1e-9) { bestEff = eff; NG = cand; }
+      const bool fit = nmf_update5_groups_fit(Kp, widestStrip);
+      for (int g : {1, 2, 4})
+      {
+        if (g > 1 && !fit) continue;
+        for (int m : {1, 2, 3, 4, 6, 8, 12, 16})
+        {
+          const int pieces = g * m;
+          if (pieces > 1 && steps / pieces < 12) continue;
+          const int64_t wgs = (strips * m + (4 / g) - 1) / (4 / g);
+          const double rounds = (double) ((wgs + 255) / 256);
+          const double perWave = (double) ((steps + pieces - 1) / pieces) * 325.0 * widestStrip + 40000.0;
+          const double cost = rounds * perWave + (g > 1 ? 6000.0 : 0.0) + (m > 1 ? 60000.0 + 3000.0 * m : 0.0);
+          if (cost < bestCost - 1.0) { bestCost = cost; NG = cand; gsz = g; ns = m; }
+        }
+      }
     }
-    int64_t waves0 = 0;
+    {
+      auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+      NG = std::max(1, std::min(maxNG, envInt("FLUHIP_RG_HNG", NG)));
+      gsz = envInt("FLUHIP_RG_HG", gsz);
+      ns = envInt("FLUHIP_RG_HM", ns);
+    }
     int ngH = 1;
     for (int b = 0; b < B; b++)
     {
-      const int w = (groups[(size_t) b] + NG - 1) / NG;
-      waves0 += w;
-      ngH = std::max(ngH, (groups[(size_t) b] + w - 1) / std::max(w, 1));
+      const int w = (groupsOf[(size_t) b] + NG - 1) / NG;
+      ngH = std::max(ngH, (groupsOf[(size_t) b] + w - 1) / std::max(w, 1));
     }
-    const int steps = (F + 3) / 4;
-    int ns = 1;
-    if (waves0 < 768) ns = (int) std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(1024 / std::max<int64_t>(waves0, 1), steps / 12), 64));
-    const int per = (steps + ns - 1) / ns;
-    std::vector<int> order((size_t) B);
-    for (int b = 0; b < B; b++) order[(size_t) b] = b;
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[(size_t) a] > groups[(size_t) b]; });
-    std::vector<std::vector<WaveDesc>> packed;
+    if (!nmf_update5_groups_fit(Kp, ngH)) gsz = 1;
+    const int pieces = gsz * ns;
+    const int per = (steps + pieces - 1) / pieces;
+    std::vector<WaveGroup> groups;
     std::vector<int> splitTab((size_t) B * 2);
     for (int b = 0; b < B; b++) { splitTab[(size_t) b * 2] = b * ns; splitTab[(size_t) b * 2 + 1] = ns; }
-    for (int b : order)
+    for (int b = 0; b < B; b++)
     {
-      const int G = groups[(size_t) b];
+      const int G = groupsOf[(size_t) b];
       const int w = (G + NG - 1) / NG;
       for (int j = 0; j < ns; j++)
       {
-        std::vector<WaveDesc> ws;
         const int base = G / w, rem = G % w;
         int g0 = 0;
         for (int st = 0; st < w; st++)
         {
           const int ng = base + (st < rem ? 1 : 0);
-          WaveDesc d;
-          d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = j * per; d.s1 = std::max(d.s0, std::min(steps, d.s0 + per));
-          d.partIdx = ns > 1 ? b * ns + j : -1;
-          d.statIdx = 0;
-          d.dIdx = (ns > 1 && st == 0) ? d.partIdx : -1;
-          if (ng > 0) ws.push_back(d);
+          WaveGroup grp;
+          grp.buf = b; grp.work = 0;
+          for (int r = 0; r < gsz; r++)
+          {
+            WaveDesc d{};
+            d.buf = b; d.g0 = g0; d.ng = ng;
+            d.s0 = (j * gsz + r) * per; d.s1 = std::max(d.s0, std::min(steps, d.s0 + per));
+            d.partIdx = (ns > 1 && r == 0) ? b * ns + j : -1;
+            d.statIdx = 0;
+            d.dIdx = (ns > 1 && st == 0 && r == 0) ? d.partIdx : -1;
+            d.grp = (r << 4) | (gsz << 8);
+            grp.work = std::max<int64_t>(grp.work, (int64_t) (d.s1 - d.s0) * ng);
+            grp.waves.push_back(d);
+          }
+          if (ng > 0) groups.push_back(std::move(grp));
           g0 += ng;
         }
-        packed.push_back(std::move(ws));
       }
     }
     std::vector<WaveDesc> list;
-    pack_list(packed, list, &c->listH.wgs);
+    pack_groups(groups, list, &c->listH.wgs);
     c->listH.ng = ngH; c->listH.partial = ns > 1 ? 1 : 0; c->listH.maxSplit = ns; c->listH.nPartials = ns > 1 ? (int64_t) B * ns : 0;
-    c->nsplitH = ns;
-    HIPCHK(ctx, c->listH.list.alloc(list.size() * sizeof(WaveDesc), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->listH.list.p, list.data(), list.size() * sizeof(WaveDesc), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, c->listH.splitTab.alloc(splitTab.size() * sizeof(int), false, s));
-    HIPCHK(ctx, hipMemcpyAsync(c->listH.splitTab.p, splitTab.data(), splitTab.size() * sizeof(int), hipMemcpyHostToDevice, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
+    c->nsplitH = pieces;
+    if (int rc = upload_list(ctx, c->listH.list, list.data(), list.size() * sizeof(WaveDesc))) return rc;
+    if (int rc = upload_list(ctx, c->listH.splitTab, splitTab.data(), splitTab.size() * sizeof(int))) return rc;
   }
   // workspaces
   const int64_t nPart = std::max(c->listW.nPartials, c->listH.nPartials);
@@ -738,6 +808,9 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   c->Tp = round_up(c->T, 32);
   c->Fp = round_up(c->F, 32);
   c->Kp = round_up(c->K, 16);
+  // ragged corpora run the work-list form of the 4x4x4 kernel, built for padded ranks 16 / 32 / 64 / 128: the padding
+  // components are zero and stay zero like the ones up to the next multiple of 16
+  if (c->ragged) c->Kp = c->K <= 16 ? 16 : (c->K <= 32 ? 32 : (c->K <= 64 ? 64 : 128));
   const size_t B = (size_t) c->B;
   HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
   HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
@@ -1308,7 +1381,7 @@ int fluhip_corpus_create_ragged(fluhip_ctx* ctx, int64_t count, const int64_t* n
   if (rc) return rc;
   // one set of launches over buffers of different lengths needs the work-list form of the factor-update kernel (padded
   // rank 16 / 32 / 64 / 128) and the block form of the STFT (it takes per-buffer lengths)
-  if (update_variant((int) round_up(K, 16)) != 5) return fail(ctx, "ragged corpora support ranks up to 128");
+  if (K > 128 || update_variant(128) != 5) return fail(ctx, "ragged corpora support ranks up to 128");
   if (!(fft == 1024 || fft == 2048 || fft == 4096) || (win % 2) != 0 || win > fft)
     return fail(ctx, "ragged corpora need an STFT shape with a block form (fft 1024 / 2048 / 4096, even window)");
   HIPCHK(ctx, hipSetDevice(ctx->device));

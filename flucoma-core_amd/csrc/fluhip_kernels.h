@@ -68,11 +68,18 @@ void launch_transpose(const double* in, int64_t ldin, int64_t strideIn, double* 
 // accumulators leave as partial `partIdx` of a split contraction ([Cp][Kp] doubles each) for the finalize launch,
 // dIdx >= 0: this wavefront also stores the column sums of its steps as denominator partial `dIdx`; partIdx < 0: the
 // wavefront covers the whole contraction and writes the result and (W update) its column statistics as part `statIdx`.
-// ng == 0: an idle slot of the last workgroup.
+// ng == 0: an idle slot of a workgroup.
+// grp: up to four consecutive wavefronts of ONE workgroup may share a strip and split its contraction between them; they
+// add their accumulators through the LDS in rank order -- no partials in memory, no finalize launch -- and the leader
+// (rank 0) carries partIdx / statIdx / dIdx.  grp = leader's wavefront index | rank << 4 | size << 8 | (1 << 16 when
+// any group of the workgroup has more than one member: every live wavefront of it then meets at one barrier).
 struct WaveDesc
 {
-  int buf, g0, ng, s0, s1, partIdx, statIdx, dIdx;
+  int buf, g0, ng, s0, s1, partIdx, statIdx, dIdx, grp, pad0, pad1, pad2;
 };
+// whether the staging of an intra-workgroup reduction fits the LDS next to nothing else (NG groups of M accumulators +
+// M column sums per lane, four wavefronts)
+inline bool nmf_update5_groups_fit(int Kp, int NG) { const int M = Kp / 4; return (NG * M + M) * 512 * 4 <= 160 * 1024; }
 
 struct UpdateArgs
 {

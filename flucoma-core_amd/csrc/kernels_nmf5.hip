@@ -126,6 +126,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   constexpr int MSTAGE = NJM * 1024;
   constexpr int WAVE_LDS = NS * (VSTAGE + MSTAGE);
   constexpr int IPS = NJV + NJM;                   // vmcnt events per stage
+  // work-list mode: a wavefront's LDS region also stages its accumulators for the intra-workgroup reduction
+  constexpr int STG_BYTES = (NG * M + M) * 512;
+  constexpr int WAVE_REGION = (LIST != 0 && STG_BYTES > WAVE_LDS && 4 * STG_BYTES <= 160 * 1024) ? STG_BYTES : WAVE_LDS;
 
   extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   const double* __restrict__ Mv = a.Mv + (int64_t) buf * a.strideM;
   double* S = a.S + (int64_t) buf * a.strideS;
 
-  char* vring = lds + wave * WAVE_LDS;
+  char* vring = lds + wave * WAVE_REGION;
   char* mring = vring + NS * VSTAGE;
 
   // ---- per-lane DMA source offsets (fixed for the whole pass) ---------------------------------
@@ -821,6 +824,38 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 
   // where the results go: split partials (a finalize launch forms the result) or the result itself + column statistics
   [[maybe_unused]] int lPart = -1, lStat = 0, lD = -1;
+  if constexpr (LIST != 0 && 4 * STG_BYTES <= 160 * 1024)
+  {
+    // ---- intra-workgroup reduction: the wavefronts that split this strip's contraction add up through the LDS ----------
+    // (every DMA of the ring has landed: vmcnt(0) above; the staging slot is the wavefront's own region)
+    const int grp = __builtin_amdgcn_readfirstlane(wd->grp);
+    if (grp >> 16)
+    {
+      const int leader = grp & 15, rank = (grp >> 4) & 15, gsize = (grp >> 8) & 15;
+      double* mine = reinterpret_cast<double*>(lds + wave * WAVE_REGION);
+      if (rank > 0)
+      {
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+          for (int m = 0; m < M; m++) mine[(g * M + m) * 64 + lane] = acc[g][m];
+#pragma unroll
+        for (int m = 0; m < M; m++) mine[(NG * M + m) * 64 + lane] = dsum[m];
+      }
+      __syncthreads();
+      if (rank > 0) return;
+      for (int r = 1; r < gsize; r++) // rank order: the sum does not depend on which wavefront finished first
+      {
+        const double* src = reinterpret_cast<const double*>(lds + (leader + r) * WAVE_REGION);
+#pragma unroll
+        for (int g = 0; g < NG; g++)
+#pragma unroll
+          for (int m = 0; m < M; m++) acc[g][m] += src[(g * M + m) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < M; m++) dsum[m] += src[(NG * M + m) * 64 + lane];
+      }
+    }
+  }
   if constexpr (LIST != 0)
   {
     lPart = __builtin_amdgcn_readfirstlane(wd->partIdx);
@@ -885,7 +920,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     static_assert(GB >= 1, "result staging does not fit the ring");
     constexpr int CPR = KP / 2;            // 16-byte chunks per row
     constexpr int NST = 16 * CPR / 64;     // store instructions per group
-    char* stg = lds + wave * WAVE_LDS;
+    char* stg = lds + wave * WAVE_REGION;
 #pragma unroll
     for (int gb = 0; gb < NG; gb += GB)
     {
@@ -1012,7 +1047,9 @@ static void launch5_list(const UpdateArgs& a, hipStream_t s)
   k.clk = a.clk; k.xcdMap = 0; k.list = a.list;
   constexpr int KP = 4 * M, SPR = KP / 2;
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
-  constexpr size_t shmem = (size_t) 4 * NS * (NJV + NJM) * 1024;
+  constexpr size_t ring = (size_t) NS * (NJV + NJM) * 1024, stg = (size_t) (NG * M + M) * 512;
+  constexpr size_t shmem = 4 * ((stg > ring && 4 * stg <= 160 * 1024) ? stg : ring);
+  static_assert(shmem <= 160 * 1024, "LDS");
   auto kern = nmf_update5_kernel<M, NG, NS, 1, 0, MODE, 1, 1>;
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int) shmem);
