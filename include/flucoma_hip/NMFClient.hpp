@@ -14,7 +14,9 @@
 #include "BufferAdaptor.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -310,6 +312,15 @@ public:
     if (nChannels > 1 && !sequentialForced())
     {
       const size_t nc = static_cast<size_t>(nChannels);
+      // FLUHIP_CLIENT_TIMING=1: wall time of the phases of the batched path on stderr (measurement aid)
+      const bool timing = std::getenv("FLUHIP_CLIENT_TIMING") != nullptr;
+      auto       tPrev = std::chrono::steady_clock::now();
+      auto       lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "  client %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPrev).count());
+        tPrev = now;
+      };
       std::vector<float> audioAll(nc * static_cast<size_t>(nFrames));
       std::vector<float> seedWAll, seedHAll;
       if (seedFilters) seedWAll.resize(nc * static_cast<size_t>(rank * nBins));
@@ -345,6 +356,7 @@ public:
                 VectorView<const float>(BufferAdaptor::Access(P.activations.get()).samps(i * rank + j));
         }
       }
+      lap("gather channels");
       fluhip_corpus* cor = nullptr;
       if (fluhip_corpus_create(mCtx, nChannels, nFrames, fftParams.winSize(), fftParams.fftSize(), hop, rank, &cor) == FLUHIP_OK)
       {
@@ -353,12 +365,14 @@ public:
           fluhip_corpus* c;
           ~Guard() { fluhip_corpus_destroy(c); }
         } guard{cor};
+        lap("corpus create");
         if (c.task() && !c.task()->iterationUpdate(0.0, 1.0)) return {S::kCancelled, ""};
         const bool wantResynth = shouldResynth && hasResynth;
         int        rc = FLUHIP_OK;
         if (wantResynth) rc = fluhip_corpus_keep_spectrum(cor, 1);
         if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(cor, audioAll.data());
         if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(cor);                                            // :240-242, all channels
+        lap("upload + stft");
         if (rc == FLUHIP_OK)
           rc = fluhip_corpus_set_factors(cor, seedFilters ? seedWAll.data() : nullptr, seedEnvelopes ? seedHAll.data() : nullptr);
         struct BatchProg
@@ -377,6 +391,7 @@ public:
         if (rc == FLUHIP_OK)
           rc = fluhip_corpus_nmf(cor, needsAnalysis ? P.iterations : 0, !fixFilters, !fixEnvelopes, P.seed,
                                  perChannelSeeds.empty() ? nullptr : perChannelSeeds.data(), cb, &prog);      // :268-271
+        lap("nmf");
         if (rc == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""};        // :273-274
         std::vector<float> outWAll, outHAll, outRAll;
         if (hasFilters && !fixFilters) outWAll.resize(nc * static_cast<size_t>(rank * nBins));
@@ -390,6 +405,7 @@ public:
           rc = fluhip_corpus_resynth_host(cor, outRAll.data());                                              // :302-334
         }
         if (rc != FLUHIP_OK) return {S::kError, "BufNMF: ", fluhip_last_error(mCtx)};
+        lap("write-back");
         for (index i = 0; i < nChannels; ++i) // buffer writes in channel order, as the reference's loop leaves them
         {
           if (!outWAll.empty())
@@ -418,6 +434,7 @@ public:
             }
           }
         }
+        lap("scatter to buffers");
         return {S::kOk, ""};
       }
       // the corpus could not be created (device memory): the channel-by-channel loop below needs one channel at a time
