@@ -31,9 +31,9 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np  # noqa: E402
 
 # MI355X peaks used for the roofline fractions.  HBM: /opt/skills/guides/MI355X_MICROARCH.md
-# (8.0 TB/s spec).  FP64 matrix: AMD datasheet 78.6 TFLOP/s (the guide has no f64 row); the
-# v_mfma_f64_16x16x4_f64 issue rate this implies (64 cycles/SIMD at 2.4 GHz) is confirmed by
-# tools/mfma_f64_probe (profiles/).
+# (8.0 TB/s spec).  FP64 matrix: AMD datasheet 78.6 TFLOP/s (the guide has no f64 row) = one
+# v_mfma_f64_4x4x4_4b per 16 cycles and SIMD at 2.4 GHz; tools/mfma_f64_probe measures 73.5 at the
+# 2.24 GHz the part runs it at (profiles/r01/mfma_f64_probe.txt).
 PEAK_HBM_GBS = 8000.0
 PEAK_FP64_MFMA_TFLOPS = 78.6
 PEAK_MHZ = 2400.0   # the clock the datasheet peak is quoted at (MI355X_MICROARCH.md "Max clock")

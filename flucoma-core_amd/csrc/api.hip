@@ -390,11 +390,9 @@ struct fluhip_corpus
   }
 };
 
-// which factor-update kernel runs (FLUHIP_NMF_KERNEL forces one for A/B runs):
-//   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (default, Kp 16 .. 128)
-//   4 = v_mfma_f64_4x4x4_4b, register-staged operands (A/B, Kp <= 64)
-//  16 = v_mfma_f64_16x16x4 (the first version, kept for comparison)
-//   0 = un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip): any rank, used above Kp = 128
+// which factor-update path runs:
+//   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (kernels_nmf5.hip): every rank up to 128, padded to 16 / 32 / 64 / 128
+//   0 = un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip): any rank, used above 128
 //       (FLUHIP_NMF_KERNEL=-1 forces it: an independent second implementation for the tests)
 static int update_variant(int Kp)
 {
@@ -404,10 +402,17 @@ static int update_variant(int Kp)
     return e ? std::atoi(e) : 0;
   }();
   if (forced == -1) return 0;
-  if (forced == 16) return 16;
-  if (forced == 4 && nmf_update4_supported(Kp)) return 4;
-  if (nmf_update5_supported(Kp)) return 5;
-  return nmf_update4_supported(Kp) ? 4 : 16;
+  return 5;
+}
+// padded rank: the 4x4x4 kernel is built for 16 / 32 / 64 / 128 (components up to the padded rank are zero and stay zero);
+// above 128 the any-rank path takes multiples of 16
+static int64_t padded_rank(int64_t K)
+{
+  if (K <= 16) return 16;
+  if (K <= 32) return 32;
+  if (K <= 64) return 64;
+  if (K <= 128) return 128;
+  return round_up(K, 16);
 }
 
 static int choose_split4(int64_t B, int C, int R, int Kp)
@@ -416,23 +421,12 @@ static int choose_split4(int64_t B, int C, int R, int Kp)
   const int64_t nSteps = (R + 3) / 4;
   const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(64, nSteps / 12)); // >= 12 steps per wavefront
   if (forceS > 0) return (int) std::min<int64_t>(std::min<int64_t>(forceS, 64), std::max<int64_t>(1, nSteps / 2)); // the finalize kernel sums at most 64 splits
-  const int64_t waves = B * nmf_update4_waves_per_buffer(C, Kp, (int) B);
+  const int64_t waves = B * nmf_update5_waves_per_buffer(C, Kp, (int) B);
   if (waves >= 768) return 1;
   // one wavefront per SIMD (the kernel's register footprint allows no more): never exceed 1024 in
   // total, a 1025th wavefront would wait for a whole pass of the others
   const int64_t s = 1024 / waves;
   return (int) std::max<int64_t>(1, std::min(s, smax));
-}
-
-static int choose_split(int64_t B, int64_t nCW, int64_t nRt)
-{
-  // enough workgroups to fill 256 CUs twice over; only single/few-buffer problems ever split
-  const int64_t have = B * nCW;
-  if (have >= 384) return 1;
-  int64_t s = (512 + have - 1) / have;
-  s = std::min<int64_t>(s, 64);
-  s = std::min<int64_t>(s, std::max<int64_t>(1, nRt / 2));
-  return (int) std::max<int64_t>(1, s);
 }
 
 // workspaces of the factor updates: split-contraction partials, denominators, column-sum pre-pass
@@ -467,7 +461,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
                                 nmf_update_wide_scratch_doubles((int) c->F, (int) c->T, (int) c->Kp, (int) B));
     HIPCHK(ctx, c->wideScratch.alloc((size_t) nd * sizeof(double), false, s));
   }
-  else if (update_variant((int) c->Kp) != 16)
+  else
   {
     c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
     c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
@@ -504,12 +498,6 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // finalize kernel when the contraction is split
     c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F, (int) c->Kp)
                                 : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
-  }
-  else
-  {
-    const int cpw = nmf_update_cols_per_wave((int) c->Kp);
-    c->nsplitW = choose_split(c->B, (c->F + 4 * cpw - 1) / (4 * cpw), (c->T + 15) / 16);
-    c->nsplitH = choose_split(c->B, (c->T + 4 * cpw - 1) / (4 * cpw), (c->F + 15) / 16);
   }
   if (int rc = alloc_update_scratch(ctx, c)) return rc;
   HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
@@ -807,10 +795,7 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   c->F = c->fft / 2 + 1;
   c->Tp = round_up(c->T, 32);
   c->Fp = round_up(c->F, 32);
-  c->Kp = round_up(c->K, 16);
-  // ragged corpora run the work-list form of the 4x4x4 kernel, built for padded ranks 16 / 32 / 64 / 128: the padding
-  // components are zero and stay zero like the ones up to the next multiple of 16
-  if (c->ragged) c->Kp = c->K <= 16 ? 16 : (c->K <= 32 ? 32 : (c->K <= 64 ? 64 : 128));
+  c->Kp = padded_rank(c->K);
   const size_t B = (size_t) c->B;
   HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
   HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
@@ -834,8 +819,8 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
 // threads), and the any-rank path (rank above 128, kernels_nmf_wide.hip) puts frames / bins in gridDim.y (<= 65535)
 static int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K)
 {
-  if (round_up(K, 16) > 1024) return fail(ctx, "ranks above 1024 are not supported");
-  if (round_up(K, 16) > 128 && std::max(T, F) > 65535)
+  if (padded_rank(K) > 1024) return fail(ctx, "ranks above 1024 are not supported");
+  if (padded_rank(K) > 128 && std::max(T, F) > 65535)
     return fail(ctx, "ranks above 128 are limited to 65535 frames and bins");
   return FLUHIP_OK;
 }
@@ -1125,11 +1110,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     {
       {
         ProfScope p(ctx, 1);
-        const int uv = update_variant(a.Kp);
-        if (uv == 5) launch_nmf_update5(a, s);
-        else if (uv == 4) launch_nmf_update4(a, s);
-        else if (uv == 0) launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
-        else launch_nmf_update(a, s);
+        if (update_variant(a.Kp) == 5) launch_nmf_update5(a, s);
+        else launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
       }
       // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
       launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
@@ -1160,9 +1142,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     }
     else
     if (uv == 5) launch_nmf_update5(a, s);
-    else if (uv == 4) launch_nmf_update4(a, s);
-    else if (uv == 0) launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
-    else launch_nmf_update(a, s);
+    else launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
   }
 }
 
@@ -1381,7 +1361,7 @@ int fluhip_corpus_create_ragged(fluhip_ctx* ctx, int64_t count, const int64_t* n
   if (rc) return rc;
   // one set of launches over buffers of different lengths needs the work-list form of the factor-update kernel (padded
   // rank 16 / 32 / 64 / 128) and the block form of the STFT (it takes per-buffer lengths)
-  if (K > 128 || update_variant(128) != 5) return fail(ctx, "ragged corpora support ranks up to 128");
+  if (update_variant((int) padded_rank(K)) != 5) return fail(ctx, "ragged corpora support ranks up to 128");
   if (!(fft == 1024 || fft == 2048 || fft == 4096) || (win % 2) != 0 || win > fft)
     return fail(ctx, "ragged corpora need an STFT shape with a block form (fft 1024 / 2048 / 4096, even window)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1754,7 +1734,7 @@ int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, 
   // shape the corpus directly from the matrix extents (no audio behind it)
   c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
   c.T = T; c.F = F;
-  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = round_up(K, 16);
+  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
   {
     HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
     HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
@@ -1886,7 +1866,7 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   c.ctx = ctx; c.B = 1; c.K = K;
   c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
   c.T = T; c.F = F;
-  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = round_up(K, 16);
+  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
   HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
   HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
   HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));

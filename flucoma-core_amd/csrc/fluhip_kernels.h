@@ -132,12 +132,8 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
 // splitTab (device, [B][2] ints, work-list mode): first partial and number of partials of every buffer; `nsplit` is
 // then the largest count
 int update_finalize_parts(int C, int Kp);
-void launch_nmf_update(const UpdateArgs& a, hipStream_t s);      // v_mfma_f64_16x16x4 form (A/B)
-int nmf_update_cols_per_wave(int Kp);
-void launch_nmf_update4(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b form
-bool nmf_update4_supported(int Kp);
-int nmf_update4_waves_per_buffer(int C, int Kp, int B);
-void launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // + LDS-DMA operand streaming
+int nmf_update5_waves_per_buffer(int C, int Kp, int B);          // the planner's strips per buffer
+void launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming
 // any rank (used above Kp = 128): un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip)
 void launch_nmf_update_wide(const UpdateArgs& a, double* scratch, hipStream_t s);
 int64_t nmf_update_wide_scratch_doubles(int R, int C, int Kp, int B);

@@ -1,26 +1,10 @@
-// kernels_nmf.hip -- gfx950 kernels for the KL-divergence NMF multiplicative updates of
-// flucoma-core's algorithm::NMF (include/flucoma/algorithms/public/NMF.hpp:144-183).
-//
-// One kernel serves both factor updates.  With V the magnitude spectrogram, the W update
-// (NMF.hpp:158-161) and the H update (:165-170) are the same contraction with the roles of the
-// factors swapped:
-//
-//   S[c][k] <- S[c][k] * ( sum_r  V[r][c] / max(Q[r][c], eps) * Mv[r][k] ) / max(sum_r Mv[r][k], eps)
-//   Q[r][c]  = sum_j Mv[r][j] * S[c][j]
-//
-//   W update: r = frame t, c = bin f,   V = mag  [T][F], Mv = H1 [T][K], S = Wf [F][K]
-//   H update: r = bin f,   c = frame t, V = magT [F][T], Mv = Wf [F][K], S = H1 [T][K]
-//
-// The F x T product W*H and the ratio V/(W*H) are never written to memory: each wavefront
-// owns a strip of 16*CB columns c, walks the contraction index r in tiles of 16, forms the
-// 16x16 tile of Q on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), divides in registers,
-// and feeds the quotient tile straight back into the matrix cores as the A operand of the
-// second contraction -- the C/D register layout of the first MFMA (row = (lane>>4)+4i,
-// col = lane&15) *is* the A layout of the second (row = lane&15, k = lane>>4) once the tile
-// is read as "rows = c, k = r", so no cross-lane shuffle or LDS transpose is needed.
-//
-// Algorithmic cost per 16 x 16 tile: K/4 + K/4 MFMAs of 2048 flop = 4*256*K flop, i.e.
-// 8*F*T*K flop per full iteration, V streamed exactly twice per iteration (once per update).
+// kernels_nmf.hip -- the small gfx950 kernels around the KL-divergence NMF multiplicative updates of flucoma-core's
+// algorithm::NMF (include/flucoma/algorithms/public/NMF.hpp:144-183): the fixed-order finalize of split contractions,
+// column clamp / L2 normalisation (:150-153, 162), column sums, the deferred-normalisation kernels (side column, norm
+// combine / apply) and the layout plumbing (scatter / gather / write-back).  The factor updates themselves are
+// kernels_nmf5.hip (v_mfma_f64_4x4x4_4b + LDS-DMA, ranks up to 128), kernels_nmf_strip.hip (one large buffer at rank <= 16)
+// and kernels_nmf_wide.hip (any rank above 128).  (The first fused kernel on v_mfma_f64_16x16x4 lived here through round 2:
+// 35.9 - 49.6 TFLOP/s peak for that instruction against 73.5 for the 4x4x4 form, profiles/r01/mfma_f64_probe.txt.)
 #include "fluhip_kernels.h"
 
 #include <algorithm>
@@ -29,185 +13,6 @@ namespace fluhip {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
-
-struct UpdKArgs
-{
-  const double* V;
-  int64_t ldv, strideV;
-  const double* Mv;
-  int64_t strideM;
-  double* S;
-  int64_t strideS;
-  int R, C, B;
-  int nCW;       // workgroups per buffer along c
-  int nRt;       // r tiles
-  int nsplit;
-  int tilesPerSplit;
-  double* part;
-  double* dpart;
-  int64_t Cp;
-  int xcdMap;
-};
-
-template <int N>
-__device__ __forceinline__ void load_row(double (&dst)[N], const double* p)
-{
-  if constexpr (N % 2 == 0)
-  {
-#pragma unroll
-    for (int j = 0; j < N; j += 2)
-    {
-      d2 t = *reinterpret_cast<const d2*>(p + j);
-      dst[j] = t[0];
-      dst[j + 1] = t[1];
-    }
-  }
-  else
-  {
-#pragma unroll
-    for (int j = 0; j < N; j++) dst[j] = p[j];
-  }
-}
-
-// NB = Kp/16, CB = 16-column blocks per wavefront.
-template <int NB, int CB, int MINW>
-__global__ __launch_bounds__(256, MINW) void nmf_update_kernel(UpdKArgs a)
-{
-  constexpr int KP = 16 * NB; // padded rank
-  constexpr int KQ = 4 * NB;  // rank elements per lane group for the Q contraction
-
-  int id = blockIdx.x;
-  int buf, cw, split;
-  if (a.xcdMap)
-  {
-    // blocks are dispatched round-robin over the 8 XCDs: keep every workgroup of one buffer
-    // on one XCD so its factor matrices stay in that XCD's L2 (speed only, never correctness)
-    int xcd = id & 7, slot = id >> 3;
-    split = slot % a.nsplit;
-    slot /= a.nsplit;
-    cw = slot % a.nCW;
-    buf = xcd + 8 * (slot / a.nCW);
-  }
-  else
-  {
-    split = id % a.nsplit;
-    cw = (id / a.nsplit) % a.nCW;
-    buf = id / (a.nsplit * a.nCW);
-  }
-  if (buf >= a.B) return;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = lane & 15, g = lane >> 4;
-  const int c0 = (cw * 4 + wave) * 16 * CB;
-  if (c0 >= a.C) return;
-
-  const double* __restrict__ V = a.V + (int64_t) buf * a.strideV;
-  const double* __restrict__ Mv = a.Mv + (int64_t) buf * a.strideM;
-  double* S = a.S + (int64_t) buf * a.strideS;
-
-  // stationary operand: B[kk = g][n = c] of the Q MFMAs, rank index j*? -> g*KQ + j
-  double sb[CB][KQ];
-#pragma unroll
-  for (int cb = 0; cb < CB; cb++) load_row<KQ>(sb[cb], S + (int64_t) (c0 + CB * c + cb) * KP + g * KQ);
-
-  d4 acc[CB][NB];
-  double dsum[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++)
-  {
-    dsum[nb] = 0.0;
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++) acc[cb][nb] = d4{0.0, 0.0, 0.0, 0.0};
-  }
-
-  const int rt0 = split * a.tilesPerSplit;
-  const int rt1 = min(rt0 + a.tilesPerSplit, a.nRt);
-
-  for (int rt = rt0; rt < rt1; ++rt)
-  {
-    const int r0 = rt * 16;
-    // moving operand, two register distributions of the same 16 x KP tile of Mv
-    double ma[KQ];        // A of the Q MFMAs:   Mv[r0 + c][g*KQ + j]
-    double mb[4][NB];     // B of the out MFMAs: Mv[r0 + g + 4i][c*NB + nb]
-    double v[4][CB];      // V[r0 + g + 4i][c0 + CB*c + cb]
-    load_row<KQ>(ma, Mv + (int64_t) (r0 + c) * KP + g * KQ);
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-      load_row<NB>(mb[i], Mv + (int64_t) (r0 + g + 4 * i) * KP + c * NB);
-      load_row<CB>(v[i], V + (int64_t) (r0 + g + 4 * i) * a.ldv + c0 + CB * c);
-    }
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-    {
-      d4 q = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int j = 0; j < KQ; j++) q = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[j], sb[cb][j], q, 0, 0, 0);
-      // q[i] = Q[r0 + g + 4i][col c of block cb]
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-      {
-        const double ratio = v[i][cb] / fmax(q[i], kEpsilon);
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++)
-          acc[cb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(ratio, mb[i][nb], acc[cb][nb], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) dsum[nb] += (mb[0][nb] + mb[1][nb]) + (mb[2][nb] + mb[3][nb]);
-  }
-
-  // denominators: column sums of Mv; lane (g,c) holds the partial over rows == g (mod 4)
-#pragma unroll
-  for (int nb = 0; nb < NB; nb++)
-  {
-    double d = dsum[nb];
-    d += __shfl_xor(d, 16);
-    d += __shfl_xor(d, 32);
-    dsum[nb] = d;
-  }
-
-  // acc[cb][nb][q] = out[col index m = g + 4q of block cb][k = c*NB + nb]
-  if (a.nsplit == 1)
-  {
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-      {
-        const int col = c0 + CB * (g + 4 * q) + cb;
-        if (col < a.C)
-        {
-          double* sp = S + (int64_t) col * KP + c * NB;
-          double sold[NB];
-          load_row<NB>(sold, sp);
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++)
-            sp[nb] = (sold[nb] * acc[cb][nb][q]) / fmax(dsum[nb], kEpsilon);
-        }
-      }
-  }
-  else
-  {
-    double* part = a.part + ((int64_t) buf * a.nsplit + split) * a.Cp * KP;
-#pragma unroll
-    for (int cb = 0; cb < CB; cb++)
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-      {
-        const int col = c0 + CB * (g + 4 * q) + cb;
-        double* pp = part + (int64_t) col * KP + c * NB;
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) pp[nb] = acc[cb][nb][q];
-      }
-    if (c0 == 0 && g == 0)
-    {
-      double* dp = a.dpart + ((int64_t) buf * a.nsplit + split) * KP + c * NB;
-#pragma unroll
-      for (int nb = 0; nb < NB; nb++) dp[nb] = dsum[nb];
-    }
-  }
-}
 
 constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 
@@ -358,45 +163,6 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
   else if (per <= 8) FLUHIP_FIN(8);
   else FLUHIP_FIN(16);
 #undef FLUHIP_FIN
-}
-
-template <int NB, int CB, int MINW>
-static void launch_update_t(const UpdateArgs& a, hipStream_t s)
-{
-  UpdKArgs k;
-  k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
-  k.Mv = a.Mv; k.strideM = a.strideM;
-  k.S = a.S; k.strideS = a.strideS;
-  k.R = a.R; k.C = a.C; k.B = a.B;
-  k.nCW = (a.C + 64 * CB - 1) / (64 * CB);
-  k.nRt = (a.R + 15) / 16;
-  k.nsplit = a.nsplit < 1 ? 1 : a.nsplit;
-  k.tilesPerSplit = (k.nRt + k.nsplit - 1) / k.nsplit;
-  k.part = a.part; k.dpart = a.dpart; k.Cp = a.Cp;
-  k.xcdMap = a.B >= 8 ? 1 : 0;
-  const int bufs = k.xcdMap ? (int) round_up(a.B, 8) : a.B;
-  const unsigned grid = (unsigned) (bufs * k.nCW * k.nsplit);
-  hipLaunchKernelGGL((nmf_update_kernel<NB, CB, MINW>), dim3(grid), dim3(256), 0, s, k);
-  if (k.nsplit > 1)
-    launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s);
-}
-
-int nmf_update_cols_per_wave(int Kp) { return Kp <= 64 ? 32 : 16; }
-
-void launch_nmf_update(const UpdateArgs& a, hipStream_t s)
-{
-  switch (a.Kp / 16)
-  {
-  case 1: launch_update_t<1, 2, 2>(a, s); break;
-  case 2: launch_update_t<2, 2, 2>(a, s); break;
-  case 3: launch_update_t<3, 2, 1>(a, s); break;
-  case 4: launch_update_t<4, 2, 1>(a, s); break;
-  case 5: launch_update_t<5, 1, 1>(a, s); break;
-  case 6: launch_update_t<6, 1, 1>(a, s); break;
-  case 7: launch_update_t<7, 1, 1>(a, s); break;
-  case 8: launch_update_t<8, 1, 1>(a, s); break;
-  default: break; // api.hip rejects Kp > 128 before getting here
-  }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1,7 +1,7 @@
 // kernels_nmf5.hip -- NMF factor update, v_mfma_f64_4x4x4_4b_f64 + LDS-DMA operand streaming.
 //
-// Same mathematics and register tiling as kernels_nmf4.hip (see there for the derivation and the
-// measured lane map).  What changes is how operands reach the wavefront: both streamed operands --
+// One kernel serves both factor updates (alg/NMF.hpp:158-161 and :165-170 are the same contraction with the factor
+// roles swapped; the register tiling and the measured lane map of the 4x4x4 MFMA are in DESIGN.md section 3).  What changes is how operands reach the wavefront: both streamed operands --
 // the 4-row slab of V under the wavefront's column strip and the 4 x Kp slab of the moving factor
 // -- are copied HBM/L2 -> LDS by `global_load_lds_dwordx4` (no VGPRs, asynchronous, counted on
 // vmcnt) into a private per-wavefront ring of NS stages, NS-1 steps ahead of their use, and read
@@ -1092,7 +1092,44 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
                            a.statPart);
 }
 
-int nmf_update4_waves_per_buffer(int C, int Kp, int B);
+static int max_groups(int M)
+{
+  if (M <= 8) return 9;
+  if (M <= 16) return 4;
+  return 2;
+}
+
+// strips (wavefronts) per buffer: fill the 1024 SIMDs in whole rounds, then as few strips as the
+// register budget allows (more groups per strip = more reuse of the moving-factor slab)
+int nmf_update5_waves_per_buffer(int C, int Kp, int B)
+{
+  const int M = Kp / 4, G = (C + 15) / 16, ngmax = max_groups(M);
+  const int wmin = (G + ngmax - 1) / ngmax;
+  static const int forceW = [] { const char* e = std::getenv("FLUHIP_PLAN_W"); return e ? std::atoi(e) : 0; }();
+  if (forceW > 0) return forceW < wmin ? wmin : (forceW > G ? G : forceW);
+  int w = wmin;
+  const int simds = 1024;
+  if ((int64_t) B * w >= simds)
+  {
+    // round the strip count up so that B*w is a multiple of the SIMD count when that is cheap
+    for (int cand = wmin; cand <= wmin + 2 && cand <= G; cand++)
+      if (((int64_t) B * cand) % simds == 0) { w = cand; break; }
+  }
+  else
+  {
+    const int64_t wfill = (simds + B - 1) / B; // strips per buffer that give every SIMD a wavefront
+    if (wfill <= G / 3 || wfill <= wmin)
+      w = (int) std::max<int64_t>(wmin, wfill);  // fill the chip by narrowing strips (>= 3 groups each)
+    else
+      w = std::max(wmin, (G + 2) / 3);           // few buffers: at most 3 groups per strip (G / 3 rounded DOWN made the
+                                                 // widest strip 4 groups -- a quarter more work per wavefront), the contraction
+                                                 // split (nsplit) supplies the rest of the parallelism
+    if (w > G) w = G;
+    if (w < 1) w = 1;
+  }
+  return w;
+}
+
 
 // ring depth bounded by the 160 KiB of LDS: 4*WPS wavefronts x NS x (V + Mv stage)
 template <int M, int NG, int WPS>
@@ -1180,7 +1217,7 @@ int nmf_update5_max_groups(int Kp) { return Kp <= 32 ? 9 : (Kp <= 64 ? 4 : 2); }
 int nmf_update5_strips(int C, int Kp, int B)
 {
   const int G = (C + 15) / 16;
-  const int w = nmf_update4_waves_per_buffer(C, Kp, B);
+  const int w = nmf_update5_waves_per_buffer(C, Kp, B);
   const bool two = k5_wps() == 2 && (Kp == 16 || Kp == 32) && 2 * w <= G && (G + 2 * w - 1) / (2 * w) <= 4;
   return two ? 2 * w : w;
 }
@@ -1205,7 +1242,7 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
   }
   const int G = (a.C + 15) / 16;
   const int w = nmf_update5_strips(a.C, a.Kp, a.B);
-  const bool two = w != nmf_update4_waves_per_buffer(a.C, a.Kp, a.B);
+  const bool two = w != nmf_update5_waves_per_buffer(a.C, a.Kp, a.B);
   const int ng = (G + w - 1) / w;
   if (two)
   {
