@@ -149,6 +149,12 @@ def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio,
+    # flushed when the process exits), so file descriptor 1 is pointed at stderr for the whole run and the line goes to
+    # the saved original at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     wl = dict(WORKLOAD)
     wl["buffers_per_gpu"], wl["iters"], wl["rank"] = args.buffers, args.iters, args.rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,7 +312,7 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
         # gfx950 rocprofv3 correction + WRITE_SIZE); only quoted for the workload they were taken on
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             try:
                 path = os.path.join("profiles", rnd, "pmc_update_kernel.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))
@@ -373,7 +379,7 @@ def main():
             gpu_job_s = elapsed_max / args.steps / B   # per-buffer share of one step
             out["cpu_baseline"]["gpu_speedup_per_buffer_job"] = (
                 out["cpu_baseline"]["bufnmf_wall_s_200iter_est"] * (iters / WORKLOAD["iters"]) / gpu_job_s)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

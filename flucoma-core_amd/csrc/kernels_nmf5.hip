@@ -71,6 +71,20 @@ constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
 #define FLUHIP_SHARED_RECIPROCAL 1
 #endif
 constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
+// The results of a launch leave with write-through (sc1) stores: with plain stores the kernel ends on tens of MB of
+// dirty L2 lines that the end-of-kernel release has to write back before the next launch may start
+// (MI355X_MICROARCH.md "publish-large": 8.2 vs 3.0 us for 64 KB per workgroup).  -DFLUHIP_EPILOGUE_SC1=0: plain stores.
+#ifndef FLUHIP_EPILOGUE_SC1
+#define FLUHIP_EPILOGUE_SC1 1
+#endif
+__device__ __forceinline__ void store_result16(double* p, double __attribute__((ext_vector_type(2))) t)
+{
+#if FLUHIP_EPILOGUE_SC1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+#else
+  *reinterpret_cast<double __attribute__((ext_vector_type(2)))*>(p) = t;
+#endif
+}
 
 // v / d for d > 0, v >= 0 in the normal range: v_rcp_f64 -> one Newton step -> quotient -> residual correction
 // (error ~2^-96 before the final rounding; exact when d == 1)
@@ -963,7 +977,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             const int r = c / CPR, piece = c % CPR;
             const d2 t = *reinterpret_cast<const d2*>(stg + (g - gb) * GRPB + r * ROWB + piece * 16);
             const int col = (g0 + g) * 16 + r;
-            if (col < a.C) *reinterpret_cast<d2*>(S + (int64_t) col * KP + piece * 2) = t;
+            if (col < a.C) store_result16(S + (int64_t) col * KP + piece * 2, t);
           }
         }
       }
