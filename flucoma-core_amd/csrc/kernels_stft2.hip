@@ -223,6 +223,13 @@ struct FftCore
     tw3pB = tw3 + jB;
   }
 
+  // the same lane positions in another staging buffer `delta` doubles further on (a wavefront that transforms several
+  // frames per round keeps one buffer per frame)
+  __device__ __forceinline__ void shift(int delta)
+  {
+    xb += delta; w1p += delta; r2p += delta; w2p += delta; r3pA += delta; r3pB += delta;
+  }
+
   template <bool SPEC>
   __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
   {
@@ -447,7 +454,10 @@ __device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, 
   }
 }
 
-template <int R1, int R2, int R3, int NW, int WINLDS, bool SPEC>
+// FPW frames per wavefront and round: a block stages NW * FPW consecutive frames before the bin-major flush, so a bin's
+// piece of the transposed copy is NW * FPW * 8 bytes -- a full 128-byte line at fft 2048 with 8 wavefronts x 2 frames
+// (64-byte pieces measured 3.3 TB/s against 4.4 - 5.9 for full lines, tools/hbm_write_probe.hip).
+template <int R1, int R2, int R3, int NW, int WINLDS, bool SPEC, int FPW = 1>
 __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 {
   constexpr int N = R1 * R2 * R3;  // complex points per frame = fft / 2
@@ -464,7 +474,8 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   double* xall = reinterpret_cast<double*>(wl + (WINLDS ? N : 0));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  double* xb = xall + wave * BUFD;
+  double* xb = xall + wave * FPW * BUFD;
+  constexpr int FPB = NW * FPW; // frames per block and round
 
   const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
   FftCore<R1, R2, R3>::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     const int64_t blk = (L & 7) * chunk + slot;
     if (slot >= chunk || blk >= a.totalBlocks) return false;
     b = (int) (blk / a.blocksPerBuf);
-    t0 = (int) (blk % a.blocksPerBuf) * NW;
+    t0 = (int) (blk % a.blocksPerBuf) * FPB;
     return true;
   };
   for (int64_t L = blockIdx.x;; L += gridDim.x)
@@ -497,44 +508,54 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     int b, t0;
     if ((L >> 3) >= chunk) break;
     if (!decode(L, b, t0)) continue;
-    const int t = t0 + wave;
     // ragged corpora: the buffer's own length decides its frame count (alg/STFT.hpp:98-99); frames past it are padding
     const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
     const int Tb = a.nTab ? (int) ((nSamples + a.hop) / a.hop) : a.T;
-    const bool active = t < Tb;
-
-    if (active)
+#pragma unroll 1
+    for (int fj = 0; fj < FPW; fj++)
     {
-      cx pts[PPL];
-      gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
-      SCHED_FENCE();
-      core.template run<SPEC>(pts, SPEC ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
-    }
-    else if (a.magT)
-    {
-      // frames past the end of the buffer: zeros into the padding columns of the bin-major copy
-#pragma unroll
-      for (int i = 0; i < PPL; i++) xb[lane + 64 * i] = 0.0;
-      if (lane == 0) xb[N] = 0.0;
-    }
-
-    if (a.magT) LDS_BARRIER();                        // every wavefront of the block has staged its frame
-    if (active && a.mag)
-    {
-      // frame-major row from the wavefront's own staging buffer, 16 bytes per lane
-      double* magRow = a.mag + (int64_t) b * a.magStride + (int64_t) t * a.ldMag;
-#pragma unroll
-      for (int q = 0; q < N / 128; q++)
+      const int t = t0 + wave * FPW + fj;
+      if (t < Tb)
       {
-        const int k = 2 * (lane + 64 * q);
-        *reinterpret_cast<d2*>(magRow + k) = *reinterpret_cast<const d2*>(xb + k);
+        cx pts[PPL];
+        gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
+        SCHED_FENCE();
+        core.template run<SPEC>(pts, SPEC ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
       }
-      if (lane == 0) magRow[N] = xb[N];
+      else if (a.magT)
+      {
+        // frames past the end of the buffer: zeros into the padding columns of the bin-major copy
+#pragma unroll
+        for (int i = 0; i < PPL; i++) core.xb[lane + 64 * i] = 0.0;
+        if (lane == 0) core.xb[N] = 0.0;
+      }
+      if (FPW > 1) core.shift(fj + 1 < FPW ? BUFD : -(FPW - 1) * BUFD);
+    }
+
+    if (a.magT) LDS_BARRIER();                        // every wavefront of the block has staged its frames
+    if (a.mag)
+    {
+#pragma unroll 1
+      for (int fj = 0; fj < FPW; fj++)
+      {
+        const int t = t0 + wave * FPW + fj;
+        if (t >= Tb) break;
+        // frame-major row from the wavefront's own staging buffer, 16 bytes per lane
+        double* magRow = a.mag + (int64_t) b * a.magStride + (int64_t) t * a.ldMag;
+        const double* xs = xb + fj * BUFD;
+#pragma unroll
+        for (int q = 0; q < N / 128; q++)
+        {
+          const int k = 2 * (lane + 64 * q);
+          *reinterpret_cast<d2*>(magRow + k) = *reinterpret_cast<const d2*>(xs + k);
+        }
+        if (lane == 0) magRow[N] = xs[N];
+      }
     }
     if (a.magT)
     {
-      // ---- bin-major copy: NW frames of a bin leave as one piece -------------------------------------------------
-      constexpr int HP = NW / 2;                      // 16-byte pieces (two frames) per bin
+      // ---- bin-major copy: the block's frames of a bin leave as one piece ------------------------------------------
+      constexpr int HP = FPB / 2;                     // 16-byte pieces (two frames) per bin
       double* outT = a.magT + (int64_t) b * a.magTStride;
       const int items = a.F * HP;
       for (int i = threadIdx.x; i < items; i += nthreads)
@@ -777,19 +798,19 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
 }
 int stft_features_bins_per_lane(int fft) { return (fft / 2 + 1 + 63) / 64; }
 
-template <int R1, int R2, int R3, int NW, int WINLDS>
+template <int R1, int R2, int R3, int NW, int WINLDS, int FPW = 1>
 static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
 {
   constexpr int N = R1 * R2 * R3;
   constexpr int BUFD = N + N / 16 + 2;
   constexpr int TW = (R2 - 1) * R1 + (R3 - 1) * R1 * R2;
-  constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * BUFD * 8;
+  constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * FPW * BUFD * 8;
   static_assert(shmem <= 160 * 1024, "LDS");
   StftBArgs k = k0;
-  k.blocksPerBuf = (k.T + NW - 1) / NW;
+  k.blocksPerBuf = (k.T + NW * FPW - 1) / (NW * FPW);
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
-  auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false>;   // the complex spectrum is kept for resynthesis / BufSTFT only
+  auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true, FPW> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false, FPW>;   // the complex spectrum is kept for resynthesis / BufSTFT only
   (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
@@ -821,7 +842,13 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
   if (a.fft == 2048)
   {
     // 8 frames per block, two wavefronts per SIMD (143 registers without the spectrum output; 12 per workgroup fit too and
-    // measured the same: the phase is bound by its stores)
+    // measured the same).  FLUHIP_STFT_FPW=2: TWO frames per wavefront and round, so that 16 frames of a bin leave as one
+    // 128-byte line of the bin-major copy instead of 64-byte pieces (the 16 staging buffers leave no room for the window in
+    // the LDS: it is read through the L1).  Built on the round-2 review's suggestion and measured on one box, back to back:
+    // 803 / 820 us against 765 / 783 us for the one-frame form (profiles/r03/stft_fpw.txt) -- full lines are not what the
+    // phase waits for (fft 1024 already writes 128-byte pieces and runs at the same bytes per second), so it stays off.
+    static const int fpw = [] { const char* e = std::getenv("FLUHIP_STFT_FPW"); return e ? std::atoi(e) : 1; }();
+    if (fpw == 2) return launch_block_t<16, 8, 8, 8, 0, 2>(k, s);
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
   }
   if (a.fft == 4096)
