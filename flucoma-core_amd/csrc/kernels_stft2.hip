@@ -637,7 +637,9 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   double* upl = scr + NW * WS;                    // [64 CH]
   double* dnl = upl + 64 * CH;                    // [64 CH]
   double* dctl = dnl + 64 * CH;                   // [nDct * nBands]
-  short* slotl = reinterpret_cast<short*>(dctl + (fa.dct ? fa.nDct * fa.nBands : 0));   // [64 CH]
+  const int dld = fa.nBands + 1;                  // DCT rows one double apart in bank phase: the four lanes of eight coefficients
+                                                  // read eight rows at once, and rows of 40 doubles would put rows j and j + 4 on one bank
+  short* slotl = reinterpret_cast<short*>(dctl + (fa.dct ? fa.nDct * dld : 0));   // [64 CH]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* xb = xall + wave * BUFD;
@@ -650,7 +652,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
   for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { upl[i] = fa.up[i]; dnl[i] = fa.dn[i]; slotl[i] = fa.slot[i]; }
   if (fa.dct)
-    for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[i] = fa.dct[i];
+    for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[(i / fa.nBands) * dld + (i % fa.nBands)] = fa.dct[i];
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
   __syncthreads();
 
@@ -731,7 +733,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       double sacc = 0.0;
       if (j < fa.nOut && fa.startCoeff + j < fa.nDct)
       {
-        const double* drow = dctl + (fa.startCoeff + j) * fa.nBands;
+        const double* drow = dctl + (fa.startCoeff + j) * dld;
         const int b1 = min((part + 1) * q, fa.nBands);
         for (int band = part * q; band < b1; band++) sacc = __builtin_fma(drow[band], bands[band], sacc);
       }
@@ -746,7 +748,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
         double sacc = 0.0;
         if (fa.startCoeff + j < fa.nDct)
         {
-          const double* drow = dctl + (fa.startCoeff + j) * fa.nBands;
+          const double* drow = dctl + (fa.startCoeff + j) * dld;
           for (int band = 0; band < fa.nBands; band++) sacc = __builtin_fma(drow[band], bands[band], sacc);
         }
         fa.out[((int64_t) b * fa.nOut + j) * a.T + t] = (float) sacc;
@@ -761,7 +763,7 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
   using Core = FftCore<R1, R2, R3>;
   constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = 66 + 66 + 64;
   const size_t shmem = ((size_t) Core::T2 + Core::T3 + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
-                       (fa.dct ? (size_t) fa.nDct * fa.nBands * 8 : 0) + (size_t) 64 * CH * 2 + 16;
+                       (fa.dct ? (size_t) fa.nDct * (fa.nBands + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
   if (shmem > 160 * 1024) return false;
   StftBArgs k = k0;
   k.blocksPerBuf = (k.T + NW - 1) / NW;
