@@ -149,12 +149,6 @@ def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
 
 def main():
     args = parse()
-    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio,
-    # flushed when the process exits), so file descriptor 1 is pointed at stderr for the whole run and the line goes to
-    # the saved original at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     wl = dict(WORKLOAD)
     wl["buffers_per_gpu"], wl["iters"], wl["rank"] = args.buffers, args.iters, args.rank
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -173,6 +167,12 @@ def main():
     if args.gpus != world:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio,
+    # flushed when the process exits), so file descriptor 1 is pointed at stderr for the whole run and the line goes to
+    # the saved original at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     # torch first: it owns the HIP runtime the process shares; our library is loaded afterwards
     import torch

@@ -373,6 +373,7 @@ struct fluhip_corpus
   // the longest buffer (the strides of every array); frames past a buffer's own count are zero padding that stays zero.
   // The factor updates run kernels_nmf5.hip in work-list mode: one WaveDesc per wavefront, dealt by work.
   bool ragged = false;
+  bool useLists = false; // the factor updates run from work lists (ragged corpora; small equal-length ones)
   std::vector<int64_t> nOf; // samples per buffer
   std::vector<int> tOf;     // frames per buffer
   DevBuf nTab, tTab;        // the same on the device
@@ -447,6 +448,22 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
   return FLUHIP_OK;
 }
 
+static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
+// where the work-list form beats the uniform split schedule for equal-length corpora (tools/batch_timing.py with
+// FLUHIP_LIST_PLAN=0|1, profiles/r03/small_batches_*.jsonl)
+static bool list_plan_pays(const fluhip_corpus* c)
+{
+  // measured at rank 32, 10 s buffers (us per iteration, uniform schedule -> lists): 1 buffer 47 -> 51, 2: 53 -> 57, 4: 73 -> 65,
+  // 8: 92 -> 73, 16: 135 -> 109, 24: 196 -> 168, 32: 250 -> 202, 48: 346 -> 289, 64: 370 -> 345, 96: 758 -> 511, 112: 878 -> 564,
+  // 128: 619 = 621 (the same schedule either way); ranks 16 / 64 / 128 at 4 and 16 buffers likewise (49 -> 49, 89 -> 76;
+  // 130 -> 98, 227 -> 193; 211 -> 160, 486 -> 476).  So: from three buffers on, while whole contractions at the widest
+  // strips do not fill the chip in whole rounds.
+  const int maxNG = nmf_update5_max_groups((int) c->Kp);
+  const int G = ((int) c->F - 1 + 15) / 16;
+  const int64_t w0 = c->B * ((G + maxNG - 1) / maxNG);
+  return c->B >= 3 && w0 < 1536 && (w0 % 1024) != 0;
+}
+
 // how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
 // workspaces; needs B, T, F, Tp, Fp, Kp
 static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
@@ -493,6 +510,16 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     {
       c->sideW = false;
       HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), false, s));
+    }
+    // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
+    // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
+    // partials in memory.  FLUHIP_LIST_PLAN=0 keeps the uniform split schedule, =1 takes the lists whenever something is split.
+    static const int listEnv = [] { const char* e = std::getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
+    if (!c->strip && c->lazy && listEnv != 0 && (listEnv == 1 || list_plan_pays(c)))
+    {
+      c->tOf.assign(B, (int) c->T);
+      c->useLists = true;
+      return plan_lists(ctx, c);
     }
     // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
     // finalize kernel when the contraction is split
@@ -567,8 +594,10 @@ int upload_list(fluhip_ctx* ctx, DevBuf& dst, const void* src, size_t bytes)
 }
 } // namespace
 
-// Work lists of the two factor updates over buffers with their own frame counts tOf[b] (a ragged corpus).
-static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
+// Work lists of the two factor updates over buffers with their own frame counts tOf[b]: ragged corpora, and equal-length
+// corpora too small to fill the chip with whole contractions (the intra-workgroup reduction is what this form has over the
+// uniform split schedule: fewer or no partials in memory, no finalize launch).
+static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   const int B = (int) c->B, Kp = (int) c->Kp, F = (int) c->F;
@@ -576,112 +605,138 @@ static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
   c->lazy = true; c->strip = false; c->nsplitW = c->nsplitH = 1;
   // ---- W update: strips over the bins (the same for every buffer), the contraction over a buffer's own frames ------------
   {
+    auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
     std::vector<int> steps((size_t) B);
     for (int b = 0; b < B; b++) steps[(size_t) b] = (c->tOf[(size_t) b] + 3) / 4;
-    // the Nyquist bin as a side column when that makes the strips narrower (fluhip_kernels.h SideColumn): a wavefront
-    // runs the loop of the widest strip of the launch, so 65 column groups over 8 strips cost every strip a ninth group
-    auto strips_for = [&](int C) { const int G = (C + 15) / 16; return (G + maxNG - 1) / maxNG; };
-    auto widest = [&](int C) { const int G = (C + 15) / 16, w = strips_for(C); return (G + w - 1) / w; };
+    // the Nyquist bin as a side column (fluhip_kernels.h SideColumn): every power-of-two transform has 16 m + 1 bins, and a
+    // wavefront runs the loop of the widest strip of the launch -- 65 column groups never deal evenly
     static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
-    c->sideW = !sideOff && nmf_side_column_supported((int) c->T, F, Kp) &&
-               (strips_for(F - 1) < strips_for(F) || (strips_for(F - 1) == strips_for(F) && widest(F - 1) < widest(F)));
+    c->sideW = !sideOff && nmf_side_column_supported((int) c->T, F, Kp);
     const int C = F - (c->sideW ? 1 : 0);
     const int G = (C + 15) / 16;
-    const int wW = strips_for(C);
-    const int ngW = (G + wW - 1) / wW;
-    // Contractions are cut into pieces when one round of wavefronts (1024 SIMDs) would stay part empty: the wavefront
-    // budget of one round (two when the whole contractions already need more than one) goes to whichever buffer has the
-    // longest pieces, until pieces are down to 12 steps -- the longest piece is what the launch takes.
-    const int64_t waves0 = (int64_t) B * wW;
-    // (FLUHIP_RG_*: schedule overrides for A/B measurements, tools/ragged_timing.py)
-    auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-    const int gmax = std::min(envInt("FLUHIP_RG_GMAX", 4), nmf_update5_groups_fit(Kp, ngW) ? 4 : 1);
-    std::vector<int> nsOf((size_t) B, 1);
-    std::vector<WaveDesc> list;
-    std::vector<int> splitTab((size_t) B * 2);
-    bool anyPartial = false;
-    int64_t pbase = 0;
-    int maxSplit = 1;
-    // One workgroup (4 wavefronts) per CU: a launch of up to 256 workgroups is one round.  The budget is lowered until the
-    // packed list -- groups of 3 leave a slot empty unless a single fills it -- is back within the rounds it was meant for.
-    const int64_t wgs0 = (waves0 + 3) / 4;
-    const int64_t roundsWanted = wgs0 <= 384 ? std::max<int64_t>(1, (wgs0 + 255) / 256) : 0; // 0: many rounds, no splitting
-    for (int64_t budgetWaves = envInt("FLUHIP_RG_WBUDGET", (int) (1024 * std::max<int64_t>(roundsWanted, 1)));; budgetWaves -= 32)
+    // One candidate schedule per strip width.  Contractions are cut into pieces when one round of wavefronts (1024 SIMDs, one
+    // workgroup of four per CU) would stay part empty: the wavefront budget goes to whichever buffer has the longest pieces
+    // (down to 12 steps); the pieces of one strip go to up to four wavefronts of one workgroup (added up through the LDS:
+    // WaveDesc::grp) and only what is left beyond four becomes partials in memory for the finalize launch.  Cost model as
+    // for the H update below: ~400 + 270 NG cycles per step of a strip of NG column groups, ~40 k per round, ~60 k per
+    // finalize launch -- narrow strips cost little per group, so few buffers take many narrow strips and few partials.
+    struct Cand
     {
-      std::fill(nsOf.begin(), nsOf.end(), 1);
-      if (roundsWanted > 0 && budgetWaves > waves0)
+      std::vector<WaveDesc> list;
+      std::vector<int> splitTab;
+      bool anyPartial = false;
+      int64_t pbase = 0;
+      int maxSplit = 1, maxPieces = 1, wgs = 0, wW = 0, ngW = 0;
+      double cost = 1e300;
+    };
+    auto build = [&](int wW, int forcedBudget) -> Cand {
+      Cand r;
+      r.wW = wW;
+      r.ngW = (G + wW - 1) / wW;
+      r.splitTab.assign((size_t) B * 2, 0);
+      const int gmax = std::min(envInt("FLUHIP_RG_GMAX", 4), nmf_update5_groups_fit(Kp, r.ngW) ? 4 : 1);
+      const int64_t waves0 = (int64_t) B * wW;
+      const int64_t wgs0 = (waves0 + 3) / 4;
+      const int64_t roundsWanted = wgs0 <= 384 ? std::max<int64_t>(1, (wgs0 + 255) / 256) : 0; // 0: many rounds, no cutting
+      std::vector<int> nsOf((size_t) B, 1);
+      for (int64_t budgetWaves = forcedBudget > 0 ? forcedBudget : 1024 * std::max<int64_t>(roundsWanted, 1);; budgetWaves -= 32)
       {
-        const int64_t budget = budgetWaves / wW;
-        auto piece = [&](int b) { return (steps[(size_t) b] + nsOf[(size_t) b] - 1) / nsOf[(size_t) b]; };
-        std::vector<std::pair<int, int>> heap; // (piece, buffer)
-        for (int b = 0; b < B; b++) heap.emplace_back(piece(b), b);
-        std::make_heap(heap.begin(), heap.end());
-        for (int64_t units = B; units < budget; units++)
+        std::fill(nsOf.begin(), nsOf.end(), 1);
+        if (roundsWanted > 0 && budgetWaves > waves0)
         {
-          std::pop_heap(heap.begin(), heap.end());
-          const int b = heap.back().second;
-          if (heap.back().first <= 12 || nsOf[(size_t) b] >= 64) break; // the longest piece cannot get shorter
-          nsOf[(size_t) b]++;
-          heap.back() = std::make_pair(piece(b), b);
-          std::push_heap(heap.begin(), heap.end());
-        }
-      }
-      // the pieces of one strip go to up to four wavefronts of one workgroup (added up through the LDS: WaveDesc::grp);
-      // only what is left beyond four becomes partials in memory for the finalize launch
-      anyPartial = false;
-      for (int b = 0; b < B; b++) anyPartial = anyPartial || nsOf[(size_t) b] > gmax;
-      std::vector<WaveGroup> groups;
-      pbase = 0;
-      maxSplit = 1;
-      for (int b = 0; b < B; b++)
-      {
-        const int ns = nsOf[(size_t) b];
-        const int per = (steps[(size_t) b] + ns - 1) / ns;
-        const int np = (ns + gmax - 1) / gmax; // partials in memory
-        splitTab[(size_t) b * 2] = (int) pbase;
-        splitTab[(size_t) b * 2 + 1] = np;
-        maxSplit = std::max(maxSplit, np);
-        int piece = 0;
-        for (int q = 0; q < np; q++)
-        {
-          const int size = ns / np + (q < ns % np ? 1 : 0);
-          const int base = G / wW, rem = G % wW;
-          int g0 = 0;
-          for (int st = 0; st < wW; st++)
+          const int64_t budget = budgetWaves / wW;
+          auto piece = [&](int b) { return (steps[(size_t) b] + nsOf[(size_t) b] - 1) / nsOf[(size_t) b]; };
+          std::vector<std::pair<int, int>> heap; // (piece, buffer)
+          for (int b = 0; b < B; b++) heap.emplace_back(piece(b), b);
+          std::make_heap(heap.begin(), heap.end());
+          for (int64_t units = B; units < budget; units++)
           {
-            const int ng = base + (st < rem ? 1 : 0);
-            WaveGroup grp;
-            grp.buf = b; grp.work = 0;
-            for (int r = 0; r < size; r++)
-            {
-              const int s0 = (piece + r) * per, s1 = std::min(steps[(size_t) b], s0 + per);
-              WaveDesc d{};
-              d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = s0; d.s1 = std::max(s0, s1);
-              d.partIdx = (anyPartial && r == 0) ? (int) pbase + q : -1;
-              d.statIdx = b * wW + st;
-              d.dIdx = (anyPartial && st == 0 && r == 0) ? d.partIdx : -1;
-              d.grp = (r << 4) | (size << 8);
-              grp.work = std::max<int64_t>(grp.work, d.s1 - d.s0);
-              grp.waves.push_back(d);
-            }
-            if (ng > 0) groups.push_back(std::move(grp));
-            g0 += ng;
+            std::pop_heap(heap.begin(), heap.end());
+            const int b = heap.back().second;
+            if (heap.back().first <= 12 || nsOf[(size_t) b] >= 64) break; // the longest piece cannot get shorter
+            nsOf[(size_t) b]++;
+            heap.back() = std::make_pair(piece(b), b);
+            std::push_heap(heap.begin(), heap.end());
           }
-          piece += size;
         }
-        pbase += np;
+        r.anyPartial = false;
+        for (int b = 0; b < B; b++) r.anyPartial = r.anyPartial || nsOf[(size_t) b] > gmax;
+        std::vector<WaveGroup> groups;
+        r.pbase = 0;
+        r.maxSplit = 1;
+        r.maxPieces = 1;
+        int64_t longest = 0;
+        for (int b = 0; b < B; b++)
+        {
+          const int ns = nsOf[(size_t) b];
+          const int per = (steps[(size_t) b] + ns - 1) / ns;
+          const int np = (ns + gmax - 1) / gmax; // partials in memory
+          r.splitTab[(size_t) b * 2] = (int) r.pbase;
+          r.splitTab[(size_t) b * 2 + 1] = np;
+          r.maxSplit = std::max(r.maxSplit, np);
+          r.maxPieces = std::max(r.maxPieces, ns);
+          longest = std::max<int64_t>(longest, per);
+          int piece = 0;
+          for (int q = 0; q < np; q++)
+          {
+            const int size = ns / np + (q < ns % np ? 1 : 0);
+            const int base = G / wW, rem = G % wW;
+            int g0 = 0;
+            for (int st = 0; st < wW; st++)
+            {
+              const int ng = base + (st < rem ? 1 : 0);
+              WaveGroup grp;
+              grp.buf = b; grp.work = 0;
+              for (int rk = 0; rk < size; rk++)
+              {
+                const int s0 = (piece + rk) * per, s1 = std::min(steps[(size_t) b], s0 + per);
+                WaveDesc d{};
+                d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = s0; d.s1 = std::max(s0, s1);
+                d.partIdx = (r.anyPartial && rk == 0) ? (int) r.pbase + q : -1;
+                d.statIdx = b * wW + st;
+                d.dIdx = (r.anyPartial && st == 0 && rk == 0) ? d.partIdx : -1;
+                d.grp = (rk << 4) | (size << 8);
+                grp.work = std::max<int64_t>(grp.work, d.s1 - d.s0);
+                grp.waves.push_back(d);
+              }
+              if (ng > 0) groups.push_back(std::move(grp));
+              g0 += ng;
+            }
+            piece += size;
+          }
+          r.pbase += np;
+        }
+        pack_groups(groups, r.list, &r.wgs);
+        const double rounds = roundsWanted == 0 ? (double) r.wgs / 256.0 : (double) ((r.wgs + 255) / 256);
+        r.cost = rounds * ((double) longest * (400.0 + 270.0 * r.ngW) + 40000.0) + (r.maxPieces > 1 ? 6000.0 : 0.0) +
+                 (r.anyPartial ? 60000.0 + 3000.0 * r.maxSplit : 0.0);
+        if (roundsWanted == 0 || r.wgs <= 256 * roundsWanted || budgetWaves <= waves0 || forcedBudget > 0) break;
       }
-      pack_groups(groups, list, &c->listW.wgs);
-      if (roundsWanted == 0 || c->listW.wgs <= 256 * roundsWanted || budgetWaves <= waves0) break;
+      return r;
+    };
+    Cand best;
+    const int forcedNG = envInt("FLUHIP_RG_WNG", 0), forcedBudget = envInt("FLUHIP_RG_WBUDGET", 0);
+    int lastW = -1;
+    for (int ngc = maxNG; ngc >= 1; ngc--)
+    {
+      if (forcedNG > 0 && ngc != std::min(forcedNG, maxNG)) continue;
+      const int wW = (G + ngc - 1) / ngc;
+      if (wW == lastW) continue; // the same strips as the wider candidate
+      lastW = wW;
+      // wide strips re-use the moving factor's rows over more columns: with enough buffers to fill the chip without cutting
+      // anything the widest form is what the batched kernel was tuned for -- narrower candidates only while the chip is not full
+      if (forcedNG == 0 && (int64_t) B * ((G + maxNG - 1) / maxNG) >= 1536 && ngc < maxNG) break;
+      Cand cnd = build(wW, forcedBudget);
+      if (cnd.cost < best.cost - 1.0) best = std::move(cnd);
     }
-    c->listW.ng = ngW; c->listW.partial = anyPartial ? 1 : 0; c->listW.maxSplit = maxSplit;
-    c->listW.nPartials = anyPartial ? pbase : 0;
-    c->listW.statParts = anyPartial ? update_finalize_parts(C, Kp) : wW;
+    c->listW.wgs = best.wgs;
+    c->listW.ng = best.ngW; c->listW.partial = best.anyPartial ? 1 : 0; c->listW.maxSplit = best.maxSplit;
+    c->listW.nPartials = best.anyPartial ? best.pbase : 0;
+    c->listW.statParts = best.anyPartial ? update_finalize_parts(C, Kp) : best.wW;
     c->stripsW = c->listW.statParts;
-    c->nsplitW = 1;
-    for (int b = 0; b < B; b++) c->nsplitW = std::max(c->nsplitW, nsOf[(size_t) b]);
-    if (int rc = upload_list(ctx, c->listW.list, list.data(), list.size() * sizeof(WaveDesc))) return rc;
-    if (int rc = upload_list(ctx, c->listW.splitTab, splitTab.data(), splitTab.size() * sizeof(int))) return rc;
+    c->nsplitW = best.maxPieces;
+    if (int rc = upload_list(ctx, c->listW.list, best.list.data(), best.list.size() * sizeof(WaveDesc))) return rc;
+    if (int rc = upload_list(ctx, c->listW.splitTab, best.splitTab.data(), best.splitTab.size() * sizeof(int))) return rc;
   }
   // ---- H update: strips over a buffer's own frames, the contraction over the bins (the same for every buffer) ------------
   {
@@ -689,9 +744,9 @@ static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
     for (int b = 0; b < B; b++) groupsOf[(size_t) b] = (c->tOf[(size_t) b] + 15) / 16;
     // Strip width NG, pieces of the bin contraction that share a workgroup (gsz: added up through the LDS) and partials in
     // memory (ns: a finalize launch) by a small cost model in shader cycles, fitted to tools/ragged_sweep.sh
-    // (profiles/r03/ragged_sweep.txt): a wavefront runs the loop of the launch's widest strip at ~325 cycles per column group
-    // and 4-row step (8 groups: 2600, 4 groups: 1300 -- width costs nothing per group), a round of up to 256 workgroups
-    // pays ~40 k cycles of prologue, epilogue and launch, a finalize launch ~60 k.
+    // and tools/batch_timing.py: a wavefront runs the loop of the launch's widest strip at ~400 + 270 NG cycles per 4-row step
+    // (measured: 1 group 695, 4: 1 370, 6: 1 780, 7: 2 250, 8: 2 620, 9: 2 775), a round of up to 256 workgroups pays ~40 k
+    // cycles of prologue, epilogue and launch, a finalize launch ~60 k.
     const int steps = (F + 3) / 4;
     int NG = maxNG, gsz = 1, ns = 1;
     double bestCost = 1e300;
@@ -715,7 +770,7 @@ static int plan_ragged(fluhip_ctx* ctx, fluhip_corpus* c)
           if (pieces > 1 && steps / pieces < 12) continue;
           const int64_t wgs = (strips * m + (4 / g) - 1) / (4 / g);
           const double rounds = (double) ((wgs + 255) / 256);
-          const double perWave = (double) ((steps + pieces - 1) / pieces) * 325.0 * widestStrip + 40000.0;
+          const double perWave = (double) ((steps + pieces - 1) / pieces) * (400.0 + 270.0 * widestStrip) + 40000.0;
           const double cost = rounds * perWave + (g > 1 ? 6000.0 : 0.0) + (m > 1 ? 60000.0 + 3000.0 * m : 0.0);
           if (cost < bestCost - 1.0) { bestCost = cost; NG = cand; gsz = g; ns = m; }
         }
@@ -808,7 +863,8 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
     HIPCHK(ctx, c->tTab.alloc(B * sizeof(int), false, s));
     HIPCHK(ctx, hipMemcpyAsync(c->nTab.p, c->nOf.data(), B * sizeof(int64_t), hipMemcpyHostToDevice, s));
     HIPCHK(ctx, hipMemcpyAsync(c->tTab.p, c->tOf.data(), B * sizeof(int), hipMemcpyHostToDevice, s));
-    return plan_ragged(ctx, c);
+    c->useLists = true;
+    return plan_lists(ctx, c);
   }
   if (int rc = plan_updates(ctx, c)) return rc;
   return FLUHIP_OK;
@@ -1082,7 +1138,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>();
-    if (c->ragged)
+    if (c->useLists)
     {
       a.list = c->listW.list.as<WaveDesc>(); a.listWGs = c->listW.wgs; a.listNG = c->listW.ng; a.listPartial = c->listW.partial;
     }
@@ -1095,7 +1151,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       {
         ProfScope p(ctx, 1);
         launch_nmf_update5(a, s);
-        if (c->ragged && c->listW.partial)
+        if (c->useLists && c->listW.partial)
           launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listW.maxSplit, a.B, s, a.nrm, a.nrmMode,
                                  a.statPart, c->listW.splitTab.as<int>());
       }
@@ -1132,7 +1188,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
-    if (c->ragged)
+    if (c->useLists)
     {
       a.list = c->listH.list.as<WaveDesc>(); a.listWGs = c->listH.wgs; a.listNG = c->listH.ng; a.listPartial = c->listH.partial;
       launch_nmf_update5(a, s);
