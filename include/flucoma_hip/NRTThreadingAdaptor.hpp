@@ -24,7 +24,11 @@ public:
   using Client = bufnmf::NMFClient;
   using ParamSetType = bufnmf::NMFParams;
 
-  explicit NRTThreadedNMFClient(ParamSetType& p, FluidContext c = {}) : mHostParams(p), mContext(c) {}
+  // ONE client for the adaptor's lifetime, handed to every task (:831 mClient{new NRTClient{mHostParams, c}}, :883): the
+  // client's device context -- and with it the cached device blocks and loaded code objects -- outlives a job
+  explicit NRTThreadedNMFClient(ParamSetType& p, FluidContext c = {})
+      : mHostParams(p), mContext(c), mClient(std::make_shared<Client>(mHostParams, mContext))
+  {}
   ~NRTThreadedNMFClient()
   {
     mQueue.clear();
@@ -49,7 +53,7 @@ public:
     if (mTask) return {};
     if (mQueue.empty()) return {Result::Status::kWarning, "Process() called on empty queue"};
     if (mSynchronous) mSynchronousDone = false;
-    mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext, mSynchronous);
+    mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, mSynchronous);
     mQueue.pop_front();
     Result result;
     if (mSynchronous)
@@ -69,7 +73,7 @@ public:
     {
       if (!mQueue.empty())
       {
-        mTask = std::make_unique<ThreadedTask>(mQueue.front(), mContext, false);
+        mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, false);
         mQueue.pop_front();
         state = kDoneStillProcessing;
       }
@@ -101,13 +105,14 @@ private:
   class ThreadedTask
   {
   public:
-    ThreadedTask(NRTJob& job, const FluidContext& host, bool synchronous) : mJob(job), mContext(mTaskState, host.device())
+    ThreadedTask(std::shared_ptr<Client> client, NRTJob& job, const FluidContext& host, bool synchronous)
+        : mJob(job), mContext(mTaskState, host.device()), mClient(std::move(client))
     {
       mContext.devices(host.devices());
       mState = kProcessing;
       if (synchronous)
       {
-        mClient = std::make_unique<Client>(mJob.params, mContext);
+        mClient->setParams(mJob.params); // :1038
         mResult = mClient->process<float>(mContext);
         mState = kDone;
         mDetached = true;
@@ -122,7 +127,7 @@ private:
       isolate(P.resynth, mResynthCopy);
       isolate(P.bases, mBasesCopy);
       isolate(P.activations, mActsCopy);
-      mClient = std::make_unique<Client>(mJob.params, mContext);
+      mClient->setParams(mJob.params);
       mFuture = mPromise.get_future();
       mThread = std::thread([this] {
         Result r = mClient->process<float>(mContext);
@@ -166,7 +171,7 @@ private:
     NRTJob                               mJob;
     FluidTask                            mTaskState;
     FluidContext                         mContext;
-    std::unique_ptr<Client>              mClient;
+    std::shared_ptr<Client>              mClient;
     std::shared_ptr<MemoryBufferAdaptor> mSourceCopy, mResynthCopy, mBasesCopy, mActsCopy;
     std::promise<Result>                 mPromise;
     std::future<Result>                  mFuture;
@@ -178,6 +183,7 @@ private:
 
   ParamSetType                  mHostParams;
   FluidContext                  mContext;
+  std::shared_ptr<Client>       mClient;
   std::deque<NRTJob>            mQueue;
   std::unique_ptr<ThreadedTask> mTask;
   bool                          mSynchronous{false};

@@ -173,10 +173,9 @@ def test_client_eight_channels_run_as_one_corpus(driver, oracle, onp, tmp_path, 
     """the channel loop of nrt/NMFClient.hpp:233 on the batched kernels.  An 8-channel x 10 s rank-32
     job through NRTThreadedNMFClient: random start, seeded bases, fixed bases + seeded activations -- channels against the
     per-channel oracle, the whole result against the channel-by-channel loop (FLUHIP_CLIENT_SEQUENTIAL=1), and the wall
-    time of the batched job against the sequential one's.  (The review asked for a quarter; measured 0.30 - 0.35: of the
-    batched job's ~29 ms, 18 are 200 iterations at 88 us -- 8 buffers are still the split-contraction regime, see DESIGN
-    "small batches" -- and ~9 are host-side work both paths pay: gathering / scattering the interleaved host buffers and a
-    context per job.  The bar here is 0.4.)"""
+    time of the batched job against the sequential one's.  (The review asked for a quarter: measured 22.3 against 90.6 ms
+    = 0.246 once the batch ran from work lists -- 200 iterations at 73 us instead of 88 -- and the adaptor kept one client,
+    hence one device context, across jobs like the reference's does.  The bar here is 0.3: boxes differ.)"""
     frames, chans = 441000, 8
     win, hop, fft, K, iters, seed = 2048, 512, 2048, 32, 200, 42
     F, T = fft // 2 + 1, frames // hop + 1
@@ -221,7 +220,7 @@ def test_client_eight_channels_run_as_one_corpus(driver, oracle, onp, tmp_path, 
         assert rel_err(acts[c * K:(c + 1) * K], ra) < 1e-6, c
     if ms:
         print(f"8-channel job: batched {ms['batched']:.1f} ms, channel by channel {ms['sequential']:.1f} ms")
-        assert ms["batched"] <= 0.4 * ms["sequential"], ms
+        assert ms["batched"] <= 0.3 * ms["sequential"], ms
 
 
 @pytest.mark.gpu
