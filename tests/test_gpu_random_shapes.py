@@ -54,3 +54,48 @@ def test_random_shape(ctx, oracle, onp, case):
         assert rel_err(mag[b], rmag) < 1e-12, plan
         rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, plan
+
+
+def _ragged_cases():
+    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP_RAGGED", "4711,14").split(","))
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(count):
+        fft = [1024, 2048, 4096][rs.randint(3)]
+        win = fft if rs.rand() < 0.7 else fft // 2
+        hop = [win // 2, win // 4, win][rs.randint(3)]
+        K = [1, 3, 16, 17, 32, 40, 64, 100][rs.randint(8)]
+        B = [2, 3, 7, 20, 90, 300][rs.randint(6)]
+        longest = [1, 5, 40, 200][rs.randint(4)]              # frames of the longest buffer
+        if K > 32:
+            B, longest = min(B, 20), min(longest, 40)
+        lens = [int(max(1, rs.randint(1, longest + 1) * hop - rs.randint(0, hop))) for _ in range(B)]
+        iters = int(rs.randint(0, 7))
+        uw, uh = [(True, True), (True, True), (True, False), (False, True)][rs.randint(4)]
+        out.append((i, B, longest, win, fft, hop, K, iters, uw, uh, tuple(lens)))
+    return out
+
+
+@pytest.mark.parametrize("case", _ragged_cases(), ids=lambda c: "r%d_B%d_T%d_w%d_f%d_h%d_K%d_i%d_%d%d" % c[:10])
+def test_random_ragged_corpus(ctx, oracle, onp, case):
+    """buffers of random different lengths in one set of launches (work lists, intra-workgroup reduction, per-buffer
+    finalize tables): whatever the planner picks, a sample of the buffers -- the shortest and the longest among them --
+    must match the oracle, and the padding frames must stay zero"""
+    import fluhip
+    _, B, _, win, fft, hop, K, iters, uw, uh, lens = case
+    lens = list(lens)
+    src = [onp.synth_audio(max(lens), 8100 + b) for b in range(3)]
+    audios = [src[b % 3][:n] for b, n in enumerate(lens)]
+    c = fluhip.RaggedCorpus(ctx, lens, win, fft, hop, K)
+    c.set_audio(audios); c.stft()
+    c.nmf(iters, seed=42, updateW=uw, updateH=uh)
+    mag, W1, H1 = c.read_f64()
+    plan = c.plan()
+    c.close()
+    for b in sorted({0, B - 1, int(np.argmin(lens)), int(np.argmax(lens))}):
+        T = (lens[b] + hop) // hop
+        _, rmag = oracle.stft_f32(audios[b], win, fft, hop)
+        assert rel_err(mag[b, :T], rmag) < 1e-12, plan
+        assert not mag[b, T:].any() and not H1[b, T:].any(), plan
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b, :T], rH) < TOL_FACTORS_TIGHT, (b, plan)
