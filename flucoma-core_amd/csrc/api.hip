@@ -597,22 +597,35 @@ int upload_list(fluhip_ctx* ctx, DevBuf& dst, const void* src, size_t bytes)
 // Work lists of the two factor updates over buffers with their own frame counts tOf[b]: ragged corpora, and equal-length
 // corpora too small to fill the chip with whole contractions (the intra-workgroup reduction is what this form has over the
 // uniform split schedule: fewer or no partials in memory, no finalize launch).
-static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
+namespace {
+struct ListSide
 {
-  hipStream_t s = ctx->stream;
-  const int B = (int) c->B, Kp = (int) c->Kp, F = (int) c->F;
+  std::vector<WaveDesc> list;
+  std::vector<int> splitTab;
+  int wgs = 0, ng = 0, partial = 0, maxSplit = 1, pieces = 1, statParts = 0;
+  int64_t nPartials = 0;
+};
+struct ListPlanHost
+{
+  ListSide W, H;
+  bool sideW = false;
+};
+} // namespace
+// pure host code (no device, no context): also reachable through fluhip_debug_plan_lists for the CPU tests
+static void build_list_plan(const std::vector<int>& tOf, int Tmax, int F, int Kp, ListPlanHost& out)
+{
+  const int B = (int) tOf.size();
   const int maxNG = nmf_update5_max_groups(Kp);
-  c->lazy = true; c->strip = false; c->nsplitW = c->nsplitH = 1;
   // ---- W update: strips over the bins (the same for every buffer), the contraction over a buffer's own frames ------------
   {
     auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
     std::vector<int> steps((size_t) B);
-    for (int b = 0; b < B; b++) steps[(size_t) b] = (c->tOf[(size_t) b] + 3) / 4;
+    for (int b = 0; b < B; b++) steps[(size_t) b] = (tOf[(size_t) b] + 3) / 4;
     // the Nyquist bin as a side column (fluhip_kernels.h SideColumn): every power-of-two transform has 16 m + 1 bins, and a
     // wavefront runs the loop of the widest strip of the launch -- 65 column groups never deal evenly
     static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
-    c->sideW = !sideOff && nmf_side_column_supported((int) c->T, F, Kp);
-    const int C = F - (c->sideW ? 1 : 0);
+    out.sideW = !sideOff && nmf_side_column_supported(Tmax, F, Kp);
+    const int C = F - (out.sideW ? 1 : 0);
     const int G = (C + 15) / 16;
     // One candidate schedule per strip width.  Contractions are cut into pieces when one round of wavefronts (1024 SIMDs, one
     // workgroup of four per CU) would stay part empty: the wavefront budget goes to whichever buffer has the longest pieces
@@ -689,7 +702,7 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
               grp.buf = b; grp.work = 0;
               for (int rk = 0; rk < size; rk++)
               {
-                const int s0 = (piece + rk) * per, s1 = std::min(steps[(size_t) b], s0 + per);
+                const int s0 = std::min(steps[(size_t) b], (piece + rk) * per), s1 = std::min(steps[(size_t) b], s0 + per); // (an empty tail piece: no steps, zeros)
                 WaveDesc d{};
                 d.buf = b; d.g0 = g0; d.ng = ng; d.s0 = s0; d.s1 = std::max(s0, s1);
                 d.partIdx = (r.anyPartial && rk == 0) ? (int) r.pbase + q : -1;
@@ -729,19 +742,18 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
       Cand cnd = build(wW, forcedBudget);
       if (cnd.cost < best.cost - 1.0) best = std::move(cnd);
     }
-    c->listW.wgs = best.wgs;
-    c->listW.ng = best.ngW; c->listW.partial = best.anyPartial ? 1 : 0; c->listW.maxSplit = best.maxSplit;
-    c->listW.nPartials = best.anyPartial ? best.pbase : 0;
-    c->listW.statParts = best.anyPartial ? update_finalize_parts(C, Kp) : best.wW;
-    c->stripsW = c->listW.statParts;
-    c->nsplitW = best.maxPieces;
-    if (int rc = upload_list(ctx, c->listW.list, best.list.data(), best.list.size() * sizeof(WaveDesc))) return rc;
-    if (int rc = upload_list(ctx, c->listW.splitTab, best.splitTab.data(), best.splitTab.size() * sizeof(int))) return rc;
+    out.W.wgs = best.wgs;
+    out.W.ng = best.ngW; out.W.partial = best.anyPartial ? 1 : 0; out.W.maxSplit = best.maxSplit;
+    out.W.nPartials = best.anyPartial ? best.pbase : 0;
+    out.W.statParts = best.anyPartial ? update_finalize_parts(C, Kp) : best.wW;
+    out.W.pieces = best.maxPieces;
+    out.W.list = std::move(best.list);
+    out.W.splitTab = std::move(best.splitTab);
   }
   // ---- H update: strips over a buffer's own frames, the contraction over the bins (the same for every buffer) ------------
   {
     std::vector<int> groupsOf((size_t) B);
-    for (int b = 0; b < B; b++) groupsOf[(size_t) b] = (c->tOf[(size_t) b] + 15) / 16;
+    for (int b = 0; b < B; b++) groupsOf[(size_t) b] = (tOf[(size_t) b] + 15) / 16;
     // Strip width NG, pieces of the bin contraction that share a workgroup (gsz: added up through the LDS) and partials in
     // memory (ns: a finalize launch) by a small cost model in shader cycles, fitted to tools/ragged_sweep.sh
     // and tools/batch_timing.py: a wavefront runs the loop of the launch's widest strip at ~400 + 270 NG cycles per 4-row step
@@ -811,7 +823,7 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
           {
             WaveDesc d{};
             d.buf = b; d.g0 = g0; d.ng = ng;
-            d.s0 = (j * gsz + r) * per; d.s1 = std::max(d.s0, std::min(steps, d.s0 + per));
+            d.s0 = std::min(steps, (j * gsz + r) * per); d.s1 = std::max(d.s0, std::min(steps, d.s0 + per));
             d.partIdx = (ns > 1 && r == 0) ? b * ns + j : -1;
             d.statIdx = 0;
             d.dIdx = (ns > 1 && st == 0 && r == 0) ? d.partIdx : -1;
@@ -824,13 +836,33 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
         }
       }
     }
-    std::vector<WaveDesc> list;
-    pack_groups(groups, list, &c->listH.wgs);
-    c->listH.ng = ngH; c->listH.partial = ns > 1 ? 1 : 0; c->listH.maxSplit = ns; c->listH.nPartials = ns > 1 ? (int64_t) B * ns : 0;
-    c->nsplitH = pieces;
-    if (int rc = upload_list(ctx, c->listH.list, list.data(), list.size() * sizeof(WaveDesc))) return rc;
-    if (int rc = upload_list(ctx, c->listH.splitTab, splitTab.data(), splitTab.size() * sizeof(int))) return rc;
+    pack_groups(groups, out.H.list, &out.H.wgs);
+    out.H.ng = ngH; out.H.partial = ns > 1 ? 1 : 0; out.H.maxSplit = ns; out.H.nPartials = ns > 1 ? (int64_t) B * ns : 0;
+    out.H.pieces = pieces;
+    out.H.splitTab = std::move(splitTab);
   }
+}
+
+static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  const int B = (int) c->B, Kp = (int) c->Kp;
+  c->lazy = true; c->strip = false;
+  ListPlanHost plan;
+  build_list_plan(c->tOf, (int) c->T, (int) c->F, Kp, plan);
+  c->sideW = plan.sideW;
+  auto take = [&](fluhip_corpus::WorkList& dst, const ListSide& src) -> int {
+    dst.wgs = src.wgs; dst.ng = src.ng; dst.partial = src.partial; dst.maxSplit = src.maxSplit; dst.nPartials = src.nPartials;
+    dst.statParts = src.statParts;
+    if (int rc = upload_list(ctx, dst.list, src.list.data(), src.list.size() * sizeof(WaveDesc))) return rc;
+    return upload_list(ctx, dst.splitTab, src.splitTab.data(), src.splitTab.size() * sizeof(int));
+  };
+  if (int rc = take(c->listW, plan.W)) return rc;
+  if (int rc = take(c->listH, plan.H)) return rc;
+  c->stripsW = plan.W.statParts;
+  c->nsplitW = plan.W.pieces;
+  c->nsplitH = plan.H.pieces;
+
   // workspaces
   const int64_t nPart = std::max(c->listW.nPartials, c->listH.nPartials);
   const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
@@ -2664,6 +2696,32 @@ int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64
 {
   return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
                          max_freq, sample_rate, 0, 0, out, frames_out);
+}
+
+int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,
+                                int64_t cap, int32_t* info8)
+{
+  if (!frames || count < 1 || bins < 1 || K < 1 || K > 128) return -1;
+  std::vector<int> tOf((size_t) count);
+  int tmax = 1;
+  for (int64_t i = 0; i < count; i++)
+  {
+    if (frames[i] < 1) return -1;
+    tOf[(size_t) i] = (int) frames[i];
+    tmax = std::max(tmax, tOf[(size_t) i]);
+  }
+  ListPlanHost plan;
+  build_list_plan(tOf, tmax, (int) bins, (int) padded_rank(K), plan);
+  const ListSide& sd = which ? plan.H : plan.W;
+  if (info8)
+  {
+    info8[0] = sd.wgs; info8[1] = sd.ng; info8[2] = sd.partial; info8[3] = sd.maxSplit; info8[4] = sd.pieces;
+    info8[5] = (int32_t) sd.nPartials; info8[6] = plan.sideW ? 1 : 0; info8[7] = sd.statParts;
+  }
+  const int64_t n = (int64_t) sd.list.size();
+  static_assert(sizeof(WaveDesc) == 12 * sizeof(int32_t), "descriptor layout");
+  if (desc) std::memcpy(desc, sd.list.data(), (size_t) std::min(n, cap) * sizeof(WaveDesc));
+  return n;
 }
 
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)

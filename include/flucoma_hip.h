@@ -281,6 +281,15 @@ int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1
  * counts before it then describe the schedule it replaces) }. */
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 
+/* Introspection for the tests (pure host code, no device needed): the work lists the planner builds for `count` buffers of
+ * frames[i] frames and `bins` bins at rank K -- which = 0 the W update's, 1 the H update's.  desc (may be NULL) receives up to
+ * `cap` descriptors of 12 ints {buffer, first column group, groups, first step, end step, partial slot, statistics slot,
+ * denominator slot, group word (leader | rank << 4 | size << 8 | barrier << 16), 0, 0, 0}, four per workgroup; info8 =
+ * {workgroups, widest strip, partials in memory 0/1, most partials per buffer, most pieces per contraction, partial slots,
+ * Nyquist side column 0/1, statistics parts per buffer}.  Returns the number of descriptors (-1: bad arguments). */
+int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,
+                                int64_t cap, int32_t* info8);
+
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
 /* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of
  * a corpus are independent jobs (clients/nrt/NMFClient.hpp:233 loop body): a pool holds one context per listed device
