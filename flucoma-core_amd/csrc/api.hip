@@ -1052,7 +1052,7 @@ static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* se
     HIPCHK(ctx, stageH.alloc((size_t) B * TK * sizeof(float), false, s));
     HIPCHK(ctx, hipMemcpyAsync(stageH.p, fi.H0f32, (size_t) B * TK * sizeof(float), hipMemcpyHostToDevice, s));
     launch_scatter_factor_f32(stageH.as<float>(), (int64_t) TK, c->H1.as<double>(), c->Tp * c->Kp,
-                              (int) c->T, (int) c->K, (int) c->Kp, B, s);
+                              (int) c->T, (int) c->K, (int) c->Kp, B, s, c->ragged ? c->tTab.as<int>() : nullptr);
   }
   else
   {
@@ -1576,7 +1576,6 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
 int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
 {
   if (!c) return FLUHIP_ERROR;
-  if (c->ragged && acts_seed) return fail(c->ctx, "activation seeds of a ragged corpus are not supported (bases are)");
   const size_t nw = (size_t) c->B * c->K * c->F, nh = (size_t) c->B * c->K * c->T;
   if (bases_seed) c->seedW32.assign(bases_seed, bases_seed + nw);
   else std::vector<float>().swap(c->seedW32);
@@ -1617,7 +1616,6 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   if (!c || !out_dev) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
   if (!c->haveFactors) return fail(ctx, "corpus has no factors: call fluhip_corpus_nmf first");
-  if (c->ragged) return fail(ctx, "resynthesis of a ragged corpus is not supported: run its buffers as equal-length groups");
   if (!c->keepSpec || !c->spec.p)
     return fail(ctx, "resynthesis needs the complex spectrogram: fluhip_corpus_keep_spectrum(c, 1) before fluhip_corpus_stft");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1635,12 +1633,15 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   {
     const double* Wb = c->Wf.as<double>() + b * c->Fp * c->Kp;
     const double* Hb = c->H1.as<double>() + b * c->Tp * c->Kp;
-    launch_vhat(Wb, 0, Hb, 0, vhat.as<double>(), c->F, 0, (int) c->T, (int) c->F, (int) c->Kp, 1, s);
+    // a ragged corpus: the buffer's own frames and samples (arrays are strided by the longest buffer's)
+    const int Tb = c->ragged ? c->tOf[(size_t) b] : (int) c->T;
+    const int64_t nb = c->ragged ? c->nOf[(size_t) b] : c->n;
+    launch_vhat(Wb, 0, Hb, 0, vhat.as<double>(), c->F, 0, Tb, (int) c->F, (int) c->Kp, 1, s);
     ResynthArgs ra;
     ra.spec = c->spec.as<double>() + b * c->T * c->F * 2; ra.Wf = Wb; ra.H1 = Hb;
     ra.Vhat = vhat.as<double>(); ra.ldV = c->F; ra.Kp = (int) c->Kp;
-    ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = (int) c->T; ra.F = (int) c->F;
-    ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = c->n;
+    ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = Tb; ra.F = (int) c->F;
+    ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = nb; ra.outStride = c->n;
     ra.trim = c->win / 2;
     for (int64_t k = 0; k < c->K; k += compsPerLaunch)
     {
@@ -1668,6 +1669,27 @@ int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out)
   int rc = fluhip_corpus_resynth_dev(c, d.as<float>());
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(out, d.p, nb, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return FLUHIP_OK;
+}
+
+int fluhip_corpus_resynth_ragged_host(fluhip_corpus* c, float* const* out)
+{
+  if (!c || !out) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf d;
+  const size_t nb = (size_t) c->B * c->K * c->n * sizeof(float);
+  HIPCHK(ctx, d.alloc(nb, true, ctx->stream));
+  int rc = fluhip_corpus_resynth_dev(c, d.as<float>());
+  if (rc) return rc;
+  for (int64_t i = 0; i < c->B; i++)
+  {
+    if (!out[i]) continue;
+    const int64_t ni = c->ragged ? c->nOf[(size_t) i] : c->n; // K rows of the buffer's own samples out of rows of the longest
+    HIPCHK(ctx, hipMemcpy2DAsync(out[i], (size_t) ni * sizeof(float), d.as<float>() + i * c->K * c->n, (size_t) c->n * sizeof(float),
+                                 (size_t) ni * sizeof(float), (size_t) c->K, hipMemcpyDeviceToHost, ctx->stream));
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLUHIP_OK;
 }

@@ -203,7 +203,7 @@ void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, in
                            int rows, int K, int Kp, int B, bool srcIsKMajor, hipStream_t s, const int* rowsTab = nullptr);
 // f32 seed variant: src[b][k][rows] floats (BufferAdaptor channel-major)
 void launch_scatter_factor_f32(const float* src, int64_t strideSrc, double* dst,
-                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s);
+                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s, const int* rowsTab = nullptr);
 
 // W1[b][k][f] = Wf[b][f][k]  (f64 and f32 flavours; f32 == clients/nrt/NMFClient.hpp:281-282)
 void launch_gather_w_f64(const double* Wf, int64_t strideW, double* W1, int64_t strideOut, int F,
@@ -270,6 +270,7 @@ struct ResynthArgs
   double* out;          // [n] f64 overlap-added, normalised, trimmed
   float* out32;         // [n] or nullptr
   int64_t n;
+  int64_t outStride = 0; // samples between the components' outputs (0: n)
   int64_t trim;         // leading samples dropped: win/2 for ISTFT::process, `padding` for BufSTFT
   int nComp = 1;        // components k .. k + nComp - 1 in one launch: frames [nComp][T][win], out / out32 [nComp][n]
   double* bigScratch = nullptr; // set (big_fft_scratch_bytes(fft, T)) when stft_needs_scratch(win, fft): global-memory passes

@@ -158,8 +158,9 @@ __global__ void resynth_ola_kernel(ResynthArgs a)
     nrm += w * w;
   }
   const double y = acc / fmax(nrm, kEpsilon); // :196
-  if (a.out) a.out[(int64_t) blockIdx.y * a.n + i] = y;
-  if (a.out32) a.out32[(int64_t) blockIdx.y * a.n + i] = (float) y;
+  const int64_t os = a.outStride > 0 ? a.outStride : a.n; // components outStride apart (ragged corpora: the longest buffer's samples)
+  if (a.out) a.out[(int64_t) blockIdx.y * os + i] = y;
+  if (a.out32) a.out32[(int64_t) blockIdx.y * os + i] = (float) y;
 }
 
 // ---- fft sizes whose frame does not fit the LDS: the inverse through the global-memory passes ---------------------

@@ -600,22 +600,23 @@ void launch_scatter_factor(const double* src, int64_t strideSrc, double* dst, in
 }
 
 __global__ void scatter_factor_f32_kernel(const float* src, int64_t strideSrc, double* dst,
-                                          int64_t strideDst, int rows, int K, int Kp)
+                                          int64_t strideDst, int rows, int K, int Kp, const int* rowsTab)
 {
   const int b = blockIdx.y;
   const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t) rows * K) return;
   const int k = (int) (idx / rows), row = (int) (idx % rows);
+  if (rowsTab && row >= rowsTab[b]) return; // ragged corpora: padding rows stay zero
   dst[(int64_t) b * strideDst + (int64_t) row * Kp + k] = (double) src[(int64_t) b * strideSrc + idx];
 }
 
 void launch_scatter_factor_f32(const float* src, int64_t strideSrc, double* dst,
-                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s)
+                               int64_t strideDst, int rows, int K, int Kp, int B, hipStream_t s, const int* rowsTab)
 {
   const int64_t total = (int64_t) rows * K;
   dim3 g((unsigned) ((total + 255) / 256), (unsigned) B);
   hipLaunchKernelGGL(scatter_factor_f32_kernel, g, dim3(256), 0, s, src, strideSrc, dst,
-                     strideDst, rows, K, Kp);
+                     strideDst, rows, K, Kp, rowsTab);
 }
 
 template <typename OutT>

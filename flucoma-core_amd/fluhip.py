@@ -52,7 +52,7 @@ EXPORTS = [
     "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create", "fluhip_corpus_create_ragged", "fluhip_corpus_frames_of", "fluhip_corpus_set_audio_ragged_host",
-    "fluhip_corpus_writeback_ragged_host",
+    "fluhip_corpus_writeback_ragged_host", "fluhip_corpus_resynth_ragged_host",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
@@ -120,6 +120,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_frames_of.restype = _i64
     L.fluhip_corpus_set_audio_ragged_host.argtypes = [_vp, ctypes.POINTER(_fp)]
     L.fluhip_corpus_writeback_ragged_host.argtypes = [_vp, ctypes.POINTER(_fp), ctypes.POINTER(_fp)]
+    L.fluhip_corpus_resynth_ragged_host.argtypes = [_vp, ctypes.POINTER(_fp)]
     L.fluhip_corpus_destroy.argtypes = [_vp]
     L.fluhip_corpus_destroy.restype = None
     for f in ("fluhip_corpus_frames", "fluhip_corpus_bins", "fluhip_corpus_device_bytes"):
@@ -522,6 +523,12 @@ class RaggedCorpus(Corpus):
         assert [a.shape[0] for a in audios] == self.lens
         ap = (_fp * self.count)(*[a.ctypes.data_as(_fp) for a in audios])
         self.ctx._check(self.ctx.lib.fluhip_corpus_set_audio_ragged_host(self.h, ap))
+
+    def resynth(self):
+        out = [np.empty((self.K, n), dtype=np.float32) for n in self.lens]
+        op = (_fp * self.count)(*[o.ctypes.data_as(_fp) for o in out])
+        self.ctx._check(self.ctx.lib.fluhip_corpus_resynth_ragged_host(self.h, op))
+        return out
 
     def writeback(self):
         bases = [np.empty((self.K, self.F), dtype=np.float32) for _ in range(self.count)]

@@ -250,8 +250,10 @@ int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const f
  * follow the buffer's frames).  Every buffer is the same independent BufNMF job as in an equal-length corpus
  * (clients/nrt/NMFClient.hpp:233 loop body).  Supported: ranks up to 128, fft 1024 / 2048 / 4096 with an even window
  * (FLUHIP_ERROR with a message otherwise: run such buffers as equal-length groups).  The other corpus entry points work
- * on a ragged corpus with T = the longest buffer's frame count: fluhip_corpus_stft, fluhip_corpus_nmf (seed / seeds),
- * fluhip_corpus_set_factors (bases only), fluhip_corpus_read_f64 (frames past a buffer's own are zero),
+ * on a ragged corpus with T (n) = the longest buffer's frame (sample) count as the stride of every per-buffer array:
+ * fluhip_corpus_stft, fluhip_corpus_nmf (seed / seeds), fluhip_corpus_set_factors (acts_seed: count x K x T, the entries
+ * past a buffer's own frames are ignored), fluhip_corpus_read_f64 (frames past a buffer's own are zero),
+ * fluhip_corpus_keep_spectrum + fluhip_corpus_resynth_dev (count x K x n, samples past a buffer's own untouched),
  * fluhip_corpus_plan. */
 int fluhip_corpus_create_ragged(fluhip_ctx* ctx, int64_t count, const int64_t* n, int64_t win, int64_t fft, int64_t hop,
                                 int64_t K, fluhip_corpus** out);
@@ -260,6 +262,8 @@ int64_t fluhip_corpus_frames_of(const fluhip_corpus* c, int64_t i);   /* T_i (T 
 int fluhip_corpus_set_audio_ragged_host(fluhip_corpus* c, const float* const* audio);
 /* bases[i]: K x F floats, acts[i]: K x T_i floats (either array, or single entries, may be NULL) */
 int fluhip_corpus_writeback_ragged_host(fluhip_corpus* c, float* const* bases, float* const* acts);
+/* out[i]: K x n[i] floats (entries may be NULL): the resynthesised components of every buffer (see fluhip_corpus_resynth_dev) */
+int fluhip_corpus_resynth_ragged_host(fluhip_corpus* c, float* const* out);
 /* write-back (clients/nrt/NMFClient.hpp:277-300) into device or host float arrays:
  * bases: count x K x F, acts: count x K x T.  Either may be NULL. */
 int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_dev);

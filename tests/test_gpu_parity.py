@@ -745,6 +745,32 @@ def test_ragged_corpus_few_buffers_split_contractions(ctx, oracle, onp):
     _check_ragged(ctx, oracle, onp, [40000, 9000, 70001], 4096, 4096, 1024, 70, 4, range(3))   # padded rank 128, fft 4096
 
 
+def test_ragged_corpus_activation_seeds_and_resynthesis(ctx, oracle, onp):
+    """the rest of the BufNMF parameter set on a ragged corpus: fixed activations (count x K x T with T the longest
+    buffer's frames; entries past a buffer's own are ignored) and the resynthesis output, against the single-channel
+    entry point buffer by buffer"""
+    import fluhip
+    lens = [12000, 5000, 20001, 257]
+    win, fft, hop, K, iters = 1024, 1024, 256, 4, 8
+    audios = [onp.synth_audio(n, 9300 + i) for i, n in enumerate(lens)]
+    c = fluhip.RaggedCorpus(ctx, lens, win, fft, hop, K)
+    rs = np.random.RandomState(8)
+    sH = rs.uniform(0.05, 1.0, (len(lens), K, c.T)).astype(np.float32)
+    c.keep_spectrum(True)
+    c.set_audio(audios); c.stft()
+    c.set_factors(None, sH)
+    c.nmf(iters, seed=42, updateH=False)
+    bases, acts = c.writeback()
+    res = c.resynth()
+    c.close()
+    for b, n in enumerate(lens):
+        T = (n + hop) // hop
+        rb, ra, rr, rc = ctx.bufnmf_channel(audios[b], win, fft, hop, K, iters, 42, updateH=False,
+                                            acts_seed=np.ascontiguousarray(sH[b, :, :T]), resynth=True)
+        assert rc == 0 and rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6, b
+        assert res[b].shape == (K, n) and rel_err(res[b], rr) < 1e-6, b
+
+
 def test_ragged_corpus_many_buffers_whole_contractions(ctx, oracle, onp):
     """the large-corpus regime: enough buffers that every (buffer, strip) wavefront keeps its whole contraction -- no
     split, results and column statistics straight from the update kernel, the Nyquist side column -- with lengths from
