@@ -343,9 +343,25 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
 constexpr int kSideUnr = 8;    // rows of a slice per row group (held in registers)
 constexpr int kSideSlices = 64; // at most; a launch uses as many as keep a slice within a block's capacity
 
+__device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t strideS, int C, int K, int Kp,
+                                                   const double* statPart, int nParts, const double* sidePart,
+                                                   int nsl, const double* wold, double* nrm, int b, double* shs, double* shm,
+                                                   double* smax);
+// fuse != nullptr: the LAST slice of a buffer to finish (an arrival ticket per buffer) runs the norm combine for it in
+// this launch -- one launch less per iteration.  The slices' partials are published by one agent-scope release per
+// workgroup and picked up behind one acquire (MI355X_MICROARCH.md, inter-workgroup visibility); the sums are taken in
+// slice order whoever arrives last, so the result does not depend on the order of arrival.
+struct SideFuse
+{
+  int* ticket;            // [B], zero between launches (the last arriver resets it)
+  double* S;              // the stationary factor, writable (the side row)
+  const double* statPart; // column statistics of the update launch, nParts per buffer
+  int nParts, K;
+  double* nrmOut;
+};
 template <int Kp>
 __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, int64_t strideS, int C, SideColumn side,
-                                                          const double* nrm, double* sidePart, double* wold)
+                                                          const double* nrm, double* sidePart, double* wold, SideFuse fuse)
 {
   typedef double d2 __attribute__((ext_vector_type(2)));
   extern __shared__ double sh[]; // [nrg][Kp] num, [nrg][Kp] den, [Kp] side row, [slice rows] quotients
@@ -430,6 +446,26 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
     p[k] = n;
     p[Kp + k] = d;
   }
+  if (!fuse.ticket) return;
+  __shared__ int isLast;
+  __shared__ double cshs[256], cshm[256], csmax[128];
+  __syncthreads();                                   // the slice's partial (and slice 0's wold) have been stored
+  if (threadIdx.x == 0)
+  {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(fuse.ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    isLast = old == nsl - 1 ? 1 : 0;
+    if (isLast)
+    {
+      __hip_atomic_store(fuse.ticket + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+  }
+  __syncthreads();
+  if (!isLast) return;
+  wnorm_combine_body(fuse.S, strideS, C, fuse.K, Kp, fuse.statPart, fuse.nParts, sidePart, nsl, wold, fuse.nrmOut, b, cshs, cshm,
+                     csmax);
 }
 
 // One workgroup per buffer, thread = (part group pg, k): adds the column statistics of the W update (one part per
@@ -437,12 +473,11 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
 // index order, the runs combined in fixed order -- and the side-column slices in slice order; writes the side
 // row (S[C-1][k] = S_old[C-1][k] num_k / max(den_k, eps), not normalised like every other row of W') and the new nrm:
 // alg/NMF.hpp:162  if (W.maxCoeff() > epsilon) W.colwise().normalize()  ->  nrm_k = sqrt(sum_c W'[c][k]^2), else 1.
-__global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
-                                                            const double* statPart, int nParts, const double* sidePart,
-                                                            int nsl, const double* wold, double* nrm)
+__device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t strideS, int C, int K, int Kp,
+                                                   const double* statPart, int nParts, const double* sidePart,
+                                                   int nsl, const double* wold, double* nrm, int b, double* shs, double* shm,
+                                                   double* smax)
 {
-  __shared__ double shs[256], shm[256], smax[128];
-  const int b = blockIdx.x;
   const int npg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, pg = threadIdx.x / Kp;
   const int per = (nParts + npg - 1) / npg;
@@ -506,6 +541,14 @@ __global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64
   }
 }
 
+__global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
+                                                            const double* statPart, int nParts, const double* sidePart,
+                                                            int nsl, const double* wold, double* nrm)
+{
+  __shared__ double shs[256], shm[256], smax[128];
+  wnorm_combine_body(Sbase, strideS, C, K, Kp, statPart, nParts, sidePart, nsl, wold, nrm, (int) blockIdx.x, shs, shm, smax);
+}
+
 // W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
 // outside the two update kernels reads W)
 __global__ void wnorm_apply_kernel(double* Sbase, int64_t strideS, int C, int Kp, double* nrm)
@@ -536,7 +579,7 @@ bool nmf_side_column_supported(int R, int C, int Kp)
 {
   return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128) && side_slices_for(R, Kp) <= kSideSlices;
 }
-int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp); }
+int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
 
 void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
                           double* nrm, const SideColumn* side, hipStream_t s)
@@ -552,10 +595,16 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     const int RS = (side->R + nsl - 1) / nsl;
     const dim3 grid((unsigned) nsl, (unsigned) B), block((unsigned) (nrg * Kp));
     const size_t sh = (size_t) (2 * nrg * Kp + Kp + RS) * sizeof(double);
-    if (Kp == 16) hipLaunchKernelGGL(side_slices_kernel<16>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
-    else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
-    else if (Kp == 64) hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
-    else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold);
+    // FLUHIP_SIDE_FUSED=0: the norm combine as its own launch (rounds 1 - 2)
+    static const bool fused = [] { const char* e = std::getenv("FLUHIP_SIDE_FUSED"); return !(e && std::atoi(e) == 0); }();
+    SideFuse fz{nullptr, nullptr, nullptr, 0, 0, nullptr};
+    if (fused)
+      fz = SideFuse{reinterpret_cast<int*>(wold + (int64_t) B * Kp), S, statPart, nStrips, K, nrm};
+    if (Kp == 16) hipLaunchKernelGGL(side_slices_kernel<16>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
+    else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
+    else if (Kp == 64) hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
+    else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
+    if (fused) return;
   }
   hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
                      nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
