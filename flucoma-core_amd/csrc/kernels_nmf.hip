@@ -595,8 +595,12 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     const int RS = (side->R + nsl - 1) / nsl;
     const dim3 grid((unsigned) nsl, (unsigned) B), block((unsigned) (nrg * Kp));
     const size_t sh = (size_t) (2 * nrg * Kp + Kp + RS) * sizeof(double);
-    // FLUHIP_SIDE_FUSED=0: the norm combine as its own launch (rounds 1 - 2)
-    static const bool fused = [] { const char* e = std::getenv("FLUHIP_SIDE_FUSED"); return !(e && std::atoi(e) == 0); }();
+    // FLUHIP_SIDE_FUSED=1: the norm combine inside this launch, by the last slice of a buffer to arrive.  Built in round 3
+    // to save a launch per iteration and measured the other way round on the bench shard, same box, alternating
+    // (profiles/r03/ab_side_fused.txt): 58 us between the two factor updates instead of 18, 217.9 k against 224.9 k
+    // buffer-iterations/s -- 2048 small workgroups each pay an agent-scope release (and the last ones an acquire) of
+    // ~1.7 us, eight deep per CU; the kernel boundary is the cheaper synchronisation here.  Off by default.
+    static const bool fused = [] { const char* e = std::getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();
     SideFuse fz{nullptr, nullptr, nullptr, 0, 0, nullptr};
     if (fused)
       fz = SideFuse{reinterpret_cast<int*>(wold + (int64_t) B * Kp), S, statPart, nStrips, K, nrm};

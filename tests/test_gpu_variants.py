@@ -43,7 +43,7 @@ assert worst < 1e-9, worst
 
 
 @pytest.mark.parametrize("env", [{"FLUHIP_NMF_KERNEL": "-1"},
-                                 {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
+                                 {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env):
