@@ -304,8 +304,11 @@ def main():
         value = world * B * iters * args.steps / elapsed_max
         # dominant kernel: nmf_update (one launch = one factor update of all B buffers; when the Nyquist bin is a
         # side column 1/F of the W update's flops run in the slice kernel between the updates -- not subtracted)
-        flop_per_launch = 4.0 * F * T * K * B
-        bytes_per_launch = (F * T * 8.0 + 2.0 * (F * K + K * T) * 8.0) * B
+        # (corpora of several rounds of wavefronts run round by round: a launch then covers one round's buffers, not all B)
+        prof_steps = args.steps if args.prof_in_timed_region else 1
+        buffers_per_launch = B * (2.0 * iters * prof_steps) / max(n_upd, 1)
+        flop_per_launch = 4.0 * F * T * K * buffers_per_launch
+        bytes_per_launch = (F * T * 8.0 + 2.0 * (F * K + K * T) * 8.0) * buffers_per_launch
         avg_ms = ms_upd / max(n_upd, 1)
         ach_tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -343,11 +346,11 @@ def main():
                        "iterations": iters, "parallelism": f"shard{world}" if world > 1 else "single"},
             "job_wall_ms_host_buffers_in_and_out": host_io_ms,
             "stft_frames_per_s": (T * B) / (stft_ms * 1e-3) if stft_ms > 0 else None,
-            "nmf_iterations_per_s_kernel_only": B / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
+            "nmf_iterations_per_s_kernel_only": buffers_per_launch / (2.0 * avg_ms * 1e-3) if avg_ms > 0 else None,
             "roofline": {"bound": "mfma", "kernel": "nmf_update5_kernel (v_mfma_f64_4x4x4_4b + LDS-DMA)", "achieved": ach_tflops,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_from_profile": traffic_src,
-                         "launches": int(n_upd), "avg_launch_ms": avg_ms,
+                         "launches": int(n_upd), "avg_launch_ms": avg_ms, "buffers_per_launch": buffers_per_launch,
                          "events": "in the timed steps" if args.prof_in_timed_region else "one extra step right behind the timed ones",
                          "profiled_step_ms": profiled_step_ms,
                          "shader_cycles_per_launch": cycles_per_launch, "sustained_mhz": sustained_mhz,

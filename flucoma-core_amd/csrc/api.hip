@@ -374,6 +374,10 @@ struct fluhip_corpus
   // The factor updates run kernels_nmf5.hip in work-list mode: one WaveDesc per wavefront, dealt by work.
   bool ragged = false;
   bool useLists = false; // the factor updates run from work lists (ragged corpora; small equal-length ones)
+  // window of buffers the next enqueue_iteration works on (0 buffers = all): corpora of several rounds of wavefronts
+  // run their iterations round by round (corpus_iterate_loop)
+  int64_t winB0 = 0, winB = 0;
+  int winStripsW = 0, winStripsH = 0;
   std::vector<int64_t> nOf; // samples per buffer
   std::vector<int> tOf;     // frames per buffer
   DevBuf nTab, tTab;        // the same on the device
@@ -1159,14 +1163,23 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     }
     return;
   }
+  // (a window of the corpus: every per-buffer array starts b0 buffers in; the scratch of the small kernels is reused)
+  const int64_t b0 = c->winB ? c->winB0 : 0;
+  const int Bw = c->winB ? (int) c->winB : B;
+  double* const magW = c->mag.as<double>() + b0 * c->Tp * c->Fp;
+  double* const magTW = c->magT.as<double>() + b0 * c->Fp * c->Tp;
+  double* const WfW = c->Wf.as<double>() + b0 * c->Fp * c->Kp;
+  double* const H1W = c->H1.as<double>() + b0 * c->Tp * c->Kp;
+  double* const wnormW = c->wnorm.p ? c->wnorm.as<double>() + b0 * c->Kp : nullptr;
   if (updateW)
   {
     // alg/NMF.hpp:158-161
     UpdateArgs a;
-    a.V = c->mag.as<double>(); a.ldv = c->Fp; a.strideV = c->Tp * c->Fp;
-    a.Mv = c->H1.as<double>(); a.strideM = c->Tp * c->Kp;
-    a.S = c->Wf.as<double>(); a.strideS = c->Fp * c->Kp;
-    a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = B; a.Kp = (int) c->Kp;
+    a.V = magW; a.ldv = c->Fp; a.strideV = c->Tp * c->Fp;
+    a.Mv = H1W; a.strideM = c->Tp * c->Kp;
+    a.S = WfW; a.strideS = c->Fp * c->Kp;
+    a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = Bw; a.Kp = (int) c->Kp;
+    if (c->winB) a.stripsOverride = c->winStripsW;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>();
@@ -1179,7 +1192,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // W' = W diag(wnorm) in memory: the kernel divides its stationary rows by wnorm, writes the new W'
       // and its per-wavefront column statistics; [side column ->] new wnorm.  alg/NMF.hpp:162 is then
       // implicit in every later use of (W', wnorm).
-      a.nrm = c->wnorm.as<double>(); a.nrmMode = 1; a.statPart = c->wscratch.as<double>();
+      a.nrm = wnormW; a.nrmMode = 1; a.statPart = c->wscratch.as<double>();
       {
         ProfScope p(ctx, 1);
         launch_nmf_update5(a, s);
@@ -1188,10 +1201,9 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
                                  a.statPart, c->listW.splitTab.as<int>());
       }
       ProfScope p(ctx, 3);
-      SideColumn sc{c->magT.as<double>() + (c->F - 1) * c->Tp, c->Fp * c->Tp, c->H1.as<double>(), c->Tp * c->Kp,
-                    (int) c->T};
-      launch_wnorm_combine(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, c->stripsW,
-                           c->wscratch.as<double>(), c->wnorm.as<double>(), c->sideW ? &sc : nullptr, s);
+      SideColumn sc{magTW + (c->F - 1) * c->Tp, c->Fp * c->Tp, H1W, c->Tp * c->Kp, (int) c->T};
+      launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                           c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s);
       c->wPending = true;
     }
     else
@@ -1202,7 +1214,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         else launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
       }
       // :162  if (W.maxCoeff() > epsilon) W.colwise().normalize()
-      launch_colnorm(c->Wf.as<double>(), c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, B, false, true,
+      launch_colnorm(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, false, true,
                      c->normScratch.as<double>(), s);
     }
   }
@@ -1210,14 +1222,15 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
   {
     // alg/NMF.hpp:165-170 (V2 is formed from the already updated W)
     UpdateArgs a;
-    a.V = c->magT.as<double>(); a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
-    a.Mv = c->Wf.as<double>(); a.strideM = c->Fp * c->Kp;
-    a.S = c->H1.as<double>(); a.strideS = c->Tp * c->Kp;
-    a.R = (int) c->F; a.C = (int) c->T; a.B = B; a.Kp = (int) c->Kp;
+    a.V = magTW; a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
+    a.Mv = WfW; a.strideM = c->Fp * c->Kp;
+    a.S = H1W; a.strideS = c->Tp * c->Kp;
+    a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp;
+    if (c->winB) a.stripsOverride = c->winStripsH;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>() + 4;
-    if (c->wPending) { a.nrm = c->wnorm.as<double>(); a.nrmMode = 2; }
+    if (c->wPending) { a.nrm = wnormW; a.nrmMode = 2; }
     ProfScope p(ctx, 1);
     const int uv = update_variant(a.Kp);
     if (c->useLists)
@@ -1243,7 +1256,41 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
   fluhip_ctx* ctx = c->ctx;
   if (!progress)
   {
-    for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
+    // Corpora of several rounds of wavefronts (more than 1024 / strips buffers) run ROUND-MAJOR: all iterations of the
+    // first 128 buffers (at 8 strips), then of the next 128, ...  Buffers are independent jobs (nrt/NMFClient.hpp:233),
+    // so the order is free, and a round's factor matrices (63 MB at the bench shape) stay in the 256 MB last-level cache
+    // from launch to launch, which the whole corpus's (500 MB at 1024 buffers) do not: 8-round launches measured 0.304 -
+    // 0.319 ms per round against 0.271 - 0.278 for one-round launches (profiles/r03/bench_v*_1024_buffers_one_gpu.json).
+    // With a progress callback the iterations stay outermost: "iteration i" means every buffer has passed it.
+    // FLUHIP_ROUND_MAJOR=0: iteration-major as before.
+    static const int roundEnv = [] { const char* e = std::getenv("FLUHIP_ROUND_MAJOR"); return e ? std::atoi(e) : 1; }();
+    int64_t chunk = 0;
+    if (roundEnv && !c->strip && !c->useLists && c->lazy && c->nsplitW == 1 && c->nsplitH == 1 && update_variant((int) c->Kp) == 5)
+    {
+      const int CW = (int) c->F - (c->sideW ? 1 : 0);
+      const int wW = nmf_update5_strips(CW, (int) c->Kp, (int) c->B), wH = nmf_update5_strips((int) c->T, (int) c->Kp, (int) c->B);
+      const int64_t per = 1024 / std::max(wW, wH);
+      if (per >= 8 && c->B >= 2 * per)
+      {
+        // the schedule of ONE round of `per` buffers, kept for every window (the update kernel would otherwise deal its
+        // strips from the number of buffers it is launched on); the W update's strips also fix the layout of its column
+        // statistics, which was planned for the whole corpus
+        const int wWc = nmf_update5_strips(CW, (int) c->Kp, (int) per), wHc = nmf_update5_strips((int) c->T, (int) c->Kp, (int) per);
+        if (wWc == wW && per * std::max(wWc, wHc) <= 1024) { chunk = per; c->winStripsW = wWc; c->winStripsH = wHc; }
+      }
+    }
+    if (chunk > 0)
+    {
+      for (int64_t b0 = 0; b0 < c->B; b0 += chunk)
+      {
+        c->winB0 = b0;
+        c->winB = std::min(chunk, c->B - b0);
+        for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
+      }
+      c->winB0 = c->winB = 0;
+    }
+    else
+      for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
     HIPCHK(ctx, hipGetLastError());
     return FLUHIP_OK;
   }

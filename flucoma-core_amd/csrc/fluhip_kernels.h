@@ -113,6 +113,9 @@ struct UpdateArgs
   // listPartial: the list's wavefronts write split partials (the caller finalizes)
   const WaveDesc* list = nullptr;
   int listWGs = 0, listNG = 0, listPartial = 0;
+  // > 0: strips (wavefronts) per buffer instead of the planner's choice for a.B buffers (windows of a larger corpus keep
+  // the schedule of one round)
+  int stripsOverride = 0;
 };
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine

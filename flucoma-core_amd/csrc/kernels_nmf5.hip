@@ -1255,8 +1255,8 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     return;
   }
   const int G = (a.C + 15) / 16;
-  const int w = nmf_update5_strips(a.C, a.Kp, a.B);
-  const bool two = w != nmf_update5_waves_per_buffer(a.C, a.Kp, a.B);
+  const int w = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips(a.C, a.Kp, a.B);
+  const bool two = a.stripsOverride > 0 ? false : w != nmf_update5_waves_per_buffer(a.C, a.Kp, a.B);
   const int ng = (G + w - 1) / w;
   if (two)
   {

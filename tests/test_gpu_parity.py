@@ -688,6 +688,35 @@ def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
     assert np.array_equal(W_sub, W_all[perm]) and np.array_equal(H_sub, H_all[perm])
 
 
+def test_corpus_of_several_rounds_runs_round_major(ctx, oracle, onp):
+    """a corpus of more buffers than one round of wavefronts holds (no progress callback) runs all iterations of a round's
+    buffers before the next round's (corpus_iterate_loop: windows of the per-buffer arrays): buffers at the window
+    edges against the oracle, partial updates, and a progress callback (iteration-major order) giving the same factors"""
+    import fluhip
+    B, n, win, fft, hop, K, iters = 2100, 2000, 256, 256, 64, 8, 7      # one strip per buffer: rounds of 1024, 1024, 52
+    distinct = [onp.synth_audio(n, 8800 + b) for b in range(5)]
+    audio = np.stack([distinct[b % 5] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    plan = c.plan()
+    assert plan["split_w"] == 1 and plan["split_h"] == 1, plan
+    c.set_audio(audio); c.stft()
+    mag = c.read_f64(factors=False)[0]
+    for uw, uh in ((True, True), (True, False), (False, True)):
+        c.nmf(iters, seed=42, updateW=uw, updateH=uh)
+        _, W1, H1 = c.read_f64(mag=False)
+        for b in (0, 1023, 1024, 2047, 2048, 2099):
+            rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, uw, uh, 42)
+            assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (uw, uh, b)
+    seen = []
+    c.nmf(iters, seed=42, progress=lambda i: seen.append(i) or True)
+    _, W2, H2 = c.read_f64(mag=False)
+    c.nmf(iters, seed=42)
+    _, W1, H1 = c.read_f64(mag=False)
+    assert seen == list(range(1, iters + 1))
+    assert np.array_equal(W1, W2) and np.array_equal(H1, H2)     # the order of independent jobs changes nothing
+    c.close()
+
+
 def test_corpus_per_buffer_seeds(ctx, oracle, onp):
     import fluhip
     B, n, win, fft, hop, K, iters = 3, 8000, 512, 512, 128, 4, 10
