@@ -48,6 +48,7 @@ struct fluhip_ctx
   std::vector<ProfRec> profRecs;
   std::vector<hipEvent_t> eventPool;
   hipDeviceProp_t props;
+  int progressLag = 8;        // iterations the device may run ahead of the last progress report (fluhip_ctx_set_progress_lag)
   void* bigFft = nullptr;     // workspace of the global-memory FFT passes (fft > 8192), grown on demand
   size_t bigFftBytes = 0;
 };
@@ -566,7 +567,7 @@ void pack_groups(std::vector<WaveGroup>& groups, std::vector<WaveDesc>& out, int
   {
     bool placed = false;
     while (firstOpen < q.size() && q[firstOpen].size() >= 4) firstOpen++;
-    for (size_t i = firstOpen; i < q.size(); i++)
+    for (size_t i = std::max(firstOpen, q.size() > 256 ? q.size() - 256 : 0); i < q.size(); i++) // (a bounded look-back: linear time)
       if (q[i].size() + g.waves.size() <= 4) { q[i].insert(q[i].end(), g.waves.begin(), g.waves.end()); placed = true; break; }
     if (!placed) q.push_back(g.waves);
   }
@@ -1298,8 +1299,9 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
   // than kLag iterations ahead of the last one it has reported: a cancel at iteration i stops the device after at
   // most kLag - 1 further iterations (alg/NMF.hpp:175-176 stops at i exactly; the client above never looks at the
   // factors of a cancelled job, clients/nrt/NMFClient.hpp:273-274).
-  constexpr int kLag = 8;
-  hipEvent_t ev[kLag];
+  constexpr int kMaxLag = 64;
+  const int kLag = std::max(1, std::min(kMaxLag, ctx->progressLag));
+  hipEvent_t ev[kMaxLag];
   for (int i = 0; i < kLag; i++) ev[i] = take_event(ctx);
   auto give_back = [&] { for (int i = 0; i < kLag; i++) ctx->eventPool.push_back(ev[i]); };
   int64_t reported = 0;
@@ -1424,6 +1426,14 @@ int fluhip_ctx_trim(fluhip_ctx* ctx)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   g_pool.trim(ctx->device);
+  return FLUHIP_OK;
+}
+
+int fluhip_ctx_set_progress_lag(fluhip_ctx* ctx, int lag)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (lag < 1 || lag > 64) return fail(ctx, "progress lag must be 1 .. 64");
+  ctx->progressLag = lag;
   return FLUHIP_OK;
 }
 

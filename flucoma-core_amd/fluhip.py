@@ -46,7 +46,7 @@ class BufNMFJob(ctypes.Structure):
 
 EXPORTS = [
     "fluhip_abi_version", "fluhip_device_count", "fluhip_ctx_create", "fluhip_ctx_destroy",
-    "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize", "fluhip_ctx_trim",
+    "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize", "fluhip_ctx_trim", "fluhip_ctx_set_progress_lag",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
     "fluhip_nmf_process_f64", "fluhip_nmf_process_views_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
     "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
@@ -90,6 +90,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_ctx_stream.restype = _vp
     L.fluhip_ctx_synchronize.argtypes = [_vp]
     L.fluhip_ctx_trim.argtypes = [_vp]
+    L.fluhip_ctx_set_progress_lag.argtypes = [_vp, ctypes.c_int]
     L.fluhip_fft_params.argtypes = [_i64, _i64, _i64, _ip, _ip, _ip, _ip]
     L.fluhip_stft_num_frames.argtypes = [_i64, _i64, _i64]
     L.fluhip_stft_num_frames.restype = _i64
@@ -220,6 +221,9 @@ class Context:
 
     def synchronize(self):
         self._check(self.lib.fluhip_ctx_synchronize(self.h))
+
+    def set_progress_lag(self, lag):
+        self._check(self.lib.fluhip_ctx_set_progress_lag(self.h, int(lag)))
 
     # ---- algorithm::STFT ----------------------------------------------------------------
     def stft(self, audio, win, fft, hop, window_type=0, want_spec=True, want_mag=True, stride=1):

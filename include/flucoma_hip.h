@@ -75,6 +75,11 @@ void*       fluhip_ctx_stream(const fluhip_ctx* ctx);
  * the driver now -- for hosts that share the GPU with other allocators (torch, RCCL). */
 int         fluhip_ctx_trim(fluhip_ctx* ctx);
 int         fluhip_ctx_synchronize(fluhip_ctx* ctx);
+/* How far the device may run ahead of the last iteration reported to a progress callback (default 8: at most 7 iterations
+ * are enqueued beyond the one a callback refuses).  lag = 1 is the reference's exact behaviour -- NMF.hpp:175-176 stops AT the
+ * iteration whose callback returns false, the factors are those of that iteration -- at the price of one host round trip per
+ * iteration (~10 - 20 us: nothing for a corpus, a third of a single small buffer's iteration). */
+int         fluhip_ctx_set_progress_lag(fluhip_ctx* ctx, int lag);
 
 /* ---- parameter arithmetic (integer, bit-exact) --------------------------------------- */
 /* clients/common/ParameterTypes.hpp:295-312 FFTParams::fftSize/hopSize/frameSize.

@@ -230,6 +230,19 @@ def test_nmf_cancel_overshoot_is_bounded(ctx, oracle):
         rW, rH, _, _ = oracle.nmf_process(X, 6, it, True, True, 1)
         errs.append(max(rel_err(W1, rW), rel_err(H1, rH)))
     assert min(errs) < TOL_FACTORS_TIGHT, errs
+    # fluhip_ctx_set_progress_lag(ctx, 1): the reference's exact behaviour (alg/NMF.hpp:175-176 returns AT the iteration whose
+    # callback refuses) -- the factors handed back are those of iteration 5, no later one
+    ctx.set_progress_lag(1)
+    try:
+        seen = []
+        W1, H1, V1, rc = ctx.nmf_process(X, 6, 200, True, True, 1, progress=lambda it: seen.append(it) or it < 5)
+        assert rc == fluhip.CANCELLED and seen == [1, 2, 3, 4, 5]
+        rW, rH, _, _ = oracle.nmf_process(X, 6, 5, True, True, 1)
+        assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT
+        with pytest.raises(fluhip.FluhipError):
+            ctx.set_progress_lag(0)
+    finally:
+        ctx.set_progress_lag(8)
 
 
 def test_nmf_zero_columns_and_rows(ctx, oracle):
