@@ -112,6 +112,7 @@ int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stri
  * one reported.  On cancellation returns FLUHIP_CANCELLED; W1/H1 then hold the factors as they stand when the device has
  * stopped -- at most 7 iterations after the one the callback refused (the reference stops at it exactly, NMF.hpp:175-176;
  * its client discards the factors of a cancelled job, clients/nrt/NMFClient.hpp:273-274) -- and V1 is left unwritten.
+ * fluhip_ctx_set_progress_lag(ctx, 1) makes the stop exact.
  * Numerics: FP64 throughout.  The quotients V / max(W H, eps) of the update loop are formed as V * (1 / d) with a Newton-
  * refined reciprocal, relative error <= 2^-46 (1.4e-14) per quotient instead of a correctly rounded division; measured,
  * the factors stay within 1e-13 of the restatement after 200 iterations (the tests assert 1e-9; north_star asks 1e-5).
