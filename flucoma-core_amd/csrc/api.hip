@@ -41,6 +41,7 @@ struct fluhip_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copyStream = nullptr; // host -> device audio uploads run beside the compute stream (created on first use)
   std::string err;
   std::map<std::tuple<int64_t, int64_t, int>, double*> windows; // (win, fft, type) -> device table
   std::map<int, double*> twiddles;                // fft -> device table
@@ -368,6 +369,7 @@ struct fluhip_corpus
   int stripGen = 0;
   DevBuf stripPart;
   bool haveMag = false, haveFactors = false;
+  bool touched = false; // work that reads the audio has been enqueued on the compute stream
   // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats
   std::vector<float> seedW32, seedH32;
   // ragged corpus (fluhip_corpus_create_ragged): buffers of different lengths in ONE set of launches.  n / T are those of
@@ -970,6 +972,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
   }
   HIPCHK(ctx, hipGetLastError());
   c->haveMag = true;
+  c->touched = true;
   return FLUHIP_OK;
 }
 
@@ -1401,6 +1404,7 @@ void fluhip_ctx_destroy(fluhip_ctx* ctx)
   for (auto& kv : ctx->twiddles) (void) hipFree(kv.second);
   for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
   for (auto e : ctx->eventPool) (void) hipEventDestroy(e);
+  if (ctx->copyStream) (void) hipStreamDestroy(ctx->copyStream);
   if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
   g_pool.trim(ctx->device); // cached device blocks go with the context
   delete ctx;
@@ -1593,8 +1597,13 @@ int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio)
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t) c->B * c->n * sizeof(float);
   if (c->audioOwn.bytes < bytes) HIPCHK(ctx, c->audioOwn.alloc(bytes, false, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(c->audioOwn.p, audio, bytes, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  // The copy runs on the context's COPY stream: whatever another corpus of this context has in flight on the compute stream
+  // (the previous slice of a pool job: its iterations) goes on beside it -- SURVEY section 7 step 5's double-buffered upload.
+  // A corpus whose own audio may still be read by enqueued work drains the compute stream first.
+  if (c->touched) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (!ctx->copyStream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking));
+  HIPCHK(ctx, hipMemcpyAsync(c->audioOwn.p, audio, bytes, hipMemcpyHostToDevice, ctx->copyStream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->copyStream)); // the caller's buffer is free again; the device copy is complete
   c->audioDev = c->audioOwn.as<float>();
   return FLUHIP_OK;
 }

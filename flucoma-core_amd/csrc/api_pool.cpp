@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
@@ -127,31 +128,46 @@ int fluhip_pool_bufnmf_job_f32(fluhip_pool* p, const fluhip_bufnmf_job* job, flu
     th.emplace_back([=, &ws] {
       Worker& w = ws[(size_t) r];
       fluhip_ctx* ctx = p->ctx[(size_t) r];
-      // a corpus handle holds at most 65535 buffers: larger shares go in slices
-      for (int64_t s0 = b0; s0 < b1 && w.rc.load() == FLUHIP_OK && !w.cancel->load(std::memory_order_acquire); s0 += 65535)
+      // A share goes in slices: a corpus handle holds at most 65535 buffers, and without a progress callback (whose
+      // "iteration i" spans the whole share) large shares are cut into slices of 256 buffers so that slice i + 1 uploads --
+      // on the context's copy stream -- while slice i iterates: the factor updates are enqueued asynchronously, the upload
+      // of the next slice blocks only this host thread, the write-back of slice i then waits for its iterations
+      // (SURVEY section 7 step 5).  Buffers are independent jobs: slicing changes no result.
+      static const bool slicesOff = [] { const char* e = std::getenv("FLUHIP_POOL_SLICES"); return e && std::atoi(e) == 0; }(); // A/B
+      const int64_t sliceMax = (!progress && !slicesOff && b1 - b0 >= 512) ? 256 : 65535;
+      auto prepare = [&](int64_t s0, int64_t nb, fluhip_corpus** out) -> int {
+        int rc = fluhip_corpus_create(ctx, nb, j.n, j.win, j.fft, j.hop, j.K, out);
+        if (rc == FLUHIP_OK && j.resynth) rc = fluhip_corpus_keep_spectrum(*out, 1);
+        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(*out, j.audio + s0 * j.n);
+        return rc;
+      };
+      fluhip_corpus* c = nullptr;
+      int rc = prepare(b0, std::min<int64_t>(sliceMax, b1 - b0), &c);
+      for (int64_t s0 = b0; s0 < b1 && rc == FLUHIP_OK && !w.cancel->load(std::memory_order_acquire); s0 += sliceMax)
       {
-        const int64_t nb = std::min<int64_t>(65535, b1 - s0);
-        fluhip_corpus* c = nullptr;
-        int rc = fluhip_corpus_create(ctx, nb, j.n, j.win, j.fft, j.hop, j.K, &c);
-        if (rc == FLUHIP_OK && j.resynth) rc = fluhip_corpus_keep_spectrum(c, 1);
-        if (rc == FLUHIP_OK) rc = fluhip_corpus_set_audio_host(c, j.audio + s0 * j.n);
-        if (rc == FLUHIP_OK) rc = fluhip_corpus_stft(c);
+        rc = fluhip_corpus_stft(c);
         if (rc == FLUHIP_OK && (j.bases_seed || j.acts_seed)) // clients/nrt/NMFClient.hpp:246-258
           rc = fluhip_corpus_set_factors(c, j.bases_seed ? j.bases_seed + s0 * j.K * F : nullptr,
                                          j.acts_seed ? j.acts_seed + s0 * j.K * T : nullptr);
         if (rc == FLUHIP_OK)
           rc = fluhip_corpus_nmf(c, j.iters, j.update_w, j.update_h, j.seed, j.seeds ? j.seeds + s0 : nullptr,
                                  progress ? worker_progress : nullptr, progress ? &w : nullptr);
+        fluhip_corpus* next = nullptr;
+        if (rc == FLUHIP_OK && s0 + sliceMax < b1) // the next slice's upload, beside this slice's iterations
+          rc = prepare(s0 + sliceMax, std::min<int64_t>(sliceMax, b1 - s0 - sliceMax), &next);
         if (rc == FLUHIP_OK)
           rc = fluhip_corpus_writeback_host(c, j.bases ? j.bases + s0 * j.K * F : nullptr, j.acts ? j.acts + s0 * j.K * T : nullptr);
         if (rc == FLUHIP_OK && j.resynth) rc = fluhip_corpus_resynth_host(c, j.resynth + s0 * j.K * j.n); // :302-334
-        if (rc != FLUHIP_OK)
-        {
-          w.err = fluhip_last_error(ctx);
-          w.rc.store(rc, std::memory_order_release);
-          if (rc != FLUHIP_CANCELLED) w.cancel->store(true, std::memory_order_release); // a failed share stops the others
-        }
+        if (rc != FLUHIP_OK) w.err = fluhip_last_error(ctx);
         if (c) fluhip_corpus_destroy(c);
+        c = next;
+      }
+      if (rc != FLUHIP_OK && w.err.empty()) w.err = fluhip_last_error(ctx);
+      if (c) fluhip_corpus_destroy(c);
+      if (rc != FLUHIP_OK)
+      {
+        w.rc.store(rc, std::memory_order_release);
+        if (rc != FLUHIP_CANCELLED) w.cancel->store(true, std::memory_order_release); // a failed share stops the others
       }
       if (w.rc.load() == FLUHIP_OK) w.done.store(j.iters, std::memory_order_release);
     });

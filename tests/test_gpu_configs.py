@@ -204,6 +204,27 @@ def test_pool_job_with_seeds_fixed_bases_and_resynthesis(ctx, oracle, onp):
     pool.close()
 
 
+def test_pool_large_share_runs_in_pipelined_slices(ctx, oracle, onp):
+    """a share of 512 buffers or more without a progress callback goes in slices of 256 whose uploads (copy stream) run
+    beside the previous slice's iterations: same floats as the one-corpus path, buffers at the slice edges vs the oracle"""
+    import fluhip
+    n, win, fft, hop, K, iters = 6000, 1024, 1024, 256, 4, 6
+    B = 600
+    distinct = [onp.synth_audio(n, 3500 + b) for b in range(7)]
+    audio = np.stack([distinct[b % 7] for b in range(B)])
+    pool = fluhip.Pool([0], ctx.lib)
+    bases, acts, rc = pool.bufnmf(audio, win, fft, hop, K, iters, seed=42)
+    assert rc == 0
+    for b in (0, 255, 256, 511, 512, 599):
+        rb, ra = oracle.bufnmf_channel(audio[b], win, fft, hop, K, iters, 42)
+        assert rel_err(bases[b], rb) < 1e-6 and rel_err(acts[b], ra) < 1e-6, b
+    seen = []
+    b2, a2, rc = pool.bufnmf(audio, win, fft, hop, K, iters, seed=42, progress=lambda it: seen.append(it) or True)   # one corpus
+    assert rc == 0 and seen == list(range(1, iters + 1))
+    assert rel_err(b2, bases) < 1e-6 and rel_err(a2, acts) < 1e-6
+    pool.close()
+
+
 def test_pool_ragged_corpus(ctx, oracle, onp):
     """fluhip_pool_bufnmf_ragged_f32: buffers of different lengths (a folder of sound files) over two contexts on device 0 --
     dealt by frame count, runs of equal length as one corpus (the batched kernels), the rest one by one (the single-buffer
