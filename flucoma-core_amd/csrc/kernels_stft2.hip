@@ -60,6 +60,7 @@ struct StftBArgs
   int blocksPerBuf;
   int64_t totalBlocks;
   const int64_t* nTab;    // ragged corpora: samples of every buffer (n is then the longest), or nullptr
+  int prefetch;           // block kernel: request the next frame's samples ahead of this frame's stores
 };
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -489,7 +490,6 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 
   FftCore<R1, R2, R3> core;
   core.init(xb, tw2, twg, lane);
-  const int nthreads = 64 * NW;
 
   // blocks are dealt so that workgroups on one XCD (blockIdx & 7) take neighbouring blocks of a buffer: their
   // segments of a bin-major row fall into the same L2
@@ -502,6 +502,39 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     b = (int) (blk / a.blocksPerBuf);
     t0 = (int) (blk % a.blocksPerBuf) * FPB;
     return true;
+  };
+  // Prefetch (one frame per round, float audio): the samples of the NEXT round's frame are requested before this round's
+  // stores are issued.  vmcnt counts loads and stores in one in-order counter, so samples requested AFTER the stores (as in
+  // round 2's loop) can only be waited for by waiting for every store of the round before -- the store drain sat exposed
+  // in front of every frame's arithmetic (the ISA had s_waitcnt vmcnt(7) behind eight fresh loads: "all stores done").
+  // Requested BEFORE them, the samples are older than the stores and the wait leaves the stores in flight: 793 / 838 us
+  // -> 697 / 691 us for the bench workload's STFT phase (profiles/r03/stft_prefetch.txt; FLUHIP_STFT_PREFETCH=0 is the
+  // round-2 order).  Requesting them before the transform instead (35 more registers) measured the same, and two
+  // 4-wavefront blocks per CU instead of one of 8 measured slower (754 / 763 us): neither is kept.
+  constexpr bool PREFETCH = FPW == 1 && PPL <= 16;         // (2048-point frames hold 32 points per lane: no registers to spare)
+  float2 raw[PPL];
+  int rawB = -1, rawT = -1;
+  auto prefetch = [&](int64_t Ln) {
+    rawB = -1;
+    if constexpr (PREFETCH)
+    {
+      int bn, t0n;
+      if (!a.audio || !a.prefetch || (Ln >> 3) >= chunk || !decode(Ln, bn, t0n)) return;
+      const int tn = t0n + wave;
+      const int64_t nS = a.nTab ? a.nTab[bn] : a.n;
+      const int Tn = a.nTab ? (int) ((nS + a.hop) / a.hop) : a.T;
+      if (tn >= Tn) return;
+      const int64_t s0 = (int64_t) tn * a.hop - a.win / 2 + a.frameOffset;
+      const float* fp = a.audio + (int64_t) bn * a.audioStride + s0;
+      if (s0 < 0 || s0 + 2 * N > nS || (reinterpret_cast<uintptr_t>(fp) & 7) != 0) return; // edge frames take the clamped gather
+      const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
+#pragma unroll
+      for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+        for (int r = 0; r < R1; r++) raw[bb * R1 + r] = lp[64 * bb + r * (N / R1)];
+      rawB = bn;
+      rawT = tn;
+    }
   };
   for (int64_t L = blockIdx.x;; L += gridDim.x)
   {
@@ -518,7 +551,20 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       if (t < Tb)
       {
         cx pts[PPL];
-        gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
+        if (PREFETCH && rawB == b && rawT == t)
+        {
+#pragma unroll
+          for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+            for (int r = 0; r < R1; r++)
+            {
+              const float2 x = raw[bb * R1 + r];
+              const d2 w = wsrc[lane + 64 * bb + r * (N / R1)];
+              pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
+            }
+        }
+        else
+          gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
         SCHED_FENCE();
         core.template run<SPEC>(pts, SPEC ? reinterpret_cast<d2*>(a.spec + (int64_t) b * a.specStride + (int64_t) t * a.F * 2) : nullptr);
       }
@@ -531,6 +577,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       }
       if (FPW > 1) core.shift(fj + 1 < FPW ? BUFD : -(FPW - 1) * BUFD);
     }
+    prefetch(L + gridDim.x);                          // ahead of this round's stores
 
     if (a.magT) LDS_BARRIER();                        // every wavefront of the block has staged its frames
     if (a.mag)
@@ -557,12 +604,14 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       // ---- bin-major copy: the block's frames of a bin leave as one piece ------------------------------------------
       constexpr int HP = FPB / 2;                     // 16-byte pieces (two frames) per bin
       double* outT = a.magT + (int64_t) b * a.magTStride;
-      const int items = a.F * HP;
-      for (int i = threadIdx.x; i < items; i += nthreads)
+      constexpr int ITEMS = (N + 1) * HP, NTHR = 64 * NW, TRIPS = (ITEMS + NTHR - 1) / NTHR; // (a.F == N + 1)
+#pragma unroll
+      for (int k = 0; k < TRIPS; k++)
       {
+        const int i = (int) threadIdx.x + k * NTHR;
         const int f = i / HP, p = i - f * HP;
         const int tc = t0 + 2 * p;
-        if (tc < a.ldMagT)
+        if (i < ITEMS && tc < a.ldMagT)
         {
           const double v0 = xall[(2 * p) * BUFD + f], v1 = xall[(2 * p + 1) * BUFD + f];
           *reinterpret_cast<d2*>(outT + (int64_t) f * a.ldMagT + tc) = d2{v0, v1};
@@ -789,7 +838,7 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
   k.window = a.window; k.twiddle = a.twiddle;
   k.mag = nullptr; k.magStride = 0; k.ldMag = 0; k.magT = nullptr; k.magTStride = 0; k.ldMagT = 0;
   k.spec = nullptr; k.specStride = 0; k.frameOffset = a.frameOffset; k.blocksPerBuf = 0; k.totalBlocks = 0;
-  k.nTab = nullptr;
+  k.nTab = nullptr; k.prefetch = 0;
   FeatFusedArgs fa;
   fa.up = up; fa.dn = dn; fa.slot = slot; fa.dct = f.dct;
   fa.nBands = f.nBands; fa.nDct = f.nDct; fa.startCoeff = f.startCoeff; fa.nOut = f.nOut;
@@ -809,6 +858,8 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
   constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * FPW * BUFD * 8;
   static_assert(shmem <= 160 * 1024, "LDS");
   StftBArgs k = k0;
+  static const int pf = [] { const char* e = std::getenv("FLUHIP_STFT_PREFETCH"); return e ? std::atoi(e) : 1; }();
+  k.prefetch = pf;
   k.blocksPerBuf = (k.T + NW * FPW - 1) / (NW * FPW);
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
