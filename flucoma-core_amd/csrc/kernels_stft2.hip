@@ -455,6 +455,39 @@ __device__ __forceinline__ void gather_points(const StftBArgs& a, int b, int t, 
   }
 }
 
+// The interior frames' samples as they lie in memory (the fast path of gather_points, split in two): requested early
+// by the frame loop -- ahead of the stores of the frame before, see stft_block_kernel -- and windowed when their turn comes.
+// false: an edge frame, an odd base or double-precision input (gather_points takes those).
+template <int R1, int N>
+__device__ __forceinline__ bool request_samples(const StftBArgs& a, int b, int t, int64_t nSamples, int lane, float2 (&raw)[N / 64])
+{
+  constexpr int NB1 = N / (64 * R1);
+  if (!a.audio) return false;
+  const int64_t s0 = (int64_t) t * a.hop - a.win / 2 + a.frameOffset;
+  const float* fp = a.audio + (int64_t) b * a.audioStride + s0;
+  if (s0 < 0 || s0 + 2 * N > nSamples || (reinterpret_cast<uintptr_t>(fp) & 7) != 0) return false;
+  const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
+#pragma unroll
+  for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+    for (int r = 0; r < R1; r++) raw[bb * R1 + r] = lp[64 * bb + r * (N / R1)];
+  return true;
+}
+template <int R1, int N>
+__device__ __forceinline__ void window_samples(const float2 (&raw)[N / 64], int lane, const d2* wsrc, cx (&pts)[N / 64])
+{
+  constexpr int NB1 = N / (64 * R1);
+#pragma unroll
+  for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+    for (int r = 0; r < R1; r++)
+    {
+      const float2 x = raw[bb * R1 + r];
+      const d2 w = wsrc[lane + 64 * bb + r * (N / R1)];
+      pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
+    }
+}
+
 // FPW frames per wavefront and round: a block stages NW * FPW consecutive frames before the bin-major flush, so a bin's
 // piece of the transposed copy is NW * FPW * 8 bytes -- a full 128-byte line at fft 2048 with 8 wavefronts x 2 frames
 // (64-byte pieces measured 3.3 TB/s against 4.4 - 5.9 for full lines, tools/hbm_write_probe.hip).
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   // -> 697 / 691 us for the bench workload's STFT phase (profiles/r03/stft_prefetch.txt; FLUHIP_STFT_PREFETCH=0 is the
   // round-2 order).  Requesting them before the transform instead (35 more registers) measured the same, and two
   // 4-wavefront blocks per CU instead of one of 8 measured slower (754 / 763 us): neither is kept.
-  constexpr bool PREFETCH = FPW == 1 && PPL <= 16;         // (2048-point frames hold 32 points per lane: no registers to spare)
+  constexpr bool PREFETCH = FPW == 1 && PPL == 16;         // fft 2048 only: fft 1024 (4 wavefronts per SIMD) measures the same either way, fft 4096 has no registers to spare
   float2 raw[PPL];
   int rawB = -1, rawT = -1;
   auto prefetch = [&](int64_t Ln) {
@@ -524,14 +557,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       const int64_t nS = a.nTab ? a.nTab[bn] : a.n;
       const int Tn = a.nTab ? (int) ((nS + a.hop) / a.hop) : a.T;
       if (tn >= Tn) return;
-      const int64_t s0 = (int64_t) tn * a.hop - a.win / 2 + a.frameOffset;
-      const float* fp = a.audio + (int64_t) bn * a.audioStride + s0;
-      if (s0 < 0 || s0 + 2 * N > nS || (reinterpret_cast<uintptr_t>(fp) & 7) != 0) return; // edge frames take the clamped gather
-      const float2* lp = reinterpret_cast<const float2*>(fp) + lane;
-#pragma unroll
-      for (int bb = 0; bb < NB1; bb++)
-#pragma unroll
-        for (int r = 0; r < R1; r++) raw[bb * R1 + r] = lp[64 * bb + r * (N / R1)];
+      if (!request_samples<R1, N>(a, bn, tn, nS, lane, raw)) return;
       rawB = bn;
       rawT = tn;
     }
@@ -552,17 +578,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       {
         cx pts[PPL];
         if (PREFETCH && rawB == b && rawT == t)
-        {
-#pragma unroll
-          for (int bb = 0; bb < NB1; bb++)
-#pragma unroll
-            for (int r = 0; r < R1; r++)
-            {
-              const float2 x = raw[bb * R1 + r];
-              const d2 w = wsrc[lane + 64 * bb + r * (N / R1)];
-              pts[bb * R1 + r] = cx{(double) x.x * w[0], (double) x.y * w[1]};
-            }
-        }
+          window_samples<R1, N>(raw, lane, wsrc, pts);
         else
           gather_points<R1, N>(a, b, t, lane, wsrc, pts, nSamples);
         SCHED_FENCE();
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       constexpr int HP = FPB / 2;                     // 16-byte pieces (two frames) per bin
       double* outT = a.magT + (int64_t) b * a.magTStride;
       constexpr int ITEMS = (N + 1) * HP, NTHR = 64 * NW, TRIPS = (ITEMS + NTHR - 1) / NTHR; // (a.F == N + 1)
-#pragma unroll
+#pragma unroll(PREFETCH ? TRIPS : 1)                  // (a compile-time count of stores is what lets the wait ahead of the next transform skip them)
       for (int k = 0; k < TRIPS; k++)
       {
         const int i = (int) threadIdx.x + k * NTHR;
@@ -699,7 +715,8 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
   Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
   for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
-  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { upl[i] = fa.up[i]; dnl[i] = fa.dn[i]; slotl[i] = fa.slot[i]; }
+  // (per-lane tables lie [i][lane] in the LDS: a lane's CH consecutive bins are CH rows apart, a row is read without bank conflicts)
+  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
   if (fa.dct)
     for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[(i / fa.nBands) * dld + (i % fa.nBands)] = fa.dct[i];
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
@@ -711,6 +728,13 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
 
   const int64_t chunk = (a.totalBlocks + 7) / 8;
+  // Round 3 measurements of this loop (config 5, 1.417 M frames, one box; profiles/r03/c5_breakdown.txt), parts switched off
+  // one at a time: everything 3.93 ms; without the sample gather 3.38; without the transform 1.92; without the band sums /
+  // DCT / stores 2.95 (the stores alone: 0.05); the loop with nothing in it 0.38.  Alone, the gather takes 0.82 ms (the HBM
+  // time of 2.9 GB of samples), the transform 2.0, the band part 1.0 -- the parts add up: 93 KB of LDS traffic per frame
+  // (transform exchanges 32, twiddles 14, window 8, staging 8 + 8, weights and DCT rows 23) keep the LDS pipe busy through
+  // all three.  Requesting the next frame's samples ahead of the feature stores (as stft_block_kernel does) changes
+  // nothing here (3.94 / 3.94 ms without, 3.92 / 3.92 with): four wavefronts per SIMD cover that wait.
   for (int64_t L = blockIdx.x;; L += gridDim.x)
   {
     const int64_t slot8 = L >> 3;
@@ -739,8 +763,8 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       double m = f <= N ? xb[f] : 0.0;
       if (fa.magNorm) { m *= scale1; en += m; }     // :86-90
       if (fa.usePower) m = m * m;
-      su = __builtin_fma(upl[f], m, su);
-      sd = __builtin_fma(dnl[f], m, sd);
+      su = __builtin_fma(upl[i * 64 + ln], m, su);
+      sd = __builtin_fma(dnl[i * 64 + ln], m, sd);
       pu[i] = su;
       pd[i] = sd;
     }
@@ -751,7 +775,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
 #pragma unroll
     for (int i = 0; i < CH; i++)
     {
-      const int sl = slotl[CH * ln + i];
+      const int sl = slotl[i * 64 + ln];
       if (sl >= 0) { bu[sl] = eu + pu[i]; bd[sl] = ed + pd[i]; }
     }
     double v = 0.0;

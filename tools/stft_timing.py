@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
 import fluhip, synth
 ctx = fluhip.Context(0)
-SHAPES = ((128, 441000, 2048, 2048, 512), (2048, 88200, 1024, 1024, 512), (128, 441000, 1024, 1024, 256))
+SHAPES = ((128, 441000, 2048, 2048, 512), (2048, 88200, 1024, 1024, 512), (128, 441000, 1024, 1024, 256), (4, 26460000, 4096, 4096, 1024))
 sel = os.environ.get('STFT_SHAPES')
 for (B, n, win, fft, hop) in (SHAPES if sel is None else [SHAPES[int(i)] for i in sel.split(',')]):
-    base = np.stack([synth.synth_audio(n, 1000 + b) for b in range(4)])
+    base = np.stack([synth.synth_audio(n, 1000 + b) for b in range(4)]) if n < 4000000 else np.stack([np.tile(synth.synth_audio(441000, 1000 + b), n // 441000) for b in range(4)])
     c = fluhip.Corpus(ctx, B, n, win, fft, hop, 4)
     c.set_audio(np.tile(base, (B // 4, 1)))
     c.stft(); ctx.synchronize()
