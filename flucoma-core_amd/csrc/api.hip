@@ -2496,10 +2496,11 @@ int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* p
 static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64_t count, int64_t n, int64_t win,
                            int64_t fft, int64_t hop, int64_t nBands, int64_t nCoefs, int64_t startCoeff,
                            double minFreq, double maxFreq, double sampleRate, int normalize, int scaleDb,
-                           float* out, int64_t* frames_out)
+                           int paddingMode, float* out, int64_t* frames_out)
 {
   if (!ctx) return FLUHIP_ERROR;
   if (!audio || !out) return fail(ctx, "null buffer");
+  if (paddingMode < 0 || paddingMode > 2) return fail(ctx, "padding mode must be 0 (None), 1 (Default) or 2 (Full)");
   if (count < 1) return fail(ctx, "need at least one buffer");
   int rc = check_shape(ctx, n, win, fft, hop, 1);
   if (rc) return rc;
@@ -2511,9 +2512,17 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   hipStream_t s = ctx->stream;
   const int64_t F = fft / 2 + 1;
   // StreamingControl bookkeeping (cc/FluidNRTClientWrapper.hpp:564-579, 642-644)
+  // userPadding.first = FFTParams::padding (cc/ParameterTypes.hpp:315-323): 0 / win/2 / win - hop; the input sits that
+  // far into the padded signal, the client's latency (= win) is added in front of the analysis, the padded length is
+  // rounded up to whole hops in Full mode (:572-574), and the first latency / hop output frames are dropped (:643-656)
   const int64_t latencyHops = win / hop;
-  const int64_t T = 1 + (n + 2 * (win / 2)) / hop - latencyHops; // paddedLength = n + win + 2 (win >> 1), :564-579
-  const int64_t frameOffset = latencyHops * hop - win;
+  const int64_t userPad = paddingMode == 0 ? 0 : paddingMode == 1 ? win / 2 : win - hop;
+  int64_t paddedLength = n + win + 2 * userPad;
+  if (paddingMode == 2) paddedLength = ((paddedLength + hop - 1) / hop) * hop;
+  const int64_t T = 1 + (paddedLength - win) / hop - latencyHops;
+  // kept frame k starts at sample latencyHops hop - win - userPad + k hop; the kernels place frame t at
+  // t hop - win/2 + frameOffset
+  const int64_t frameOffset = latencyHops * hop - win + win / 2 - userPad;
   if (T < 1) return fail(ctx, "not enough frames");
   if (frames_out) *frames_out = T;
   const int64_t Tp = round_up(T, 32), Fp = round_up(F, 32);
@@ -2770,20 +2779,35 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   return FLUHIP_OK;
 }
 
+int fluhip_bufmelbands_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
+                                  int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
+                                  double sample_rate, int normalize, int scale_db, int padding_mode, float* out,
+                                  int64_t* frames_out)
+{
+  return features_common(ctx, false, audio, count, n, win, fft, hop, n_bands, 0, 0, min_freq, max_freq,
+                         sample_rate, normalize, scale_db, padding_mode, out, frames_out);
+}
 int fluhip_bufmelbands_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
                            int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
                            double sample_rate, int normalize, int scale_db, float* out, int64_t* frames_out)
 {
-  return features_common(ctx, false, audio, count, n, win, fft, hop, n_bands, 0, 0, min_freq, max_freq,
-                         sample_rate, normalize, scale_db, out, frames_out);
+  return fluhip_bufmelbands_padded_f32(ctx, audio, count, n, win, fft, hop, n_bands, min_freq, max_freq, sample_rate,
+                                       normalize, scale_db, 1, out, frames_out);
 }
 
+int fluhip_bufmfcc_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                              int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
+                              double max_freq, double sample_rate, int padding_mode, float* out, int64_t* frames_out)
+{
+  return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
+                         max_freq, sample_rate, 0, 0, padding_mode, out, frames_out);
+}
 int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
                        int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
                        double max_freq, double sample_rate, float* out, int64_t* frames_out)
 {
-  return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
-                         max_freq, sample_rate, 0, 0, out, frames_out);
+  return fluhip_bufmfcc_padded_f32(ctx, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
+                                   max_freq, sample_rate, 1, out, frames_out);
 }
 
 int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,

@@ -49,7 +49,8 @@ EXPORTS = [
     "fluhip_last_error", "fluhip_ctx_device_info", "fluhip_ctx_stream", "fluhip_ctx_synchronize", "fluhip_ctx_trim", "fluhip_ctx_set_progress_lag",
     "fluhip_fft_params", "fluhip_stft_num_frames", "fluhip_stft_f64", "fluhip_stft_f32",
     "fluhip_nmf_process_f64", "fluhip_nmf_process_views_f64", "fluhip_nmf_process_frames_f64", "fluhip_nndsvd_f64", "fluhip_bufnmfseed_f32",
-    "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32",
+    "fluhip_bufnmf_channel_f32", "fluhip_bufmelbands_f32", "fluhip_bufmfcc_f32", "fluhip_bufmelbands_padded_f32",
+    "fluhip_bufmfcc_padded_f32",
     "fluhip_bufstft_forward_f32", "fluhip_bufstft_inverse_f32",
     "fluhip_corpus_create", "fluhip_corpus_create_ragged", "fluhip_corpus_frames_of", "fluhip_corpus_set_audio_ragged_host",
     "fluhip_corpus_writeback_ragged_host", "fluhip_corpus_resynth_ragged_host",
@@ -113,6 +114,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
                                          ctypes.c_int, ctypes.c_int, _fp, _ip]
     L.fluhip_bufmfcc_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
                                      _fp, _ip]
+    L.fluhip_bufmelbands_padded_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                                ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _ip]
+    L.fluhip_bufmfcc_padded_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                            ctypes.c_int, _fp, _ip]
     L.fluhip_bufstft_forward_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _fp, _ip]
     L.fluhip_bufstft_inverse_f32.argtypes = [_vp, _fp, _fp, _i64, _i64, _i64, _i64, ctypes.c_int, _fp, _ip]
     L.fluhip_corpus_create.argtypes = [_vp, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.POINTER(_vp)]
@@ -332,30 +337,45 @@ class Context:
 
     # ---- feature pipeline -----------------------------------------------------------------
     @staticmethod
-    def feature_frames(n, win, hop):
-        return 1 + (n + 2 * (win // 2)) // hop - win // hop
+    def feature_frames(n, win, hop, padding_mode=1):
+        pad = (0, win // 2, win - hop)[padding_mode]
+        padded = n + win + 2 * pad
+        if padding_mode == 2:
+            padded = -(-padded // hop) * hop
+        return 1 + (padded - win) // hop - win // hop
 
     def bufmfcc(self, audio, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0,
-                sr=44100.0):
+                sr=44100.0, padding_mode=1):
         audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
         count, n = audio.shape
-        T = self.feature_frames(n, win, hop)
+        T = self.feature_frames(n, win, hop, padding_mode)
         out = np.empty((count, n_coefs, T), dtype=np.float32)
         Tr = _i64(0)
-        self._check(self.lib.fluhip_bufmfcc_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, n_coefs,
-                                                start_coeff, lo, hi, sr, _f(out), ctypes.byref(Tr)))
+        if padding_mode == 1:
+            rc = self.lib.fluhip_bufmfcc_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, n_coefs,
+                                             start_coeff, lo, hi, sr, _f(out), ctypes.byref(Tr))
+        else:
+            rc = self.lib.fluhip_bufmfcc_padded_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, n_coefs,
+                                                    start_coeff, lo, hi, sr, padding_mode, _f(out), ctypes.byref(Tr))
+        self._check(rc)
         assert Tr.value == T
         return out
 
     def bufmelbands(self, audio, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0, normalize=True,
-                    scale_db=False):
+                    scale_db=False, padding_mode=1):
         audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
         count, n = audio.shape
-        T = self.feature_frames(n, win, hop)
+        T = self.feature_frames(n, win, hop, padding_mode)
         out = np.empty((count, n_bands, T), dtype=np.float32)
         Tr = _i64(0)
-        self._check(self.lib.fluhip_bufmelbands_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr,
-                                                    int(normalize), int(scale_db), _f(out), ctypes.byref(Tr)))
+        if padding_mode == 1:
+            rc = self.lib.fluhip_bufmelbands_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr,
+                                                 int(normalize), int(scale_db), _f(out), ctypes.byref(Tr))
+        else:
+            rc = self.lib.fluhip_bufmelbands_padded_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr,
+                                                        int(normalize), int(scale_db), padding_mode, _f(out),
+                                                        ctypes.byref(Tr))
+        self._check(rc)
         assert Tr.value == T
         return out
 

@@ -222,6 +222,18 @@ int fluhip_bufmelbands_f32(fluhip_ctx* ctx, const float* audio, int64_t count, i
 int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
                        int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
                        double max_freq, double sample_rate, float* out, int64_t* frames_out);
+/* The same with the wrapper's "padding" parameter (None / Default / Full = 0 / 1 / 2; the two calls above are mode 1):
+ * userPadding = FFTParams::padding = 0 / win/2 / win - hop (clients/common/ParameterTypes.hpp:315-323,
+ * FluidNRTClientWrapper.hpp:357-364), paddedLength = n + win + 2 userPadding, rounded up to whole hops in Full mode
+ * (:572-574), T = 1 + (paddedLength - win)/hop - win/hop, kept frame k starting at sample
+ * (win/hop) hop - win - userPadding + k hop. */
+int fluhip_bufmelbands_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
+                                  int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
+                                  double sample_rate, int normalize, int scale_db, int padding_mode, float* out,
+                                  int64_t* frames_out);
+int fluhip_bufmfcc_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                              int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
+                              double max_freq, double sample_rate, int padding_mode, float* out, int64_t* frames_out);
 
 /* ---- corpus: many independent equal-shape buffers, resident in HBM --------------------- */
 /* The data-parallel form of the same path (BASELINE config 4): `count` mono buffers of n

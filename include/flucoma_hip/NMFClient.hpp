@@ -52,6 +52,16 @@ struct NMFParams
   index                                seed{-1};
   FFTParams                            fftSettings{1024, -1, -1};
 
+  // the buffer parameters, for the job layer's deep copies and copy-back (NRTThreadingAdaptor.hpp)
+  template <class In, class Out>
+  void forEachBuffer(In&& in, Out&& out)
+  {
+    in(source);
+    out(resynth);
+    out(bases);
+    out(activations);
+  }
+
   // the clamping the reference's constraints apply when a value is set
   void constrain()
   {

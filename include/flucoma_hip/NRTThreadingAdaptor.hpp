@@ -1,10 +1,16 @@
-// NRTThreadingAdaptor.hpp -- job layer of the BufNMF drop-in.
+// NRTThreadingAdaptor.hpp -- job layer of the buffer-processing drop-ins (BufNMF; BufSTFT, BufNMFSeed, BufMFCC and
+// BufMelBands in their own headers).
 //
 // Mirrors client::NRTThreadingAdaptor + ThreadedTask,
 // include/flucoma/clients/common/FluidNRTClientWrapper.hpp:788-1132: a queue of parameter sets,
 // synchronous execution on the caller thread or one std::thread per job, deep copies of every
 // buffer parameter before the worker starts (:1045-1046) and copy-back to the host's buffers from
 // the thread that polls checkProgress (:1089-1100), progress and cancellation through FluidTask.
+// Generic over the client, like the reference's template: a client names its parameter set `ParamSetViewType`, and the
+// parameter set tells the adaptor which of its members are buffers --
+//   template <class In, class Out> void forEachBuffer(In&& in, Out&& out)
+// calls in(std::shared_ptr<const BufferAdaptor>&) for every InputBufferParam and out(std::shared_ptr<BufferAdaptor>&)
+// for every BufferParam (the reference walks its parameter tuple for the same two types, :1045-1046, :1093-1097).
 #pragma once
 
 #include "NMFClient.hpp"
@@ -18,18 +24,19 @@ namespace fluhip {
 
 enum ProcessState { kNoProcess, kProcessing, kDone, kDoneStillProcessing }; // cc/FluidBaseClient.hpp:32
 
-class NRTThreadedNMFClient
+template <class NRTClient>
+class NRTThreadingAdaptor
 {
 public:
-  using Client = bufnmf::NMFClient;
-  using ParamSetType = bufnmf::NMFParams;
+  using Client = NRTClient;
+  using ParamSetType = typename NRTClient::ParamSetViewType;
 
   // ONE client for the adaptor's lifetime, handed to every task (:831 mClient{new NRTClient{mHostParams, c}}, :883): the
   // client's device context -- and with it the cached device blocks and loaded code objects -- outlives a job
-  explicit NRTThreadedNMFClient(ParamSetType& p, FluidContext c = {})
+  explicit NRTThreadingAdaptor(ParamSetType& p, FluidContext c = {})
       : mHostParams(p), mContext(c), mClient(std::make_shared<Client>(mHostParams, mContext))
   {}
-  ~NRTThreadedNMFClient()
+  ~NRTThreadingAdaptor()
   {
     mQueue.clear();
     if (mTask)
@@ -113,24 +120,27 @@ private:
       if (synchronous)
       {
         mClient->setParams(mJob.params); // :1038
-        mResult = mClient->process<float>(mContext);
+        mResult = mClient->template process<float>(mContext);
         mState = kDone;
         mDetached = true;
         return;
       }
       // deep copies: the worker only ever touches MemoryBufferAdaptors
-      ParamSetType& P = mJob.params;
-      if (P.source) { mSourceCopy = std::make_shared<MemoryBufferAdaptor>(P.source); P.source = mSourceCopy; }
-      auto isolate = [](std::shared_ptr<BufferAdaptor>& b, std::shared_ptr<MemoryBufferAdaptor>& keep) {
-        if (b) { keep = std::make_shared<MemoryBufferAdaptor>(b); b = keep; }
-      };
-      isolate(P.resynth, mResynthCopy);
-      isolate(P.bases, mBasesCopy);
-      isolate(P.activations, mActsCopy);
+      mJob.params.forEachBuffer(
+          [this](std::shared_ptr<const BufferAdaptor>& b) {
+            if (!b) return;
+            mInputCopies.push_back(std::make_shared<MemoryBufferAdaptor>(b));
+            b = mInputCopies.back();
+          },
+          [this](std::shared_ptr<BufferAdaptor>& b) {
+            if (!b) return;
+            mOutputCopies.push_back(std::make_shared<MemoryBufferAdaptor>(b));
+            b = mOutputCopies.back();
+          });
       mClient->setParams(mJob.params);
       mFuture = mPromise.get_future();
       mThread = std::thread([this] {
-        Result r = mClient->process<float>(mContext);
+        Result r = mClient->template process<float>(mContext);
         mState = kDone;
         mPromise.set_value(r);
         if (mJob.callback) mJob.callback();
@@ -159,8 +169,7 @@ private:
         if (mResult.ok() || mResult.status() == Result::Status::kWarning)
         {
           // copy-back happens on the polling (host) thread, like :1089-1100
-          for (auto* b : {&mResynthCopy, &mBasesCopy, &mActsCopy})
-            if (*b) (*b)->copyToOrigin(mResult);
+          for (auto& b : mOutputCopies) b->copyToOrigin(mResult);
         }
       }
       result = mResult;
@@ -172,7 +181,7 @@ private:
     FluidTask                            mTaskState;
     FluidContext                         mContext;
     std::shared_ptr<Client>              mClient;
-    std::shared_ptr<MemoryBufferAdaptor> mSourceCopy, mResynthCopy, mBasesCopy, mActsCopy;
+    std::vector<std::shared_ptr<MemoryBufferAdaptor>> mInputCopies, mOutputCopies;
     std::promise<Result>                 mPromise;
     std::future<Result>                  mFuture;
     std::thread                          mThread;
@@ -190,5 +199,8 @@ private:
   bool                          mQueueEnabled{false};
   bool                          mSynchronousDone{false};
 };
+
+// FlucomaClients.cmake:101 (BufNMF ... CLASS NRTThreadedNMFClient), clients/nrt/NMFClient.hpp:341-342
+using NRTThreadedNMFClient = NRTThreadingAdaptor<bufnmf::NMFClient>;
 
 } // namespace fluhip

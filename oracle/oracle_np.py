@@ -311,21 +311,33 @@ def drum_like(n, seed=7):
 # rt/MFCCClient.hpp:86-131, rt/MelBandsClient.hpp:77-119, StreamingControl framing
 # (cc/FluidNRTClientWrapper.hpp:551-660)
 # --------------------------------------------------------------------------------------
-def feature_frames(n: int, win: int, hop: int):
-    """(T, first-sample offset of frame 0) of the buffered feature clients with default padding:
-    nAnalysisFrames = 1 + (n + 2 win - win) // hop, minus win // hop latency frames; analysis frame j
-    sees padded[j hop - win, j hop), audio sits at padded[win // 2 :]."""
-    n_analysis = 1 + (n + 2 * (win // 2)) // hop   # paddedLength = n + win + 2 (win >> 1), less one window
+def feature_padding(win: int, hop: int, padding_mode: int) -> int:
+    """FFTParams::padding, cc/ParameterTypes.hpp:315-323: None / Default / Full."""
+    return [0, win >> 1, win - hop][padding_mode]
+
+
+def feature_frames(n: int, win: int, hop: int, padding_mode: int = 1):
+    """(T, first-sample offset of frame 0) of the buffered feature clients (StreamingControl,
+    cc/FluidNRTClientWrapper.hpp:551-660): the audio sits userPadding = FFTParams::padding samples into a padded signal
+    of n + latency + 2 userPadding samples (latency = win; rounded up to whole hops in Full mode, :572-574),
+    nAnalysisFrames = 1 + (paddedLength - win) // hop, analysis frame j sees padded[(j + 1) hop - win, (j + 1) hop)
+    ... of the client's FluidSource, whose delay puts kept frame k (the first win // hop are dropped, :643-656) at audio
+    sample latencyHops hop - win - userPadding + k hop (streaming_control_frame_starts RUNS the model and agrees)."""
+    pad = feature_padding(win, hop, padding_mode)
+    padded = n + win + 2 * pad
+    if padding_mode == 2:
+        padded = -(-padded // hop) * hop
+    n_analysis = 1 + (padded - win) // hop
     latency_hops = win // hop
     T = n_analysis - latency_hops
-    start0 = latency_hops * hop - win - win // 2
+    start0 = latency_hops * hop - win - pad
     return T, start0
 
 
-def framed_magnitude(audio, win, fft, hop):
+def framed_magnitude(audio, win, fft, hop, padding_mode=1):
     audio = np.asarray(audio, dtype=np.float64)
     n = audio.shape[0]
-    T, start0 = feature_frames(n, win, hop)
+    T, start0 = feature_frames(n, win, hop, padding_mode)
     w = hann(win)
     idx = start0 + np.arange(T)[:, None] * hop + np.arange(win)[None, :]
     ok = (idx >= 0) & (idx < n)
@@ -365,15 +377,15 @@ def melbands(mag, filt, win, mag_norm, use_power, log_output):
 
 
 def bufmelbands_channel(audio_f32, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0,
-                        normalize=True, scale_db=False):
-    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop)
+                        normalize=True, scale_db=False, padding_mode=1):
+    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop, padding_mode)
     filt = mel_filters(lo, hi, n_bands, fft // 2 + 1, sr)
     return melbands(mag, filt, win, normalize, False, scale_db).T.astype(np.float32)
 
 
 def bufmfcc_channel(audio_f32, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0,
-                    sr=44100.0):
-    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop)
+                    sr=44100.0, padding_mode=1):
+    mag = framed_magnitude(np.asarray(audio_f32, dtype=np.float32).astype(np.float64), win, fft, hop, padding_mode)
     filt = mel_filters(lo, hi, n_bands, fft // 2 + 1, sr)
     bands = melbands(mag, filt, win, False, False, True)
     n_out = min(n_coefs + start_coeff, n_bands)
@@ -505,7 +517,7 @@ class FluidSinkModel:
         return out
 
 
-def streaming_control_frame_starts(n, win, hop):
+def streaming_control_frame_starts(n, win, hop, padding_mode=1):
     """First audio sample index of every frame the offline-wrapped feature clients keep, found by RUNNING the model:
     StreamingControl (cc/FluidNRTClientWrapper.hpp:551-660) pads the input by win/2 in front (userPadding.first for
     the default padding of the analysis clients), feeds it to the client in host blocks of `hop` samples
@@ -513,9 +525,11 @@ def streaming_control_frame_starts(n, win, hop):
     FluidSource (cc/BufferedProcess.hpp:78-95), and the first latency/hop output columns are dropped (:643-656).
     The padded signal here carries sample INDICES (audio sample i -> value i + 1, padding -> 0), so the pulled frames
     say where they came from.  Returns (T, [start sample of kept frame k])."""
-    pad = win // 2                                 # FFTParams::padding, default mode (cc/ParameterTypes.hpp:315-323)
+    pad = feature_padding(win, hop, padding_mode)  # FFTParams::padding (cc/ParameterTypes.hpp:315-323)
     latency = win                                  # analysis clients: latency() = winSize
     padded_len = n + latency + 2 * pad             # :564-569: totalPadding = latency + 2 userPadding.first; audio at [pad, pad + n)
+    if padding_mode == 2:                          # :572-574
+        padded_len = -(-padded_len // hop) * hop
     n_analysis = 1 + (padded_len - win) // hop
     padded = np.zeros(padded_len + hop, dtype=np.int64)
     padded[pad:pad + n] = np.arange(1, n + 1)

@@ -9,6 +9,19 @@
 //                     <outprefix> [<bases_seed.f32> <acts_seed.f32>]
 //   client_driver cancel <frames>
 //   client_driver pool <count> <frames>      (fluhip_pool_* from a C++ host: two contexts on device 0 vs one)
+// and the clients of SURVEY 8 (f): BufSTFT, BufNMFSeed, BufMFCC, BufMelBands
+//   client_driver errors2
+//   client_driver stft <in.f32> <frames> <chans> <win> <hop> <fft> <padding> <startFrame> <numFrames> <async> <outprefix>
+//                      (forward into magnitude / phase buffers, then the inverse from those buffers)
+//   client_driver seed <in.f32> <frames> <win> <hop> <fft> <minRank> <maxRank> <coverage> <method> <seed> <async> <outprefix>
+//   client_driver mfcc <in.f32> <frames> <chans> <win> <hop> <fft> <padding> <nBands> <nCoefs> <startCoeff>
+//                      <startFrame> <numFrames> <startChan> <numChans> <async> <outprefix>
+//   client_driver melbands <in.f32> <frames> <chans> <win> <hop> <fft> <padding> <nBands> <normalize> <scale>
+//                      <startFrame> <numFrames> <startChan> <numChans> <async> <outprefix>
+#include "../../include/flucoma_hip/BufSTFTClient.hpp"
+#include "../../include/flucoma_hip/MFCCClient.hpp"
+#include "../../include/flucoma_hip/MelBandsClient.hpp"
+#include "../../include/flucoma_hip/NMFSeedClient.hpp"
 #include "../../include/flucoma_hip/NRTThreadingAdaptor.hpp"
 
 #include <chrono>
@@ -112,11 +125,198 @@ static int runErrors()
   return 0;
 }
 
+// one job through a threading adaptor, on the caller's thread or on the adaptor's own with progress polling
+template <class Adaptor, class Params>
+static Result runJob(Params& p, bool async)
+{
+  Adaptor adaptor(p);
+  Result  r;
+  adaptor.enqueue(p);
+  if (!async)
+  {
+    adaptor.setSynchronous(true);
+    return adaptor.process();
+  }
+  report("process", adaptor.process());
+  ProcessState st = kProcessing;
+  while (st == kProcessing)
+  {
+    st = adaptor.checkProgress(r);
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  }
+  return r;
+}
+
+static int runErrors2()
+{
+  // the validation branches of nrt/BufSTFTClient.hpp:84-107,189-216, nrt/NMFSeedClient.hpp:75-88 and
+  // cc/FluidNRTClientWrapper.hpp:313-328 that need no device
+  FluidContext ctx;
+  {
+    fluhip::bufstft::BufSTFTParams    p;
+    fluhip::bufstft::BufferSTFTClient client(p, ctx);
+    report("stft_no_source", client.process<float>(ctx));
+    p.source = makeBuffer(1, 4096);
+    report("stft_no_outputs", client.process<float>(ctx));
+    p.magnitude = makeBuffer(1, 1);
+    p.startFrame = 5000;
+    report("stft_bad_start_frame", client.process<float>(ctx));
+    p.startFrame = 0;
+    p.numFrames = 5000;
+    report("stft_too_many_frames", client.process<float>(ctx));
+    p.numFrames = -1;
+    p.fftSettings = FFTParams(1024, 512, 131072); // 65537 bins
+    report("stft_too_many_bins", client.process<float>(ctx));
+    p.fftSettings = FFTParams(1024, 512, 1024);
+    p.inverse = 1;
+    report("istft_needs_both", client.process<float>(ctx));
+    p.phase = makeBuffer(513, 9);
+    report("istft_no_resynth", client.process<float>(ctx));
+    p.resynth = makeBuffer(1, 1);
+    p.magnitude = makeBuffer(513, 8);
+    report("istft_size_mismatch", client.process<float>(ctx));
+    p.magnitude = makeBuffer(512, 9);
+    p.phase = makeBuffer(512, 9);
+    report("istft_wrong_channels", client.process<float>(ctx));
+  }
+  {
+    fluhip::nndsvd::NMFSeedParams p;
+    fluhip::nndsvd::NMFSeedClient client(p, ctx);
+    report("seed_no_source", client.process<float>(ctx));
+    p.source = makeBuffer(2, 4096);
+    report("seed_two_channels", client.process<float>(ctx));
+  }
+  {
+    fluhip::mfcc::NRTMFCCParams p;
+    fluhip::NRTMFCCClient       client(p, ctx);
+    report("mfcc_no_source", client.process<float>(ctx));
+    p.source = makeBuffer(2, 4096);
+    p.startChan = 2;
+    report("mfcc_bad_start_chan", client.process<float>(ctx));
+    p.startChan = 0;
+    report("mfcc_no_output", client.process<float>(ctx));
+    fluhip::melbands::NRTMelBandsParams q;
+    fluhip::NRTMelBandsClient           mel(q, ctx);
+    q.source = makeBuffer(1, 4096);
+    q.numChans = 2;
+    report("melbands_too_many_chans", mel.process<float>(ctx));
+    q.numChans = -1;
+    report("melbands_no_output", mel.process<float>(ctx));
+    // constraints of the parameter tables (rt/MFCCClient.hpp:38-49)
+    p.numCoeffs = 50;
+    p.numBands = 1000;
+    p.startCoeff = 7;
+    p.constrain();
+    std::printf("mfcc_constraints|%d|%ld %ld %ld\n", (p.numBands == 513 && p.numCoeffs == 50 && p.startCoeff == 1) ? 1 : 0,
+                (long) p.numBands, (long) p.numCoeffs, (long) p.startCoeff);
+  }
+  return 0;
+}
+
 int main(int argc, char** argv)
 {
   if (argc < 2) return 2;
   const std::string mode = argv[1];
   if (mode == "errors") return runErrors();
+  if (mode == "errors2") return runErrors2();
+
+  if (mode == "stft")
+  {
+    if (argc < 13) return 2;
+    auto      in = readFile(argv[2]);
+    const idx frames = std::atol(argv[3]), chans = std::atol(argv[4]);
+    fluhip::bufstft::BufSTFTParams p;
+    p.source = makeBuffer(chans, frames, in.data());
+    p.fftSettings = FFTParams(std::atol(argv[5]), std::atol(argv[6]), std::atol(argv[7]));
+    p.padding = std::atol(argv[8]);
+    p.startFrame = std::atol(argv[9]);
+    p.numFrames = std::atol(argv[10]);
+    const bool        async = std::atoi(argv[11]) != 0;
+    const std::string prefix = argv[12];
+    p.constrain();
+    auto mag = makeBuffer(1, 1), phase = makeBuffer(1, 1), resynth = makeBuffer(1, 1);
+    p.magnitude = mag;
+    p.phase = phase;
+    report("forward", runJob<fluhip::NRTThreadedBufferSTFTClient>(p, async));
+    writeBuffer(prefix + "_mag.bin", mag);
+    writeBuffer(prefix + "_phase.bin", phase);
+    p.inverse = 1;
+    p.resynth = resynth;
+    report("inverse", runJob<fluhip::NRTThreadedBufferSTFTClient>(p, async));
+    writeBuffer(prefix + "_resynth.bin", resynth);
+    return 0;
+  }
+
+  if (mode == "seed")
+  {
+    if (argc < 14) return 2;
+    auto      in = readFile(argv[2]);
+    const idx frames = std::atol(argv[3]);
+    fluhip::nndsvd::NMFSeedParams p;
+    p.source = makeBuffer(1, frames, in.data());
+    p.fftSettings = FFTParams(std::atol(argv[4]), std::atol(argv[5]), std::atol(argv[6]));
+    p.minComponents = std::atol(argv[7]);
+    p.maxComponents = std::atol(argv[8]);
+    p.coverage = std::atof(argv[9]);
+    p.method = std::atol(argv[10]);
+    p.seed = std::atol(argv[11]);
+    const bool        async = std::atoi(argv[12]) != 0;
+    const std::string prefix = argv[13];
+    p.constrain();
+    auto bases = makeBuffer(1, 1), acts = makeBuffer(1, 1);
+    p.bases = bases;
+    p.activations = acts;
+    report("result", runJob<fluhip::NRTThreadedNMFSeedClient>(p, async));
+    writeBuffer(prefix + "_bases.bin", bases);
+    writeBuffer(prefix + "_acts.bin", acts);
+    return 0;
+  }
+
+  if (mode == "mfcc" || mode == "melbands")
+  {
+    if (argc < 18) return 2;
+    auto      in = readFile(argv[2]);
+    const idx frames = std::atol(argv[3]), chans = std::atol(argv[4]);
+    auto      features = makeBuffer(1, 1);
+    auto      wrapper = [&](fluhip::NRTControlParams& w) {
+      w.source = makeBuffer(chans, frames, in.data());
+      w.padding = std::atol(argv[8]);
+      w.startFrame = std::atol(argv[12]);
+      w.numFrames = std::atol(argv[13]);
+      w.startChan = std::atol(argv[14]);
+      w.numChans = std::atol(argv[15]);
+      w.features = features;
+    };
+    const FFTParams   fft(std::atol(argv[5]), std::atol(argv[6]), std::atol(argv[7]));
+    const bool        async = std::atoi(argv[16]) != 0;
+    const std::string prefix = argv[17];
+    Result            r;
+    if (mode == "mfcc")
+    {
+      fluhip::mfcc::NRTMFCCParams p;
+      wrapper(p);
+      p.fftSettings = fft;
+      p.numBands = std::atol(argv[9]);
+      p.numCoeffs = std::atol(argv[10]);
+      p.startCoeff = std::atol(argv[11]);
+      p.constrain();
+      r = runJob<fluhip::NRTThreadedMFCCClient>(p, async);
+    }
+    else
+    {
+      fluhip::melbands::NRTMelBandsParams p;
+      wrapper(p);
+      p.fftSettings = fft;
+      p.numBands = std::atol(argv[9]);
+      p.normalize = std::atol(argv[10]);
+      p.scale = std::atol(argv[11]);
+      p.constrain();
+      r = runJob<fluhip::NRTThreadedMelBandsClient>(p, async);
+    }
+    report("result", r);
+    writeBuffer(prefix + "_features.bin", features);
+    return 0;
+  }
 
   if (mode == "cancel")
   {

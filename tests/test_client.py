@@ -1,5 +1,6 @@
-"""The C++17 host-side client (include/flucoma_hip/*.hpp: BufferAdaptor, NMFClient,
-NRTThreadedNMFClient) driven through tests/cpp/client_driver.cpp.
+"""The C++17 host-side clients (include/flucoma_hip/*.hpp: BufferAdaptor, NMFClient and the clients of SURVEY 8 (f) --
+BufferSTFTClient, NMFSeedClient, NRTMFCCClient, NRTMelBandsClient -- each behind the generic NRTThreadingAdaptor)
+driven through tests/cpp/client_driver.cpp.
 
 CPU part: parameter validation, Result codes and the exact user-visible messages of
 include/flucoma/clients/nrt/NMFClient.hpp:100-185 and clients/common/BufferAdaptor.hpp:175-208.
@@ -230,3 +231,144 @@ def test_pool_from_a_cpp_host(driver, ctx):
     r = run(driver, "pool", 7, 30000)
     assert r["pool_rc"][0] == 0 and r["pool_rc"][1] == "0"
     assert r["pool_match"][0] == 1, r["pool_match"]
+
+
+# ---- the clients of SURVEY 8 (f): BufSTFT, BufNMFSeed, BufMFCC, BufMelBands ----------------------------------------
+def test_validation_messages_of_the_other_clients(driver):
+    """nrt/BufSTFTClient.hpp:84-107,189-216, nrt/NMFSeedClient.hpp:75-88, cc/FluidNRTClientWrapper.hpp:313-328: the
+    user-visible strings (typos included) and the parameter constraints of rt/MFCCClient.hpp:38-49; no device needed"""
+    r = run(driver, "errors2")
+    assert r["stft_no_source"] == (ERROR, "No input buffer supplied")
+    assert r["stft_no_outputs"] == (ERROR, "Neither magnitude nor phase buffer supplied")
+    assert r["stft_bad_start_frame"] == (ERROR, "Input buffer  invalid start frame 5000")
+    assert r["stft_too_many_frames"] == (ERROR, "Input buffer : not enough frames")
+    assert r["stft_too_many_bins"] == (ERROR, "Can produce up to 65536 channels. Split your data up and try again")
+    assert r["istft_needs_both"] == (ERROR, "Need both magnutude and phase buffers for inverse transform")
+    assert r["istft_no_resynth"] == (ERROR, "No resynthesis buffer supplied")
+    assert r["istft_size_mismatch"] == (ERROR, "Magnitude and Phase buffer sizes don't match")
+    assert r["istft_wrong_channels"] == (ERROR, "Wrong number of channels for FFT sizee of 1024 got 512 expected 513")
+    assert r["seed_no_source"] == (ERROR, "Source Buffer Supplied But Invalid")
+    assert r["seed_two_channels"] == (ERROR, "Only one channel supported")
+    assert r["mfcc_no_source"] == (ERROR, "Input buffer not set")
+    assert r["mfcc_bad_start_chan"] == (ERROR, "Input buffer  invalid start channel 2")
+    assert r["mfcc_no_output"] == (ERROR, "No valid output has been set")
+    assert r["melbands_too_many_chans"] == (ERROR, "Input buffer : not enough channels")
+    assert r["melbands_no_output"] == (ERROR, "No valid output has been set")
+    assert r["mfcc_constraints"][0] == 1, r["mfcc_constraints"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+@pytest.mark.parametrize("win,hop,fft,padding", [(1024, 256, 1024, 1), (1000, 300, 1024, 2), (512, 128, 2048, 0)])
+def test_bufstft_client(driver, onp, tmp_path, use_async, win, hop, fft, padding, ctx):
+    """BufferSTFTClient forward then inverse (nrt/BufSTFTClient.hpp:81-276) through the threading adaptor: buffer
+    shapes and sample rates, magnitude / phase against the numpy restatement, channel 0 read whatever startChan says
+    (:152), and the resynthesis against the restated inverse of the same float buffers"""
+    frames, chans = 20000, 2
+    audio = np.stack([onp.synth_audio(frames, 900 + c) for c in range(chans)], axis=1)
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    start, num = 1500, 15000
+    prefix = str(tmp_path / "o")
+    r = run(driver, "stft", inp, frames, chans, win, hop, fft, padding, start, num, use_async, prefix)
+    assert r["forward"] == (OK, "") and r["inverse"] == (OK, "")
+    mag, sr_m = read_buffer(prefix + "_mag.bin")
+    ph, sr_p = read_buffer(prefix + "_phase.bin")
+    x = np.ascontiguousarray(audio[start:start + num, 0])
+    rm, rp = onp.bufstft_forward(x, win, fft, hop, padding)
+    assert mag.shape == rm.shape == ph.shape                                  # bins x hops: channel = bin (:168-178)
+    assert sr_m == pytest.approx(44100.0 / hop) and sr_p == pytest.approx(44100.0 / hop)
+    assert np.abs(mag - rm).max() / np.abs(rm).max() < 1e-6
+    strong = rm > 1e-3 * rm.max()                                             # the phase of an empty bin is noise
+    d = np.angle(np.exp(1j * (ph.astype(np.float64) - rp)))[strong]
+    assert np.abs(d).max() < 1e-3
+    out, sr_o = read_buffer(prefix + "_resynth.bin")
+    ref = onp.bufstft_inverse(mag, ph, win, fft, hop, padding)
+    assert out.shape == (1, ref.shape[0]) and sr_o == pytest.approx(44100.0)  # mags.sampleRate() * hop (:233)
+    # std::polar in single precision on both sides; the overlap-add divides float rounding by the summed squared window,
+    # nearly zero on the outermost samples: weighted by that divisor (as in tests/test_gpu_parity.py)
+    w2 = onp.hann(win) ** 2
+    nrm = np.zeros((mag.shape[1] - 1) * hop + win)
+    for t in range(mag.shape[1]):
+        nrm[t * hop:t * hop + win] += w2
+    pad = onp.bufstft_padding(win, hop, padding)
+    nrm = np.maximum(nrm[pad:pad + out.shape[1]], 2.220446049250313e-16)
+    assert (np.abs(out[0] - ref) * np.minimum(nrm, 1.0)).max() < 2e-6 * max(1.0, np.abs(mag).max() / fft)
+    if padding == 1 and win % hop == 0:                                       # COLA: the input comes back
+        m = min(num, out.shape[1])
+        assert np.abs(out[0, win:m - win] - x[win:m - win]).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+def test_bufnmfseed_client(driver, oracle, onp, tmp_path, use_async, ctx):
+    """NMFSeedClient (nrt/NMFSeedClient.hpp:73-131): both output buffers resized to the rank found (:108-118), bases at
+    sampleRate / fft, activations at sampleRate / hop, method 0 against STFT (C oracle) -> NNDSVD (numpy / LAPACK)"""
+    frames = 30000
+    x = onp.synth_audio(frames, 77)
+    inp = tmp_path / "in.f32"
+    x.astype(np.float32).tofile(inp)
+    win, hop, fft, max_rank = 1024, 256, 1024, 12
+    prefix = str(tmp_path / "o")
+    r = run(driver, "seed", inp, frames, win, hop, fft, 1, max_rank, 0.7, 0, 42, use_async, prefix)
+    assert r["result"] == (OK, "")
+    bases, sr_b = read_buffer(prefix + "_bases.bin")
+    acts, sr_a = read_buffer(prefix + "_acts.bin")
+    _, mag = oracle.stft_f32(x, win, fft, hop)
+    rW, rH, rk, *_ = onp.nndsvd(mag, max_rank, 1, max_rank, 0.7, 0, 42)
+    assert bases.shape == (rk, fft // 2 + 1) and acts.shape == (rk, frames // hop + 1)
+    assert sr_b == pytest.approx(44100.0 / fft) and sr_a == pytest.approx(44100.0 / hop)
+    ra = rH.T.astype(np.float32) * np.float32(1.0 / rH.max())
+    assert rel_err(bases, rW[:rk].astype(np.float32)) < 1e-5 and rel_err(acts, ra[:rk]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+@pytest.mark.parametrize("padding", [0, 1, 2])
+def test_bufmfcc_client(driver, onp, tmp_path, use_async, padding, ctx):
+    """NRTMFCCClient (rt/MFCCClient.hpp:86-175 behind StreamingControl, cc/FluidNRTClientWrapper.hpp:551-660): a
+    3-channel buffer with frame and channel offsets is one batch on the device; feature i of channel j lands in buffer
+    channel i + j * numCoeffs (:650-655), frames = kept hops, sample rate = sampleRate / hop"""
+    frames, chans = 24000, 3
+    audio = np.stack([onp.synth_audio(frames, 600 + c) for c in range(chans)], axis=1)
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    win, hop, fft, n_bands, n_coefs, start_coeff = 1024, 256, 1024, 40, 13, 1
+    start_frame, num_frames, start_chan, num_chans = 500, 20000, 1, 2
+    prefix = str(tmp_path / "o")
+    r = run(driver, "mfcc", inp, frames, chans, win, hop, fft, padding, n_bands, n_coefs, start_coeff, start_frame,
+            num_frames, start_chan, num_chans, use_async, prefix)
+    assert r["result"] == (OK, "")
+    feat, sr = read_buffer(prefix + "_features.bin")
+    T, _ = onp.feature_frames(num_frames, win, hop, padding)
+    assert feat.shape == (num_chans * n_coefs, T) and sr == pytest.approx(44100.0 / hop)
+    for j in range(num_chans):
+        x = np.ascontiguousarray(audio[start_frame:start_frame + num_frames, start_chan + j])
+        ref = onp.bufmfcc_channel(x, win, fft, hop, n_bands, n_coefs, start_coeff, padding_mode=padding)
+        got = feat[j * n_coefs:(j + 1) * n_coefs]
+        assert np.abs(got - ref).max() < 2e-3 and np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalize,scale", [(1, 0), (0, 1)])
+def test_bufmelbands_client(driver, onp, tmp_path, normalize, scale, ctx):
+    """NRTMelBandsClient (rt/MelBandsClient.hpp:77-159): normalize / scale enums, whole stereo buffer"""
+    frames, chans = 16000, 2
+    audio = np.stack([onp.synth_audio(frames, 650 + c) for c in range(chans)], axis=1)
+    inp = tmp_path / "in.f32"
+    audio.astype(np.float32).tofile(inp)
+    win, hop, fft, n_bands = 1000, 300, 1024, 24
+    prefix = str(tmp_path / "o")
+    r = run(driver, "melbands", inp, frames, chans, win, hop, fft, 1, n_bands, normalize, scale, 0, -1, 0, -1, 1, prefix)
+    assert r["result"] == (OK, "")
+    feat, sr = read_buffer(prefix + "_features.bin")
+    T, _ = onp.feature_frames(frames, win, hop, 1)
+    assert feat.shape == (chans * n_bands, T) and sr == pytest.approx(44100.0 / hop)
+    for j in range(chans):
+        ref = onp.bufmelbands_channel(np.ascontiguousarray(audio[:, j]), win, fft, hop, n_bands,
+                                      normalize=bool(normalize), scale_db=bool(scale))
+        got = feat[j * n_bands:(j + 1) * n_bands]
+        if scale:
+            assert np.abs(got - ref).max() < 2e-3
+        else:
+            assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5

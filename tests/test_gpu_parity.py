@@ -1003,6 +1003,24 @@ def test_bufmfcc_vs_oracle(ctx, oracle, onp, n, win, fft, hop):
         assert np.abs(got[b] - ref).max() / np.abs(ref).max() < 1e-5
 
 
+@pytest.mark.parametrize("padding_mode", [0, 2])
+@pytest.mark.parametrize("n,win,fft,hop", [(88200, 1024, 1024, 512), (12345, 1000, 1024, 300), (5024, 301, 512, 75)])
+def test_bufmfcc_padding_modes(ctx, onp, n, win, fft, hop, padding_mode):
+    """The wrapper's "padding" parameter (None / Full; Default is every other test): frame count and positions of
+    StreamingControl (cc/FluidNRTClientWrapper.hpp:557-579, 643-656) against the numpy restatement, whose closed form
+    tests/test_oracle.py derives from the FluidSource model for all three modes."""
+    audio = np.stack([onp.synth_audio(n, 7100 + b) for b in range(2)])
+    got = ctx.bufmfcc(audio, win, fft, hop, padding_mode=padding_mode)
+    mb = ctx.bufmelbands(audio, win, fft, hop, padding_mode=padding_mode)
+    for b in range(2):
+        ref = onp.bufmfcc_channel(audio[b], win, fft, hop, padding_mode=padding_mode)
+        assert got[b].shape == ref.shape
+        assert np.abs(got[b] - ref).max() < 2e-3
+        assert np.abs(got[b] - ref).max() / np.abs(ref).max() < 1e-5
+        refm = onp.bufmelbands_channel(audio[b], win, fft, hop, padding_mode=padding_mode)
+        assert np.abs(mb[b] - refm).max() / np.abs(refm).max() < 1e-5
+
+
 def test_bufmfcc_options(ctx, oracle, onp):
     x = onp.synth_audio(40000, 99)
     for (nb, nc, sc) in ((40, 13, 1), (20, 20, 0), (64, 5, 0), (100, 13, 1)):
@@ -1097,18 +1115,20 @@ def test_stft_gaussian_window_needs_odd_size(ctx):
 
 
 @pytest.mark.parametrize("n,win,fft,hop", [(20000, 1024, 1024, 256), (9999, 512, 512, 100), (5024, 301, 512, 75)])
-def test_feature_frame_positions_follow_fluidsource(ctx, onp, n, win, fft, hop):
+@pytest.mark.parametrize("padding_mode", [0, 1, 2])
+def test_feature_frame_positions_follow_fluidsource(ctx, onp, n, win, fft, hop, padding_mode):
     """Frame indexing of the HIP feature path against the restated FluidSource chain
     (tests/clients/common/TestFluidSource.cpp:17-59 pins that restatement): a unit impulse at sample p lights up exactly
     the kept frames whose window covers p (the Hann window is zero at its first sample only)."""
-    T, starts = onp.streaming_control_frame_starts(n, win, hop)
+    T, starts = onp.streaming_control_frame_starts(n, win, hop, padding_mode)
     for p in (0, 1, win // 2, n // 3, n - 2, n - 1):
         x = np.zeros(n, dtype=np.float32)
         x[p] = 1.0
-        mb = ctx.bufmelbands(x, win, fft, hop, n_bands=8, lo=20.0, hi=20000.0, normalize=False, scale_db=False)[0]
+        mb = ctx.bufmelbands(x, win, fft, hop, n_bands=8, lo=20.0, hi=20000.0, normalize=False, scale_db=False,
+                             padding_mode=padding_mode)[0]
         assert mb.shape[1] == T
         lit = mb.sum(axis=0) > 0
-        _, start0 = onp.feature_frames(n, win, hop)
+        _, start0 = onp.feature_frames(n, win, hop, padding_mode)
         for k in range(T):
             s = starts[k] if starts[k] is not None else start0 + k * hop
             covered = s < p < s + win          # i = p - s in 1 .. win-1: non-zero window sample
