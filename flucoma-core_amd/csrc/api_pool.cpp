@@ -399,4 +399,73 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
   return rc;
 }
 
+
+// ---- feature pipeline over the pool (BASELINE config 5: "... over 8192 x 2 s slices ... 1 -> 8 GPU scaling") ----------------
+// The slices are independent analyses (one StreamingControl run each, cc/FluidNRTClientWrapper.hpp:598-630): contiguous
+// blocks of slices per device, every device reads its block of the caller's audio and writes its block of the features.
+static int pool_features(fluhip_pool* p, bool mfcc, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                         int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq, double max_freq,
+                         double sample_rate, int normalize, int scale_db, int padding_mode, float* out, int64_t* frames_out)
+{
+  if (!p) return FLUHIP_ERROR;
+  p->err.clear();
+  if (!audio || !out || count < 1 || n < 1 || win < 1 || hop < 1) { p->err = "null / empty corpus"; return FLUHIP_ERROR; }
+  if (padding_mode < 0 || padding_mode > 2) { p->err = "padding mode must be 0 (None), 1 (Default) or 2 (Full)"; return FLUHIP_ERROR; }
+  const int world = (int) p->ctx.size();
+  // frames per slice, as the single-device entry points count them (include/flucoma_hip.h)
+  const int64_t userPad = padding_mode == 0 ? 0 : padding_mode == 1 ? win / 2 : win - hop;
+  int64_t padded = n + win + 2 * userPad;
+  if (padding_mode == 2) padded = ((padded + hop - 1) / hop) * hop;
+  const int64_t T = 1 + (padded - win) / hop - win / hop;
+  if (T < 1) { p->err = "not enough frames"; return FLUHIP_ERROR; }
+  const int64_t nOut = mfcc ? n_coefs : n_bands;
+  std::vector<int> rcs((size_t) world, FLUHIP_OK);
+  std::vector<std::string> errs((size_t) world);
+  std::vector<std::thread> th;
+  for (int r = 0; r < world; r++)
+  {
+    int64_t b0, b1;
+    fluhip_shard_range(count, world, r, &b0, &b1);
+    if (b1 <= b0) continue;
+    th.emplace_back([=, &rcs, &errs] {
+      fluhip_ctx* ctx = p->ctx[(size_t) r];
+      int64_t Tr = 0;
+      const float* a = audio + b0 * n;
+      float* o = out + b0 * nOut * T;
+      const int rc = mfcc ? fluhip_bufmfcc_padded_f32(ctx, a, b1 - b0, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
+                                                      max_freq, sample_rate, padding_mode, o, &Tr)
+                          : fluhip_bufmelbands_padded_f32(ctx, a, b1 - b0, n, win, fft, hop, n_bands, min_freq, max_freq,
+                                                          sample_rate, normalize, scale_db, padding_mode, o, &Tr);
+      rcs[(size_t) r] = rc;
+      if (rc != FLUHIP_OK) errs[(size_t) r] = fluhip_last_error(ctx);
+      else if (Tr != T) { rcs[(size_t) r] = FLUHIP_ERROR; errs[(size_t) r] = "frame count differs between the pool and the device path"; }
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int r = 0; r < world; r++)
+    if (rcs[(size_t) r] != FLUHIP_OK)
+    {
+      p->err = "device " + std::to_string(p->device[(size_t) r]) + ": " + errs[(size_t) r];
+      return rcs[(size_t) r];
+    }
+  if (frames_out) *frames_out = T;
+  return FLUHIP_OK;
+}
+
+int fluhip_pool_bufmfcc_f32(fluhip_pool* p, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                            int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq, double max_freq,
+                            double sample_rate, int padding_mode, float* out, int64_t* frames_out)
+{
+  return pool_features(p, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq, max_freq, sample_rate, 0, 0,
+                       padding_mode, out, frames_out);
+}
+
+int fluhip_pool_bufmelbands_f32(fluhip_pool* p, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                                int64_t hop, int64_t n_bands, double min_freq, double max_freq, double sample_rate, int normalize,
+                                int scale_db, int padding_mode, float* out, int64_t* frames_out)
+{
+  return pool_features(p, false, audio, count, n, win, fft, hop, n_bands, 0, 0, min_freq, max_freq, sample_rate, normalize, scale_db,
+                       padding_mode, out, frames_out);
+}
+
 } // extern "C"

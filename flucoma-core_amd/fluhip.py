@@ -61,7 +61,8 @@ EXPORTS = [
     "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_debug_plan_lists",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
-    "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
+    "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_pool_bufmfcc_f32",
+    "fluhip_pool_bufmelbands_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
 ]
 
 
@@ -159,6 +160,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_pool_device.argtypes = [_vp, ctypes.c_int]
     L.fluhip_pool_last_error.argtypes = [_vp]
     L.fluhip_pool_last_error.restype = ctypes.c_char_p
+    L.fluhip_pool_bufmfcc_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                          ctypes.c_int, _fp, _ip]
+    L.fluhip_pool_bufmelbands_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dbl,
+                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, _fp, _ip]
     L.fluhip_pool_bufnmf_f32.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_int, ctypes.c_int,
                                          _i64, _ip, _fp, _fp, PROGRESS_FN, _vp]
     L.fluhip_pool_bufnmf_job_f32.argtypes = [_vp, ctypes.POINTER(BufNMFJob), PROGRESS_FN, _vp]
@@ -609,6 +614,35 @@ class Pool:
         if rc not in (OK, CANCELLED):
             raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
         return bases, acts, rc
+
+    def bufmfcc(self, audio, win, fft, hop, n_bands=40, n_coefs=13, start_coeff=0, lo=20.0, hi=20000.0, sr=44100.0,
+                padding_mode=1):
+        """fluhip_pool_bufmfcc_f32: BASELINE config 5 over several devices, slices dealt in contiguous blocks"""
+        audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        count, n = audio.shape
+        T = Context.feature_frames(n, win, hop, padding_mode)
+        out = np.empty((count, n_coefs, T), dtype=np.float32)
+        Tr = _i64(0)
+        rc = self.lib.fluhip_pool_bufmfcc_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, n_coefs, start_coeff, lo, hi, sr,
+                                              padding_mode, _f(out), ctypes.byref(Tr))
+        if rc != OK:
+            raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
+        assert Tr.value == T
+        return out
+
+    def bufmelbands(self, audio, win, fft, hop, n_bands=40, lo=20.0, hi=20000.0, sr=44100.0, normalize=True, scale_db=False,
+                    padding_mode=1):
+        audio = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        count, n = audio.shape
+        T = Context.feature_frames(n, win, hop, padding_mode)
+        out = np.empty((count, n_bands, T), dtype=np.float32)
+        Tr = _i64(0)
+        rc = self.lib.fluhip_pool_bufmelbands_f32(self.h, _f(audio), count, n, win, fft, hop, n_bands, lo, hi, sr, int(normalize),
+                                                  int(scale_db), padding_mode, _f(out), ctypes.byref(Tr))
+        if rc != OK:
+            raise FluhipError(rc, self.lib.fluhip_pool_last_error(self.h).decode())
+        assert Tr.value == T
+        return out
 
     def bufnmf_job(self, audio, win, fft, hop, K, iters, seed=42, updateW=True, updateH=True, seeds=None, bases_seed=None,
                    acts_seed=None, resynth=False, progress=None):

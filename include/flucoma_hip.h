@@ -360,6 +360,16 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* pool, const float* const* audio, 
                                   int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                                   const int64_t* seeds, float* const* bases, float* const* acts, fluhip_progress_fn progress,
                                   void* user);
+/* The feature pipeline over the pool (BASELINE config 5, "1 -> 8 GPU scaling"): `count` equal-length slices, dealt in
+ * contiguous blocks; audio: count x n host floats, out: count x nFeatures x T host floats (see fluhip_bufmfcc_padded_f32 /
+ * fluhip_bufmelbands_padded_f32 for the arguments).  The slices are independent analyses: no exchange between devices. */
+int fluhip_pool_bufmfcc_f32(fluhip_pool* pool, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                            int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
+                            double max_freq, double sample_rate, int padding_mode, float* out, int64_t* frames_out);
+int fluhip_pool_bufmelbands_f32(fluhip_pool* pool, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
+                                int64_t hop, int64_t n_bands, double min_freq, double max_freq, double sample_rate,
+                                int normalize, int scale_db, int padding_mode, float* out, int64_t* frames_out);
+
 /* the dealing itself (integer arithmetic, also used by the multi-process launcher): contiguous blocks [begin, end) of
  * n_items over `world` ranks; and the greedy longest-processing-time deal for ragged corpora (cost ~ T F K per buffer,
  * ties to the lower index / rank): rank_of_item[i] = rank of item i */

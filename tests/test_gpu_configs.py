@@ -176,6 +176,26 @@ def test_pool_two_contexts_shard_a_corpus(ctx, oracle, onp):
     pool.close(); one.close()
 
 
+def test_pool_feature_pipeline_over_two_contexts(ctx, onp):
+    """fluhip_pool_bufmfcc_f32 / fluhip_pool_bufmelbands_f32 (BASELINE config 5's multi-device form): seven slices dealt
+    4 + 3 over two contexts on device 0; bit-identical to the single-context call (the slices are independent analyses),
+    one slice against the numpy restatement, all three padding modes"""
+    import fluhip
+    n, win, fft, hop = 20000, 1024, 1024, 512
+    audio = np.stack([onp.synth_audio(n, 5100 + b) for b in range(7)])
+    pool = fluhip.Pool([0, 0], ctx.lib)
+    for mode in (1, 0, 2):
+        got = pool.bufmfcc(audio, win, fft, hop, padding_mode=mode)
+        assert np.array_equal(got, ctx.bufmfcc(audio, win, fft, hop, padding_mode=mode))
+        ref = onp.bufmfcc_channel(audio[5], win, fft, hop, padding_mode=mode)
+        assert got[5].shape == ref.shape and np.abs(got[5] - ref).max() < 2e-3
+    mb = pool.bufmelbands(audio, win, fft, hop, n_bands=24, normalize=False, scale_db=True)
+    assert np.array_equal(mb, ctx.bufmelbands(audio, win, fft, hop, n_bands=24, normalize=False, scale_db=True))
+    with pytest.raises(fluhip.FluhipError):
+        pool.bufmfcc(audio[:, :100], 1024, 1024, 512, n_bands=4000)          # refused by every device, message passed on
+    pool.close()
+
+
 def test_pool_job_with_seeds_fixed_bases_and_resynthesis(ctx, oracle, onp):
     """fluhip_pool_bufnmf_job_f32: the batched form with everything the BufNMF parameter set has -- Seed / Fixed factors
     (basesMode / actMode) and the resynthesis output -- over two contexts on device 0 (shares 3 + 2): fixed bases with
