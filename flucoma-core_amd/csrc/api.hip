@@ -506,6 +506,21 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       const int64_t passes = (c->B * w + 1023) / 1024, passes1 = (c->B * w1 + 1023) / 1024;
       c->sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
     }
+    else if (c->lazy && !sideOff && c->nsplitW > 1 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp))
+    {
+      // Split contraction (few buffers): without the 16 m + 1-th bin the strips deal evenly and the pieces get shorter --
+      // config 3 (2 x 2049 bins, rank 128): 130 strips x 7 pieces of 923 steps (910 wavefronts) -> 128 strips x 8 pieces
+      // of 808 steps (1024 wavefronts).  Taken when the longest piece shrinks.
+      const int s1 = choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp);
+      const int64_t nSteps = (c->T + 3) / 4;
+      const int64_t w = c->B * nmf_update5_waves_per_buffer((int) c->F, (int) c->Kp, (int) c->B);
+      const int64_t w1 = c->B * nmf_update5_waves_per_buffer((int) c->F - 1, (int) c->Kp, (int) c->B);
+      if (s1 > 1 && w1 * s1 <= 1024 && w * c->nsplitW <= 1024 && (nSteps + s1 - 1) / s1 < (nSteps + c->nsplitW - 1) / c->nsplitW)
+      {
+        c->sideW = true;
+        c->nsplitW = s1;
+      }
+    }
     // A single buffer of rank <= 16 runs the frame-strip schedule while one round of workgroups covers it (at most 6 frame
     // quads per CU: 71 s at hop 512): two launches per iteration instead of five and V read once.  Longer buffers and
     // batches stay with the split / batched kernels, which win there (tools/strip_vs_split.py).  FLUHIP_STRIP=0 off,
@@ -530,7 +545,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     }
     // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
     // finalize kernel when the contraction is split
-    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F, (int) c->Kp)
+    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp)
                                 : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
   }
   if (int rc = alloc_update_scratch(ctx, c)) return rc;

@@ -288,7 +288,16 @@ __global__ void colsum_part_kernel(const double* Mvbase, int64_t strideM, int R,
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
   const int rbeg = chunk * kSumRows, rend = min(rbeg + kSumRows, R);
   double t = 0.0;
-  for (int r = rbeg + rg; r < rend; r += nrg) t += Mv[(int64_t) r * Kp + k];
+  int r = rbeg + rg;
+  for (; r + 7 * nrg < rend; r += 8 * nrg) // eight independent loads in flight, summed in row order (at rank 128 a thread's 128
+  {                                        // rows, one dependent load after the other, made this pre-pass 43 us on config 3)
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = Mv[(int64_t) (r + u * nrg) * Kp + k];
+#pragma unroll
+    for (int u = 0; u < 8; u++) t += v[u];
+  }
+  for (; r < rend; r += nrg) t += Mv[(int64_t) r * Kp + k];
   sh[rg * Kp + k] = t;
   __syncthreads();
   if (rg == 0)
@@ -341,12 +350,13 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
 // block pays one memory latency); row groups are combined in fixed order and the slice's (num, den) go
 // to scratch for wnorm_combine_kernel.  No atomics: run-to-run bit-identical.
 constexpr int kSideUnr = 8;    // rows of a slice per row group (held in registers)
-constexpr int kSideSlices = 64; // at most; a launch uses as many as keep a slice within a block's capacity
+constexpr int kSideSlices = 256; // at most; up to there a launch uses as many as keep a slice within a block's capacity (longer
+                                 // buffers: a slice goes through the block in chunks)
 
 __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t strideS, int C, int K, int Kp,
                                                    const double* statPart, int nParts, const double* sidePart,
                                                    int nsl, const double* wold, double* nrm, int b, double* shs, double* shm,
-                                                   double* smax);
+                                                   double* smax, double* shn = nullptr, double* shd = nullptr);
 // fuse != nullptr: the LAST slice of a buffer to finish (an arrival ticket per buffer) runs the norm combine for it in
 // this launch -- one launch less per iteration.  The slices' partials are published by one agent-scope release per
 // workgroup and picked up behind one acquire (MI355X_MICROARCH.md, inter-workgroup visibility); the sums are taken in
@@ -371,16 +381,9 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
   const int k = threadIdx.x % Kp, rg = threadIdx.x / Kp;
   const double* Mv = side.Mv + (int64_t) b * side.strideM;
   const int RS = (side.R + nsl - 1) / nsl;
-  const int r0 = slice * RS, r1 = min(r0 + RS, side.R);
+  const int r0s = slice * RS, r1s = min(r0s + RS, side.R);
   double* wsh = sh + 2 * nrg * Kp;
   double* ratio = wsh + Kp;
-  double m2[kSideUnr];
-#pragma unroll
-  for (int u = 0; u < kSideUnr; u++)
-  {
-    const int r = r0 + u * nrg + rg;
-    m2[u] = r < r1 ? Mv[(int64_t) r * Kp + k] : 0.0;
-  }
   // the stationary row, normalised the way the update kernel normalises its rows (S = W' / nrm)
   if (rg == 0)
   {
@@ -388,48 +391,82 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
     wsh[k] = w;
     if (slice == 0) wold[(int64_t) b * Kp + k] = w;
   }
-  // pass 1: HP adjacent threads per row of the slice (one up to rank 64, two at rank 128), KH values each
+  // pass 1: HP adjacent threads per row of the chunk (one up to rank 64, two at rank 128), KH values each
   constexpr int HP = Kp > 64 ? Kp / 64 : 1, KH = Kp / HP;
+  constexpr int NRG = 256 / Kp;
+  constexpr int cap = Kp >= 64 ? 256 / HP : (NRG * kSideUnr < 256 ? NRG * kSideUnr : 256);   // rows a block takes at a time (side_chunk_rows)
+  constexpr int UG = cap / (NRG * kSideUnr) > 1 ? cap / (NRG * kSideUnr) : 1;               // pass-2 rounds per chunk
   const int rl = (int) threadIdx.x / HP, hp = (int) threadIdx.x % HP;
-  const int r = r0 + rl; // RS * HP <= blockDim
-  double mrow[KH];
-  double vr = 0.0;
-  if (r < r1)
+  double num = 0.0, den = 0.0;
+  // a slice longer than one block's capacity (long buffers: more than kSideSlices x cap rows) goes chunk by chunk; up to
+  // there the loop runs once and the sums are taken in the order they always were
+  for (int r0 = r0s; r0 == r0s || r0 < r1s; r0 += cap)
   {
-    const double* m = Mv + (int64_t) r * Kp + hp * KH;
+    const int r1 = min(r0 + cap, r1s);
+    double m2[kSideUnr];
 #pragma unroll
-    for (int j = 0; j < KH; j += 2)
+    for (int u = 0; u < kSideUnr; u++)
     {
-      const d2 t = *reinterpret_cast<const d2*>(m + j);
-      mrow[j] = t[0];
-      mrow[j + 1] = t[1];
+      const int r = r0 + u * nrg + rg;
+      m2[u] = r < r1 ? Mv[(int64_t) r * Kp + k] : 0.0;
     }
-    vr = side.vcol[(int64_t) b * side.strideV + r];
-  }
-  __syncthreads();
-  {
-    double q0 = 0.0, q1 = 0.0;
+    const int r = r0 + rl;
+    double mrow[KH];
+    double vr = 0.0;
     if (r < r1)
     {
+      const double* m = Mv + (int64_t) r * Kp + hp * KH;
 #pragma unroll
       for (int j = 0; j < KH; j += 2)
       {
-        q0 = fma(mrow[j], wsh[hp * KH + j], q0);
-        q1 = fma(mrow[j + 1], wsh[hp * KH + j + 1], q1);
+        const d2 t = *reinterpret_cast<const d2*>(m + j);
+        mrow[j] = t[0];
+        mrow[j + 1] = t[1];
+      }
+      vr = side.vcol[(int64_t) b * side.strideV + r];
+    }
+    __syncthreads();                                   // the side row is in the LDS; the chunk before is done with `ratio`
+    {
+      double q0 = 0.0, q1 = 0.0;
+      if (r < r1)
+      {
+#pragma unroll
+        for (int j = 0; j < KH; j += 2)
+        {
+          q0 = fma(mrow[j], wsh[hp * KH + j], q0);
+          q1 = fma(mrow[j + 1], wsh[hp * KH + j + 1], q1);
+        }
+      }
+      double q = q0 + q1;
+      if (HP == 2) q += __shfl_xor(q, 1);
+      if (r < r1 && hp == 0) ratio[rl] = vr / fmax(q, kEpsilon);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSideUnr; u++)
+    {
+      const int rr = r0 + u * nrg + rg;
+      num = fma(rr < r1 ? ratio[rr - r0] : 0.0, m2[u], num);
+      den += m2[u];
+    }
+#pragma unroll 1
+    for (int g = 1; g < UG; g++)
+    {
+      if (r0 + g * kSideUnr * nrg >= r1) break;
+#pragma unroll
+      for (int u = 0; u < kSideUnr; u++)
+      {
+        const int rr = r0 + (g * kSideUnr + u) * nrg + rg;
+        m2[u] = rr < r1 ? Mv[(int64_t) rr * Kp + k] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < kSideUnr; u++)
+      {
+        const int rr = r0 + (g * kSideUnr + u) * nrg + rg;
+        num = fma(rr < r1 ? ratio[rr - r0] : 0.0, m2[u], num);
+        den += m2[u];
       }
     }
-    double q = q0 + q1;
-    if (HP == 2) q += __shfl_xor(q, 1);
-    if (r < r1 && hp == 0) ratio[rl] = vr / fmax(q, kEpsilon);
-  }
-  __syncthreads();
-  double num = 0.0, den = 0.0;
-#pragma unroll
-  for (int u = 0; u < kSideUnr; u++)
-  {
-    const int rr = r0 + u * nrg + rg;
-    num = fma(rr < r1 ? ratio[rr - r0] : 0.0, m2[u], num);
-    den += m2[u];
   }
   sh[rg * Kp + k] = num;
   sh[(nrg + rg) * Kp + k] = den;
@@ -448,7 +485,7 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
   }
   if (!fuse.ticket) return;
   __shared__ int isLast;
-  __shared__ double cshs[256], cshm[256], csmax[128];
+  __shared__ double cshs[1024], cshm[1024], csmax[128];
   __syncthreads();                                   // the slice's partial (and slice 0's wold) have been stored
   if (threadIdx.x == 0)
   {
@@ -476,7 +513,7 @@ __global__ __launch_bounds__(256) void side_slices_kernel(const double* Sbase, i
 __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t strideS, int C, int K, int Kp,
                                                    const double* statPart, int nParts, const double* sidePart,
                                                    int nsl, const double* wold, double* nrm, int b, double* shs, double* shm,
-                                                   double* smax)
+                                                   double* smax, double* shn, double* shd)
 {
   const int npg = blockDim.x / Kp;
   const int k = threadIdx.x % Kp, pg = threadIdx.x / Kp;
@@ -499,9 +536,13 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
   shs[threadIdx.x] = t;
   shm[threadIdx.x] = m;
   double n = 0.0, d = 0.0, wo = 0.0;
-  if (sidePart && pg == 0)
+  // (a 1024-thread block -- long factors, launch_wnorm_combine -- deals the slices over its part groups as well)
+  const bool dealSlices = blockDim.x > 256;
+  const int sper = dealSlices ? (nsl + npg - 1) / npg : nsl;
+  const int sl0 = dealSlices ? min(nsl, pg * sper) : 0, sl1 = dealSlices ? min(nsl, sl0 + sper) : nsl;
+  if (sidePart && (pg == 0 || dealSlices))
   {
-    for (int j0 = 0; j0 < nsl; j0 += 16) // sixteen slices' loads in flight at a time, summed in slice order
+    for (int j0 = sl0; j0 < sl1; j0 += 16) // sixteen slices' loads in flight at a time, summed in slice order
     {
       double pn[16], pd[16];
 #pragma unroll
@@ -513,9 +554,14 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
       }
 #pragma unroll
       for (int j = 0; j < 16; j++)
-        if (j0 + j < nsl) { n += pn[j]; d += pd[j]; }
+        if (j0 + j < sl1) { n += pn[j]; d += pd[j]; }
     }
-    wo = wold[(int64_t) b * Kp + k];
+    if (pg == 0) wo = wold[(int64_t) b * Kp + k];
+  }
+  if (dealSlices)
+  {
+    shn[threadIdx.x] = n;
+    shd[threadIdx.x] = d;
   }
   __syncthreads();
   if (pg == 0)
@@ -523,6 +569,8 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
     t = shs[k];
     m = shm[k];
     for (int g = 1; g < npg; g++) { t += shs[g * Kp + k]; m = fmax(m, shm[g * Kp + k]); }
+    if (dealSlices)
+      for (int g = 1; g < npg; g++) { n += shn[g * Kp + k]; d += shd[g * Kp + k]; }
     if (sidePart)
     {
       const double wnew = (k < K) ? (wo * n) / fmax(d, kEpsilon) : 0.0;
@@ -541,12 +589,15 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
   }
 }
 
-__global__ __launch_bounds__(256) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
-                                                            const double* statPart, int nParts, const double* sidePart,
-                                                            int nsl, const double* wold, double* nrm)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
+                                                                const double* statPart, int nParts, const double* sidePart,
+                                                                int nsl, const double* wold, double* nrm)
 {
-  __shared__ double shs[256], shm[256], smax[128];
-  wnorm_combine_body(Sbase, strideS, C, K, Kp, statPart, nParts, sidePart, nsl, wold, nrm, (int) blockIdx.x, shs, shm, smax);
+  __shared__ double shs[THREADS], shm[THREADS], smax[128];
+  __shared__ double shn[THREADS > 256 ? THREADS : 1], shd[THREADS > 256 ? THREADS : 1];
+  wnorm_combine_body(Sbase, strideS, C, K, Kp, statPart, nParts, sidePart, nsl, wold, nrm, (int) blockIdx.x, shs, shm, smax, shn,
+                     shd);
 }
 
 // W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
@@ -569,15 +620,23 @@ __global__ void fill_ones_kernel(double* p, int64_t n)
 
 // slices of the contraction per buffer: as few as keep a slice within one block's capacity (8 rows per row group in
 // pass 2, HP threads per row in pass 1), 16 at least
-static int side_slices_for(int R, int Kp)
+// rows a side-column block takes at a time: what pass 1 covers with one thread (two at rank 128) per row; pass 2 holds
+// kSideUnr rows per row group in registers and, from rank 64 on (4 / 2 row groups), goes through the chunk in several such
+// rounds (with two groups of 128 threads and one round, long buffers went 16 rows at a time: 37 us per iteration on config 3)
+static int side_chunk_rows(int Kp)
 {
   const int nrg = 256 / Kp;
-  const int cap = std::min(nrg * kSideUnr, 256 / (Kp > 64 ? Kp / 64 : 1));
-  return std::max(16, (R + cap - 1) / cap);
+  return Kp >= 64 ? 256 / (Kp > 64 ? Kp / 64 : 1) : std::min(nrg * kSideUnr, 256);
+}
+static int side_slices_for(int R, int Kp)
+{
+  const int cap = side_chunk_rows(Kp);
+  return std::min(kSideSlices, std::max(16, (R + cap - 1) / cap));
 }
 bool nmf_side_column_supported(int R, int C, int Kp)
 {
-  return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128) && side_slices_for(R, Kp) <= kSideSlices;
+  (void) R; // any length: slices beyond a block's capacity are taken in chunks
+  return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128);
 }
 int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
 
@@ -592,9 +651,8 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   {
     const int nrg = 256 / Kp;
     nsl = side_slices_for(side->R, Kp);
-    const int RS = (side->R + nsl - 1) / nsl;
     const dim3 grid((unsigned) nsl, (unsigned) B), block((unsigned) (nrg * Kp));
-    const size_t sh = (size_t) (2 * nrg * Kp + Kp + RS) * sizeof(double);
+    const size_t sh = (size_t) (2 * nrg * Kp + Kp + side_chunk_rows(Kp)) * sizeof(double);
     // FLUHIP_SIDE_FUSED=1: the norm combine inside this launch, by the last slice of a buffer to arrive.  Built in round 3
     // to save a launch per iteration and measured the other way round on the bench shard, same box, alternating
     // (profiles/r03/ab_side_fused.txt): 58 us between the two factor updates instead of 18, 217.9 k against 224.9 k
@@ -610,8 +668,14 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     if (fused) return;
   }
-  hipLaunchKernelGGL(wnorm_combine_kernel, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
-                     nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
+  // one block per buffer sums nStrips statistics parts and nsl side slices per component: 1024 threads where that is long
+  // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
+  if (nStrips > 128 || nsl > 64)
+    hipLaunchKernelGGL(wnorm_combine_kernel<1024>, dim3((unsigned) B), dim3(1024), 0, s, S, strideS, C, K, Kp, statPart,
+                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
+  else
+    hipLaunchKernelGGL(wnorm_combine_kernel<256>, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
+                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)
