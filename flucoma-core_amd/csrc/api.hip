@@ -1706,6 +1706,43 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   if (rc) return rc;
   rc = get_twiddle(ctx, c->fft, &ttab);
   if (rc) return rc;
+  // Batched form (kernels_stft2.hip resynth_seq_kernel): every component of a group of buffers in one launch, the
+  // overlap-add in registers -- no windowed frames in memory (the per-buffer path below writes and re-reads K T win doubles
+  // per buffer: 58 GB each way on the bench shard, 85 ms against 113 ms for 200 iterations).  FLUHIP_RESYNTH_BATCH=0 off.
+  static const int batchEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_BATCH"); return e ? std::atoi(e) : 1; }();
+  if (batchEnv != 0 && resynth_batch_supported((int) c->win, (int) c->fft, (int) c->hop))
+  {
+    // buffers per launch: the reciprocal V-hat of a group within ~1 GiB
+    const int64_t perBuf = c->T * c->F * (int64_t) sizeof(double);
+    const int64_t group = std::max<int64_t>(1, std::min<int64_t>(c->B, ((int64_t) 1 << 30) / perBuf));
+    DevBuf mult, wt, nrm;
+    HIPCHK(ctx, mult.alloc((size_t) (group * perBuf), false, s));
+    HIPCHK(ctx, wt.alloc((size_t) (group * c->K * c->F) * sizeof(double), false, s));
+    HIPCHK(ctx, nrm.alloc((size_t) c->hop * sizeof(double), false, s));
+    launch_resynth_normaliser(wtab, (int) c->win, (int) c->hop, nrm.as<double>(), s);
+    for (int64_t b0 = 0; b0 < c->B; b0 += group)
+    {
+      const int nb = (int) std::min(group, c->B - b0);
+      const double* Wb = c->Wf.as<double>() + b0 * c->Fp * c->Kp;
+      const double* Hb = c->H1.as<double>() + b0 * c->Tp * c->Kp;
+      launch_resynth_mult(Wb, c->Fp * c->Kp, Hb, c->Tp * c->Kp, wt.as<double>(), mult.as<double>(), (int) c->T, (int) c->F,
+                          (int) c->K, (int) c->Kp, nb, s);
+      ResynthBatchArgs ra;
+      ra.spec = c->spec.as<double>() + b0 * c->T * c->F * 2; ra.specStride = c->T * c->F * 2;
+      ra.mult = mult.as<double>(); ra.multStride = c->T * c->F;
+      ra.Wt = wt.as<double>(); ra.wtStride = c->K * c->F;
+      ra.H1 = Hb; ra.hStride = c->Tp * c->Kp;
+      ra.Kp = (int) c->Kp; ra.K = (int) c->K;
+      ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = (int) c->T; ra.F = (int) c->F; ra.B = nb;
+      ra.window = wtab; ra.twiddle = ttab; ra.nrmTab = nrm.as<double>();
+      ra.out32 = out_dev + b0 * c->K * c->n; ra.n = c->n; ra.outStride = c->n; ra.trim = c->win / 2;
+      ra.nTab = c->ragged ? c->nTab.as<int64_t>() + b0 : nullptr;
+      if (!launch_resynth_batch(ra, s)) return fail(ctx, "batched resynthesis refused a shape it had accepted");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(s)); // the workspaces go out of scope
+    return FLUHIP_OK;
+  }
   DevBuf vhat, frames;
   HIPCHK(ctx, vhat.alloc((size_t) c->T * c->F * sizeof(double), false, s));
   const int64_t compsPerLaunch = std::max<int64_t>(1, std::min<int64_t>(c->K, ((int64_t) 1 << 30) / (c->T * c->win * 8)));
@@ -2370,37 +2407,13 @@ int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, in
   if (rc) return rc;                                                             // :273-274
   rc = fluhip_corpus_writeback_host(&c, bases_out, acts_out);                    // :277-300
   if (rc) return rc;
-  if (resynth_out) // :302-334  estimate -> ratio mask -> ISTFT per component
+  if (resynth_out) // :302-334  estimate -> ratio mask -> ISTFT per component (the corpus form, one buffer)
   {
-    const double *wtab = nullptr, *ttab = nullptr;
-    rc = get_window(ctx, win, fft, c.windowType, &wtab);
-    if (rc) return rc;
-    rc = get_twiddle(ctx, fft, &ttab);
-    if (rc) return rc;
-    DevBuf vhat, frames, out32;
-    HIPCHK(ctx, vhat.alloc((size_t) c.T * c.F * sizeof(double), false, s));
-    const int64_t compsPerLaunch = std::max<int64_t>(1, std::min<int64_t>(K, ((int64_t) 1 << 30) / (c.T * win * 8)));
-    HIPCHK(ctx, frames.alloc((size_t) compsPerLaunch * c.T * win * sizeof(double), false, s));
+    DevBuf out32;
     HIPCHK(ctx, out32.alloc((size_t) K * n * sizeof(float), false, s));
-    // mask.init(outputMags): outputMags = V1 = (W*H)^T of NMF::process (NMF.hpp:182, NMFClient.hpp:305-306)
-    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, vhat.as<double>(), c.F, 0, (int) c.T, (int) c.F,
-                (int) c.Kp, 1, s);
-    ResynthArgs ra;
-    ra.spec = c.spec.as<double>(); ra.Wf = c.Wf.as<double>(); ra.H1 = c.H1.as<double>();
-    ra.Vhat = vhat.as<double>(); ra.ldV = c.F; ra.Kp = (int) c.Kp;
-    ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) c.T; ra.F = (int) c.F;
-    ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr; ra.n = n;
-    ra.trim = win / 2;
-    for (int64_t k = 0; k < K; k += compsPerLaunch) // all components of a launch share the frame grid
-    {
-      ra.k = (int) k;
-      ra.nComp = (int) std::min(compsPerLaunch, K - k);
-      ra.out32 = out32.as<float>() + k * n;
-      ra.bigScratch = big_fft_scratch(ctx, ra.win, ra.fft, ra.T);
-      if (stft_needs_scratch(ra.win, ra.fft) && !ra.bigScratch) return FLUHIP_ERROR;
-      launch_resynth(ra, s);
-    }
-    HIPCHK(ctx, hipGetLastError());
+    c.haveFactors = true;
+    rc = fluhip_corpus_resynth_dev(&c, out32.as<float>());
+    if (rc) return rc;
     HIPCHK(ctx, hipMemcpyAsync(resynth_out, out32.p, (size_t) K * n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));
   }

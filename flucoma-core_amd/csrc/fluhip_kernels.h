@@ -281,6 +281,40 @@ struct ResynthArgs
 // Wf == nullptr: no ratio mask (plain inverse STFT of `spec`)
 void launch_resynth(const ResynthArgs& a, hipStream_t s);
 
+// Batched resynthesis (kernels_stft2.hip, resynth_seq_kernel): every component of every buffer of a corpus in one launch.
+// A wavefront owns (buffer, component, a run of hop slots) and walks the frames that cover the run IN ORDER: masked
+// spectrum -> inverse real transform in registers (the forward passes of the STFT kernels on the conjugate) -> window ->
+// added to 2 win doubles of running overlap-add state held in registers; after each frame the oldest `hop` samples are
+// final (divided by the window-power normaliser) and leave as floats, the state shifts by hop.  No frames in memory,
+// no second pass, and a sample's frames are added in increasing frame order like the reference's sequential overlap-add.
+struct ResynthBatchArgs
+{
+  const double* spec;    // [B][T][F] interleaved complex
+  int64_t specStride;
+  const double* mult;    // [B][T][F]  1 / max(Vhat, eps)   (launch_resynth_mult)
+  int64_t multStride;
+  const double* Wt;      // [B][K][F]  W transposed (component-major rows)
+  int64_t wtStride;
+  const double* H1;      // [B][Tp][Kp]
+  int64_t hStride;
+  int Kp, K;
+  int win, fft, hop, T, F, B;
+  const double* window;  // [max(win, fft)], zero past win
+  const double* twiddle; // [fft/2] e^{-2 pi i m / fft}
+  const double* nrmTab;  // [hop] normaliser of a position covered by win / hop frames (resynth_normaliser_table)
+  float* out32;          // [B][K][outStride]
+  int64_t n, outStride;
+  int64_t trim;
+  const int64_t* nTab = nullptr; // ragged corpora: samples per buffer (T, n are then the longest buffer's)
+};
+bool resynth_batch_supported(int win, int fft, int hop);
+void launch_resynth_normaliser(const double* window, int win, int hop, double* tab /*[hop]*/, hipStream_t s);
+bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s);
+// mult[b][t][f] = 1 / max(sum_k W[f][k] H[t][k], eps) and Wt[b][k][f] = W[f][k] (alg/NMF.hpp:33-42 estimate's V-hat,
+// alg/RatioMask.hpp:39-41)
+void launch_resynth_mult(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt, double* mult,
+                         int T, int F, int K, int Kp, int B, hipStream_t s);
+
 // BufSTFT plumbing: spec [T][F] c128 <-> float magnitude / phase, bin-major [F][T]
 void launch_spec_to_magphase(const double* spec, int T, int F, float* mag, float* phase, hipStream_t s);
 void launch_polar_to_spec(const float* mag, const float* phase, int T, int F, double* spec, hipStream_t s);

@@ -234,6 +234,15 @@ struct FftCore
   template <bool SPEC>
   __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
   {
+    cx p3[PPL];
+    passes(pts, p3);
+    split<SPEC>(p3, specRow);
+  }
+
+  // the three passes of the complex transform: points m = lane + 64 bb + r N/R1 in, bins j + r NS3 out (j = lane, and for
+  // the two-butterfly forms jB = NS3 - lane as well: registers bb R3 + r)
+  __device__ __forceinline__ void passes(cx (&pts)[PPL], cx (&p3)[PPL])
+  {
   SCHED_FENCE();
   // ---- pass 1 (Ns = 1): butterfly j = lane + 64 bb, outputs at j R1 + r ------------------------------
 #pragma unroll
@@ -280,7 +289,6 @@ struct FftCore
   }
   SCHED_FENCE();
   // exchange 2 -> distribution of pass 3: outputs of butterfly j at (j - k) R2 + k + r NS2
-  cx p3[PPL];
   auto in3 = [&](int bb, int r) -> const double* {
     return (LOCAL && bb == 1 ? r3pB : r3pA) + (NS3 + NS3 / 16) * r;
   };
@@ -316,6 +324,11 @@ struct FftCore
     for (int r = 0; r < R3; r++) p3[bb * R3 + r] = v[r];
   }
   SCHED_FENCE();
+  }
+
+  template <bool SPEC>
+  __device__ __forceinline__ void split(cx (&p3)[PPL], d2* specRow)
+  {
   // ---- real-FFT split (util/FFT.hpp:99-106) + magnitude (alg/STFT.hpp:61-66) ------------------------------
   // bin k = j + r NS3 pairs with N - k = (NS3 - j) + (R3 - 1 - r) NS3  (j > 0), or r -> R3 - r for j = 0
   // the products of the per-lane factors with the compile-time constants are loop invariant, and hoisted they
@@ -621,7 +634,8 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
       constexpr int HP = FPB / 2;                     // 16-byte pieces (two frames) per bin
       double* outT = a.magT + (int64_t) b * a.magTStride;
       constexpr int ITEMS = (N + 1) * HP, NTHR = 64 * NW, TRIPS = (ITEMS + NTHR - 1) / NTHR; // (a.F == N + 1)
-#pragma unroll(PREFETCH ? TRIPS : 1)                  // (a compile-time count of stores is what lets the wait ahead of the next transform skip them)
+      constexpr int UNR = PREFETCH ? TRIPS : 1;       // (a compile-time count of stores is what lets the wait ahead of the next transform skip them)
+#pragma unroll UNR
       for (int k = 0; k < TRIPS; k++)
       {
         const int i = (int) threadIdx.x + k * NTHR;
@@ -939,6 +953,290 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
     return launch_block_t<8, 8, 8, 16, 1>(k, s);
   }
   return false;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Batched resynthesis (fluhip_kernels.h ResynthBatchArgs):
+//   algorithm::NMF::estimate      include/flucoma/algorithms/public/NMF.hpp:33-42       est[t][f] = H1[t][k] W1[k][f]
+//   algorithm::RatioMask::process include/flucoma/algorithms/public/RatioMask.hpp:33-57  Y = X min(est (1/max(Vhat,eps)), 1)
+//   algorithm::ISTFT::process     include/flucoma/algorithms/public/STFT.hpp:178-199     inverse real FFT, 1/fft, window,
+//                                                                                       overlap-add, / max(sum w^2, eps), trim
+//   driver                        include/flucoma/clients/nrt/NMFClient.hpp:302-334
+// Arithmetic as in resynth_frames_kernel / resynth_ola_kernel (kernels_istft.hip): Z[k] = conj(E[k] + i O[k]) from the
+// masked bins k and N - k, forward transform of N = fft/2 points, x[2m] = Re z / N, x[2m+1] = -Im z / N, times the window.
+// The input point k = lane + 64 r pairs with N - k, the point of lane 64 - l in register N/64 - 1 - r (lane 0 pairs
+// within itself: register N/64 - r, and bin 0 with the Nyquist bin): one ds_bpermute round, no LDS buffer.
+// The transform's outputs m = j + r NS3 (j = lane, and NS3 - lane for the two-butterfly forms) are 2 NS3 samples apart
+// from register to register: a hop of S 2 NS3 samples shifts the overlap-add state by S registers, all in the lane.
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int R1, int R2, int R3, int NW, int S>
+__global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a, int runSlots, int runsPerBuf, int kGroups)
+{
+  using Core = FftCore<R1, R2, R3>;
+  constexpr int N = Core::N, PPL = Core::PPL, BUFD = Core::BUFD, NS3 = Core::NS3, NB3 = Core::NB3;
+  static_assert(Core::NB1 == 1, "one pass-1 butterfly per lane: point k = lane + 64 r");
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  d2* tw2 = reinterpret_cast<d2*>(lds);
+  d2* wl = tw2 + Core::T2 + Core::T3;             // [N] window pairs
+  double* nrml = reinterpret_cast<double*>(wl + N); // [hop]
+  double* xall = nrml + a.hop;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xb = xall + wave * BUFD;
+  const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
+  Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
+  for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
+  for (int m = threadIdx.x; m < a.hop; m += 64 * NW) nrml[m] = a.nrmTab[m];
+  __syncthreads();
+  Core core;
+  core.init(xb, tw2, twg, lane);
+
+  // task: the workgroups of one (buffer, run) sit on one XCD (workgroup i runs on XCD i & 7), NW components each
+  const int64_t wg = blockIdx.x;
+  const int64_t slot8 = wg >> 3;
+  const int64_t pair = (slot8 / kGroups) * 8 + (wg & 7);
+  const int comp = (int) (slot8 % kGroups) * NW + wave;
+  const int b = (int) (pair / runsPerBuf), run = (int) (pair % runsPerBuf);
+  if (b >= a.B || comp >= a.K) return;            // (no workgroup barrier below)
+  const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
+  const int Tb = a.nTab ? (int) ((nSamples + a.hop) / a.hop) : a.T;
+  const int cover = a.win / a.hop;                // frames over a position (hop | win)
+  static_assert(S >= 1 && S <= R3 / 2, "registers the state shifts per frame: hop = S 2 NS3 samples");
+  const int sFirst = (int) (a.trim / a.hop);
+  const int sLast = (int) ((nSamples - 1 + a.trim) / a.hop);
+  const int sa = sFirst + run * runSlots;
+  const int sb = min(sa + runSlots, sLast + 1);
+  if (sa > sLast) return;
+
+  const double* spec = a.spec + (int64_t) b * a.specStride;
+  const double* mult = a.mult + (int64_t) b * a.multStride;
+  const double* wrow = a.Wt + (int64_t) b * a.wtStride + (int64_t) comp * a.F;
+  const double* hcol = a.H1 + (int64_t) b * a.hStride + comp;
+  float* out = a.out32 + ((int64_t) b * a.K + comp) * a.outStride;
+  const bool pairStores = (reinterpret_cast<uintptr_t>(out) & 7) == 0 && (a.trim & 1) == 0;
+  const double inv = 1.0 / (double) N;
+  const int srcAddr = ((64 - lane) & 63) * 4;
+  const bool l0 = lane == 0;
+  // output samples of this lane in a frame: 2 m, 2 m + 1 with m = jA + r NS3 (and jB + r NS3)
+  const int jA = lane, jB = NB3 == 2 ? (lane == 0 ? NS3 / 2 : NS3 - lane) : 0;
+
+  cx acc[PPL];
+#pragma unroll
+  for (int i = 0; i < PPL; i++) acc[i] = cx{0.0, 0.0};
+
+  for (int t = sa - (cover - 1); t < sb; t++)
+  {
+    if (t >= 0 && t < Tb)
+    {
+      // ---- masked bins of this lane: k = lane + 64 r ----------------------------------------------------------------
+      int ln = lane;
+      asm volatile("" : "+v"(ln));                  // (opaque: nothing of the frame-invariant loads is kept across frames)
+      const double hk = hcol[(int64_t) t * a.Kp];
+      const d2* srow = reinterpret_cast<const d2*>(spec + (int64_t) t * a.F * 2);
+      const double* mrow = mult + (int64_t) t * a.F;
+      cx Y[PPL];
+#pragma unroll
+      for (int r = 0; r < PPL; r++)
+      {
+        const int f = ln + 64 * r;
+        const d2 x = srow[f];
+        const double m = fmin((hk * wrow[f]) * mrow[f], 1.0);   // NMF.hpp:41, RatioMask.hpp:52-56 (exponent 1)
+        Y[r] = cx{x[0] * m, x[1] * m};
+      }
+      if (l0) Y[0].im = 0.0;                         // packed DC (util/FFT.hpp:155-160)
+      // the Nyquist bin, partner of bin 0 (lane 0)
+      double yn = 0.0;
+      {
+        const d2 x = srow[N];
+        const double m = fmin((hk * wrow[N]) * mrow[N], 1.0);
+        yn = x[0] * m;
+      }
+      cx pts[PPL];
+#pragma unroll
+      for (int ii = 0; ii < PPL; ii++)
+      {
+        // (order 0, PPL-1, 1, PPL-2, ...: point r needs the bins of registers r, PPL-1-r and -- lane 0 -- PPL-r, so the
+        //  masked bins die as the points are formed instead of all sixteen living beside all sixteen points)
+        const int r = (ii & 1) ? PPL - 1 - (ii >> 1) : (ii >> 1);
+        // partner N - k: lane 64 - l, register PPL - 1 - r; lane 0: its own register PPL - r (r > 0), the Nyquist bin (r = 0)
+        const cx z = Y[PPL - 1 - r];
+        const int lo0 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.re) & 0xffffffff));
+        const int hi0 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.re) >> 32));
+        const int lo1 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.im) & 0xffffffff));
+        const int hi1 = __builtin_amdgcn_ds_bpermute(srcAddr, (int) (__double_as_longlong(z.im) >> 32));
+        cx Xn = cx{__longlong_as_double(((long long) hi0 << 32) | (unsigned) lo0),
+                   __longlong_as_double(((long long) hi1 << 32) | (unsigned) lo1)};
+        const cx own = r == 0 ? cx{yn, 0.0} : Y[PPL - r];
+        if (l0) Xn = own;
+        const cx X = Y[r];
+        // E = (X + conj Xn) / 2, D = (X - conj Xn) / 2, O = D conj(w), Z = E + i O, point = conj Z
+        const double er = 0.5 * (X.re + Xn.re), ei = 0.5 * (X.im - Xn.im);
+        const double dr = 0.5 * (X.re - Xn.re), di = 0.5 * (X.im + Xn.im);
+        const d2 w = twg[ln + 64 * r];               // e^{-2 pi i k / fft}
+        const double orr = dr * w[0] + di * w[1], oi = di * w[0] - dr * w[1];
+        pts[r] = cx{er - oi, -(ei + orr)};
+      }
+      cx p3[PPL];
+      core.passes(pts, p3);
+      // ---- x[2m] = Re / N, x[2m+1] = -Im / N, times the window, onto the running state -----------------------------------
+#pragma unroll
+      for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+        for (int r = 0; r < R3; r++)
+        {
+          const int i = bb * R3 + r;
+          const int m = (bb == 0 ? jA : jB) + r * NS3;
+          const d2 w = wl[m];
+          acc[i].re += (p3[i].re * inv) * w[0];
+          acc[i].im += (-p3[i].im * inv) * w[1];
+        }
+    }
+    // ---- the oldest hop samples are final: slot t --------------------------------------------------------------------
+    if (t >= sa)
+    {
+      const int64_t p0 = (int64_t) t * a.hop;
+      const bool interior = t - (cover - 1) >= 0 && t <= Tb - 1;
+#pragma unroll
+      for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+        for (int r = 0; r < R3; r++)
+        {
+          if (r >= S) continue;
+          const int i = bb * R3 + r;
+          const int m = (bb == 0 ? jA : jB) + r * NS3;
+          const int q = 2 * m;
+          double n0, n1;
+          if (interior) { n0 = nrml[q]; n1 = nrml[q + 1]; }
+          else
+          {
+            // frames t' with t' hop <= p < t' hop + win, 0 <= t' < T, in increasing order (resynth_ola_kernel)
+            n0 = 0.0; n1 = 0.0;
+            for (int tt = max(0, t - (cover - 1)); tt <= min(t, Tb - 1); tt++)
+            {
+              const int off = (t - tt) * a.hop + q;
+              const d2 w = wl[off >> 1];
+              n0 += w[0] * w[0];
+              n1 += w[1] * w[1];
+            }
+          }
+          const double y0 = acc[i].re / fmax(n0, kEpsilon), y1 = acc[i].im / fmax(n1, kEpsilon);
+          const int64_t i0 = p0 + q - a.trim;
+          if (pairStores && i0 >= 0 && i0 + 1 < nSamples) *reinterpret_cast<float2*>(out + i0) = float2{(float) y0, (float) y1};
+          else
+          {
+            if (i0 >= 0 && i0 < nSamples) out[i0] = (float) y0;
+            if (i0 + 1 >= 0 && i0 + 1 < nSamples) out[i0 + 1] = (float) y1;
+          }
+        }
+    }
+    // ---- shift the state by one hop ---------------------------------------------------------------------------------
+#pragma unroll
+    for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+      for (int r = 0; r < R3; r++)
+      {
+        const int i = bb * R3 + r;
+        if constexpr (true) acc[i] = (r + S < R3) ? acc[bb * R3 + ((r + S < R3) ? r + S : 0)] : cx{0.0, 0.0};
+      }
+  }
+}
+
+__global__ void resynth_mult_kernel(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt,
+                                    double* mult, int T, int F, int K, int Kp)
+{
+  // block = (8 frames, buffer): thread f sums k ascending for the 8 frames; block row 0 also writes the transposed W
+  extern __shared__ double hs[]; // [8][Kp]
+  const int b = blockIdx.y, t0 = blockIdx.x * 8;
+  const double* W = Wf + (int64_t) b * strideW;
+  const double* H = H1 + (int64_t) b * strideH;
+  for (int i = threadIdx.x; i < 8 * Kp; i += blockDim.x)
+  {
+    const int tt = i / Kp, k = i % Kp;
+    hs[i] = t0 + tt < T ? H[(int64_t) (t0 + tt) * Kp + k] : 0.0;
+  }
+  __syncthreads();
+  for (int f = threadIdx.x; f < F; f += blockDim.x)
+  {
+    double s[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; tt++) s[tt] = 0.0;
+    const double* w = W + (int64_t) f * Kp;
+    for (int k = 0; k < K; k++)
+    {
+      const double wk = w[k];
+#pragma unroll
+      for (int tt = 0; tt < 8; tt++) s[tt] = __builtin_fma(wk, hs[tt * Kp + k], s[tt]);
+      if (blockIdx.x == 0) Wt[((int64_t) b * K + k) * F + f] = wk;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 8; tt++)
+      if (t0 + tt < T) mult[((int64_t) b * T + t0 + tt) * F + f] = 1.0 / fmax(s[tt], kEpsilon); // RatioMask.hpp:39-41
+  }
+}
+
+} // namespace
+
+__global__ void resynth_nrm_kernel(const double* window, int win, int hop, double* tab)
+{
+  // normaliser of a padded position covered by all win / hop frames: sum of window^2 over the covering frames in
+  // increasing frame order, i.e. decreasing offset (resynth_ola_kernel)
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= hop) return;
+  double acc = 0.0;
+  for (int j = win / hop - 1; j >= 0; j--)
+  {
+    const double w = window[q + j * hop];
+    acc += w * w;
+  }
+  tab[q] = acc;
+}
+void launch_resynth_normaliser(const double* window, int win, int hop, double* tab, hipStream_t s)
+{
+  hipLaunchKernelGGL(resynth_nrm_kernel, dim3((unsigned) ((hop + 255) / 256)), dim3(256), 0, s, window, win, hop, tab);
+}
+
+void launch_resynth_mult(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt, double* mult,
+                         int T, int F, int K, int Kp, int B, hipStream_t s)
+{
+  hipLaunchKernelGGL(resynth_mult_kernel, dim3((unsigned) ((T + 7) / 8), (unsigned) B), dim3(256), (size_t) 8 * Kp * sizeof(double), s,
+                     Wf, strideW, H1, strideH, Wt, mult, T, F, K, Kp);
+}
+
+bool resynth_batch_supported(int win, int fft, int hop)
+{
+  // fft 2048: outputs 256 samples apart from register to register; the hop a whole number of those and a divisor of the window
+  return fft == 2048 && win == fft && (hop == 256 || hop == 512 || hop == 1024);
+}
+
+bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s)
+{
+  if (!resynth_batch_supported(a.win, a.fft, a.hop) || a.F != a.fft / 2 + 1) return false;
+  constexpr int NW = 8;
+  using Core = FftCore<16, 8, 8>;
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + Core::N) * 16 + (size_t) a.hop * 8 + (size_t) NW * Core::BUFD * 8;
+  const int64_t sFirst = a.trim / a.hop, sLast = (a.n - 1 + a.trim) / a.hop;
+  const int64_t slots = sLast - sFirst + 1;
+  static const int runEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_RUN"); return e ? std::atoi(e) : 0; }();
+  const int runSlots = runEnv > 0 ? runEnv : 64;            // + win / hop - 1 frames of run-in: 5 % at hop = win / 4
+  const int runsPerBuf = (int) ((slots + runSlots - 1) / runSlots);
+  const int kGroups = (a.K + NW - 1) / NW;
+  const int64_t pairs = (int64_t) a.B * runsPerBuf;
+  const int64_t wgs = ((pairs + 7) / 8) * 8 * kGroups;
+  auto go = [&](auto kern) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+    hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3(64 * NW), shmem, s, a, runSlots, runsPerBuf, kGroups);
+  };
+  switch (a.hop / 256)
+  {
+  case 1: go(resynth_seq_kernel<16, 8, 8, NW, 1>); break;
+  case 2: go(resynth_seq_kernel<16, 8, 8, NW, 2>); break;
+  case 4: go(resynth_seq_kernel<16, 8, 8, NW, 4>); break;
+  default: return false;
+  }
+  return true;
 }
 
 } // namespace fluhip

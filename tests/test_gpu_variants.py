@@ -39,12 +39,22 @@ for b in (0, 8):
     worst = max(worst, rel_err(mag[b], rmag) * 1e3, rel_err(W1[b], rW), rel_err(H1[b], rH))
 print("plan", c.plan()["kernel"], "worst", worst)
 assert worst < 1e-9, worst
+# resynthesis at fft 2048 against the oracle (FLUHIP_RESYNTH_BATCH=0: the per-buffer frame + overlap-add kernels there;
+# FLUHIP_STFT_PREFETCH=0: the STFT's round-2 load order)
+x = oracle_np.synth_audio(30000, 77)
+bases, acts, res, rc = ctx.bufnmf_channel(x, 2048, 2048, 512, 3, 8, 42, resynth=True)
+spec, mag1 = o.stft_f32(x, 2048, 2048, 512)
+rW, rH, rV, _ = o.nmf_process(mag1, 3, 8, True, True, 42)
+for k in range(3):
+    ref = o.resynth_component(spec, rW, rH, rV, k, 2048, 2048, 512, 30000)
+    assert np.abs(res[k] - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-5, k
 '''
 
 
 @pytest.mark.parametrize("env", [{"FLUHIP_NMF_KERNEL": "-1"},
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
-                                 {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"}],
+                                 {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"},
+                                 {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_STFT_PREFETCH": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env):
     e = dict(os.environ)
