@@ -1207,20 +1207,25 @@ void launch_resynth_mult(const double* Wf, int64_t strideW, const double* H1, in
 
 bool resynth_batch_supported(int win, int fft, int hop)
 {
-  // fft 2048: outputs 256 samples apart from register to register; the hop a whole number of those and a divisor of the window
-  return fft == 2048 && win == fft && (hop == 256 || hop == 512 || hop == 1024);
+  // the transform's outputs lie 2 NS3 samples apart from register to register (256 at fft 2048, 128 at fft 1024): the hop
+  // 1, 2 or 4 of those (and so a divisor of the window)
+  if (win != fft) return false;
+  if (fft == 2048) return hop == 256 || hop == 512 || hop == 1024;
+  if (fft == 1024) return hop == 128 || hop == 256 || hop == 512;
+  return false;
 }
 
-bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s)
+template <int R1, int R2, int R3, int NW>
+static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
 {
-  if (!resynth_batch_supported(a.win, a.fft, a.hop) || a.F != a.fft / 2 + 1) return false;
-  constexpr int NW = 8;
-  using Core = FftCore<16, 8, 8>;
+  using Core = FftCore<R1, R2, R3>;
   const size_t shmem = ((size_t) Core::T2 + Core::T3 + Core::N) * 16 + (size_t) a.hop * 8 + (size_t) NW * Core::BUFD * 8;
   const int64_t sFirst = a.trim / a.hop, sLast = (a.n - 1 + a.trim) / a.hop;
   const int64_t slots = sLast - sFirst + 1;
   static const int runEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_RUN"); return e ? std::atoi(e) : 0; }();
-  const int runSlots = runEnv > 0 ? runEnv : 64;            // + win / hop - 1 frames of run-in: 5 % at hop = win / 4
+  // a run's first win / hop - 1 frames only fill the state: 2 % at 128 slots and hop = win / 4 (measured on the bench shard:
+  // 32 slots 26.1 ms, 64: 26.1, 128: 25.3, 256: 28.8 -- too few workgroups per buffer there)
+  const int runSlots = runEnv > 0 ? runEnv : 128;
   const int runsPerBuf = (int) ((slots + runSlots - 1) / runSlots);
   const int kGroups = (a.K + NW - 1) / NW;
   const int64_t pairs = (int64_t) a.B * runsPerBuf;
@@ -1229,14 +1234,21 @@ bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s)
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
     hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3(64 * NW), shmem, s, a, runSlots, runsPerBuf, kGroups);
   };
-  switch (a.hop / 256)
+  switch (a.hop / (2 * Core::NS3))
   {
-  case 1: go(resynth_seq_kernel<16, 8, 8, NW, 1>); break;
-  case 2: go(resynth_seq_kernel<16, 8, 8, NW, 2>); break;
-  case 4: go(resynth_seq_kernel<16, 8, 8, NW, 4>); break;
+  case 1: go(resynth_seq_kernel<R1, R2, R3, NW, 1>); break;
+  case 2: go(resynth_seq_kernel<R1, R2, R3, NW, 2>); break;
+  case 4: go(resynth_seq_kernel<R1, R2, R3, NW, 4>); break;
   default: return false;
   }
   return true;
+}
+
+bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s)
+{
+  if (!resynth_batch_supported(a.win, a.fft, a.hop) || a.F != a.fft / 2 + 1) return false;
+  if (a.fft == 2048) return launch_resynth_batch_t<16, 8, 8, 8>(a, s);
+  return launch_resynth_batch_t<8, 8, 8, 8>(a, s);
 }
 
 } // namespace fluhip

@@ -665,15 +665,15 @@ def test_corpus_resynthesis_matches_single_channel_path(ctx, onp):
     assert rel_err(out.sum(axis=1), audio) < 1e-4
 
 
-@pytest.mark.parametrize("hop", [256, 512, 1024])
+@pytest.mark.parametrize("fft,hop", [(2048, 256), (2048, 512), (2048, 1024), (1024, 128), (1024, 256), (1024, 512)])
 @pytest.mark.parametrize("B,n,K", [(3, 30001, 5), (2, 9000, 9), (1, 1500, 2)])
-def test_corpus_batched_resynthesis(ctx, onp, B, n, K, hop):
-    """fft 2048 at hops of 256 / 512 / 1024: the batched resynthesis (resynth_seq_kernel: every component of every buffer
+def test_corpus_batched_resynthesis(ctx, onp, B, n, K, fft, hop):
+    """fft 2048 at hops of 256 / 512 / 1024 and fft 1024 at 128 / 256 / 512: the batched resynthesis (resynth_seq_kernel: every component of every buffer
     in one launch, the overlap-add in registers) against the single-channel entry point's frame + overlap-add kernels,
     themselves checked against the oracle; odd lengths, ranks that do not fill a workgroup of eight components, a buffer
     shorter than the window"""
     import fluhip
-    win = fft = 2048
+    win = fft
     iters = 6
     audio = np.stack([onp.synth_audio(n, 5200 + b) for b in range(B)])
     c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
@@ -1005,7 +1005,8 @@ def test_corpus_c4_shape_properties(ctx, onp):
 @pytest.mark.parametrize("n,win,fft,hop,K", [(20000, 1024, 1024, 256, 3), (9000, 512, 1024, 128, 2),
                                              (44100, 2048, 2048, 512, 4), (5000, 64, 64, 16, 2),
                                              (30001, 2048, 2048, 256, 3), (30001, 2048, 2048, 1024, 9),   # the batched
-                                             (1500, 2048, 2048, 512, 2)])                                   # kernel's hops
+                                             (1500, 2048, 2048, 512, 2), (20001, 1024, 1024, 128, 4),     # kernel's hops
+                                             (20001, 1024, 1024, 512, 10)])
 def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
     x = onp.synth_audio(n, 4242)
     iters = 30
