@@ -994,11 +994,19 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
   Core core;
   core.init(xb, tw2, twg, lane);
 
-  // task: the workgroups of one (buffer, run) sit on one XCD (workgroup i runs on XCD i & 7), NW components each
+  // task: the workgroups of one (buffer, run) sit on one XCD (workgroup i runs on XCD i & 7), NW components each; at
+  // ranks below NW a workgroup takes NW / K (buffer, run) pairs instead
   const int64_t wg = blockIdx.x;
   const int64_t slot8 = wg >> 3;
-  const int64_t pair = (slot8 / kGroups) * 8 + (wg & 7);
-  const int comp = (int) (slot8 % kGroups) * NW + wave;
+  int64_t pair = (slot8 / kGroups) * 8 + (wg & 7);
+  int comp = (int) (slot8 % kGroups) * NW + wave;
+  if (a.K < NW)
+  {
+    const int ppw = NW / a.K;
+    if (wave >= ppw * a.K) return;
+    pair = pair * ppw + wave / a.K;
+    comp = wave % a.K;
+  }
   const int b = (int) (pair / runsPerBuf), run = (int) (pair % runsPerBuf);
   if (b >= a.B || comp >= a.K) return;            // (no workgroup barrier below)
   const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
@@ -1223,12 +1231,17 @@ static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
   const int64_t sFirst = a.trim / a.hop, sLast = (a.n - 1 + a.trim) / a.hop;
   const int64_t slots = sLast - sFirst + 1;
   static const int runEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_RUN"); return e ? std::atoi(e) : 0; }();
-  // a run's first win / hop - 1 frames only fill the state: 2 % at 128 slots and hop = win / 4 (measured on the bench shard:
-  // 32 slots 26.1 ms, 64: 26.1, 128: 25.3, 256: 28.8 -- too few workgroups per buffer there)
-  const int runSlots = runEnv > 0 ? runEnv : 128;
-  const int runsPerBuf = (int) ((slots + runSlots - 1) / runSlots);
+  // A run's first win / hop - 1 frames only fill the state (2 % at 128 slots and hop = win / 4; measured on the bench shard:
+  // 32 slots 26.1 ms, 64: 26.1, 128: 25.3, 256: 28.8 -- too few workgroups per buffer there).  Few buffers / components:
+  // shorter runs, down to 8 slots, until there are some 1024 workgroups (a single buffer's frames are otherwise walked by
+  // a handful of wavefronts one after the other).
   const int kGroups = (a.K + NW - 1) / NW;
-  const int64_t pairs = (int64_t) a.B * runsPerBuf;
+  const int ppw = a.K < NW ? NW / a.K : 1;
+  int runSlots = 128;
+  while (runSlots > 8 && (((slots + runSlots - 1) / runSlots) * a.B + ppw - 1) / ppw * kGroups < 1024) runSlots /= 2;
+  if (runEnv > 0) runSlots = runEnv;
+  const int runsPerBuf = (int) ((slots + runSlots - 1) / runSlots);
+  const int64_t pairs = ((int64_t) a.B * runsPerBuf + ppw - 1) / ppw;
   const int64_t wgs = ((pairs + 7) / 8) * 8 * kGroups;
   auto go = [&](auto kern) {
     (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
