@@ -280,6 +280,8 @@ struct ResynthArgs
 };
 // Wf == nullptr: no ratio mask (plain inverse STFT of `spec`)
 void launch_resynth(const ResynthArgs& a, hipStream_t s);
+// dst[c][r] = src[r][c], floats (rows x cols, row strides lds / ldd)
+void launch_transpose_f32(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int64_t cols, hipStream_t s);
 
 // Batched resynthesis (kernels_stft2.hip, resynth_seq_kernel): every component of every buffer of a corpus in one launch.
 // A wavefront owns (buffer, component, a run of hop slots) and walks the frames that cover the run IN ORDER: masked

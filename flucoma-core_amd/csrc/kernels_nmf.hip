@@ -686,6 +686,26 @@ void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double
   launch_fill_ones(nrm, (int64_t) B * Kp, s);
 }
 
+// dst[c][r] = src[r][c] for a rows x cols float matrix (row strides lds / ldd): 32 x 32 tiles through the LDS
+__global__ void transpose_f32_kernel(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int64_t cols)
+{
+  __shared__ float tile[32][33];
+  const int64_t c0 = (int64_t) blockIdx.x * 32;
+  const int r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < rows && c0 + tx < cols) tile[j][tx] = src[(int64_t) (r0 + j) * lds_ + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < cols && r0 + tx < rows) dst[(c0 + j) * ldd + r0 + tx] = tile[tx][j];
+}
+void launch_transpose_f32(const float* src, int64_t lds_, float* dst, int64_t ldd, int rows, int64_t cols, hipStream_t s)
+{
+  // (the long dimension on grid x)
+  hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned) ((cols + 31) / 32), (unsigned) ((rows + 31) / 32)), dim3(256), 0, s, src,
+                     lds_, dst, ldd, rows, cols);
+}
+
 void launch_fill_ones(double* p, int64_t n, hipStream_t s)
 {
   hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, s, p, n);

@@ -58,7 +58,7 @@ EXPORTS = [
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
     "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
-    "fluhip_corpus_resynth_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
+    "fluhip_corpus_resynth_host", "fluhip_corpus_resynth_interleaved_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_debug_plan_lists",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
     "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_pool_bufmfcc_f32",
@@ -145,6 +145,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_keep_spectrum.argtypes = [_vp, ctypes.c_int]
     L.fluhip_corpus_resynth_dev.argtypes = [_vp, _vp]
     L.fluhip_corpus_resynth_host.argtypes = [_vp, _fp]
+    L.fluhip_corpus_resynth_interleaved_host.argtypes = [_vp, _fp, _i64]
     L.fluhip_prof_enable.argtypes = [_vp, ctypes.c_int]
     L.fluhip_prof_reset.argtypes = [_vp]
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
@@ -499,6 +500,14 @@ class Corpus:
         """[count, K, n] f32: every component of every buffer resynthesised (NMFClient.hpp:302-334)"""
         out = np.empty((self.count, self.K, self.n), dtype=np.float32)
         self.ctx._check(self.ctx.lib.fluhip_corpus_resynth_host(self.h, _f(out)))
+        return out
+
+    def resynth_interleaved(self, frame_stride=None):
+        """fluhip_corpus_resynth_interleaved_host: [n][frame_stride] floats, component k of buffer b in column b K + k"""
+        chans = self.count * self.K
+        fs = chans if frame_stride is None else frame_stride
+        out = np.zeros((self.n, fs), dtype=np.float32)
+        self.ctx._check(self.ctx.lib.fluhip_corpus_resynth_interleaved_host(self.h, _f(out), fs))
         return out
 
     def plan(self):

@@ -292,6 +292,11 @@ int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts);
 int fluhip_corpus_keep_spectrum(fluhip_corpus* c, int on);
 int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev);
 int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out);
+/* The resynthesis written the way an interleaved host buffer holds it (frames x channels, like MemoryBufferAdaptor,
+ * clients/common/MemoryBufferAdaptor.hpp:96-100): out[t * frame_stride + b * K + k] = component k of buffer b at sample t,
+ * i.e. what resynth.samps(b * rank + k) <<= ... leaves there (clients/nrt/NMFClient.hpp:321-326), transposed on the device
+ * and streamed to the host through pinned staging blocks.  frame_stride >= count x K floats; equal-length corpora only. */
+int fluhip_corpus_resynth_interleaved_host(fluhip_corpus* c, float* out, int64_t frame_stride);
 /* raw f64 results for parity tests: mag count x T x F, W1 count x K x F, H1 count x T x K */
 int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1);
 /* How the factor updates of this corpus are scheduled on the device (introspection for tests, benchmarks and

@@ -142,6 +142,14 @@ def test_client_resynthesis(driver, oracle, onp, tmp_path, ctx):
     for c in range(2):
         total = res[c * K:(c + 1) * K].sum(axis=0)
         assert np.abs(total[win:-win] - audio[win:-win, c]).max() < 0.02
+        # every component against the oracle (the two channels run as one corpus; the result reaches the interleaved host
+        # buffer transposed on the device, fluhip_corpus_resynth_interleaved_host)
+        x = np.ascontiguousarray(audio[:, c].astype(np.float32))
+        spec, mag = oracle.stft_f32(x, win, fft, hop)
+        W1, H1, V1, _ = oracle.nmf_process(mag, K, iters, True, True, 42)
+        for k in range(K):
+            ref = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, frames)
+            assert np.abs(res[c * K + k] - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-5, (c, k)
 
 
 @pytest.mark.gpu

@@ -688,6 +688,25 @@ def test_corpus_batched_resynthesis(ctx, onp, B, n, K, fft, hop):
     assert rel_err(out.sum(axis=1), audio) < 1e-4
 
 
+def test_corpus_resynthesis_interleaved_and_pinned_copy(ctx, onp):
+    """fluhip_corpus_resynth_interleaved_host: the resynthesis as an interleaved host buffer holds it (frames x channels),
+    transposed on the device -- the same floats as the channel-major form, with and without padding columns; a corpus large
+    enough (80 MB) that both results leave through the pinned staging blocks"""
+    import fluhip
+    B, n, win, fft, hop, K = 5, 500001, 1024, 1024, 512, 8
+    audio = np.stack([onp.synth_audio(n, 5300 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.keep_spectrum(True)
+    c.set_audio(audio); c.stft(); c.nmf(3, seed=42)
+    ref = c.resynth()                                        # [B][K][n]
+    inter = c.resynth_interleaved()                          # [n][B K]
+    wide = c.resynth_interleaved(B * K + 3)                  # [n][B K + 3], the last three columns untouched
+    c.close()
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    assert np.array_equal(inter, ref.reshape(B * K, n).T)
+    assert np.array_equal(wide[:, :B * K], inter) and (wide[:, B * K:] == 0).all()
+
+
 def test_ragged_corpus_batched_resynthesis(ctx, onp):
     """the same on buffers of different lengths (per-buffer frame counts and sample counts inside one launch)"""
     import fluhip
