@@ -7,6 +7,8 @@
 // 35.9 - 49.6 TFLOP/s peak for that instruction against 73.5 for the 4x4x4 form, profiles/r01/mfma_f64_probe.txt.)
 #include "fluhip_kernels.h"
 
+#include <cstdlib>
+
 #include <algorithm>
 
 namespace fluhip {
@@ -631,6 +633,9 @@ static int side_chunk_rows(int Kp)
 static int side_slices_for(int R, int Kp)
 {
   const int cap = side_chunk_rows(Kp);
+  // FLUHIP_SIDE_SLICES=n (tests): at most n slices, so that ordinary shapes take several chunks per slice
+  static const int cap2 = [] { const char* e = std::getenv("FLUHIP_SIDE_SLICES"); return e ? std::max(1, std::atoi(e)) : 0; }();
+  if (cap2 > 0) return std::min(std::min(kSideSlices, cap2), std::max(1, (R + cap - 1) / cap));
   return std::min(kSideSlices, std::max(16, (R + cap - 1) / cap));
 }
 bool nmf_side_column_supported(int R, int C, int Kp)

@@ -39,6 +39,19 @@ for b in (0, 8):
     worst = max(worst, rel_err(mag[b], rmag) * 1e3, rel_err(W1[b], rW), rel_err(H1[b], rH))
 print("plan", c.plan()["kernel"], "worst", worst)
 assert worst < 1e-9, worst
+# the batched regime with the Nyquist side column (FLUHIP_SIDE_SLICES=2: its slices then go through the block in chunks,
+# as on buffers of more than 256 x 64 frames), ranks 32 and 128
+for K in (32, 128):
+    audio = np.stack([oracle_np.synth_audio(70000, 1100 + (b % 3)) for b in range(128)])
+    c = fluhip.Corpus(ctx, 128, 70000, 2048, 2048, 512, K)
+    c.set_audio(audio); c.stft(); c.nmf(4, seed=42)
+    mag, W1, H1 = c.read_f64()
+    assert c.plan()["side_column"] == 1 or os.environ.get("FLUHIP_NO_SIDE") or os.environ.get("FLUHIP_NMF_KERNEL") or os.environ.get("FLUHIP_NO_LAZY"), c.plan()
+    for b in (1, 127):
+        _, rmag = o.stft_f32(audio[b], 2048, 2048, 512)
+        rW, rH, _, _ = o.nmf_process(rmag, K, 4, True, True, 42)
+        assert max(rel_err(W1[b], rW), rel_err(H1[b], rH)) < 1e-9, (K, b)
+    c.close()
 # resynthesis at fft 2048 against the oracle (FLUHIP_RESYNTH_BATCH=0: the per-buffer frame + overlap-add kernels there;
 # FLUHIP_STFT_PREFETCH=0: the STFT's round-2 load order)
 x = oracle_np.synth_audio(30000, 77)
@@ -54,7 +67,7 @@ for k in range(3):
 @pytest.mark.parametrize("env", [{"FLUHIP_NMF_KERNEL": "-1"},
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"},
-                                 {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_STFT_PREFETCH": "0"}],
+                                 {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_STFT_PREFETCH": "0"}, {"FLUHIP_SIDE_SLICES": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env):
     e = dict(os.environ)
