@@ -1910,8 +1910,9 @@ int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts)
   if (acts) HIPCHK(ctx, da.alloc(na, false, ctx->stream));
   int rc = fluhip_corpus_writeback_dev(c, bases ? db.as<float>() : nullptr, acts ? da.as<float>() : nullptr);
   if (rc) return rc;
-  if (bases) HIPCHK(ctx, hipMemcpyAsync(bases, db.p, nb, hipMemcpyDeviceToHost, ctx->stream));
-  if (acts) HIPCHK(ctx, hipMemcpyAsync(acts, da.p, na, hipMemcpyDeviceToHost, ctx->stream));
+  // (large corpora: through the pinned staging blocks, copy_to_host)
+  if (bases && (rc = copy_to_host(ctx, bases, nb, db.p, nb, nb, 1, ctx->stream))) return rc;
+  if (acts && (rc = copy_to_host(ctx, acts, na, da.p, na, na, 1, ctx->stream))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLUHIP_OK;
 }
