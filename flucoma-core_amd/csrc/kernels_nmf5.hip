@@ -1181,7 +1181,8 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         //  whole-strip regime -- components 24, 26, 28, 30 of the first four columns of every strip, found by the round-3
         //  variants test on a 128-buffer corpus; single buffers pass -- and since nothing ever selected it there it was
         //  switched off rather than debugged.)
-        const int eff = (mode >= 0 && !(mode == 2 && M < 16)) ? mode : (M >= 16 ? 2 : 1);
+        static const int anyM = [] { const char* e = std::getenv("FLUHIP_K5_MODE_ANY"); return e ? std::atoi(e) : 0; }(); // (debugging)
+        const int eff = (mode >= 0 && !(mode == 2 && M < 16 && !anyM)) ? mode : (M >= 16 ? 2 : 1);
         if constexpr (M == 32)
         {
           // rank 65..128: the in-place overlapped form only fits without the M column-sum accumulators;
