@@ -707,6 +707,42 @@ def test_corpus_resynthesis_interleaved_and_pinned_copy(ctx, onp):
     assert np.array_equal(wide[:, :B * K], inter) and (wide[:, B * K:] == 0).all()
 
 
+@pytest.mark.parametrize("n", [1, 100, 511, 512, 513, 2047, 2049])
+def test_batched_resynthesis_of_tiny_buffers(ctx, oracle, onp, n):
+    """buffers shorter than a hop / a window (one to five frames, all of them edge frames whose normaliser is the direct
+    sum): the batched kernel against the oracle"""
+    win = fft = 2048
+    hop, K, iters = 512, 2, 3
+    x = onp.synth_audio(max(n, 64), 31 + n)[:n]
+    bases, acts, res, rc = ctx.bufnmf_channel(x, win, fft, hop, K, iters, 42, resynth=True)
+    assert rc == 0 and res.shape == (K, n)
+    spec, mag = oracle.stft_f32(x, win, fft, hop)
+    W1, H1, V1, _ = oracle.nmf_process(mag, K, iters, True, True, 42)
+    for k in range(K):
+        ref = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, n)
+        assert np.abs(res[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9, (k, np.abs(res[k] - ref).max())
+
+
+def test_resynthesis_at_bench_shape_adds_up(ctx, onp):
+    """size-independent property at the bench workload's buffer shape (16 x 10 s, rank 32): exponent-1 ratio masks are a
+    partition of unity, so the 32 components of a buffer add back up to its samples; and the interleaved form holds the
+    same floats"""
+    import fluhip
+    B, n, K = 16, 441000, 32
+    base = [onp.synth_audio(n, 1000 + b) for b in range(4)]
+    audio = np.stack([base[b % 4] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, K)
+    c.keep_spectrum(True)
+    c.set_audio(audio); c.stft(); c.nmf(5, seed=42)
+    out = c.resynth()
+    inter = c.resynth_interleaved()
+    c.close()
+    assert np.isfinite(out).all()
+    assert np.abs(out.sum(axis=1) - audio).max() < 2e-4
+    assert np.array_equal(inter, out.reshape(B * K, n).T)
+    assert np.array_equal(out[0], out[4]) and not np.array_equal(out[0], out[1])      # equal buffers, equal results
+
+
 def test_ragged_corpus_batched_resynthesis(ctx, onp):
     """the same on buffers of different lengths (per-buffer frame counts and sample counts inside one launch)"""
     import fluhip
