@@ -134,6 +134,16 @@ public:
   Result process(FluidContext& c)
   {
     using S = Result::Status;
+    struct WholeCall // FLUHIP_CLIENT_TIMING=1: the whole of process(), destructors of its locals included
+    {
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      ~WholeCall()
+      {
+        if (std::getenv("FLUHIP_CLIENT_TIMING"))
+          std::fprintf(stderr, "  client %-22s %8.3f ms\n", "process(), whole",
+                       std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      }
+    } wholeCall;
     const NMFParams& P = *mParams;
     index            nFrames = P.numFrames;
     index            nChannels = P.numChans;
@@ -217,13 +227,9 @@ public:
       mDevice = c.device();
     }
 
-    std::vector<float> mono(static_cast<size_t>(nFrames));
-    std::vector<float> seedW, seedH, outW, outH, outR;
-    if (seedFilters) seedW.resize(static_cast<size_t>(rank * nBins));
-    if (seedEnvelopes) seedH.resize(static_cast<size_t>(rank * nWindows));
-    if (hasFilters && !fixFilters) outW.resize(static_cast<size_t>(rank * nBins));
-    if (hasEnvelopes && !fixEnvelopes) outH.resize(static_cast<size_t>(rank * nWindows));
-    if (shouldResynth && hasResynth) outR.resize(static_cast<size_t>(rank * nFrames));
+    // scratch of the channel-by-channel loop (sized where that loop starts: the batched path does not use it, and
+    // rank x nFrames zero-filled floats were 9 ms of an 8-channel x 10 s job)
+    std::vector<float> mono, seedW, seedH, outW, outH, outR;
 
     const double progressTotal =
         static_cast<double>((needsAnalysis ? P.iterations : 0) + ((shouldResynth && hasResynth) ? 3 * rank : 0)); // :229-230
@@ -354,13 +360,14 @@ public:
       const size_t nc = static_cast<size_t>(nChannels);
       // FLUHIP_CLIENT_TIMING=1: wall time of the phases of the batched path on stderr (measurement aid)
       const bool timing = std::getenv("FLUHIP_CLIENT_TIMING") != nullptr;
-      auto       tPrev = std::chrono::steady_clock::now();
+      auto       tPrev = wholeCall.t0;
       auto       lap = [&](const char* what) {
         if (!timing) return;
         const auto now = std::chrono::steady_clock::now();
         std::fprintf(stderr, "  client %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tPrev).count());
         tPrev = now;
       };
+      lap("checks + resizes");
       std::vector<float> audioAll(nc * static_cast<size_t>(nFrames));
       std::vector<float> seedWAll, seedHAll;
       if (seedFilters) seedWAll.resize(nc * static_cast<size_t>(rank * nBins));
@@ -496,6 +503,12 @@ public:
       // the corpus could not be created (device memory): the channel-by-channel loop below needs one channel at a time
     }
 
+    mono.resize(static_cast<size_t>(nFrames));
+    if (seedFilters) seedW.resize(static_cast<size_t>(rank * nBins));
+    if (seedEnvelopes) seedH.resize(static_cast<size_t>(rank * nWindows));
+    if (hasFilters && !fixFilters) outW.resize(static_cast<size_t>(rank * nBins));
+    if (hasEnvelopes && !fixEnvelopes) outH.resize(static_cast<size_t>(rank * nWindows));
+    if (shouldResynth && hasResynth) outR.resize(static_cast<size_t>(rank * nFrames));
     for (index i = 0; i < nChannels; ++i)
     {
       if (c.task() && !c.task()->iterationUpdate(static_cast<double>(i), static_cast<double>(nChannels)))

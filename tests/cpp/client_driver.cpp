@@ -453,6 +453,7 @@ int main(int argc, char** argv)
         const auto t0 = std::chrono::steady_clock::now();
         r = adaptor.process();
         ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (std::getenv("CLIENT_REPEAT_PRINT")) std::fprintf(stderr, "repeat %d: %.3f ms\n", rep, ms);
       }
       std::printf("elapsed_ms|1|%.3f\n", ms);
     }
