@@ -89,17 +89,17 @@ static int fail(fluhip_ctx* ctx, const std::string& msg, int status)
   } while (0)
 
 // Large results to pageable host memory: a plain hipMemcpy stages them through the runtime's small pinned buffers (measured
-// 4.7 - 5.3 GB/s: 85 - 95 ms for the 451 MB of an 8-channel x 32-component resynthesis).  Here: two pinned blocks of 16 MiB,
+// 4.7 - 5.3 GB/s: 85 - 95 ms for the 451 MB of an 8-channel x 32-component resynthesis).  Here: two pinned blocks of 8 MiB,
 // the DMA of block i + 1 running while the host copies block i to its place.  `rows` rows of `width` bytes, source rows
 // spitch and destination rows dpitch bytes apart (a contiguous copy: rows = 1).  Work queued on `s` before the call is
 // complete when it returns.  Small copies take the plain path.
 static int copy_to_host(fluhip_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
                         hipStream_t s)
 {
-  constexpr size_t kStage = (size_t) 16 << 20;
+  constexpr size_t kStage = (size_t) 8 << 20;
   const size_t total = width * rows;
   static const int off = [] { const char* e = std::getenv("FLUHIP_PINNED_D2H"); return e && std::atoi(e) == 0 ? 1 : 0; }();
-  if (off || total < 4 * kStage || width > kStage)
+  if (off || total < 2 * kStage || width > kStage)
   {
     HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, s));
     HIPCHK(ctx, hipStreamSynchronize(s));

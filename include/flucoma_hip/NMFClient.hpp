@@ -355,7 +355,7 @@ public:
     // iteration of every channel, so it counts nChannels of the progressTotal * nChannels steps (the arithmetic of
     // :261-267 summed over the channel loop).  FLUHIP_CLIENT_SEQUENTIAL=1 keeps the channel-by-channel loop (A/B, tests);
     // a corpus that does not fit the device falls back to it as well.
-    if (nChannels > 1 && !sequentialForced())
+    if (!sequentialForced()) // (a mono job is a corpus of one: the same path, and its resynthesis reaches an interleaved buffer in place)
     {
       const size_t nc = static_cast<size_t>(nChannels);
       // FLUHIP_CLIENT_TIMING=1: wall time of the phases of the batched path on stderr (measurement aid)
