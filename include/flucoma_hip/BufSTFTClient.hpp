@@ -142,12 +142,9 @@ private:
     if (hops != numHops) return {S::kError, "frame count of the device path differs from the client's: ", hops, " vs ", numHops};
 
     // :168-178  buffer channel = bin, buffer frame = hop (mags.allFrames().transpose() <<= tmpMags)
-    auto scatter = [&](BufferAdaptor::Access& dst, const std::vector<float>& src) {
-      for (index bin = 0; bin < numBins; ++bin)
-        dst.samps(bin) <<= VectorView<const float>(src.data() + bin * numHops, numHops);
-    };
-    if (haveMag) scatter(mags, magOut);
-    if (havePhase) scatter(phases, phaseOut);
+    // (block by block of frames: 1025 strided passes over an interleaved buffer otherwise)
+    if (haveMag) scatterChannels(mags, 0, numBins, magOut.data(), numHops);
+    if (havePhase) scatterChannels(phases, 0, numBins, phaseOut.data(), numHops);
     return {};
   }
 
@@ -181,11 +178,8 @@ private:
 
     const index        numBins = mags.numChans();
     std::vector<float> magIn((size_t) (numBins * numFrames)), phaseIn((size_t) (numBins * numFrames));
-    for (index bin = 0; bin < numBins; ++bin)
-    {
-      VectorView<float>(magIn.data() + bin * numFrames, numFrames) <<= mags.samps(bin);
-      VectorView<float>(phaseIn.data() + bin * numFrames, numFrames) <<= phases.samps(bin);
-    }
+    gatherChannels(mags, 0, numBins, magIn.data(), numFrames);
+    gatherChannels(phases, 0, numBins, phaseIn.data(), numFrames);
     int64_t nOut = 0;
     int     rc = fluhip_bufstft_inverse_f32(mDevice.get(), magIn.data(), phaseIn.data(), numFrames, winSize, fftSize, hopSize,
                                             (int) P.padding, nullptr, &nOut);

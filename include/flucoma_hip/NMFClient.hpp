@@ -83,36 +83,6 @@ struct NMFParams
   }
 };
 
-// Channel-major floats [nch][n] into the channels [ch0, ch0 + nch) of a buffer (the `samps(c) <<= row` loops of
-// nrt/NMFClient.hpp:281-282, 295-298, 321-326), block by block of frames: an interleaved destination is then written a few
-// cache lines at a time instead of in nch strided passes over the whole buffer (8 channels x 32 components x 441 000 samples:
-// 576 ms of strided passes).  Same values in the same places.
-inline void scatterChannels(BufferAdaptor::Access& dst, index ch0, index nch, const float* src, index n)
-{
-  constexpr index kBlock = 256;
-  for (index t0 = 0; t0 < n; t0 += kBlock)
-  {
-    const index len = std::min(kBlock, n - t0);
-    for (index j = 0; j < nch; ++j) dst.samps(t0, len, ch0 + j) <<= VectorView<const float>(src + j * n + t0, len);
-  }
-}
-// base pointer and frame stride of a buffer whose channels are interleaved in one array (frame-major, like
-// MemoryBufferAdaptor, clients/common/MemoryBufferAdaptor.hpp:96-100); nullptr for any other layout
-inline float* interleavedBase(BufferAdaptor::Access& b, index& frameStride)
-{
-  const index nch = b.numChans();
-  if (nch < 1 || b.numFrames() < 1) return nullptr;
-  auto v0 = b.samps(0);
-  if (v0.stride < nch) return nullptr;
-  for (index c = 1; c < nch; c = (c == nch - 1 ? nch : nch - 1)) // the second and the last channel
-  {
-    auto v = b.samps(c);
-    if (v.data() != v0.data() + c || v.stride != v0.stride) return nullptr;
-  }
-  frameStride = v0.stride;
-  return v0.data();
-}
-
 class NMFClient
 {
 public:
