@@ -9,6 +9,7 @@
 // class.  Element type is float, a buffer is frames x channels, views may be strided.
 #pragma once
 #include <algorithm>
+#include <cstring>
 
 #include "Types.hpp"
 
@@ -156,6 +157,20 @@ inline float* interleavedBase(BufferAdaptor::Access& b, index& frameStride)
   return v0.data();
 }
 
+inline const float* interleavedBase(const BufferAdaptor::ReadAccess& b, index& frameStride)
+{
+  const index nch = b.numChans();
+  if (nch < 1 || b.numFrames() < 1) return nullptr;
+  auto v0 = b.samps(0);
+  if (v0.stride < nch) return nullptr;
+  for (index c = 1; c < nch; c = (c == nch - 1 ? nch : nch - 1))
+  {
+    auto v = b.samps(c);
+    if (v.data() != v0.data() + c || v.stride != v0.stride) return nullptr;
+  }
+  frameStride = v0.stride;
+  return v0.data();
+}
 // the other direction: the channels [ch0, ch0 + nch) of a buffer into channel-major floats [nch][n], block by block of frames
 inline void gatherChannels(const BufferAdaptor::ReadAccess& src, index ch0, index nch, float* dst, index n)
 {
@@ -174,8 +189,18 @@ public:
       : mData(static_cast<size_t>(frames * chans), 0.f), mFrames(frames), mChans(chans), mSampleRate(sampleRate)
   {}
   // deep copy of any adaptor: the thread-isolation step of cc/FluidNRTClientWrapper.hpp:1045-1046
-  explicit MemoryBufferAdaptor(const std::shared_ptr<BufferAdaptor>& other) { copyFrom(other.get()); mOrigin = other; }
-  explicit MemoryBufferAdaptor(const std::shared_ptr<const BufferAdaptor>& other) { copyFrom(other.get()); }
+  explicit MemoryBufferAdaptor(const std::shared_ptr<BufferAdaptor>& other, bool contents = true) { rebind(other, contents); }
+  explicit MemoryBufferAdaptor(const std::shared_ptr<const BufferAdaptor>& other) { copyFrom(other.get(), true); }
+
+  // the copy taken again from `other` into the storage this object already has (the job layer keeps the copies of one job
+  // for the next: a fresh 451 MB resynthesis buffer per job is ~100 ms of page faults).  contents == false: shape, sample
+  // rate and flags only -- for a buffer the client only ever writes (it resizes it and fills every sample)
+  void rebind(const std::shared_ptr<BufferAdaptor>& other, bool contents = true)
+  {
+    copyFrom(other.get(), contents);
+    mOrigin = other;
+  }
+  const std::shared_ptr<BufferAdaptor>& origin() const { return mOrigin; }
 
   // cc/MemoryBufferAdaptor.hpp:51-67
   void copyToOrigin(Result& r)
@@ -186,11 +211,21 @@ public:
     if (numChans() != dst.numChans() || numFrames() != dst.numFrames())
       r = dst.resize(numFrames(), numChans(), mSampleRate);
     if (r.ok() && dst.valid())
-      for (index c = 0; c < numChans(); ++c)
+    {
+      index  stride = 0;
+      float* base = interleavedBase(dst, stride);
+      if (base && stride == numChans())
+        std::memcpy(base, mData.data(), sizeof(float) * static_cast<size_t>(numFrames() * numChans()));
+      else
       {
-        auto d = dst.samps(c);
-        VectorView<float>(d.ptr, numFrames(), d.stride) <<= VectorView<const float>(samps(c));
+        constexpr index kBlock = 256; // (as in copyFrom: block by block of frames)
+        for (index t0 = 0; t0 < numFrames(); t0 += kBlock)
+        {
+          const index len = std::min(kBlock, numFrames() - t0);
+          for (index c = 0; c < numChans(); ++c) dst.samps(t0, len, c) <<= VectorView<const float>(samps(t0, len, c));
+        }
       }
+    }
   }
 
   std::string asString() const override { return ""; }
@@ -198,7 +233,7 @@ public:
   const float* raw() const { return mData.data(); }
 
 private:
-  void copyFrom(const BufferAdaptor* other)
+  void copyFrom(const BufferAdaptor* other, bool contents)
   {
     BufferAdaptor::ReadAccess src(other);
     mExists = src.exists();
@@ -209,8 +244,23 @@ private:
     {
       mFrames = src.numFrames();
       mChans = src.numChans();
-      mData.assign(static_cast<size_t>(mFrames * mChans), 0.f);
-      for (index c = 0; c < mChans; ++c) samps(c) <<= src.samps(0, mFrames, c);
+      // block by block of frames (cc/MemoryBufferAdaptor.hpp:125-131 copies channel by channel: on two interleaved buffers
+      // that is numChans strided passes over both)
+      index        stride = 0;
+      const float* base = contents ? interleavedBase(src, stride) : nullptr;
+      if (!contents) mData.resize(static_cast<size_t>(mFrames * mChans));
+      else if (base && stride == mChans) // the same layout as this one: one pass, allocation and copy together
+        mData.assign(base, base + mFrames * mChans);
+      else
+      {
+        mData.resize(static_cast<size_t>(mFrames * mChans));
+        constexpr index kBlock = 256;
+        for (index t0 = 0; t0 < mFrames; t0 += kBlock)
+        {
+          const index len = std::min(kBlock, mFrames - t0);
+          for (index c = 0; c < mChans; ++c) samps(t0, len, c) <<= src.samps(t0, len, c);
+        }
+      }
     }
   }
 

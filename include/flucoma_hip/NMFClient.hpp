@@ -56,8 +56,14 @@ struct NMFParams
   template <class In, class Out>
   void forEachBuffer(In&& in, Out&& out)
   {
+    forEachBuffer(in, out, out);
+  }
+  // (third visitor: buffers process() never reads -- it resizes the resynthesis buffer and fills every sample)
+  template <class In, class Out, class OutOnly>
+  void forEachBuffer(In&& in, Out&& out, OutOnly&& outOnly)
+  {
     in(source);
-    out(resynth);
+    outOnly(resynth);
     out(bases);
     out(activations);
   }

@@ -24,6 +24,25 @@ namespace fluhip {
 
 enum ProcessState { kNoProcess, kProcessing, kDone, kDoneStillProcessing }; // cc/FluidBaseClient.hpp:32
 
+namespace impl {
+// parameter sets with write-only buffers offer forEachBuffer(in, out, outOnly); the others forEachBuffer(in, out)
+template <class P, class In, class Out, class OutOnly>
+auto forEachBufferImpl(P& p, In&& in, Out&& out, OutOnly&& outOnly, int) -> decltype(p.forEachBuffer(in, out, outOnly), void())
+{
+  p.forEachBuffer(in, out, outOnly);
+}
+template <class P, class In, class Out, class OutOnly>
+void forEachBufferImpl(P& p, In&& in, Out&& out, OutOnly&&, long)
+{
+  p.forEachBuffer(in, out);
+}
+} // namespace impl
+template <class P, class In, class Out, class OutOnly>
+void forEachBufferOf(P& p, In&& in, Out&& out, OutOnly&& outOnly)
+{
+  impl::forEachBufferImpl(p, in, out, outOnly, 0);
+}
+
 template <class NRTClient>
 class NRTThreadingAdaptor
 {
@@ -60,7 +79,7 @@ public:
     if (mTask) return {};
     if (mQueue.empty()) return {Result::Status::kWarning, "Process() called on empty queue"};
     if (mSynchronous) mSynchronousDone = false;
-    mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, mSynchronous);
+    mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, mSynchronous, mCopyCache);
     mQueue.pop_front();
     Result result;
     if (mSynchronous)
@@ -80,7 +99,7 @@ public:
     {
       if (!mQueue.empty())
       {
-        mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, false);
+        mTask = std::make_unique<ThreadedTask>(mClient, mQueue.front(), mContext, false, mCopyCache);
         mQueue.pop_front();
         state = kDoneStillProcessing;
       }
@@ -112,8 +131,9 @@ private:
   class ThreadedTask
   {
   public:
-    ThreadedTask(std::shared_ptr<Client> client, NRTJob& job, const FluidContext& host, bool synchronous)
-        : mJob(job), mContext(mTaskState, host.device()), mClient(std::move(client))
+    ThreadedTask(std::shared_ptr<Client> client, NRTJob& job, const FluidContext& host, bool synchronous,
+                 std::vector<std::shared_ptr<MemoryBufferAdaptor>>& cache)
+        : mJob(job), mContext(mTaskState, host.device()), mClient(std::move(client)), mCache(cache)
     {
       mContext.devices(host.devices());
       mState = kProcessing;
@@ -126,17 +146,28 @@ private:
         return;
       }
       // deep copies: the worker only ever touches MemoryBufferAdaptors
-      mJob.params.forEachBuffer(
+      // (a copy the adaptor still holds from its last job for the same host buffer is refilled instead of allocated anew;
+      //  a parameter set may name buffers the client only writes -- forEachBuffer's optional third visitor -- and those
+      //  copies take shape and flags only)
+      auto isolate = [this](std::shared_ptr<BufferAdaptor>& b, bool contents) {
+        if (!b) return;
+        std::shared_ptr<MemoryBufferAdaptor> copy;
+        for (auto& old : mCache)
+          if (old && old->origin() == b && old.use_count() == 1) { copy = old; break; }
+        if (copy) copy->rebind(b, contents);
+        else copy = std::make_shared<MemoryBufferAdaptor>(b, contents);
+        mOutputCopies.push_back(copy);
+        b = copy;
+      };
+      forEachBufferOf(
+          mJob.params,
           [this](std::shared_ptr<const BufferAdaptor>& b) {
             if (!b) return;
             mInputCopies.push_back(std::make_shared<MemoryBufferAdaptor>(b));
             b = mInputCopies.back();
           },
-          [this](std::shared_ptr<BufferAdaptor>& b) {
-            if (!b) return;
-            mOutputCopies.push_back(std::make_shared<MemoryBufferAdaptor>(b));
-            b = mOutputCopies.back();
-          });
+          [&](std::shared_ptr<BufferAdaptor>& b) { isolate(b, true); }, [&](std::shared_ptr<BufferAdaptor>& b) { isolate(b, false); });
+      mCache = mOutputCopies; // what the next job may reuse
       mClient->setParams(mJob.params);
       mFuture = mPromise.get_future();
       mThread = std::thread([this] {
@@ -182,6 +213,7 @@ private:
     FluidContext                         mContext;
     std::shared_ptr<Client>              mClient;
     std::vector<std::shared_ptr<MemoryBufferAdaptor>> mInputCopies, mOutputCopies;
+    std::vector<std::shared_ptr<MemoryBufferAdaptor>>& mCache;
     std::promise<Result>                 mPromise;
     std::future<Result>                  mFuture;
     std::thread                          mThread;
@@ -193,6 +225,7 @@ private:
   ParamSetType                  mHostParams;
   FluidContext                  mContext;
   std::shared_ptr<Client>       mClient;
+  std::vector<std::shared_ptr<MemoryBufferAdaptor>> mCopyCache; // the buffer copies of the last job (storage reused by the next)
   std::deque<NRTJob>            mQueue;
   std::unique_ptr<ThreadedTask> mTask;
   bool                          mSynchronous{false};

@@ -12,6 +12,6 @@ drv = os.path.join(ROOT, "flucoma-core_amd", "lib", "client_driver")
 for env in ({}, {"CLIENT_RESYNTH": "1"}):
     e = dict(os.environ); e.update(env); e["CLIENT_REPEAT"] = "5"; e["CLIENT_REPEAT_PRINT"] = "1"
     if os.environ.get("LAPS"): e["FLUHIP_CLIENT_TIMING"] = "1"
-    args = [drv, "run", inp, frames, chans, 2048, 512, 2048, 32, 100, 42, 0, 0, 0, 0, -1, 0, -1, os.path.join(d, "o")]
+    args = [drv, "run", inp, frames, chans, 2048, 512, 2048, 32, 100, 42, 0, 0, int(os.environ.get("ASYNC", "0")), 0, -1, 0, -1, os.path.join(d, "o")]
     out = subprocess.run([str(x) for x in args], capture_output=True, text=True, env=e)
-    print(env, [l for l in out.stdout.splitlines() if "elapsed" in l or "result" in l], out.stderr[-900:])
+    print(env, [l for l in out.stdout.splitlines() if "elapsed" in l or "result" in l or "wall" in l], out.stderr[-900:])
