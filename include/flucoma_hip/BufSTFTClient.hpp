@@ -41,10 +41,15 @@ struct BufSTFTParams
   template <class In, class Out>
   void forEachBuffer(In&& in, Out&& out)
   {
+    forEachBuffer(in, out, out);
+  }
+  // (third visitor: buffers the client only writes -- magnitude / phase going forward, the resynthesis going back)
+  template <class In, class Out, class OutOnly>
+  void forEachBuffer(In&& in, Out&& out, OutOnly&& outOnly)
+  {
     in(source);
-    out(magnitude);
-    out(phase);
-    out(resynth);
+    if (inverse == 0) { outOnly(magnitude); outOnly(phase); out(resynth); }
+    else { out(magnitude); out(phase); outOnly(resynth); }
   }
 
   void constrain()

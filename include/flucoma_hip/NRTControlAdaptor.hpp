@@ -36,8 +36,13 @@ struct NRTControlParams
   template <class In, class Out>
   void forEachBuffer(In&& in, Out&& out)
   {
+    forEachBuffer(in, out, out);
+  }
+  template <class In, class Out, class OutOnly>
+  void forEachBuffer(In&& in, Out&&, OutOnly&& outOnly)
+  {
     in(source);
-    out(features);
+    outOnly(features); // resized and filled, never read
   }
   void constrainWrapper()
   {
