@@ -241,6 +241,26 @@ def test_pool_from_a_cpp_host(driver, ctx):
     assert r["pool_match"][0] == 1, r["pool_match"]
 
 
+def test_host_buffer_plumbing_without_a_device(driver, tmp_path):
+    """tests/cpp/host_buffers_check.cpp under -fsanitize=address,undefined: block-wise scatter / gather against the
+    channel-by-channel loops (interleaved and planar host buffers), interleaved-layout detection, MemoryBufferAdaptor deep
+    copies / copy-back / refilled and shape-only copies, and the generic NRTThreadingAdaptor with a client that needs no
+    device (worker thread, copy-back on the polling thread, write-only buffers, copies reused by the next job)"""
+    lib = os.path.dirname(driver)
+    exe = tmp_path / "host_buffers_check"
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-Wall", "-Wextra",
+           "-Werror", "-pthread", os.path.join(ROOT, "tests", "cpp", "host_buffers_check.cpp"), "-o", str(exe), "-L" + lib,
+           "-lflucoma_hip", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"]
+    b = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert b.returncode == 0, b.stderr[-3000:]
+    e = dict(os.environ)
+    e["ASAN_OPTIONS"] = "detect_leaks=0"
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=e)
+    assert out.returncode == 0, out.stdout + out.stderr[-3000:]
+    lines = out.stdout.split()
+    assert out.stdout.count("ok ") == 11 and "FAILED" not in out.stdout, out.stdout
+
+
 # ---- the clients of SURVEY 8 (f): BufSTFT, BufNMFSeed, BufMFCC, BufMelBands ----------------------------------------
 def test_validation_messages_of_the_other_clients(driver):
     """nrt/BufSTFTClient.hpp:84-107,189-216, nrt/NMFSeedClient.hpp:75-88, cc/FluidNRTClientWrapper.hpp:313-328: the
