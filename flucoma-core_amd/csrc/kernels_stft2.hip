@@ -972,7 +972,7 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
-template <int R1, int R2, int R3, int NW, int S>
+template <int R1, int R2, int R3, int NW, int S, bool SHARED = false>
 __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a, int runSlots, int runsPerBuf, int kGroups)
 {
   using Core = FftCore<R1, R2, R3>;
@@ -986,6 +986,12 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* xb = xall + wave * BUFD;
+  // SHARED: the eight wavefronts of the workgroup are eight components of one (buffer, run) and walk the same frames: the
+  // frame's spectrum row and reciprocal V-hat row are brought into the LDS once per workgroup, by LDS-DMA, a frame ahead
+  // (two row buffers), instead of every wavefront loading them through its registers at the head of its frame
+  constexpr int XROW = (N + 2) * 2, MROW = N + 2;  // doubles per row buffer (spectrum complex, reciprocal V-hat), 16-byte multiples
+  double* xrow = xall + NW * BUFD;                // [2][XROW]
+  double* mrowS = xrow + 2 * XROW;                // [2][MROW]
   const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
   Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
   for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
@@ -1008,7 +1014,10 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
     comp = wave % a.K;
   }
   const int b = (int) (pair / runsPerBuf), run = (int) (pair % runsPerBuf);
-  if (b >= a.B || comp >= a.K) return;            // (no workgroup barrier below)
+  if (b >= a.B) return;                           // (the whole workgroup)
+  const bool active = comp < a.K;                 // SHARED: idle wavefronts still fetch and meet the barriers
+  if (!SHARED && !active) return;                 // (no workgroup barrier below)
+  if (!active) comp = 0;
   const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
   const int Tb = a.nTab ? (int) ((nSamples + a.hop) / a.hop) : a.T;
   const int cover = a.win / a.hop;                // frames over a position (hop | win)
@@ -1035,9 +1044,42 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
 #pragma unroll
   for (int i = 0; i < PPL; i++) acc[i] = cx{0.0, 0.0};
 
-  for (int t = sa - (cover - 1); t < sb; t++)
+  // SHARED: rows of frame t into row buffer `which` (every wavefront of the workgroup takes its 1 KB pieces)
+  auto fetch_rows = [&](int t, int which) {
+    if constexpr (SHARED)
+    {
+      if (t < 0 || t >= Tb) return;
+      const char* xs = reinterpret_cast<const char*>(spec + (int64_t) t * a.F * 2);
+      const char* ms = reinterpret_cast<const char*>(mult + (int64_t) t * a.F);
+      char* xd = reinterpret_cast<char*>(xrow + which * XROW);
+      char* md = reinterpret_cast<char*>(mrowS + which * MROW);
+      constexpr int XI = N / (64 * NW) > 0 ? N / (64 * NW) : 1;   // spectrum: N 16-byte bins, 1 KB per instruction
+#pragma unroll
+      for (int j = 0; j < XI; j++)
+      {
+        const int cb = (XI * wave + j) * 64;
+        if (cb < N)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (xs + (int64_t) (cb + lane) * 16),
+                                           (__attribute__((address_space(3))) void*) (xd + cb * 16), 16, 0, 0);
+      }
+      const int cbm = wave * 64;                                  // reciprocal V-hat: N / 2 16-byte pairs
+      if (cbm < N / 2)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*) (ms + (int64_t) (cbm + lane) * 16),
+                                         (__attribute__((address_space(3))) void*) (md + cbm * 16), 16, 0, 0);
+    }
+  };
+  const int tFirst = sa - (cover - 1);
+  if constexpr (SHARED)
   {
-    if (t >= 0 && t < Tb)
+    fetch_rows(tFirst, 0);
+    __syncthreads();                                 // (drains the DMA: s_waitcnt vmcnt(0) is part of the barrier)
+  }
+
+  for (int t = tFirst; t < sb; t++)
+  {
+    const int which = (t - tFirst) & 1;
+    fetch_rows(t + 1 < sb ? t + 1 : -1, which ^ 1);   // the next frame's rows, a frame ahead
+    if (active && t >= 0 && t < Tb)
     {
       // ---- masked bins of this lane: k = lane + 64 r ----------------------------------------------------------------
       int ln = lane;
@@ -1045,13 +1087,16 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
       const double hk = hcol[(int64_t) t * a.Kp];
       const d2* srow = reinterpret_cast<const d2*>(spec + (int64_t) t * a.F * 2);
       const double* mrow = mult + (int64_t) t * a.F;
+      const d2* srowL = reinterpret_cast<const d2*>(xrow + which * XROW);
+      const double* mrowL = mrowS + which * MROW;
       cx Y[PPL];
 #pragma unroll
       for (int r = 0; r < PPL; r++)
       {
         const int f = ln + 64 * r;
-        const d2 x = srow[f];
-        const double m = fmin((hk * wrow[f]) * mrow[f], 1.0);   // NMF.hpp:41, RatioMask.hpp:52-56 (exponent 1)
+        const d2 x = SHARED ? srowL[f] : srow[f];
+        const double mu = SHARED ? mrowL[f] : mrow[f];
+        const double m = fmin((hk * wrow[f]) * mu, 1.0);        // NMF.hpp:41, RatioMask.hpp:52-56 (exponent 1)
         Y[r] = cx{x[0] * m, x[1] * m};
       }
       if (l0) Y[0].im = 0.0;                         // packed DC (util/FFT.hpp:155-160)
@@ -1103,7 +1148,7 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
         }
     }
     // ---- the oldest hop samples are final: slot t --------------------------------------------------------------------
-    if (t >= sa)
+    if (active && t >= sa)
     {
       const int64_t p0 = (int64_t) t * a.hop;
       const bool interior = t - (cover - 1) >= 0 && t <= Tb - 1;
@@ -1149,6 +1194,7 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
         const int i = bb * R3 + r;
         if constexpr (true) acc[i] = (r + S < R3) ? acc[bb * R3 + ((r + S < R3) ? r + S : 0)] : cx{0.0, 0.0};
       }
+    if constexpr (SHARED) __syncthreads();          // the next frame's rows have landed; everyone is done with this frame's
   }
 }
 
@@ -1243,15 +1289,31 @@ static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
   const int runsPerBuf = (int) ((slots + runSlots - 1) / runSlots);
   const int64_t pairs = ((int64_t) a.B * runsPerBuf + ppw - 1) / ppw;
   const int64_t wgs = ((pairs + 7) / 8) * 8 * kGroups;
-  auto go = [&](auto kern) {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
-    hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3(64 * NW), shmem, s, a, runSlots, runsPerBuf, kGroups);
+  // the workgroup's spectrum / V-hat rows through the LDS (see the kernel) from rank NW on: 25.3 -> 19.2 ms on the bench shard,
+  // alternating on one box; FLUHIP_RESYNTH_SHARED=0: every wavefront loads its own
+  static const int sharedEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_SHARED"); return e ? std::atoi(e) : 1; }();
+  const bool shared = sharedEnv != 0 && a.K >= NW;
+  const size_t shmemS = shmem + (size_t) (2 * (Core::N + 2) * 2 + 2 * (Core::N + 2)) * 8;
+  auto go = [&](auto kern, size_t sh) {
+    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) sh);
+    hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3(64 * NW), sh, s, a, runSlots, runsPerBuf, kGroups);
   };
+  if (shared && shmemS <= 160 * 1024)
+  {
+    switch (a.hop / (2 * Core::NS3))
+    {
+    case 1: go(resynth_seq_kernel<R1, R2, R3, NW, 1, true>, shmemS); break;
+    case 2: go(resynth_seq_kernel<R1, R2, R3, NW, 2, true>, shmemS); break;
+    case 4: go(resynth_seq_kernel<R1, R2, R3, NW, 4, true>, shmemS); break;
+    default: return false;
+    }
+    return true;
+  }
   switch (a.hop / (2 * Core::NS3))
   {
-  case 1: go(resynth_seq_kernel<R1, R2, R3, NW, 1>); break;
-  case 2: go(resynth_seq_kernel<R1, R2, R3, NW, 2>); break;
-  case 4: go(resynth_seq_kernel<R1, R2, R3, NW, 4>); break;
+  case 1: go(resynth_seq_kernel<R1, R2, R3, NW, 1>, shmem); break;
+  case 2: go(resynth_seq_kernel<R1, R2, R3, NW, 2>, shmem); break;
+  case 4: go(resynth_seq_kernel<R1, R2, R3, NW, 4>, shmem); break;
   default: return false;
   }
   return true;

@@ -61,13 +61,20 @@ rW, rH, rV, _ = o.nmf_process(mag1, 3, 8, True, True, 42)
 for k in range(3):
     ref = o.resynth_component(spec, rW, rH, rV, k, 2048, 2048, 512, 30000)
     assert np.abs(res[k] - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-5, k
+# (rank 9: two workgroups of eight wavefronts per run, the second with one live component -- the shared-row form)
+bases, acts, res, rc = ctx.bufnmf_channel(x, 2048, 2048, 512, 9, 4, 42, resynth=True)
+rW, rH, rV, _ = o.nmf_process(mag1, 9, 4, True, True, 42)
+for k in range(9):
+    ref = o.resynth_component(spec, rW, rH, rV, k, 2048, 2048, 512, 30000)
+    assert np.abs(res[k] - ref).max() / max(np.abs(ref).max(), 1e-12) < 1e-5, k
 '''
 
 
 @pytest.mark.parametrize("env", [{"FLUHIP_NMF_KERNEL": "-1"},
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"},
-                                 {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_STFT_PREFETCH": "0"}, {"FLUHIP_SIDE_SLICES": "2"}],
+                                 {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
+                                 {"FLUHIP_SIDE_SLICES": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env):
     e = dict(os.environ)
