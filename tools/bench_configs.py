@@ -1,6 +1,6 @@
 """One JSON line per BASELINE config (c1 .. c5), through the C ABI, with the roofline computed as in bench.py.
 
-    python tools/bench_configs.py [c1] [c2] [c3] [c4x1] [c5] [--no-cpu] [--prof]
+    python tools/bench_configs.py [c1] [c2] [c3] [c4x1] [c5] [resynth] [--no-cpu] [--prof]
 
 The configs other than c4 are parity-test shapes, not bench.py lines; this tool is what DESIGN section 6 quotes for
 them and what the rocprofv3 summaries under profiles/ were taken on (tools/profile_configs.sh).  Work per unit is
@@ -221,6 +221,46 @@ def run_c5(ctx, with_cpu):
     print(json.dumps(res), flush=True)
 
 
+def run_resynth(ctx):
+    """SURVEY 8 f1 at the bench shard's shape: every component of 128 x 10 s buffers at rank 32 resynthesised on the device
+    (fluhip_corpus_resynth_dev: estimate -> ratio mask -> inverse STFT -> overlap-add, NMFClient.hpp:302-334)."""
+    import ctypes
+    B, n, K, win, fft, hop = 128, 441000, 32, 2048, 2048, 512
+    base = np.stack([synth.synth_audio(n, 1000 + b) for b in range(4)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.keep_spectrum(True)
+    c.set_audio(np.tile(base, (B // 4, 1))); c.stft(); c.nmf(10, seed=42); ctx.synchronize()
+    out = torch.empty((B, K, n), dtype=torch.float32, device="cuda")
+    ptr = ctypes.c_void_p(out.data_ptr())
+    assert ctx.lib.fluhip_corpus_resynth_dev(c.h, ptr) == 0
+    ctx.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        assert ctx.lib.fluhip_corpus_resynth_dev(c.h, ptr) == 0
+    ctx.synchronize()
+    dd = (time.perf_counter() - t0) / reps
+    T, F = c.T, c.F
+    frames = B * K * T
+    err = float((out[0].sum(dim=0).cpu() - torch.from_numpy(base[0])).abs().max())
+    # algorithmic bytes: the spectrum, W and H once per buffer, the float samples of every component out (SURVEY 8d style:
+    # what must cross HBM once); the V-hat reciprocal the implementation stores and re-reads is extra
+    nbytes = B * (T * F * 16.0 + (F + T) * K * 8.0) + B * K * n * 4.0
+    flops = frames * (2.5 * fft * np.log2(fft) + 2 * fft + 6 * F)       # inverse real FFT + window / overlap-add + mask
+    res = {"config": "resynth", "workload": "resynthesis of every component of the bench shard: 128 x 10 s mono, fft 2048 / hop 512, "
+                                            "rank 32 (third BufNMF output, resident in HBM)",
+           "metric": "component frames/s", "unit": "frames/s", "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "value": frames / dd, "ms": dd * 1e3, "shape": {"buffers": B, "components": K, "frames": T, "samples": n},
+           "components_add_up_max_abs_err": err,
+           "roofline": {"bound": "hbm", "achieved": nbytes / dd / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": nbytes / dd / 1e9 / PEAK_HBM_GBS, "bytes": nbytes, "traffic": None,
+                        "other_view": {"TFLOP/s (vector FP64)": flops / dd / 1e12},
+                        "per": "whole call (reciprocal V-hat pre-pass + the batched kernel)"},
+           "device": device_line(ctx)}
+    c.close()
+    print(json.dumps(res), flush=True)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     with_cpu = "--no-cpu" not in sys.argv
@@ -229,6 +269,8 @@ def main():
     for name in names:
         if name == "c5":
             run_c5(ctx, with_cpu)
+        elif name == "resynth":
+            run_resynth(ctx)
         else:
             run_nmf_config(ctx, name, with_cpu)
     ctx.close()
