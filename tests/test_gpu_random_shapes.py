@@ -99,3 +99,32 @@ def test_random_ragged_corpus(ctx, oracle, onp, case):
         assert not mag[b, T:].any() and not H1[b, T:].any(), plan
         rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b, :T], rH) < TOL_FACTORS_TIGHT, (b, plan)
+
+
+def _resynth_cases():
+    # FLUHIP_SWEEP_RESYNTH="seed,count": resynthesis shapes (the batched register-overlap-add kernel and, for hops it does not
+    # cover, the per-buffer kernels)
+    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP_RESYNTH", "99,16").split(","))
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(count):
+        fft = [1024, 2048, 2048, 512][rs.randint(4)]
+        hop = fft // [2, 4, 8, 4, 3][rs.randint(5)]
+        K = [1, 2, 3, 7, 8, 9, 16, 17, 33][rs.randint(9)]
+        n = int(rs.randint(1, 40)) * hop + int(rs.randint(0, hop))
+        out.append((i, n, fft, hop, K, int(rs.randint(0, 5))))
+    return out
+
+
+@pytest.mark.parametrize("case", _resynth_cases(), ids=lambda c: "r%d_n%d_f%d_h%d_K%d_i%d" % c)
+def test_random_resynthesis(ctx, oracle, onp, case):
+    _, n, fft, hop, K, iters = case
+    x = onp.synth_audio(max(n, 64), 8100 + n % 97)[:n]
+    bases, acts, res, rc = ctx.bufnmf_channel(x, fft, fft, hop, K, iters, 42, resynth=True)
+    assert rc == 0 and res.shape == (K, n) and np.isfinite(res).all()
+    spec, mag = oracle.stft_f32(x, fft, fft, hop)
+    W1, H1, V1, _ = oracle.nmf_process(mag, K, iters, True, True, 42)
+    for k in sorted({0, K - 1, K // 2}):
+        ref = oracle.resynth_component(spec, W1, H1, V1, k, fft, fft, hop, n)
+        assert np.abs(res[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9, (k, np.abs(res[k] - ref).max())
+
