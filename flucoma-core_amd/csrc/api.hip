@@ -1780,7 +1780,7 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
     const int64_t group = std::max<int64_t>(1, std::min<int64_t>(c->B, ((int64_t) 1 << 30) / perBuf));
     DevBuf mult, wt, nrm;
     HIPCHK(ctx, mult.alloc((size_t) (group * perBuf), false, s));
-    HIPCHK(ctx, wt.alloc((size_t) (group * c->K * c->F) * sizeof(double), false, s));
+    HIPCHK(ctx, wt.alloc((size_t) (group * c->Kp * c->F) * sizeof(double), false, s));
     HIPCHK(ctx, nrm.alloc((size_t) c->hop * sizeof(double), false, s));
     launch_resynth_normaliser(wtab, (int) c->win, (int) c->hop, nrm.as<double>(), s);
     for (int64_t b0 = 0; b0 < c->B; b0 += group)
@@ -1793,7 +1793,7 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
       ResynthBatchArgs ra;
       ra.spec = c->spec.as<double>() + b0 * c->T * c->F * 2; ra.specStride = c->T * c->F * 2;
       ra.mult = mult.as<double>(); ra.multStride = c->T * c->F;
-      ra.Wt = wt.as<double>(); ra.wtStride = c->K * c->F;
+      ra.Wt = wt.as<double>(); ra.wtStride = c->Kp * c->F;
       ra.H1 = Hb; ra.hStride = c->Tp * c->Kp;
       ra.Kp = (int) c->Kp; ra.K = (int) c->K;
       ra.win = (int) c->win; ra.fft = (int) c->fft; ra.hop = (int) c->hop; ra.T = (int) c->T; ra.F = (int) c->F; ra.B = nb;

@@ -295,7 +295,7 @@ struct ResynthBatchArgs
   int64_t specStride;
   const double* mult;    // [B][T][F]  1 / max(Vhat, eps)   (launch_resynth_mult)
   int64_t multStride;
-  const double* Wt;      // [B][K][F]  W transposed (component-major rows)
+  const double* Wt;      // [B][Kp][F]  W transposed (component-major rows)
   int64_t wtStride;
   const double* H1;      // [B][Tp][Kp]
   int64_t hStride;
@@ -312,7 +312,7 @@ struct ResynthBatchArgs
 bool resynth_batch_supported(int win, int fft, int hop);
 void launch_resynth_normaliser(const double* window, int win, int hop, double* tab /*[hop]*/, hipStream_t s);
 bool launch_resynth_batch(const ResynthBatchArgs& a, hipStream_t s);
-// mult[b][t][f] = 1 / max(sum_k W[f][k] H[t][k], eps) and Wt[b][k][f] = W[f][k] (alg/NMF.hpp:33-42 estimate's V-hat,
+// Wt[b][k][f] = W[f][k] (Kp x F per buffer) and mult[b][t][f] = 1 / max(sum_k W[f][k] H[t][k], eps) (alg/NMF.hpp:33-42 estimate's V-hat,
 // alg/RatioMask.hpp:39-41)
 void launch_resynth_mult(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt, double* mult,
                          int T, int F, int K, int Kp, int B, hipStream_t s);

@@ -1198,13 +1198,15 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
   }
 }
 
-__global__ void resynth_mult_kernel(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt,
-                                    double* mult, int T, int F, int K, int Kp)
+__global__ void resynth_mult_kernel(const double* Wt, int64_t strideWt, const double* H1, int64_t strideH, double* mult, int T,
+                                    int F, int K, int Kp)
 {
-  // block = (8 frames, buffer): thread f sums k ascending for the 8 frames; block row 0 also writes the transposed W
+  // block = (8 frames, buffer): thread f sums k ascending for the 8 frames, W read component-major (Wt[k][f]: consecutive
+  // threads, consecutive addresses -- with W as it lies, [f][Kp], every thread walked its own 256-byte row: 1.4 ms on
+  // the bench shard)
   extern __shared__ double hs[]; // [8][Kp]
   const int b = blockIdx.y, t0 = blockIdx.x * 8;
-  const double* W = Wf + (int64_t) b * strideW;
+  const double* W = Wt + (int64_t) b * strideWt;
   const double* H = H1 + (int64_t) b * strideH;
   for (int i = threadIdx.x; i < 8 * Kp; i += blockDim.x)
   {
@@ -1217,13 +1219,11 @@ __global__ void resynth_mult_kernel(const double* Wf, int64_t strideW, const dou
     double s[8];
 #pragma unroll
     for (int tt = 0; tt < 8; tt++) s[tt] = 0.0;
-    const double* w = W + (int64_t) f * Kp;
     for (int k = 0; k < K; k++)
     {
-      const double wk = w[k];
+      const double wk = W[(int64_t) k * F + f];
 #pragma unroll
       for (int tt = 0; tt < 8; tt++) s[tt] = __builtin_fma(wk, hs[tt * Kp + k], s[tt]);
-      if (blockIdx.x == 0) Wt[((int64_t) b * K + k) * F + f] = wk;
     }
 #pragma unroll
     for (int tt = 0; tt < 8; tt++)
@@ -1255,8 +1255,10 @@ void launch_resynth_normaliser(const double* window, int win, int hop, double* t
 void launch_resynth_mult(const double* Wf, int64_t strideW, const double* H1, int64_t strideH, double* Wt, double* mult,
                          int T, int F, int K, int Kp, int B, hipStream_t s)
 {
+  // Wt[b][k][f] = W[b][f][k] (Kp rows of F per buffer), then the reciprocal V-hat from it
+  launch_transpose(Wf, Kp, strideW, Wt, F, (int64_t) Kp * F, F, Kp, B, s);
   hipLaunchKernelGGL(resynth_mult_kernel, dim3((unsigned) ((T + 7) / 8), (unsigned) B), dim3(256), (size_t) 8 * Kp * sizeof(double), s,
-                     Wf, strideW, H1, strideH, Wt, mult, T, F, K, Kp);
+                     Wt, (int64_t) Kp * F, H1, strideH, mult, T, F, K, Kp);
 }
 
 bool resynth_batch_supported(int win, int fft, int hop)
