@@ -1265,7 +1265,8 @@ bool resynth_batch_supported(int win, int fft, int hop)
 {
   // the transform's outputs lie 2 NS3 samples apart from register to register (256 at fft 2048, 128 at fft 1024): the hop
   // 1, 2 or 4 of those (and so a divisor of the window)
-  if (win != fft) return false;
+  // (a window shorter than the transform: the samples past it meet a zero window and the state's upper registers stay zero)
+  if (win > fft || win < hop || win % hop != 0 || (win & 1)) return false;
   if (fft == 2048) return hop == 256 || hop == 512 || hop == 1024;
   if (fft == 1024) return hop == 128 || hop == 256 || hop == 512;
   return false;

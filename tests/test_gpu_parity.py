@@ -1061,7 +1061,8 @@ def test_corpus_c4_shape_properties(ctx, onp):
                                              (44100, 2048, 2048, 512, 4), (5000, 64, 64, 16, 2),
                                              (30001, 2048, 2048, 256, 3), (30001, 2048, 2048, 1024, 9),   # the batched
                                              (1500, 2048, 2048, 512, 2), (20001, 1024, 1024, 128, 4),     # kernel's hops
-                                             (20001, 1024, 1024, 512, 10)])
+                                             (20001, 1024, 1024, 512, 10), (15000, 1024, 2048, 256, 3),    # win < fft
+                                             (15000, 512, 2048, 512, 4), (7000, 256, 1024, 128, 9)])
 def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
     x = onp.synth_audio(n, 4242)
     iters = 30
@@ -1076,7 +1077,7 @@ def test_resynthesis_vs_oracle(ctx, oracle, onp, n, win, fft, hop, K):
         assert np.abs(res[k] - ref).max() / scale < 1e-5      # float output of an f64 pipeline
         total += res[k]
     # soft masks sum to ~1: the components add back up to the input (away from the edges)
-    if n > 3 * win:
+    if n > 3 * win and hop <= win // 2:           # (hop = win: the window's zeros lose samples, nothing adds back up)
         assert np.abs(total[win:-win] - x[win:-win]).max() < 0.02
 
 
