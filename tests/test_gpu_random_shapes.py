@@ -109,22 +109,23 @@ def _resynth_cases():
     out = []
     for i in range(count):
         fft = [1024, 2048, 2048, 512][rs.randint(4)]
-        hop = fft // [2, 4, 8, 4, 3][rs.randint(5)]
+        win = fft // [1, 1, 2, 4][rs.randint(4)]
+        hop = win // [2, 4, 8, 4, 3, 1][rs.randint(6)]
         K = [1, 2, 3, 7, 8, 9, 16, 17, 33][rs.randint(9)]
         n = int(rs.randint(1, 40)) * hop + int(rs.randint(0, hop))
-        out.append((i, n, fft, hop, K, int(rs.randint(0, 5))))
+        out.append((i, n, win, fft, hop, K, int(rs.randint(0, 5))))
     return out
 
 
-@pytest.mark.parametrize("case", _resynth_cases(), ids=lambda c: "r%d_n%d_f%d_h%d_K%d_i%d" % c)
+@pytest.mark.parametrize("case", _resynth_cases(), ids=lambda c: "r%d_n%d_w%d_f%d_h%d_K%d_i%d" % c)
 def test_random_resynthesis(ctx, oracle, onp, case):
-    _, n, fft, hop, K, iters = case
+    _, n, win, fft, hop, K, iters = case
     x = onp.synth_audio(max(n, 64), 8100 + n % 97)[:n]
-    bases, acts, res, rc = ctx.bufnmf_channel(x, fft, fft, hop, K, iters, 42, resynth=True)
+    bases, acts, res, rc = ctx.bufnmf_channel(x, win, fft, hop, K, iters, 42, resynth=True)
     assert rc == 0 and res.shape == (K, n) and np.isfinite(res).all()
-    spec, mag = oracle.stft_f32(x, fft, fft, hop)
+    spec, mag = oracle.stft_f32(x, win, fft, hop)
     W1, H1, V1, _ = oracle.nmf_process(mag, K, iters, True, True, 42)
     for k in sorted({0, K - 1, K // 2}):
-        ref = oracle.resynth_component(spec, W1, H1, V1, k, fft, fft, hop, n)
+        ref = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, n)
         assert np.abs(res[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9, (k, np.abs(res[k] - ref).max())
 
