@@ -723,7 +723,7 @@ def test_batched_resynthesis_of_tiny_buffers(ctx, oracle, onp, n):
         assert np.abs(res[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9, (k, np.abs(res[k] - ref).max())
 
 
-def test_resynthesis_at_bench_shape_adds_up(ctx, onp):
+def test_resynthesis_at_bench_shape_adds_up(ctx, oracle, onp):
     """size-independent property at the bench workload's buffer shape (16 x 10 s, rank 32): exponent-1 ratio masks are a
     partition of unity, so the 32 components of a buffer add back up to its samples; and the interleaved form holds the
     same floats"""
@@ -741,6 +741,12 @@ def test_resynthesis_at_bench_shape_adds_up(ctx, onp):
     assert np.abs(out.sum(axis=1) - audio).max() < 2e-4
     assert np.array_equal(inter, out.reshape(B * K, n).T)
     assert np.array_equal(out[0], out[4]) and not np.array_equal(out[0], out[1])      # equal buffers, equal results
+    # and two components of one buffer against the oracle at full length (runs of 128 hop slots, rows shared through the LDS)
+    spec, mag = oracle.stft_f32(audio[1], 2048, 2048, 512)
+    W1, H1, V1, _ = oracle.nmf_process(mag, K, 5, True, True, 42)
+    for k in (5, 31):
+        ref = oracle.resynth_component(spec, W1, H1, V1, k, 2048, 2048, 512, n)
+        assert np.abs(out[1, k] - ref).max() <= 1e-5 * np.abs(ref).max(), k
 
 
 def test_ragged_corpus_batched_resynthesis(ctx, onp):
