@@ -1980,12 +1980,15 @@ static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int
   rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n);
   if (rc) return rc;
   if (frames_out) *frames_out = c.T;
-  if (mag)
-    HIPCHK(ctx, hipMemcpy2DAsync(mag, (size_t) c.F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
-                                 (size_t) c.F * sizeof(double), (size_t) c.T, hipMemcpyDeviceToHost, ctx->stream));
+  // (long buffers: through the pinned staging blocks -- a minute of audio at fft 2048 is 42 + 85 MB)
+  if (mag && (rc = copy_to_host(ctx, mag, (size_t) c.F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
+                                (size_t) c.F * sizeof(double), (size_t) c.T, ctx->stream)))
+    return rc;
   if (spec)
-    HIPCHK(ctx, hipMemcpyAsync(spec, c.spec.p, (size_t) c.T * c.F * 2 * sizeof(double), hipMemcpyDeviceToHost,
-                               ctx->stream));
+  {
+    const size_t nb = (size_t) c.T * c.F * 2 * sizeof(double);
+    if ((rc = copy_to_host(ctx, spec, nb, c.spec.p, nb, nb, 1, ctx->stream))) return rc;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return FLUHIP_OK;
 }
