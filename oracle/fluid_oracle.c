@@ -1,6 +1,10 @@
 /*
  * fluid_oracle.c -- CPU restatement of flucoma-core's BufNMF hot path (see fluid_oracle.h).
- * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see header).  Plain C11, no dependencies.
+ * TEST INFRASTRUCTURE ONLY.  Plain C11, no dependencies.
+ * PARITY: the NMF arithmetic (W, H, V-hat) is UNPINNED -- the reference's tests hold no known answers for it and its
+ * algorithms cannot be built here (see header).  The STFT -> magnitude -> mel -> DCT chain IS pinned to outputs of the
+ * reference itself: the 299 recomputable rows of its pre-analysed demo corpus (Resources/Data/flucoma_corpus_mfcc.json,
+ * tests/test_oracle.py::test_oracles_reproduce_the_references_pre_analysed_corpus) come out to the float32 the file stores.
  *
  * Reference files followed (relative to /root/reference/include/flucoma/):
  *   algorithms/public/WindowFuncs.hpp:41-45   Hann

@@ -5,7 +5,14 @@
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, link or call it, and
  * there only as the checker / the timed CPU baseline, never as the thing shipped.
  *
- * PARITY UNPINNED: the reference (flucoma-core, C++17 header-only) cannot be compiled in
+ * PARITY, two halves.
+ * PINNED to outputs of the reference itself: the STFT -> magnitude -> mel -> DCT chain (fo_stft's framing, window and
+ * transform as the buffered clients drive them, fo_bufmfcc_channel).  flucoma-core ships the analysis of its demo corpus by
+ * a FluCoMa build (Resources/Data/flucoma_corpus_mfcc.json: mean and deviation of BufMFCC's coefficients 1..13 per slice);
+ * the 299 slices whose audio is in the checkout come out of this file to the float32 the JSON stores
+ * (tests/test_oracle.py::test_oracles_reproduce_the_references_pre_analysed_corpus; four of them are the fixture
+ * tests/golden/reference_corpus_mfcc.npz).
+ * UNPINNED: the NMF arithmetic.  The reference (flucoma-core, C++17 header-only) cannot be compiled in
  * this image -- every header on the path needs Eigen 3.4.0, HISSTools_Library@f3292ad and
  * foonathan/memory, all network FetchContent dependencies (reference CMakeLists.txt:54-123)
  * that are absent -- and its own test-suite holds no known-answer vectors for STFT spectra

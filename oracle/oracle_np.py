@@ -1,7 +1,9 @@
 """Independent numpy restatement of flucoma-core's BufNMF hot path.
 
-TEST INFRASTRUCTURE ONLY (see oracle/fluid_oracle.h).  PARITY UNPINNED by the reference's own
-tests; this file exists so that two independently written restatements (this one: numpy
+TEST INFRASTRUCTURE ONLY (see oracle/fluid_oracle.h).  PARITY: the NMF arithmetic is UNPINNED by anything the
+reference holds; the STFT -> magnitude -> mel -> DCT chain reproduces the reference's own pre-analysed demo corpus
+(Resources/Data/flucoma_corpus_mfcc.json: 299 recomputable slices to the float32 it stores --
+tests/test_oracle.py::test_oracles_reproduce_the_references_pre_analysed_corpus).  This file exists so that two independently written restatements (this one: numpy
 pocketfft + BLAS matmul; fluid_oracle.c: hand-rolled radix-2 FFT + blocked loops) must agree
 to <=1e-12 before either is trusted, and to mint the fixtures under tests/golden/
 (tools/make_golden.py).
