@@ -1130,8 +1130,8 @@ def test_bufmfcc_against_the_references_own_corpus_rows(ctx):
     """tests/golden/reference_corpus_mfcc.npz: four slices of flucoma-core's demo corpus with the rows of its
     Resources/Data/flucoma_corpus_mfcc.json -- the mean and deviation of BufMFCC's coefficients 1..13 over each slice, as a
     FluCoMa build computed them (tools/make_reference_mfcc_fixture.py; tests/test_oracle.py holds both oracles against all
-    299 recomputable slices).  The HIP path against outputs of the reference itself: its float features (the logarithm is
-    taken in single precision) agree to 1e-4 on values up to 60."""
+    299 recomputable slices).  The HIP path against outputs of the reference itself: measured 1.6e-6 .. 3.8e-6 on values up to
+    60, the float32 the JSON stores."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_corpus_mfcc.npz"))
     x = (g["pcm16"].astype(np.float64) / 32768.0).astype(np.float32)
     pts = g["points"]
@@ -1139,7 +1139,7 @@ def test_bufmfcc_against_the_references_own_corpus_rows(ctx):
         seg = np.ascontiguousarray(x[int(pts[j]):int(pts[j + 1])])
         m = ctx.bufmfcc(seg, 1024, 1024, 512, n_bands=40, n_coefs=13, start_coeff=1)[0].astype(np.float64)
         got = np.concatenate([m.mean(axis=1), m.std(axis=1)])
-        assert np.abs(got - g["expected"][j]).max() < 1e-4, (j, np.abs(got - g["expected"][j]).max())
+        assert np.abs(got - g["expected"][j]).max() < 2e-5, (j, np.abs(got - g["expected"][j]).max())
 
 
 def test_bufmfcc_options(ctx, oracle, onp):
