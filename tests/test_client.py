@@ -400,3 +400,24 @@ def test_bufmelbands_client(driver, onp, tmp_path, normalize, scale, ctx):
             assert np.abs(got - ref).max() < 2e-3
         else:
             assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_bufmfcc_client_reproduces_the_references_corpus_rows(driver, tmp_path, ctx):
+    """the way the reference's demo corpus was analysed -- BufMFCC with startFrame / numFrames per slice, startCoeff 1 --
+    through NRTMFCCClient on the fixture's audio, against the rows a FluCoMa build computed
+    (tests/golden/reference_corpus_mfcc.npz, Resources/Data/flucoma_corpus_mfcc.json): mean and deviation per coefficient"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "reference_corpus_mfcc.npz"))
+    x = (g["pcm16"].astype(np.float64) / 32768.0).astype(np.float32)
+    inp = tmp_path / "in.f32"
+    x.tofile(inp)
+    pts = g["points"]
+    for j in range(len(pts) - 1):
+        prefix = str(tmp_path / ("s%d" % j))
+        r = run(driver, "mfcc", inp, len(x), 1, 1024, 512, 1024, 1, 40, 13, 1, int(pts[j]), int(pts[j + 1] - pts[j]), 0, 1, j & 1, prefix)
+        assert r["result"] == (OK, "")
+        feat, sr = read_buffer(prefix + "_features.bin")
+        m = feat.astype(np.float64)
+        got = np.concatenate([m.mean(axis=1), m.std(axis=1)])
+        assert feat.shape[0] == 13 and np.abs(got - g["expected"][j]).max() < 2e-5, (j, np.abs(got - g["expected"][j]).max())
+
