@@ -41,7 +41,7 @@ print("plan", c.plan()["kernel"], "worst", worst)
 assert worst < 1e-9, worst
 # the batched regime with the Nyquist side column (FLUHIP_SIDE_SLICES=2: its slices then go through the block in chunks,
 # as on buffers of more than 256 x 64 frames), ranks 32 and 128
-for K in (32, 128):
+for K in (32, 64, 128):
     audio = np.stack([oracle_np.synth_audio(70000, 1100 + (b % 3)) for b in range(128)])
     c = fluhip.Corpus(ctx, 128, 70000, 2048, 2048, 512, K)
     c.set_audio(audio); c.stft(); c.nmf(4, seed=42)
