@@ -129,3 +129,24 @@ def test_random_resynthesis(ctx, oracle, onp, case):
         ref = oracle.resynth_component(spec, W1, H1, V1, k, win, fft, hop, n)
         assert np.abs(res[k] - ref).max() <= 1e-5 * max(np.abs(ref).max(), 1e-12) + 1e-9, (k, np.abs(res[k] - ref).max())
 
+
+@pytest.mark.parametrize("K,B,frames,fft", [(64, 130, 33, 256), (48, 40, 120, 256), (128, 130, 33, 256), (100, 40, 120, 256),
+                                            (128, 130, 5, 512), (64, 130, 7, 512), (128, 64, 61, 1024), (64, 64, 90, 1024)])
+def test_wide_rank_batches(ctx, oracle, onp, K, B, frames, fft):
+    """ranks 33..128 in the batched regime (whole strips, the in-place pipeline form with / without the column-sum pre-pass):
+    many buffers, few frames -- the corner the random sweep above keeps small for the oracle's sake"""
+    import fluhip
+    hop = fft // 4
+    n = frames * hop - 3
+    distinct = [onp.synth_audio(n, 7300 + b) for b in range(3)]
+    audio = np.stack([distinct[b % 3] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, fft, fft, hop, K)
+    c.set_audio(audio); c.stft(); c.nmf(3, seed=42)
+    mag, W1, H1 = c.read_f64()
+    plan = c.plan()
+    c.close()
+    for b in (0, 1, B - 1):
+        _, rmag = oracle.stft_f32(audio[b], fft, fft, hop)
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, 3, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
+
