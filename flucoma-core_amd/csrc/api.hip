@@ -412,6 +412,9 @@ struct fluhip_corpus
   const float* audioDev = nullptr; // borrowed or owned (audioOwn)
   DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
   int nsplitW = 1, nsplitH = 1;
+  // H update in two launches (plan_tail): the first tailStripsH strips of every buffer (tailColsH frames) as whole
+  // contractions, the rest (tailRestH strips) with the contraction cut into tailSplitH pieces; 0 = one launch
+  int tailSplitH = 0, tailStripsH = 0, tailRestH = 0, tailColsH = 0;
   // deferred normalisation of W inside the iteration loop (fluhip_kernels.h UpdateArgs::nrm)
   bool lazy = false;     // the shape takes the two-launch-per-factor fast path
   bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
@@ -500,17 +503,61 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   const size_t B = (size_t) c->B;
-  const int ns = std::max(c->nsplitW, c->nsplitH);
+  const int ns = std::max(std::max(c->nsplitW, c->nsplitH), c->tailSplitH);
   if (ns > 1 && !c->strip)
   {
     const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
     HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
   }
-  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * ns * c->Kp * sizeof(double)), true, s));
+  // (the tail launch keeps its denominator slots behind the first launch's B x Kp)
+  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * std::max(ns, 1 + c->tailSplitH) * c->Kp * sizeof(double)), true, s));
   if (c->Kp > 64)
     HIPCHK(ctx, c->csumScratch.alloc((size_t) colsum_scratch_doubles((int) std::max(c->T, c->F), (int) c->Kp, (int) B) *
                                          sizeof(double), false, s));
   return FLUHIP_OK;
+}
+
+// A whole-contraction update whose wavefronts need a last, poorly filled round of the 1024 SIMDs (config 3's H update: 2 x 808
+// strips = 1.58 rounds, paid as 2) goes out as TWO launches: the strips that fill whole rounds as before, then the remaining
+// strips with their contraction cut into `split` pieces (uniform split schedule: partials + finalize), which deals the tail
+// over the chip in short rounds -- 513 + 2 x 171 steps instead of 2 x 513.  Costs in 4-row steps of this strip width:
+// ~20 k cycles of prologue + epilogue per wavefront, partials written and read back at ~3 TB/s plus the finalize launch.
+// Returns the split (0: one launch pays) and the strips per buffer of the first launch.  FLUHIP_TAIL_SPLIT: 0 off, n forces n
+// pieces; FLUHIP_TAIL_SLOTS: the wavefronts of a round (tests: small corpora take the path).
+static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
+{
+  static const int forceS = [] { const char* e = std::getenv("FLUHIP_TAIL_SPLIT"); return e ? std::atoi(e) : -1; }();
+  static const int slotsEnv = [] { const char* e = std::getenv("FLUHIP_TAIL_SLOTS"); return e ? std::atoi(e) : 0; }();
+  *stripsA = 0;
+  if (forceS == 0) return 0;
+  const int64_t slots = slotsEnv > 0 ? slotsEnv : 1024;
+  const int G = (C + 15) / 16;
+  const int w = nmf_update5_strips(C, Kp, (int) B);
+  const int ng = (G + w - 1) / w;
+  const int64_t total = B * w;
+  const int64_t roundsA = total / slots;
+  if (roundsA < 1 || roundsA > 3 || total % slots == 0) return 0;
+  const int wA = (int) std::min<int64_t>(w - 1, roundsA * slots / B);
+  if (wA < 1) return 0;
+  const int64_t nRest = B * (w - wA);
+  const int64_t nSteps = (R + 3) / 4;
+  const double cycles = 400.0 + 270.0 * ng * (Kp / 32.0); // per step (measured: rank 32 400 + 270 NG; rank 128, 2 groups 2 376)
+  const double ovh = 20000.0 / cycles, stepUs = cycles / 2300.0;
+  const double cur = (double) ((total + slots - 1) / slots) * (nSteps + ovh);
+  const int64_t restCols = C - (int64_t) wA * ng * 16;
+  int best = 0;
+  double bestCost = 0.93 * cur; // a clear win only
+  const int smax = (int) std::min<int64_t>(8, nSteps / 12);
+  for (int sp = 2; sp <= smax; sp++)
+  {
+    if (forceS > 0 && sp != std::min(forceS, smax)) continue;
+    const double finUs = 2.0 * sp * B * restCols * Kp * 8.0 / 3.0e6 + 8.0;
+    const double cost = (double) ((B * wA + slots - 1) / slots) * (nSteps + ovh) +
+                        (double) ((nRest * sp + slots - 1) / slots) * ((nSteps + sp - 1) / sp + ovh) + finUs / stepUs;
+    if (cost < bestCost || (forceS > 0 && best == 0)) { best = sp; bestCost = cost; }
+  }
+  if (best) *stripsA = wA;
+  return best;
 }
 
 static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
@@ -535,6 +582,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   const size_t B = (size_t) c->B;
+  c->tailSplitH = 0;
   if (update_variant((int) c->Kp) == 0)
   {
     c->nsplitW = c->nsplitH = 1;
@@ -605,6 +653,20 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // finalize kernel when the contraction is split
     c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp)
                                 : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
+    c->tailSplitH = 0;
+    if (!c->strip && c->lazy && c->nsplitH == 1)
+    {
+      int wA = 0;
+      const int sp = plan_tail(c->B, (int) c->T, (int) c->F, (int) c->Kp, &wA);
+      if (sp > 1)
+      {
+        const int G = ((int) c->T + 15) / 16, w = nmf_update5_strips((int) c->T, (int) c->Kp, (int) c->B);
+        c->tailSplitH = sp;
+        c->tailStripsH = wA;
+        c->tailRestH = w - wA;
+        c->tailColsH = wA * ((G + w - 1) / w) * 16;
+      }
+    }
   }
   if (int rc = alloc_update_scratch(ctx, c)) return rc;
   HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
@@ -1318,8 +1380,21 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listH.maxSplit, a.B, s, a.nrm, a.nrmMode,
                                nullptr, c->listH.splitTab.as<int>());
     }
-    else
-    if (uv == 5) launch_nmf_update5(a, s);
+    else if (uv == 5 && c->tailSplitH > 1 && !c->winB)
+    {
+      // two launches (plan_tail): whole contractions for the frames that fill whole rounds, split ones for the rest
+      UpdateArgs a1 = a;
+      a1.C = c->tailColsH; a1.stripsOverride = c->tailStripsH; a1.nsplit = 1;
+      launch_nmf_update5(a1, s);
+      UpdateArgs a2 = a;
+      a2.V = a.V + c->tailColsH; a2.S = a.S + (int64_t) c->tailColsH * c->Kp; a2.C = a.C - c->tailColsH;
+      a2.stripsOverride = c->tailRestH; a2.nsplit = c->tailSplitH;
+      a2.dpart = a.dpart + (int64_t) Bw * c->Kp;
+      if (c->Kp > 64) a2.colsumGiven = a.dpart; // (the first launch's pre-pass left the column sums of W there)
+      a2.clk = nullptr;                         // the clock stamps stay those of the whole-contraction wavefront
+      launch_nmf_update5(a2, s);
+    }
+    else if (uv == 5) launch_nmf_update5(a, s);
     else launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
   }
 }
@@ -2961,7 +3036,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
   if (!c || !out8) return FLUHIP_ERROR;
   out8[0] = update_variant((int) c->Kp);
   out8[1] = c->nsplitW;
-  out8[2] = c->nsplitH;
+  out8[2] = c->nsplitH | ((int64_t) c->tailSplitH << 16); // (tail split of the two-launch H update in the high half)
   out8[3] = c->lazy ? 1 : 0;
   out8[4] = c->sideW ? 1 : 0;
   out8[5] = c->stripsW;

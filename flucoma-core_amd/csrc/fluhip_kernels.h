@@ -107,6 +107,9 @@ struct UpdateArgs
   // rank 65..128: workspace of colsum_scratch_doubles() for the column sums of Mv (see launch_colsum); also
   // needs dpart of at least B * nsplit * Kp doubles
   double* colsumScratch = nullptr;
+  // rank 65..128, optional: the column sums of Mv already taken by an earlier launch of the same update ([B][Kp], dense) --
+  // copied into the denominator slots instead of a second pre-pass (the tail launch of a two-launch update)
+  const double* colsumGiven = nullptr;
   // kernels_nmf5.hip: {launches, shader cycles, 100 MHz ticks} of one wavefront per launch, accumulated (or null)
   long long* clk = nullptr;
   // kernels_nmf5.hip work-list mode: listWGs workgroups of 4 wavefronts, list[4 * listWGs]; listNG = the widest strip;

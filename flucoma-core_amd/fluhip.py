@@ -514,7 +514,10 @@ class Corpus:
         out = (ctypes.c_int64 * 8)()
         self.ctx._check(self.ctx.lib.fluhip_corpus_plan(self.h, out))
         keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank", "strip")
-        return dict(zip(keys, [int(v) for v in out]))
+        d = dict(zip(keys, [int(v) for v in out]))
+        d["tail_h"] = d["split_h"] >> 16  # pieces of the tail launch of a two-launch H update (0: one launch)
+        d["split_h"] &= 0xFFFF
+        return d
 
     def update_clocks(self, reset=False):
         """per factor update: launches, shader cycles and 100 MHz ticks of one wavefront per launch, summed since the last reset;

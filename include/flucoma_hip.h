@@ -301,7 +301,8 @@ int fluhip_corpus_resynth_interleaved_host(fluhip_corpus* c, float* out, int64_t
 int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1);
 /* How the factor updates of this corpus are scheduled on the device (introspection for tests, benchmarks and
  * bug reports; no effect on results beyond summation order): out8 = { kernel form (5 = 4x4x4 MFMA + LDS-DMA, ranks up to
- * 128; 0 = the un-fused any-rank path above that), contraction splits of the W update, of the H update,
+ * 128; 0 = the un-fused any-rank path above that), contraction splits of the W update, of the H update (low 16 bits;
+ * bits 16.. = the pieces of the tail launch when the H update goes out as two launches, 0 otherwise),
  * deferred column normalisation of W (alg/NMF.hpp:162 applied on load) 0/1, Nyquist bin as a side column 0/1,
  * wavefronts per buffer of the W update, padded rank, frame-strip schedule 0/1 (a single buffer of rank <= 16: the H
  * update local to a strip of frames, the W update's numerator as per-workgroup partials + a reduce launch; the split

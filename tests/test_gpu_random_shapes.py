@@ -150,3 +150,24 @@ def test_wide_rank_batches(ctx, oracle, onp, K, B, frames, fft):
         rW, rH, _, _ = oracle.nmf_process(rmag, K, 3, True, True, 42)
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
 
+
+
+@pytest.mark.parametrize("K,frames", [(128, 20000), (100, 17001), (64, 36000), (128, 40000)])
+def test_two_launch_h_update(ctx, oracle, onp, K, frames):
+    """two long buffers at a wide rank: the H update's wavefronts need a poorly filled last round, so it goes out as two
+    launches -- whole contractions for the frames that fill whole rounds, split ones for the rest (api.hip plan_tail)"""
+    import fluhip
+    fft, hop, B, iters = 1024, 256, 2, 3
+    n = frames * hop - 5
+    audio = np.stack([onp.synth_audio(n, 7400 + b) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, fft, fft, hop, K)
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    plan = c.plan()
+    c.close()
+    if not os.environ.get("FLUHIP_TAIL_SPLIT"):
+        assert plan["tail_h"] > 1 and plan["split_h"] == 1, plan
+    for b in range(B):
+        _, rmag = oracle.stft_f32(audio[b], fft, fft, hop)
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
