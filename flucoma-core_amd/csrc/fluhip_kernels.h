@@ -123,8 +123,11 @@ struct UpdateArgs
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine
 int colsum_scratch_doubles(int R, int Kp, int B);
+// zeroSlots: rows of Kp behind each buffer's sums that are cleared along with it (out[b * outStride + (1 + z) * Kp + k])
 void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, double* out, int64_t outStride,
-                   double* scratch, hipStream_t s);
+                   double* scratch, hipStream_t s, int zeroSlots = 0);
+// the same output from sums [B][Kp] taken earlier
+void launch_colsum_spread(const double* sums, int Kp, int B, double* out, int64_t outStride, int zeroSlots, hipStream_t s);
 
 // S[c][k] <- S[c][k] * (sum_r (V[r][c] / max(sum_j Mv[r][j] S[c][j], eps)) * Mv[r][k])
 //                    / max(sum_r Mv[r][k], eps)

@@ -310,7 +310,9 @@ __global__ void colsum_part_kernel(const double* Mvbase, int64_t strideM, int R,
   }
 }
 
-__global__ void colsum_combine_kernel(const double* part, int nch, int Kp, double* out, int64_t outStride)
+// zeroSlots: that many further rows of Kp behind the sums are cleared (the other splits' denominator slots); nch == 0 with
+// part = [B][Kp] sums already taken: copy them
+__global__ void colsum_combine_kernel(const double* part, int nch, int Kp, double* out, int64_t outStride, int zeroSlots)
 {
   const int b = blockIdx.x, k = threadIdx.x;
   const double* p = part + (int64_t) b * nch * Kp + k;
@@ -325,13 +327,15 @@ __global__ void colsum_combine_kernel(const double* part, int nch, int Kp, doubl
     for (int u = 0; u < 8; u++) t += v[u];
   }
   for (; j < nch; j++) t += p[(int64_t) j * Kp];
+  if (nch == 0) t = part[(int64_t) b * Kp + k];
   out[(int64_t) b * outStride + k] = t;
+  for (int z = 1; z <= zeroSlots; z++) out[(int64_t) b * outStride + (int64_t) z * Kp + k] = 0.0;
 }
 
 int colsum_scratch_doubles(int R, int Kp, int B) { return ((R + kSumRows - 1) / kSumRows) * Kp * B; }
 
 void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, double* out, int64_t outStride,
-                   double* scratch, hipStream_t s)
+                   double* scratch, hipStream_t s, int zeroSlots)
 {
   int nrg = 256 / Kp;
   if (nrg < 1) nrg = 1;
@@ -339,7 +343,13 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned) nch, (unsigned) B), dim3((unsigned) (nrg * Kp)),
                      (size_t) nrg * Kp * sizeof(double), s, Mv, strideM, R, Kp, scratch, nch);
   hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, scratch, nch, Kp, out,
-                     outStride);
+                     outStride, zeroSlots);
+}
+
+void launch_colsum_spread(const double* sums, int Kp, int B, double* out, int64_t outStride, int zeroSlots, hipStream_t s)
+{
+  hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, sums, 0, Kp, out, outStride,
+                     zeroSlots);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1190,12 +1190,9 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
           if (eff == 2 && a.colsumScratch)
           {
             const int ns = a.nsplit < 1 ? 1 : a.nsplit;
-            (void) hipMemsetAsync(a.dpart, 0, (size_t) a.B * ns * a.Kp * sizeof(double), s);
-            if (a.colsumGiven)
-              (void) hipMemcpy2DAsync(a.dpart, (size_t) ns * a.Kp * sizeof(double), a.colsumGiven, (size_t) a.Kp * sizeof(double),
-                                      (size_t) a.Kp * sizeof(double), (size_t) a.B, hipMemcpyDeviceToDevice, s);
-            else
-              launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s);
+            // slot (buffer, split 0) of dpart takes the sums, the other splits' slots zero (the finalize adds them up)
+            if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
+            else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
             launch5_t<M, NG, NS, WPS, 0, 2, 0>(a, w, s);
             return;
           }
