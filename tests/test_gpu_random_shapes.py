@@ -152,22 +152,28 @@ def test_wide_rank_batches(ctx, oracle, onp, K, B, frames, fft):
 
 
 
-@pytest.mark.parametrize("K,frames", [(128, 20000), (100, 17001), (64, 36000), (128, 40000)])
-def test_two_launch_h_update(ctx, oracle, onp, K, frames):
+@pytest.mark.parametrize("K,frames,mode", [(128, 20000, "both"), (100, 17001, "both"), (64, 36000, "both"), (128, 40000, "both"),
+                                           (128, 18000, "fixed_w"), (128, 18000, "progress")])
+def test_two_launch_h_update(ctx, oracle, onp, K, frames, mode):
     """two long buffers at a wide rank: the H update's wavefronts need a poorly filled last round, so it goes out as two
-    launches -- whole contractions for the frames that fill whole rounds, split ones for the rest (api.hip plan_tail)"""
+    launches -- whole contractions for the frames that fill whole rounds, split ones for the rest (api.hip plan_tail);
+    also with the bases fixed (no deferred normalisation in the H update) and with a progress callback per iteration"""
     import fluhip
     fft, hop, B, iters = 1024, 256, 2, 3
     n = frames * hop - 5
     audio = np.stack([onp.synth_audio(n, 7400 + b) for b in range(B)])
     c = fluhip.Corpus(ctx, B, n, fft, fft, hop, K)
-    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    seen = []
+    c.set_audio(audio); c.stft()
+    c.nmf(iters, seed=42, updateW=mode != "fixed_w", progress=(lambda i: seen.append(i) or True) if mode == "progress" else None)
     mag, W1, H1 = c.read_f64()
     plan = c.plan()
     c.close()
     if not os.environ.get("FLUHIP_TAIL_SPLIT"):
         assert plan["tail_h"] > 1 and plan["split_h"] == 1, plan
+    if mode == "progress":
+        assert seen == list(range(1, iters + 1)), seen
     for b in range(B):
         _, rmag = oracle.stft_f32(audio[b], fft, fft, hop)
-        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, mode != "fixed_w", True, 42)
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
