@@ -506,8 +506,12 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
   const int ns = std::max(std::max(c->nsplitW, c->nsplitH), c->tailSplitH);
   if (ns > 1 && !c->strip)
   {
-    const size_t Cp = (size_t) std::max(c->Fp, c->Tp);
-    HIPCHK(ctx, c->part.alloc(B * ns * Cp * c->Kp * sizeof(double), true, s));
+    // partial numerators [B][pieces][rows][Kp]: the W update's rows are the bins, the H update's the frames (of the tail launch:
+    // the frames behind the whole-contraction ones); the launches set UpdateArgs::Cp to their own row count
+    const size_t rowsW = c->nsplitW > 1 ? (size_t) c->nsplitW * c->Fp : 0;
+    const size_t rowsH = c->nsplitH > 1 ? (size_t) c->nsplitH * c->Tp : 0;
+    const size_t rowsT = c->tailSplitH > 1 ? (size_t) c->tailSplitH * round_up(c->T - c->tailColsH, 32) : 0;
+    HIPCHK(ctx, c->part.alloc(B * std::max(std::max(rowsW, rowsH), rowsT) * c->Kp * sizeof(double), true, s));
   }
   // (the tail launch keeps its denominator slots behind the first launch's B x Kp)
   HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * std::max(ns, 1 + c->tailSplitH) * c->Kp * sizeof(double)), true, s));
@@ -1320,7 +1324,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = Bw; a.Kp = (int) c->Kp;
     if (c->winB) a.stripsOverride = c->winStripsW;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
-    a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
+    a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Fp; a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>();
     if (c->useLists)
     {
@@ -1367,7 +1371,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp;
     if (c->winB) a.stripsOverride = c->winStripsH;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
-    a.Cp = std::max(c->Fp, c->Tp); a.colsumScratch = c->csumScratch.as<double>();
+    a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Tp; a.colsumScratch = c->csumScratch.as<double>();
     a.clk = c->clk.as<long long>() + 4;
     if (c->wPending) { a.nrm = wnormW; a.nrmMode = 2; }
     ProfScope p(ctx, 1);
@@ -1388,7 +1392,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       launch_nmf_update5(a1, s);
       UpdateArgs a2 = a;
       a2.V = a.V + c->tailColsH; a2.S = a.S + (int64_t) c->tailColsH * c->Kp; a2.C = a.C - c->tailColsH;
-      a2.stripsOverride = c->tailRestH; a2.nsplit = c->tailSplitH;
+      a2.stripsOverride = c->tailRestH; a2.nsplit = c->tailSplitH; a2.Cp = round_up(a2.C, 32);
       a2.dpart = a.dpart + (int64_t) Bw * c->Kp;
       if (c->Kp > 64) a2.colsumGiven = a.dpart; // (the first launch's pre-pass left the column sums of W there)
       a2.clk = nullptr;                         // the clock stamps stay those of the whole-contraction wavefront
