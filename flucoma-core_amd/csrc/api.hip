@@ -558,7 +558,8 @@ static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
     const double finUs = 2.0 * sp * B * restCols * Kp * 8.0 / 3.0e6 + 8.0;
     const double cost = (double) ((B * wA + slots - 1) / slots) * (nSteps + ovh) +
                         (double) ((nRest * sp + slots - 1) / slots) * ((nSteps + sp - 1) / sp + ovh) + finUs / stepUs;
-    if (cost < bestCost || (forceS > 0 && best == 0)) { best = sp; bestCost = cost; }
+    // (more pieces only for a clear gain: they cost memory, and config 3 measures the same with 3 and 5)
+    if ((best == 0 ? cost < bestCost : cost < 0.97 * bestCost) || (forceS > 0 && best == 0)) { best = sp; bestCost = cost; }
   }
   if (best) *stripsA = wA;
   return best;
@@ -3033,6 +3034,22 @@ int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bi
   static_assert(sizeof(WaveDesc) == 12 * sizeof(int32_t), "descriptor layout");
   if (desc) std::memcpy(desc, sd.list.data(), (size_t) std::min(n, cap) * sizeof(WaveDesc));
   return n;
+}
+
+int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4)
+{
+  if (count < 1 || frames < 1 || bins < 1 || K < 1 || !out4) return FLUHIP_ERROR;
+  const int Kp = (int) padded_rank(K);
+  out4[0] = out4[1] = out4[2] = out4[3] = 0;
+  if (update_variant(Kp) != 5) return FLUHIP_OK;
+  int wA = 0;
+  const int sp = plan_tail(count, (int) frames, (int) bins, Kp, &wA);
+  if (sp > 1)
+  {
+    const int G = ((int) frames + 15) / 16, w = nmf_update5_strips((int) frames, Kp, (int) count);
+    out4[0] = sp; out4[1] = wA; out4[2] = w - wA; out4[3] = (int64_t) wA * ((G + w - 1) / w) * 16;
+  }
+  return FLUHIP_OK;
 }
 
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)

@@ -318,6 +318,11 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,
                                 int64_t cap, int32_t* info8);
 
+/* Likewise for the two-launch form of the H update (api.hip plan_tail): `count` equal-length buffers of `frames` frames and
+ * `bins` bins at rank K.  out4 = {pieces of the tail launch's contraction (0: the update stays one launch), strips per buffer
+ * of the first launch, strips per buffer of the tail launch, frames per buffer in the first launch}. */
+int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4);
+
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
 /* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of
  * a corpus are independent jobs (clients/nrt/NMFClient.hpp:233 loop body): a pool holds one context per listed device

@@ -123,3 +123,35 @@ def test_work_list_schedule_choices(fluhip_lib_path):
     assert w["partial"] == 0 and 1 < w["pieces"] <= 4 and w["wgs"] <= 256 and w["ng"] < 8
     with pytest.raises(Exception):
         _plan(lib, [0, 5], 1025, 32, 0)
+
+
+def _tail(lib, count, frames, bins, K):
+    out = (ctypes.c_int64 * 4)()
+    assert lib.fluhip_debug_plan_tail(count, frames, bins, K, out) == 0
+    return tuple(int(v) for v in out)
+
+
+def test_two_launch_plan_of_the_h_update(fluhip_lib_path):
+    """api.hip plan_tail (pure host code): a whole-contraction H update whose wavefronts leave a poorly filled last round of the
+    1024 SIMDs is cut into a launch of whole rounds and a split tail; exact fills and single rounds stay one launch"""
+    import fluhip
+    lib = fluhip.load_library(fluhip_lib_path)
+    # config 3: 2 x 25840 frames, 2049 bins, rank 128 -> 2 x 808 strips of 32 frames: 2 x 512 whole, 2 x 296 in three pieces
+    sp, wA, wB, cols = _tail(lib, 2, 25840, 2049, 128)
+    assert (sp, wA, wB, cols) == (3, 512, 296, 512 * 32)
+    # the same channel on its own: 808 strips, a single round -- nothing to cut
+    assert _tail(lib, 1, 25840, 2049, 128)[0] == 0
+    # the bench shard (128 x 862 frames, rank 32): 1024 strips, exactly one round
+    assert _tail(lib, 128, 862, 1025, 32)[0] == 0
+    # a schedule whatever the shape: the first launch fills whole rounds, both launches cover the frames once
+    for count, frames, bins, K in [(2, 20000, 513, 128), (2, 17001, 513, 100), (2, 36000, 513, 64), (2, 40000, 513, 128),
+                                   (1, 70000, 1025, 128), (3, 30000, 2049, 128), (2, 16384 + 32, 513, 128)]:
+        sp, wA, wB, cols = _tail(lib, count, frames, bins, K)
+        if sp == 0:
+            continue
+        assert 2 <= sp <= 8 and wA >= 1 and wB >= 1
+        assert count * wA <= 3 * 1024 and count * (wA + 1) > 1024 * (count * wA // 1024) and cols % 16 == 0 and 0 < cols < frames
+        width = cols // wA                       # frames per strip of the first launch: whole column groups
+        assert width % 16 == 0 and wB * width >= frames - cols > (wB - 1) * width - 16
+    # rank above 128: another kernel form, never two launches
+    assert _tail(lib, 2, 40000, 513, 200) == (0, 0, 0, 0)
