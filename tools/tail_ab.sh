@@ -1,3 +1,4 @@
+# config 3 with the H update as one launch (FLUHIP_TAIL_SPLIT=0) against two (api.hip plan_tail; =3 / =5 force the pieces), alternating on one box
 set -x
 cd /root/repo
 timeout 600 python -m pytest tests/test_gpu_random_shapes.py -m gpu -q -k two_launch 2>&1 | tail -5
