@@ -1447,7 +1447,29 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
       c->winB0 = c->winB = 0;
     }
     else
-      for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
+    {
+      // FLUHIP_GRAPH_ITERS=n (experiment, default off -- DESIGN.md "hipGraph"): after the first iteration, runs of n iterations
+      // are captured once as a hipGraph and replayed; the last iterations (fewer than n + 1) are enqueued as usual.  n even: the
+      // frame-strip schedule alternates two statistics buffers.  Not with the profiler's events in the stream.
+      static const int graphN = [] { const char* e = std::getenv("FLUHIP_GRAPH_ITERS"); return e ? std::atoi(e) & ~1 : 0; }();
+      int64_t i = 0;
+      if (graphN >= 2 && !ctx->prof && iters >= 2 * (int64_t) graphN + 2)
+      {
+        enqueue_iteration(c, updateW, updateH, false);
+        i = 1;
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        for (int g = 0; g < graphN; g++) enqueue_iteration(c, updateW, updateH, false);
+        HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &graph));
+        HIPCHK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        for (; i + graphN < iters; i += graphN) HIPCHK(ctx, hipGraphLaunch(exec, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (experiment: the graph is dropped right away)
+        (void) hipGraphExecDestroy(exec);
+        (void) hipGraphDestroy(graph);
+      }
+      for (; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
+    }
     HIPCHK(ctx, hipGetLastError());
     return FLUHIP_OK;
   }
