@@ -541,13 +541,16 @@ static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
   const int64_t total = B * w;
   const int64_t roundsA = total / slots;
   if (roundsA < 1 || roundsA > 3 || total % slots == 0) return 0;
-  const int wA = (int) std::min<int64_t>(w - 1, roundsA * slots / B);
-  if (wA < 1) return 0;
-  const int64_t nRest = B * (w - wA);
+  // (a workgroup is four wavefronts of ONE buffer and one workgroup fills a CU: strips are dealt in fours, and a launch
+  //  occupies round_up(strips, 4) slots per buffer -- 200 buffers x 5 strips are 400 workgroups, two rounds, not 1000 slots)
+  int wA = (int) std::min<int64_t>(w - 1, roundsA * slots / B);
+  wA -= wA % 4;
+  if (wA < 4) return 0;
+  const int64_t nRest = B * round_up(w - wA, 4);
   const int64_t nSteps = (R + 3) / 4;
   const double cycles = 400.0 + 270.0 * ng * (Kp / 32.0); // per step (measured: rank 32 400 + 270 NG; rank 128, 2 groups 2 376)
   const double ovh = 20000.0 / cycles, stepUs = cycles / 2300.0;
-  const double cur = (double) ((total + slots - 1) / slots) * (nSteps + ovh);
+  const double cur = (double) ((B * round_up(w, 4) + slots - 1) / slots) * (nSteps + ovh);
   const int64_t restCols = C - (int64_t) wA * ng * 16;
   int best = 0;
   double bestCost = 0.93 * cur; // a clear win only
@@ -573,12 +576,13 @@ static bool list_plan_pays(const fluhip_corpus* c)
   // measured at rank 32, 10 s buffers (us per iteration, uniform schedule -> lists): 1 buffer 47 -> 51, 2: 53 -> 57, 4: 73 -> 65,
   // 8: 92 -> 73, 16: 135 -> 109, 24: 196 -> 168, 32: 250 -> 202, 48: 346 -> 289, 64: 370 -> 345, 96: 758 -> 511, 112: 878 -> 564,
   // 128: 619 = 621 (the same schedule either way); ranks 16 / 64 / 128 at 4 and 16 buffers likewise (49 -> 49, 89 -> 76;
-  // 130 -> 98, 227 -> 193; 211 -> 160, 486 -> 476).  So: from three buffers on, while whole contractions at the widest
-  // strips do not fill the chip in whole rounds.
+  // 130 -> 98, 227 -> 193; 211 -> 160, 486 -> 476).  Between one and two rounds (profiles/r03/midsize_ab.txt, two rounds of
+  // the uniform schedule = ~1 250 us): 144 buffers 729, 176: 854, 200: 1 007, 232: 1 102, 250: 1 153.  So: from three buffers on,
+  // while whole contractions at the widest strips do not fill the chip in whole rounds, up to two rounds.
   const int maxNG = nmf_update5_max_groups((int) c->Kp);
   const int G = ((int) c->F - 1 + 15) / 16;
   const int64_t w0 = c->B * ((G + maxNG - 1) / maxNG);
-  return c->B >= 3 && w0 < 1536 && (w0 % 1024) != 0;
+  return c->B >= 3 && w0 < 2048 && (w0 % 1024) != 0;
 }
 
 // how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
