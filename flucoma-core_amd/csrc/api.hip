@@ -578,11 +578,20 @@ static bool list_plan_pays(const fluhip_corpus* c)
   // 128: 619 = 621 (the same schedule either way); ranks 16 / 64 / 128 at 4 and 16 buffers likewise (49 -> 49, 89 -> 76;
   // 130 -> 98, 227 -> 193; 211 -> 160, 486 -> 476).  Between one and two rounds (profiles/r03/midsize_ab.txt, two rounds of
   // the uniform schedule = ~1 250 us): 144 buffers 729, 176: 854, 200: 1 007, 232: 1 102, 250: 1 153.  So: from three buffers on,
-  // while whole contractions at the widest strips do not fill the chip in whole rounds, up to two rounds.
+  // while whole contractions at the widest strips do not fill the chip in whole rounds.
   const int maxNG = nmf_update5_max_groups((int) c->Kp);
   const int G = ((int) c->F - 1 + 15) / 16;
   const int64_t w0 = c->B * ((G + maxNG - 1) / maxNG);
-  return c->B >= 3 && w0 < 2048 && (w0 % 1024) != 0;
+  // Beyond one round the lists win as well, whole rounds or not (profiles/r03/midsize_ab.txt parts 3 - 4, uniform schedule in
+  // round-major windows -> lists: 288 buffers 1 723 -> 1 475 us, 400: 2 300 -> 2 015, 520: 2 864 -> 2 589, 900: 4 568 -> 4 320,
+  // 1000: 4 586 -> 4 424; exact multiples of a round 256: 1 222 -> 1 206, 512: 2 346 -> 2 285, 1024: 4 611 -> 4 485, and with a
+  // progress callback -- iteration-major launches of several rounds -- 512: 2 427 -> 2 234, 1024: 5 157 -> 4 452): several
+  // thousand workgroups handed out as CUs free up keep the chip busy across what the uniform launch runs as lock-step rounds.
+  // Exactly one round (the bench shard: 128 buffers) is the same schedule either way and stays on the uniform kernel.
+  // (Measured at rank 32.  The wide ranks keep the earlier rule: the list kernel's rank-128 instantiation -- grouped refill, column
+  //  sums in the kernel -- runs 3 580 cycles per step against the uniform one's 2 376.)
+  if (c->Kp > 32) return c->B >= 3 && w0 < 1536 && (w0 % 1024) != 0;
+  return c->B >= 3 && w0 != 1024;
 }
 
 // how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their

@@ -1,0 +1,7 @@
+for B in 256 512 1024 128; do
+  for v in "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do
+    echo "B=$B $v: $(env $v timeout 400 python tools/batch_timing.py $B 10 32 40 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); print(round(d['us_per_iteration'],1), 'us/it, with progress', round(d['us_per_iteration_progress'],1), d['plan'])")"
+  done
+done
