@@ -1446,7 +1446,13 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
         // strips from the number of buffers it is launched on); the W update's strips also fix the layout of its column
         // statistics, which was planned for the whole corpus
         const int wWc = nmf_update5_strips(CW, (int) c->Kp, (int) per), wHc = nmf_update5_strips((int) c->T, (int) c->Kp, (int) per);
-        if (wWc == wW && per * std::max(wWc, wHc) <= 1024) { chunk = per; c->winStripsW = wWc; c->winStripsH = wHc; }
+        // (both updates must fill most of a round at that window: short buffers at a wide rank -- 128 x 1.6 s, rank 128: 32
+        //  strips over the bins, 5 over the frames -- ran H updates of 160 wavefronts per window: 1 510 us per iteration against
+        //  608 iteration-major, tools/wide_list_ab.sh)
+        if (wWc == wW && per * std::max(wWc, wHc) <= 1024 && per * std::min(wWc, wHc) >= 768)
+        {
+          chunk = per; c->winStripsW = wWc; c->winStripsH = wHc;
+        }
       }
     }
     if (chunk > 0)
