@@ -590,8 +590,15 @@ static bool list_plan_pays(const fluhip_corpus* c)
   // Exactly one round (the bench shard: 128 buffers) is the same schedule either way and stays on the uniform kernel.
   // (Measured at rank 32.  The wide ranks keep the earlier rule: the list kernel's rank-128 instantiation -- grouped refill, column
   //  sums in the kernel -- runs 3 580 cycles per step against the uniform one's 2 376.)
+  // Rank 128 (profiles/r03/plan_regimes.txt): 4 buffers 211 -> 160 on the lists, but 16: 452 -> 500, 24: 581 -> 820, 32: 639 -> 818,
+  // 40: 902 (uniform, two-launch H update) -> 1 330 -- lists only while whole contractions fill less than half a round.
+  if (c->Kp > 64) return c->B >= 3 && w0 < 512;
   if (c->Kp > 32) return c->B >= 3 && w0 < 1536 && (w0 % 1024) != 0;
-  return c->B >= 3 && w0 != 1024;
+  // One or two buffers (rank <= 32; a single buffer of rank <= 16 that fits the frame-strip schedule never gets here): the
+  // uniform split schedule up to ~45 s of frames in all (1 x 30 s 62.5 us per iteration against 66.7, 2 x 10 s 53 against 57),
+  // lists beyond (1 x 60 s 80.5 -> 72.8, 1 x 300 s 253 -> 163, 2 x 30 s 79.3 -> 71.3, 2 x 300 s 454 -> 340).
+  if (c->B <= 2) return c->B * c->T * c->F >= 4200000;
+  return w0 != 1024;
 }
 
 // how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
