@@ -588,13 +588,14 @@ static bool list_plan_pays(const fluhip_corpus* c)
   // progress callback -- iteration-major launches of several rounds -- 512: 2 427 -> 2 234, 1024: 5 157 -> 4 452): several
   // thousand workgroups handed out as CUs free up keep the chip busy across what the uniform launch runs as lock-step rounds.
   // Exactly one round (the bench shard: 128 buffers) is the same schedule either way and stays on the uniform kernel.
-  // (Measured at rank 32.  The wide ranks keep the earlier rule: the list kernel's rank-128 instantiation -- grouped refill, column
-  //  sums in the kernel -- runs 3 580 cycles per step against the uniform one's 2 376.)
+  // (Rank 128 apart: the list kernel's instantiation there -- grouped refill, column sums in the kernel -- runs 3 580 cycles per
+  //  step against the uniform one's 2 376.)
   // Rank 128 (profiles/r03/plan_regimes.txt): 4 buffers 211 -> 160 on the lists, but 16: 452 -> 500, 24: 581 -> 820, 32: 639 -> 818,
   // 40: 902 (uniform, two-launch H update) -> 1 330 -- lists only while whole contractions fill less than half a round.
   if (c->Kp > 64) return c->B >= 3 && w0 < 512;
-  if (c->Kp > 32) return c->B >= 3 && w0 < 1536 && (w0 % 1024) != 0;
-  // One or two buffers (rank <= 32; a single buffer of rank <= 16 that fits the frame-strip schedule never gets here): the
+  // Rank 64 follows rank 32 (100 x 10 s 1 333 -> 1 043, 300: 2 999 -> 2 771, 128 x 2 s 330 -> 317, 1 x 60 s 131 -> 106, 1 x 300 s
+  // 417 -> 263, 2 x 300 s 800 -> 614; 40 x 10 s 456 -> 473 the one loss).
+  // One or two buffers (rank <= 64; a single buffer of rank <= 16 that fits the frame-strip schedule never gets here): the
   // uniform split schedule up to ~45 s of frames in all (1 x 30 s 62.5 us per iteration against 66.7, 2 x 10 s 53 against 57),
   // lists beyond (1 x 60 s 80.5 -> 72.8, 1 x 300 s 253 -> 163, 2 x 30 s 79.3 -> 71.3, 2 x 300 s 454 -> 340).
   if (c->B <= 2) return c->B * c->T * c->F >= 4200000;

@@ -169,7 +169,7 @@ def test_two_launch_h_update(ctx, oracle, onp, K, frames, mode):
     mag, W1, H1 = c.read_f64()
     plan = c.plan()
     c.close()
-    if not os.environ.get("FLUHIP_TAIL_SPLIT") and K > 32:   # (at rank <= 32 two buffers this long run on the work lists)
+    if not os.environ.get("FLUHIP_TAIL_SPLIT") and K > 64:   # (up to rank 64 two buffers this long run on the work lists)
         assert plan["tail_h"] > 1 and plan["split_h"] == 1, plan
     if mode == "progress":
         assert seen == list(range(1, iters + 1)), seen

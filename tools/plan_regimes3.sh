@@ -1,0 +1,16 @@
+# rank 64: uniform schedule (FLUHIP_LIST_PLAN=0) against work lists (=1)
+while read B secs K it; do
+  for v in "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do
+    echo "B=$B secs=$secs K=$K $v: $(env $v timeout 300 python tools/batch_timing.py $B $secs $K $it 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline()); p = d['plan']; print(round(d['us_per_iteration'],1), 'us/it, with progress', round(d['us_per_iteration_progress'],1), 'splits', p['split_w'], p['split_h'], 'tail', p['tail_h'], 'strips_w', p['strips_w'])")"
+  done
+done <<'LIST'
+40 10 64 30
+100 10 64 30
+300 10 64 20
+128 2 64 40
+1 60 64 40
+1 300 64 30
+2 300 64 30
+LIST
