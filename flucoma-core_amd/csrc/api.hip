@@ -592,7 +592,8 @@ static bool list_plan_pays(const fluhip_corpus* c)
   //  step against the uniform one's 2 376.)
   // Rank 128 (profiles/r03/plan_regimes.txt): 4 buffers 211 -> 160 on the lists, but 16: 452 -> 500, 24: 581 -> 820, 32: 639 -> 818,
   // 40: 902 (uniform, two-launch H update) -> 1 330 -- lists only while whole contractions fill less than half a round.
-  if (c->Kp > 64) return c->B >= 3 && w0 < 512;
+  // (few buffers, 10 s each: 3: 177 -> 167, 4: 168 -> 163, 8: 240 -> 273, 12: 516 -> 405; long ones lose: 4 x 60 s 558 -> 753)
+  if (c->Kp > 64) return c->B >= 3 && w0 < 512 && c->T <= 2048;
   // Rank 64 follows rank 32 (100 x 10 s 1 333 -> 1 043, 300: 2 999 -> 2 771, 128 x 2 s 330 -> 317, 1 x 60 s 131 -> 106, 1 x 300 s
   // 417 -> 263, 2 x 300 s 800 -> 614; 40 x 10 s 456 -> 473 the one loss).
   // One or two buffers (rank <= 64; a single buffer of rank <= 16 that fits the frame-strip schedule never gets here): the
