@@ -571,7 +571,8 @@ static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
 static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
 // where the work-list form beats the uniform split schedule for equal-length corpora (tools/batch_timing.py with
 // FLUHIP_LIST_PLAN=0|1, profiles/r03/small_batches_*.jsonl)
-static bool list_plan_pays(const fluhip_corpus* c)
+struct PlanShape { int64_t B, T, F, Kp; }; // what the choice of schedule depends on (also reachable without a corpus: fluhip_debug_plan_kind)
+static bool list_plan_pays(const PlanShape* c)
 {
   // measured at rank 32, 10 s buffers (us per iteration, uniform schedule -> lists): 1 buffer 47 -> 51, 2: 53 -> 57, 4: 73 -> 65,
   // 8: 92 -> 73, 16: 135 -> 109, 24: 196 -> 168, 32: 250 -> 202, 48: 346 -> 289, 64: 370 -> 345, 96: 758 -> 511, 112: 878 -> 564,
@@ -670,7 +671,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
     // partials in memory.  FLUHIP_LIST_PLAN=0 keeps the uniform split schedule, =1 takes the lists whenever something is split.
     static const int listEnv = [] { const char* e = std::getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
-    if (!c->strip && c->lazy && listEnv != 0 && (listEnv == 1 || list_plan_pays(c)))
+    if (!c->strip && c->lazy && listEnv != 0 && (listEnv == 1 || [&] { const PlanShape ps{c->B, c->T, c->F, c->Kp}; return list_plan_pays(&ps); }()))
     {
       c->tOf.assign(B, (int) c->T);
       c->useLists = true;
@@ -3084,6 +3085,15 @@ int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bi
   static_assert(sizeof(WaveDesc) == 12 * sizeof(int32_t), "descriptor layout");
   if (desc) std::memcpy(desc, sd.list.data(), (size_t) std::min(n, cap) * sizeof(WaveDesc));
   return n;
+}
+
+int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t K)
+{
+  if (count < 1 || frames < 1 || bins < 1 || K < 1) return -1;
+  const int Kp = (int) padded_rank(K);
+  if (update_variant(Kp) != 5) return 0;
+  const PlanShape ps{count, frames, bins, Kp};
+  return list_plan_pays(&ps) ? 1 : 0;
 }
 
 int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4)

@@ -322,6 +322,10 @@ int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bi
  * `bins` bins at rank K.  out4 = {pieces of the tail launch's contraction (0: the update stays one launch), strips per buffer
  * of the first launch, strips per buffer of the tail launch, frames per buffer in the first launch}. */
 int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4);
+/* Which schedule family an equal-length corpus of that shape gets when nothing else decides first (a single buffer of rank <= 16
+ * that fits the frame-strip schedule never asks): 1 = the work lists, 0 = the uniform schedule; -1: bad arguments.  The rules are
+ * measured ones (api.hip list_plan_pays, profiles/r03/plan_regimes.txt); the CPU tests pin them for the BASELINE shapes. */
+int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t K);
 
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
 /* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of

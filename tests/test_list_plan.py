@@ -155,3 +155,21 @@ def test_two_launch_plan_of_the_h_update(fluhip_lib_path):
         assert width % 16 == 0 and wB * width >= frames - cols > (wB - 1) * width - 16
     # rank above 128: another kernel form, never two launches
     assert _tail(lib, 2, 40000, 513, 200) == (0, 0, 0, 0)
+
+
+def test_schedule_family_of_the_baseline_shapes(fluhip_lib_path):
+    """api.hip list_plan_pays (pure host code): the measured rules, pinned for the shapes whose records are under profiles/r03/"""
+    import fluhip
+    lib = fluhip.load_library(fluhip_lib_path)
+    kind = lambda B, T, F, K: lib.fluhip_debug_plan_kind(B, T, F, K)  # noqa: E731
+    assert kind(128, 862, 1025, 32) == 0        # the bench shard: exactly one round of wavefronts, uniform kernel
+    assert kind(1024, 862, 1025, 32) == 1       # the whole config-4 corpus on one GPU
+    assert kind(8, 862, 1025, 32) == 1 and kind(200, 862, 1025, 32) == 1 and kind(3, 862, 1025, 32) == 1
+    assert kind(1, 862, 1025, 32) == 0 and kind(2, 862, 1025, 32) == 0          # one c4 buffer, a stereo pair of them
+    assert kind(1, 25840, 1025, 32) == 1 and kind(2, 2584, 1025, 32) == 1       # 1 x 300 s, 2 x 30 s
+    assert kind(1, 2584, 1025, 32) == 0                                         # 1 x 30 s
+    assert kind(2, 25840, 2049, 128) == 0       # config 3: uniform schedule (with the two-launch H update)
+    assert kind(40, 862, 1025, 128) == 0 and kind(4, 862, 1025, 128) == 1 and kind(4, 5168, 1025, 128) == 0
+    assert kind(100, 862, 1025, 64) == 1 and kind(1, 25840, 1025, 64) == 1
+    assert kind(2, 40000, 513, 200) == 0        # above rank 128: the un-fused path, no lists
+    assert kind(0, 1, 1, 1) == -1
