@@ -177,3 +177,24 @@ def test_two_launch_h_update(ctx, oracle, onp, K, frames, mode):
         _, rmag = oracle.stft_f32(audio[b], fft, fft, hop)
         rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, mode != "fixed_w", True, 42)
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
+
+
+@pytest.mark.parametrize("K,B,seconds", [(32, 1, 100), (20, 1, 70), (64, 1, 60), (32, 2, 40)])
+def test_long_buffers_on_the_work_lists(ctx, oracle, onp, K, B, seconds):
+    """one or two long buffers at ranks up to 64: past ~45 s of frames in all the planner hands them to the work lists (api.hip
+    list_plan_pays, profiles/r03/plan_regimes.txt) -- the contraction of every strip cut into pieces added up inside a workgroup"""
+    import fluhip
+    fft, hop, iters = 2048, 512, 4
+    n = seconds * 44100
+    audio = np.stack([np.resize(onp.synth_audio(1_000_000, 7600 + b), n) for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, fft, fft, hop, K)
+    if not os.environ.get("FLUHIP_LIST_PLAN"):
+        assert ctx.lib.fluhip_debug_plan_kind(B, c.T, c.F, K) == 1
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64()
+    plan = c.plan()
+    c.close()
+    for b in range(B):
+        _, rmag = oracle.stft_f32(audio[b], fft, fft, hop)
+        rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (plan, b)
