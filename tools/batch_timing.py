@@ -1,5 +1,5 @@
 """Where the time of a small batch goes (the channels of one multichannel BufNMF job as one corpus):
-    python tools/batch_timing.py [B] [seconds] [K] [iters]
+    python tools/batch_timing.py [B] [seconds] [K] [iters] [fft] [hop]
 wall times of upload / STFT / NMF (with and without a progress callback) / write-back, the schedule the corpus got and the
 per-class kernel times of the iteration loop."""
 import sys, os, time, json
@@ -12,10 +12,12 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+fft = int(sys.argv[5]) if len(sys.argv) > 5 else 2048
+hop = int(sys.argv[6]) if len(sys.argv) > 6 else fft // 4
 n = int(secs * 44100)
 ctx = fluhip.Context(0)
 audio = np.stack([synth.synth_audio(n, 800 + b) for b in range(B)])
-c = fluhip.Corpus(ctx, B, n, 2048, 2048, 512, K)
+c = fluhip.Corpus(ctx, B, n, fft, fft, hop, K)
 
 
 def timed(f):
