@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--rank", type=int, default=WORKLOAD["rank"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU baseline budget")
+    ap.add_argument("--configs", default="auto",
+                    help="BASELINE configs timed behind the headline and reported under `configs`: 'auto' = c2,c3,c5 when the "
+                         "headline workload is the default one on one GPU, 'none', or a comma list of c1,c2,c3,c4x1,c5")
     ap.add_argument("--prof-in-timed-region", action="store_true",
                     help="bracket every update launch by HIP events inside the timed steps (the round-1/2 behaviour) "
                          "instead of in one extra step right behind them")
@@ -226,6 +229,14 @@ def main():
     bases = torch.empty((B, K, F), dtype=torch.float32, device="cuda")
     acts = torch.empty((B, K, T), dtype=torch.float32, device="cuda")
     gathered = {}
+    # receive (and, on the gloo rehearsal path, host staging) buffers of the gather: allocated once, outside the timed steps
+    host_b = host_a = None
+    if use_dist:
+        if backend != "nccl":
+            host_b = torch.empty(bases.shape, dtype=bases.dtype).pin_memory()
+            host_a = torch.empty(acts.shape, dtype=acts.dtype).pin_memory()
+        gathered["bases"] = sharding.gather_buffer(bases if backend == "nccl" else host_b, world)
+        gathered["acts"] = sharding.gather_buffer(acts if backend == "nccl" else host_a, world)
 
     def step():
         corpus.stft()
@@ -233,9 +244,13 @@ def main():
         corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
         ctx.synchronize()
         if use_dist:  # the one collective of the path: final dictionary/activation gather (RCCL)
-            src_b, src_a = (bases, acts) if backend == "nccl" else (bases.cpu(), acts.cpu())
-            gathered["bases"] = sharding.gather_results(src_b, dist, world)
-            gathered["acts"] = sharding.gather_results(src_a, dist, world)
+            if backend == "nccl":
+                src_b, src_a = bases, acts
+            else:
+                host_b.copy_(bases); host_a.copy_(acts)
+                src_b, src_a = host_b, host_a
+            sharding.gather_results(src_b, dist, world, out=gathered["bases"])
+            sharding.gather_results(src_a, dist, world, out=gathered["acts"])
 
     def fence():
         if use_dist:
@@ -275,9 +290,16 @@ def main():
     clocks = corpus.update_clocks()
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    # which global buffers every rank held (rank r must hold shard_range(world * B, world, r): the rehearsal test checks it)
+    rng = torch.tensor([g_begin, g_end], dtype=torch.int64, device=tmax.device)
+    ranges = torch.empty((world, 2), dtype=torch.int64, device=tmax.device)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_gather_into_tensor(ranges, rng)
+    else:
+        ranges[0] = rng
     elapsed_max = float(tmax.item())
+    shard_ranges = [[int(a), int(b)] for a, b in ranges.cpu().tolist()]
 
     # the same job with host buffers in and out (pageable memory over PCIe), once, outside the timed region:
     # SURVEY 8(d) "end-to-end BufNMF wall-clock (H2D -> W/H D2H)"
@@ -373,6 +395,7 @@ def main():
             "device": {"name": name, "arch": arch, "compute_units": cus,
                        "corpus_device_bytes": corpus.device_bytes()},
             "result_finite": finite, "result_checksum": checksum, "total_buffers": world * B,
+            "shard_ranges": shard_ranges,
             "backend": ("single process" if not use_dist else
                         ("rccl" if backend == "nccl" else backend + " (ranks share devices)") +
                         (" (one-rank group: the collectives of the N > 1 job executed on one GPU)" if world == 1 else "")),
@@ -382,11 +405,28 @@ def main():
             gpu_job_s = elapsed_max / args.steps / B   # per-buffer share of one step
             out["cpu_baseline"]["gpu_speedup_per_buffer_job"] = (
                 out["cpu_baseline"]["bufnmf_wall_s_200iter_est"] * (iters / WORKLOAD["iters"]) / gpu_job_s)
+        # the other BASELINE configs, timed by this process right behind the headline (outside its timed region): c2 and
+        # c3 are the shapes SURVEY 8(d) names beside c4, c5 is the feature pipeline.  One GPU, default workload only.
+        names = []
+        if args.configs == "auto":
+            headline = (B, K, iters) == (WORKLOAD["buffers_per_gpu"], WORKLOAD["rank"], WORKLOAD["iters"])
+            names = ["c2", "c3", "c5"] if (world == 1 and headline) else []
+        elif args.configs != "none":
+            names = [c for c in args.configs.split(",") if c]
+        if names and world == 1:
+            corpus.close()
+            corpus = None
+            del audio_dev, bases, acts
+            torch.cuda.empty_cache()
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            out["configs"] = bench_configs.bench_line_configs(ctx, names)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    corpus.close()
+    if corpus is not None:
+        corpus.close()
     ctx.close()
 
 

@@ -2,7 +2,14 @@
 
     python flucoma-core_amd/build.py [--force]
 
-Outputs flucoma-core_amd/lib/libflucoma_hip.so (git-ignored, shipped to the GPU box by gpurun).
+Outputs flucoma-core_amd/lib/libflucoma_hip.so (git-ignored, shipped to the GPU box by gpurun): the production library,
+one schedule per shape, no experiment switches.  build_ab() makes the two measurement builds beside it:
+
+    lib_ab/libflucoma_hip_ab.so   -DFLUHIP_AB_SWITCHES: the FLUHIP_* environment switches of DESIGN section 6b are live
+                                  (csrc/fluhip_env.h); tests/test_gpu_variants.py and the tools/ A/B scripts load it
+                                  (FLUHIP_AB=1 or FLUHIP_LIB=<path> for the Python binding)
+    lib_ab/libflucoma_hip_qc.so   the same with -DFLUHIP_QUOTIENT_CORRECTION=1: the factor-update quotients with the residual
+                                  correction (rounding-level instead of <= 2^-46), for the two-quotient comparison
 """
 from __future__ import annotations
 
@@ -16,6 +23,16 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libflucoma_hip.so")
+ABDIR = os.path.join(HERE, "lib_ab")
+LIB_AB = os.path.join(ABDIR, "libflucoma_hip_ab.so")
+LIB_QC = os.path.join(ABDIR, "libflucoma_hip_qc.so")
+# variant -> (object directory, extra defines, files compiled for it; the others are taken from `base`), base variant
+VARIANTS = {
+    "default": (OBJ, [], None, None),
+    "ab": (os.path.join(HERE, "build_ab"), ["-DFLUHIP_AB_SWITCHES"], None, None),
+    "qc": (os.path.join(HERE, "build_qc"), ["-DFLUHIP_AB_SWITCHES", "-DFLUHIP_QUOTIENT_CORRECTION=1"],
+           ["kernels_nmf5.hip", "kernels_nmf_strip.hip"], "ab"),
+}
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf_strip.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api.hip", "api_pool.cpp"]
@@ -41,14 +58,18 @@ def _newer(target, sources):
 EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans"], "kernels_nmf.hip": ["-fno-honor-nans"]}
 
 
-def _compile(src):
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+def _compile(src, variant="default"):
+    objdir, defines, only, base = VARIANTS[variant]
+    if only is not None and src not in only:
+        return _compile(src, base)
+    os.makedirs(objdir, exist_ok=True)
+    obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
     if _newer(obj, [path] + _deps() + [os.path.abspath(__file__)]):
         if src.endswith(".cpp"):   # host-only C++ above the C ABI: no device code, plain g++
-            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", "-c", path, "-o", obj]
+            cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", *defines, "-c", path, "-o", obj]
         else:
-            cmd = [HIPCC, *CXXFLAGS, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj]
+            cmd = [HIPCC, *CXXFLAGS, *defines, *EXTRA_FLAGS.get(src, []), "-c", path, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -57,25 +78,35 @@ def _compile(src):
     return obj
 
 
-def build(force: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
-    os.makedirs(LIBDIR, exist_ok=True)
+def _build_variant(variant: str, lib: str, force: bool = False) -> str:
+    objdir = VARIANTS[variant][0]
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(os.path.dirname(lib), exist_ok=True)
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if force:
         for s in srcs:
-            o = os.path.join(OBJ, os.path.splitext(s)[0] + ".o")
+            o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
             if os.path.exists(o):
                 os.remove(o)
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(_compile, srcs))
-    if force or _newer(LIB, objs):
-        tmp = LIB + f".tmp{os.getpid()}"
+    with ThreadPoolExecutor(max_workers=max(4, (os.cpu_count() or 4) - 2)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, variant), srcs))
+    if force or _newer(lib, objs):
+        tmp = lib + f".tmp{os.getpid()}"
         cmd = [HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-pthread", "-o", tmp, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-        os.replace(tmp, LIB)
-    return LIB
+        os.replace(tmp, lib)
+    return lib
+
+
+def build(force: bool = False) -> str:
+    return _build_variant("default", LIB, force)
+
+
+def build_ab(force: bool = False):
+    """the two measurement builds (see the module docstring); returns (ab, qc)"""
+    return _build_variant("ab", LIB_AB, force), _build_variant("qc", LIB_QC, force)
 
 
 def build_host_tests() -> str:
@@ -87,7 +118,8 @@ def build_host_tests() -> str:
                     for f in os.listdir(os.path.join(root, "include", "flucoma_hip"))]
     deps.append(os.path.join(root, "include", "flucoma_hip.h"))
     if _newer(out, deps) or _newer(out, [LIB]):
-        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", src, "-o", out, "-L" + LIBDIR,
+        # -DFLUHIP_AB_SWITCHES: the test driver keeps the client's channel-by-channel switch (FLUHIP_CLIENT_SEQUENTIAL)
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-DFLUHIP_AB_SWITCHES", src, "-o", out, "-L" + LIBDIR,
                "-lflucoma_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
@@ -100,3 +132,5 @@ def build_host_tests() -> str:
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv))
     print(build_host_tests())
+    if "--ab" in sys.argv:
+        print(*build_ab(force="--force" in sys.argv))

@@ -98,7 +98,7 @@ static int copy_to_host(fluhip_ctx* ctx, void* dst, size_t dpitch, const void* s
 {
   constexpr size_t kStage = (size_t) 8 << 20;
   const size_t total = width * rows;
-  static const int off = [] { const char* e = std::getenv("FLUHIP_PINNED_D2H"); return e && std::atoi(e) == 0 ? 1 : 0; }();
+  static const int off = [] { const char* e = fluhip::ab_getenv("FLUHIP_PINNED_D2H"); return e && std::atoi(e) == 0 ? 1 : 0; }();
   if (off || total < 2 * kStage || width > kStage)
   {
     HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, s));
@@ -467,7 +467,7 @@ static int update_variant(int Kp)
 {
   if (Kp > 128) return 0;
   static const int forced = [] {
-    const char* e = std::getenv("FLUHIP_NMF_KERNEL");
+    const char* e = fluhip::ab_getenv("FLUHIP_NMF_KERNEL");
     return e ? std::atoi(e) : 0;
   }();
   if (forced == -1) return 0;
@@ -486,7 +486,7 @@ static int64_t padded_rank(int64_t K)
 
 static int choose_split4(int64_t B, int C, int R, int Kp)
 {
-  static const int forceS = [] { const char* e = std::getenv("FLUHIP_PLAN_SPLIT"); return e ? std::atoi(e) : 0; }();
+  static const int forceS = [] { const char* e = fluhip::ab_getenv("FLUHIP_PLAN_SPLIT"); return e ? std::atoi(e) : 0; }();
   const int64_t nSteps = (R + 3) / 4;
   const int64_t smax = std::max<int64_t>(1, std::min<int64_t>(64, nSteps / 12)); // >= 12 steps per wavefront
   if (forceS > 0) return (int) std::min<int64_t>(std::min<int64_t>(forceS, 64), std::max<int64_t>(1, nSteps / 2)); // the finalize kernel sums at most 64 splits
@@ -530,8 +530,8 @@ static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
 // pieces; FLUHIP_TAIL_SLOTS: the wavefronts of a round (tests: small corpora take the path).
 static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
 {
-  static const int forceS = [] { const char* e = std::getenv("FLUHIP_TAIL_SPLIT"); return e ? std::atoi(e) : -1; }();
-  static const int slotsEnv = [] { const char* e = std::getenv("FLUHIP_TAIL_SLOTS"); return e ? std::atoi(e) : 0; }();
+  static const int forceS = [] { const char* e = fluhip::ab_getenv("FLUHIP_TAIL_SPLIT"); return e ? std::atoi(e) : -1; }();
+  static const int slotsEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_TAIL_SLOTS"); return e ? std::atoi(e) : 0; }();
   *stripsA = 0;
   if (forceS == 0) return 0;
   const int64_t slots = slotsEnv > 0 ? slotsEnv : 1024;
@@ -626,8 +626,8 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // Fast path: W stays un-normalised in memory during the loop (UpdateArgs::nrm), the column statistics
     // come out of the update kernel's epilogue and the Nyquist bin is a side column when that shortens the
     // widest strip of the MFMA kernel (fluhip_kernels.h SideColumn).
-    static const int lazyOff = [] { const char* e = std::getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
-    static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    static const int lazyOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
+    static const int sideOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
     c->lazy = !lazyOff && update_variant((int) c->Kp) == 5;
     c->sideW = false;
     if (c->lazy && !sideOff && c->nsplitW == 1 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
@@ -659,7 +659,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // quads per CU: 71 s at hop 512): two launches per iteration instead of five and V read once.  Longer buffers and
     // batches stay with the split / batched kernels, which win there (tools/strip_vs_split.py).  FLUHIP_STRIP=0 off,
     // =1 wherever the kernel supports the shape.
-    static const int stripEnv = [] { const char* e = std::getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
+    static const int stripEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
     c->strip = c->lazy && stripEnv != 0 && nmf_strip_supported((int) c->F, (int) c->T, (int) c->Kp) &&
                (stripEnv == 1 || (c->B == 1 && nmf_strip_workgroups((int) c->T) <= 512));
     if (c->strip)
@@ -670,7 +670,7 @@ static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
     // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
     // partials in memory.  FLUHIP_LIST_PLAN=0 keeps the uniform split schedule, =1 takes the lists whenever something is split.
-    static const int listEnv = [] { const char* e = std::getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
+    static const int listEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
     if (!c->strip && c->lazy && listEnv != 0 && (listEnv == 1 || [&] { const PlanShape ps{c->B, c->T, c->F, c->Kp}; return list_plan_pays(&ps); }()))
     {
       c->tOf.assign(B, (int) c->T);
@@ -788,12 +788,12 @@ static void build_list_plan(const std::vector<int>& tOf, int Tmax, int F, int Kp
   const int maxNG = nmf_update5_max_groups(Kp);
   // ---- W update: strips over the bins (the same for every buffer), the contraction over a buffer's own frames ------------
   {
-    auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+    auto envInt = [](const char* name, int dflt) { const char* e = fluhip::ab_getenv(name); return e ? std::atoi(e) : dflt; };
     std::vector<int> steps((size_t) B);
     for (int b = 0; b < B; b++) steps[(size_t) b] = (tOf[(size_t) b] + 3) / 4;
     // the Nyquist bin as a side column (fluhip_kernels.h SideColumn): every power-of-two transform has 16 m + 1 bins, and a
     // wavefront runs the loop of the widest strip of the launch -- 65 column groups never deal evenly
-    static const int sideOff = [] { const char* e = std::getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    static const int sideOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
     out.sideW = !sideOff && nmf_side_column_supported(Tmax, F, Kp);
     const int C = F - (out.sideW ? 1 : 0);
     const int G = (C + 15) / 16;
@@ -959,7 +959,7 @@ static void build_list_plan(const std::vector<int>& tOf, int Tmax, int F, int Kp
       }
     }
     {
-      auto envInt = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+      auto envInt = [](const char* name, int dflt) { const char* e = fluhip::ab_getenv(name); return e ? std::atoi(e) : dflt; };
       NG = std::max(1, std::min(maxNG, envInt("FLUHIP_RG_HNG", NG)));
       gsz = envInt("FLUHIP_RG_HG", gsz);
       ns = envInt("FLUHIP_RG_HM", ns);
@@ -1443,7 +1443,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
     // 0.319 ms per round against 0.271 - 0.278 for one-round launches (profiles/r03/bench_v*_1024_buffers_one_gpu.json).
     // With a progress callback the iterations stay outermost: "iteration i" means every buffer has passed it.
     // FLUHIP_ROUND_MAJOR=0: iteration-major as before.
-    static const int roundEnv = [] { const char* e = std::getenv("FLUHIP_ROUND_MAJOR"); return e ? std::atoi(e) : 1; }();
+    static const int roundEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_ROUND_MAJOR"); return e ? std::atoi(e) : 1; }();
     int64_t chunk = 0;
     if (roundEnv && !c->strip && !c->useLists && c->lazy && c->nsplitW == 1 && c->nsplitH == 1 && update_variant((int) c->Kp) == 5)
     {
@@ -1480,7 +1480,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
       // FLUHIP_GRAPH_ITERS=n (experiment, default off -- DESIGN.md "hipGraph"): after the first iteration, runs of n iterations
       // are captured once as a hipGraph and replayed; the last iterations (fewer than n + 1) are enqueued as usual.  n even: the
       // frame-strip schedule alternates two statistics buffers.  Not with the profiler's events in the stream.
-      static const int graphN = [] { const char* e = std::getenv("FLUHIP_GRAPH_ITERS"); return e ? std::atoi(e) & ~1 : 0; }();
+      static const int graphN = [] { const char* e = fluhip::ab_getenv("FLUHIP_GRAPH_ITERS"); return e ? std::atoi(e) & ~1 : 0; }();
       int64_t i = 0;
       if (graphN >= 2 && !ctx->prof && iters >= 2 * (int64_t) graphN + 2)
       {
@@ -1903,7 +1903,7 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   // Batched form (kernels_stft2.hip resynth_seq_kernel): every component of a group of buffers in one launch, the
   // overlap-add in registers -- no windowed frames in memory (the per-buffer path below writes and re-reads K T win doubles
   // per buffer: 58 GB each way on the bench shard, 85 ms against 113 ms for 200 iterations).  FLUHIP_RESYNTH_BATCH=0 off.
-  static const int batchEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_BATCH"); return e ? std::atoi(e) : 1; }();
+  static const int batchEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_RESYNTH_BATCH"); return e ? std::atoi(e) : 1; }();
   if (batchEnv != 0 && resynth_batch_supported((int) c->win, (int) c->fft, (int) c->hop))
   {
     // buffers per launch: the reciprocal V-hat of a group within ~1 GiB
@@ -2855,7 +2855,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
     std::vector<int64_t> interval((size_t) F, -1); // interval of bin f, -1: no band touches it
     bool ok = nBands <= 64 && (!mfcc || nDct * nBands <= 4096) && !stft_needs_scratch(win, fft) && (fft == 1024 || fft == 2048) &&
               (win % 2) == 0;
-    if (const char* e = std::getenv("FLUHIP_FEAT_FUSED")) // A/B and tests: 0 forces the two-kernel form
+    if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_FUSED")) // A/B and tests: 0 forces the two-kernel form
       if (std::atoi(e) == 0) ok = false;
     std::vector<int64_t> peak((size_t) nBands, 0);
     for (int64_t b = 0; ok && b < nBands; b++)
@@ -2936,7 +2936,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
       const bool outDev = hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeDevice;
       (void) hipGetLastError();
       int64_t chunkBytes = (int64_t) 1 << 31;
-      if (const char* e = std::getenv("FLUHIP_FEAT_CHUNK_BYTES")) chunkBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
+      if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CHUNK_BYTES")) chunkBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
       const int64_t chunkB = (audDev && outDev) ? count
                                                 : std::max<int64_t>(1, std::min<int64_t>(count, chunkBytes / (n * (int64_t) sizeof(float))));
       if (!audDev) HIPCHK(ctx, dAud.alloc((size_t) chunkB * n * sizeof(float), false, s));
@@ -2987,7 +2987,7 @@ static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64
   // buffers are processed in chunks that keep the magnitude scratch around 2 GiB
   const int64_t perBuf = Tp * Fp * (int64_t) sizeof(double);
   int64_t scratchBytes = 2LL << 30;
-  if (const char* e = std::getenv("FLUHIP_FEAT_CHUNK_BYTES")) scratchBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
+  if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CHUNK_BYTES")) scratchBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
   const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(count, 65535), scratchBytes / perBuf));
   HIPCHK(ctx, dAudio.alloc((size_t) chunk * n * sizeof(float), false, s));
   HIPCHK(ctx, dMag.alloc((size_t) chunk * perBuf, true, s));

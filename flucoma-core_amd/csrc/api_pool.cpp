@@ -8,6 +8,7 @@
 // one host process owns all devices ("D2H per GPU is equally valid").  Built on the public corpus entry
 // points only, so it is also a usage example of them.  Plain C++17, no HIP in this file.
 #include "../../include/flucoma_hip.h"
+#include "fluhip_env.h"
 
 #include <algorithm>
 #include <atomic>
@@ -133,7 +134,7 @@ int fluhip_pool_bufnmf_job_f32(fluhip_pool* p, const fluhip_bufnmf_job* job, flu
       // on the context's copy stream -- while slice i iterates: the factor updates are enqueued asynchronously, the upload
       // of the next slice blocks only this host thread, the write-back of slice i then waits for its iterations
       // (SURVEY section 7 step 5).  Buffers are independent jobs: slicing changes no result.
-      static const bool slicesOff = [] { const char* e = std::getenv("FLUHIP_POOL_SLICES"); return e && std::atoi(e) == 0; }(); // A/B
+      static const bool slicesOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_POOL_SLICES"); return e && std::atoi(e) == 0; }(); // A/B
       const int64_t sliceMax = (!progress && !slicesOff && b1 - b0 >= 512) ? 256 : 65535;
       auto prepare = [&](int64_t s0, int64_t nb, fluhip_corpus** out) -> int {
         int rc = fluhip_corpus_create(ctx, nb, j.n, j.win, j.fft, j.hop, j.K, out);

@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fluhip_env.h"
+
 namespace fluhip {
 
 constexpr double kEpsilon = 2.220446049250313e-16; // util/AlgorithmUtils.hpp:19

@@ -644,7 +644,7 @@ static int side_slices_for(int R, int Kp)
 {
   const int cap = side_chunk_rows(Kp);
   // FLUHIP_SIDE_SLICES=n (tests): at most n slices, so that ordinary shapes take several chunks per slice
-  static const int cap2 = [] { const char* e = std::getenv("FLUHIP_SIDE_SLICES"); return e ? std::max(1, std::atoi(e)) : 0; }();
+  static const int cap2 = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_SLICES"); return e ? std::max(1, std::atoi(e)) : 0; }();
   if (cap2 > 0) return std::min(std::min(kSideSlices, cap2), std::max(1, (R + cap - 1) / cap));
   return std::min(kSideSlices, std::max(16, (R + cap - 1) / cap));
 }
@@ -673,7 +673,7 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     // (profiles/r03/ab_side_fused.txt): 58 us between the two factor updates instead of 18, 217.9 k against 224.9 k
     // buffer-iterations/s -- 2048 small workgroups each pay an agent-scope release (and the last ones an acquire) of
     // ~1.7 us, eight deep per CU; the kernel boundary is the cheaper synchronisation here.  Off by default.
-    static const bool fused = [] { const char* e = std::getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();
+    static const bool fused = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();
     SideFuse fz{nullptr, nullptr, nullptr, 0, 0, nullptr};
     if (fused)
       fz = SideFuse{reinterpret_cast<int*>(wold + (int64_t) B * Kp), S, statPart, nStrips, K, nrm};

@@ -733,7 +733,7 @@ static void launch_strip_q(const StripK& k, int B, hipStream_t s)
   {
     if constexpr (NPW == 9)
     {
-      static const int instr = [] { const char* e = std::getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
+      static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
       if (instr && k.doH && k.doW) { launch_strip_t<9, kNQ, true>(k, B, s); return; }
     }
     launch_strip_t<NPW, kNQ>(k, B, s);

@@ -688,7 +688,7 @@ void launch_stft(const StftArgs& a, hipStream_t s)
     return;
   }
   {
-    static const bool generic = std::getenv("FLUHIP_STFT_GENERIC") != nullptr;
+    static const bool generic = fluhip::ab_getenv("FLUHIP_STFT_GENERIC") != nullptr;
     // wave-per-frame kernels: power-of-two fft with an even window (pairs of window values)
     if (!generic && (a.win % 2) == 0)
     {

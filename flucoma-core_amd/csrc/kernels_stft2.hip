@@ -896,7 +896,7 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
   constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * FPW * BUFD * 8;
   static_assert(shmem <= 160 * 1024, "LDS");
   StftBArgs k = k0;
-  static const int pf = [] { const char* e = std::getenv("FLUHIP_STFT_PREFETCH"); return e ? std::atoi(e) : 1; }();
+  static const int pf = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_PREFETCH"); return e ? std::atoi(e) : 1; }();
   k.prefetch = pf;
   k.blocksPerBuf = (k.T + NW * FPW - 1) / (NW * FPW);
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
@@ -917,7 +917,7 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
 bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int64_t ldMagT, hipStream_t s)
 {
   if ((a.win % 2) != 0 || a.win > a.fft) return false;
-  static const bool off = [] { const char* e = std::getenv("FLUHIP_STFT_BLOCK"); return e && std::atoi(e) == 0; }();
+  static const bool off = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_BLOCK"); return e && std::atoi(e) == 0; }();
   if (off) return false;   // A/B: the round-1 wave kernel + transposing copy
   StftBArgs k;
   k.audio = a.audio; k.audio64 = a.audio64; k.n = a.n; k.audioStride = a.audioStride;
@@ -938,7 +938,7 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
     // the LDS: it is read through the L1).  Built on the round-2 review's suggestion and measured on one box, back to back:
     // 803 / 820 us against 765 / 783 us for the one-frame form (profiles/r03/stft_fpw.txt) -- full lines are not what the
     // phase waits for (fft 1024 already writes 128-byte pieces and runs at the same bytes per second), so it stays off.
-    static const int fpw = [] { const char* e = std::getenv("FLUHIP_STFT_FPW"); return e ? std::atoi(e) : 1; }();
+    static const int fpw = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_FPW"); return e ? std::atoi(e) : 1; }();
     if (fpw == 2) return launch_block_t<16, 8, 8, 8, 0, 2>(k, s);
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
   }
@@ -1279,7 +1279,7 @@ static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
   const size_t shmem = ((size_t) Core::T2 + Core::T3 + Core::N) * 16 + (size_t) a.hop * 8 + (size_t) NW * Core::BUFD * 8;
   const int64_t sFirst = a.trim / a.hop, sLast = (a.n - 1 + a.trim) / a.hop;
   const int64_t slots = sLast - sFirst + 1;
-  static const int runEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_RUN"); return e ? std::atoi(e) : 0; }();
+  static const int runEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_RESYNTH_RUN"); return e ? std::atoi(e) : 0; }();
   // A run's first win / hop - 1 frames only fill the state (2 % at 128 slots and hop = win / 4; measured on the bench shard:
   // 32 slots 26.1 ms, 64: 26.1, 128: 25.3, 256: 28.8 -- too few workgroups per buffer there).  Few buffers / components:
   // shorter runs, down to 8 slots, until there are some 1024 workgroups (a single buffer's frames are otherwise walked by
@@ -1294,7 +1294,7 @@ static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
   const int64_t wgs = ((pairs + 7) / 8) * 8 * kGroups;
   // the workgroup's spectrum / V-hat rows through the LDS (see the kernel) from rank NW on: 25.3 -> 19.2 ms on the bench shard,
   // alternating on one box; FLUHIP_RESYNTH_SHARED=0: every wavefront loads its own
-  static const int sharedEnv = [] { const char* e = std::getenv("FLUHIP_RESYNTH_SHARED"); return e ? std::atoi(e) : 1; }();
+  static const int sharedEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_RESYNTH_SHARED"); return e ? std::atoi(e) : 1; }();
   const bool shared = sharedEnv != 0 && a.K >= NW;
   const size_t shmemS = shmem + (size_t) (2 * (Core::N + 2) * 2 + 2 * (Core::N + 2)) * 8;
   auto go = [&](auto kern, size_t sh) {

@@ -12,8 +12,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FLUHIP_LIB: another build of the library (A/B timing of two source states on one GPU box)
-LIB_PATH = os.environ.get("FLUHIP_LIB") or os.path.join(_HERE, "lib", "libflucoma_hip.so")
+# FLUHIP_LIB: another build of the library (A/B timing of two source states on one GPU box); FLUHIP_AB=1: the build with the
+# experiment switches of DESIGN 6b compiled in (build.py build_ab) -- the production library does not read them
+LIB_AB_PATH = os.path.join(_HERE, "lib_ab", "libflucoma_hip_ab.so")
+LIB_QC_PATH = os.path.join(_HERE, "lib_ab", "libflucoma_hip_qc.so")
+LIB_PATH = os.environ.get("FLUHIP_LIB") or (LIB_AB_PATH if os.environ.get("FLUHIP_AB") == "1" else
+                                            os.path.join(_HERE, "lib", "libflucoma_hip.so"))
 
 OK, WARNING, ERROR, CANCELLED = 0, 1, 2, 3
 

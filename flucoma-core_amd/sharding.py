@@ -30,15 +30,23 @@ def balanced_assignment(costs, world: int):
     return out
 
 
-def gather_results(local, dist_module, world: int):
+def gather_buffer(local, world: int):
+    """The receive side of gather_results, allocated ONCE by a caller that gathers every step (bench.py): 31 MB per rank
+    for the config-4 shard, i.e. a world x 31 MB allocation that has no place inside a timed step."""
+    import torch
+    return torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+
+
+def gather_results(local, dist_module, world: int, out=None):
     """All-gather equal-shape per-rank result tensors so that every rank holds the whole corpus'
     dictionaries / activations in global buffer order (rank-major == contiguous-block order).
-    `local` is [B_local, ...]; returns [world * B_local, ...]."""
-    import torch
+    `local` is [B_local, ...]; returns [world * B_local, ...] (`out` when the caller supplies the buffer)."""
     if world == 1 and not (dist_module is not None and dist_module.is_initialized()):
         return local
     # with an initialised process group the collective runs for ANY world size, also a one-rank group: bench.py with
     # FLUHIP_BENCH_BACKEND set and the 1-GPU RCCL test execute exactly what the N > 1 job executes
-    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if out is None:
+        out = gather_buffer(local, world)
+    assert out.shape[0] == world * local.shape[0] and out.dtype == local.dtype and out.device == local.device
     dist_module.all_gather_into_tensor(out, local.contiguous())
     return out

@@ -544,8 +544,12 @@ public:
 private:
   static bool sequentialForced()
   {
+#ifdef FLUHIP_AB_SWITCHES // test / measurement builds of a host: the channel-by-channel loop on request
     const char* e = std::getenv("FLUHIP_CLIENT_SEQUENTIAL");
     return e && std::atoi(e) != 0;
+#else
+    return false;
+#endif
   }
   NMFParams*  mParams;
   fluhip_ctx* mCtx{nullptr};

@@ -50,6 +50,27 @@ def fluhip_lib_path():
 
 
 @pytest.fixture(scope="session")
+def ab_lib_paths():
+    """The two measurement builds (build.py build_ab): (experiment switches live, + the corrected quotient).  Built here
+    when missing or stale -- the tests that exercise the non-production kernel forms build what they load."""
+    spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build_ab()
+
+
+@pytest.fixture(scope="session")
+def ab_ctx(ab_lib_paths):
+    """a context of the build whose FLUHIP_* experiment switches are live (tests that set one in-process)"""
+    import fluhip
+    lib = fluhip.load_library(ab_lib_paths[0])
+    assert lib.fluhip_device_count() > 0, "no HIP device visible: gpu tests need a real MI355X"
+    c = fluhip.Context(0, lib)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
 def driver(fluhip_lib_path):
     """tests/cpp/client_driver.cpp built against the in-tree library: the C++17 host client as a host wrapper uses it"""
     spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))

@@ -22,10 +22,11 @@ def _tiled(onp, n, seed):
 
 
 def test_c2_full_size_vs_oracle(ctx, oracle, onp):
-    """BASELINE config 2 (60 s mono, fft 2048 / hop 512, rank 16) through the client-level entry point, 20 of its 200
-    iterations, against the oracle on the same samples: spectrogram <= 1e-12, factors <= 1e-9 (f64), float outputs."""
+    """BASELINE config 2 (60 s mono, fft 2048 / hop 512, rank 16) through the client-level entry point, ALL 200 of its
+    iterations, against the oracle on the same samples (lean mode: the "ones" GEMMs as sums, ~10 s of one core):
+    spectrogram <= 1e-12, factors <= 1e-9 (f64), float outputs."""
     import fluhip
-    n, win, fft, hop, K, iters = 2646000, 2048, 2048, 512, 16, 20
+    n, win, fft, hop, K, iters = 2646000, 2048, 2048, 512, 16, 200
     x = _tiled(onp, n, 1000)
     c = fluhip.Corpus(ctx, 1, n, win, fft, hop, K)
     assert (c.T, c.F) == (5168, 1025)
@@ -75,9 +76,11 @@ def test_c3_stereo_through_the_threaded_client(driver, oracle, onp, tmp_path, ct
 
 
 def test_c3_decimated_twin_all_iterations_shape(driver, oracle, onp, tmp_path, ctx):
-    """the same stereo job on a 12 s twin (fft 4096 / hop 1024, rank 128), more iterations, both channels vs the oracle"""
+    """the same stereo job on a 12 s twin (fft 4096 / hop 1024, rank 128), ALL 500 iterations of config 3, both channels
+    vs the oracle (~30 s of one core per channel): the long-iteration regime at rank 128 -- entries decaying to eps,
+    the deferred normalisation carried over 500 updates -- against the restatement, not only by properties"""
     frames, chans = 529200, 2
-    win, hop, fft, K, iters, seed = 4096, 1024, 4096, 128, 12, 42
+    win, hop, fft, K, iters, seed = 4096, 1024, 4096, 128, 500, 42
     audio = np.stack([onp.synth_audio(frames, 1000 + c) for c in range(chans)], axis=1)
     inp = tmp_path / "c3s.f32"
     audio.astype(np.float32).tofile(inp)
@@ -92,12 +95,13 @@ def test_c3_decimated_twin_all_iterations_shape(driver, oracle, onp, tmp_path, c
 
 
 @pytest.mark.parametrize("fused", [1, 0])
-def test_c5_multi_chunk_feature_path(ctx, oracle, onp, fused):
+def test_c5_multi_chunk_feature_path(ab_ctx, oracle, onp, fused):
     """BASELINE config 5's shape at a count that takes fluhip_bufmfcc_f32 through several chunks of its staging
     buffers (the chunk loop, its per-chunk offsets and synchronisation), in both forms -- the fused STFT -> mel -> DCT
     kernel and the two-kernel form with the magnitudes in HBM: first / boundary / last slices against the oracle,
     every slice against the single-slice call of the same audio.  (FLUHIP_FEAT_CHUNK_BYTES shrinks the chunks: at their
     production size of 2 GiB a test would need tens of thousands of slices to cross one.)"""
+    ctx = ab_ctx                                 # the build in which the two switches below are live
     n, win, fft, hop = 88200, 1024, 1024, 512
     distinct = np.stack([onp.synth_audio(n, 1000 + b) for b in range(16)])
     count = 3000
@@ -348,6 +352,29 @@ def test_bench_two_ranks_as_a_bare_command():
     # buffers per launch), which moves f64 sums by rounding only
     assert two["result_checksum"] == pytest.approx(one["result_checksum"], rel=1e-6)
     assert two["value"] > 0 and two["steps"] == 2
+
+
+def test_bench_eight_ranks_rehearsed_on_one_gpu():
+    """The 8-rank job of BASELINE config 4 rehearsed on the one GPU that exists: `python bench.py --gpus 8`
+    as the driver's SCALE run issues it, ranks sharing device 0 over gloo -- rendezvous on 127.0.0.1, eight processes each
+    synthesising and uploading its own shard, the gather into buffers allocated once outside the steps -- against one rank
+    running the same 32 buffers: same order-sensitive checksum, rank r holds shard_range(32, 8, r), under two minutes."""
+    import time
+    sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
+    import sharding
+    common = ["--steps", "1", "--warmup", "1", "--iters", "3", "--no-cpu-baseline"]
+    t0 = time.perf_counter()
+    eight = _bench(["--gpus", "8", "--buffers", "4", *common], env={"FLUHIP_BENCH_BACKEND": "gloo"})
+    wall = time.perf_counter() - t0
+    one = _bench(["--gpus", "1", "--buffers", "32", *common])
+    assert eight["n_gpus"] == 8 and eight["total_buffers"] == one["total_buffers"] == 8 * 4
+    assert eight["shard_ranges"] == [list(sharding.shard_range(32, 8, r)) for r in range(8)]
+    assert one["shard_ranges"] == [[0, 32]]
+    assert eight["result_finite"] and "gloo" in eight["backend"]
+    assert eight["result_checksum"] == pytest.approx(one["result_checksum"], rel=1e-6)
+    assert "configs" not in eight and "configs" not in one        # the other configs ride on the default headline only
+    print(f"bench.py --gpus 8 on one GPU: {wall:.1f} s wall")
+    assert wall < 120.0, wall
 
 
 def test_bench_one_rank_rccl_group_executes_the_collectives():

@@ -93,9 +93,10 @@ assert worst < 1e-9, worst
 '''
 
 
-def test_strip_schedule_against_the_oracle():
+def test_strip_schedule_against_the_oracle(ab_lib_paths):
     e = dict(os.environ)
     e["FLUHIP_STRIP"] = "1"
+    e["FLUHIP_LIB"] = ab_lib_paths[0]
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
 

@@ -76,9 +76,50 @@ for k in range(9):
                                  {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
                                  {"FLUHIP_SIDE_SLICES": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-def test_alternative_kernel_forms_against_the_oracle(env):
+def test_alternative_kernel_forms_against_the_oracle(env, ab_lib_paths):
     e = dict(os.environ)
     e.update(env)
+    e["FLUHIP_LIB"] = ab_lib_paths[0]        # the build that reads the switches; the production library ignores them
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=600, env=e)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
     assert ("plan 0 " if env.get("FLUHIP_NMF_KERNEL") == "-1" else "plan 5 ") in p.stdout, p.stdout
+
+
+def test_the_two_quotients_after_500_iterations_at_rank_128(ab_lib_paths, fluhip_lib_path):
+    """The factor updates take V / max(WH, eps) with a Newton-refined reciprocal (relative error <= 2^-46, kernels_nmf5.hip
+    `quotient`); -DFLUHIP_QUOTIENT_CORRECTION=1 adds the residual step that makes it a rounding-level quotient.  Config 3's
+    regime -- rank 128, all 500 iterations, 12 s twin of the 10-minute channel -- with BOTH builds against the oracle
+    (<= 1e-9 each, the bar of every other parity test) and against each other; the distances go to
+    gpurun_out/quotient_500it_rank128.json (copied to profiles/ per round)."""
+    import json
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fluhip
+    import oracle_c
+    import oracle_np
+    from helpers import rel_err
+    n, win, fft, hop, K, iters = 529200, 4096, 4096, 1024, 128, 500
+    x = oracle_np.synth_audio(n, 1000)
+    got = {}
+    for tag, path in (("default", fluhip_lib_path), ("corrected", ab_lib_paths[1])):
+        lib = fluhip.load_library(path)
+        c0 = fluhip.Context(0, lib)
+        c = fluhip.Corpus(c0, 1, n, win, fft, hop, K)
+        c.set_audio(x[None, :]); c.stft(); c.nmf(iters, seed=42)
+        mag, W1, H1 = c.read_f64()
+        got[tag] = (W1[0].copy(), H1[0].copy())
+        c.close(); c0.close()
+    o = oracle_c.get("native")
+    rW, rH, _, _ = o.nmf_process(mag[0], K, iters, True, True, 42)
+    rec = {"shape": {"frames": int(mag.shape[1]), "bins": int(mag.shape[2]), "rank": K, "iterations": iters}}
+    for tag, (W1, H1) in got.items():
+        rec[tag + "_vs_oracle"] = {"W": rel_err(W1, rW), "H": rel_err(H1, rH)}
+        assert rel_err(W1, rW) < 1e-9 and rel_err(H1, rH) < 1e-9, (tag, rec)
+    rec["default_vs_corrected"] = {"W": rel_err(got["default"][0], got["corrected"][0]),
+                                   "H": rel_err(got["default"][1], got["corrected"][1])}
+    print(json.dumps(rec))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "quotient_500it_rank128.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert rec["default_vs_corrected"]["W"] < 1e-9 and rec["default_vs_corrected"]["H"] < 1e-9

@@ -230,6 +230,26 @@ def test_reference_wav_c1_when_available(oracle, onp):
     assert rel_err(bases, b2) < 1e-6 and rel_err(acts, a2) < 1e-6
 
 
+def test_c1_fixture_both_oracles(oracle, onp):
+    """tests/golden/reference_c1.npz (tools/make_reference_c1_fixture.py): BASELINE config 1 on its named input -- the
+    bundled loop's own samples travel as data -- and what both restatements make of it (T = 887, F = 513, rank 3,
+    50 iterations, seed 42): the C oracle and the numpy oracle reproduce the stored probes here, the HIP path on the GPU
+    (tests/test_gpu_parity.py::test_c1_on_the_named_input)."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_c1.npz"))
+    win, fft, hop, K, iters, seed = (int(v) for v in g["params"])
+    x = g["pcm16"].astype(np.float32) / 32768.0
+    assert len(x) == 453932 and (win, fft, hop, K, iters, seed) == (1024, 1024, 512, 3, 50, 42)
+    bases, acts, mag = oracle.bufnmf_channel(x, win, fft, hop, K, iters, seed, want_mag=True)
+    assert mag.shape == tuple(g["frames_bins"]) == (887, 513)
+    pb, pa = g["probe_bases_idx"], g["probe_acts_idx"]
+    assert np.array_equal(bases[pb[:, 0], pb[:, 1]], g["probe_bases_c"])
+    assert np.array_equal(acts[pa[:, 0], pa[:, 1]], g["probe_acts_c"])
+    assert rel_err(mag[::97, ::31], g["mag_probe"]) < 1e-14
+    assert np.allclose(g["probe_bases_c"], g["probe_bases_np"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(g["probe_acts_c"], g["probe_acts_np"], rtol=1e-6, atol=1e-9)
+    assert np.allclose(g["sums_c"], g["sums_np"], rtol=1e-6)
+
+
 def test_process_frame_c_vs_numpy():
     """alg/NMF.hpp:45-89 restated twice (C and numpy) must agree; and the update must not move a frame
     that the dictionary already explains exactly (fixed point of the KL multiplicative update)."""

@@ -79,7 +79,11 @@ def _worker(rank, world, port, q):
         acts.append(aa)
     lb, la = torch.from_numpy(np.stack(bases)), torch.from_numpy(np.stack(acts))
     gb = sharding.gather_results(lb, dist, world)
-    ga = sharding.gather_results(la, dist, world)
+    # the form bench.py uses: the receive buffer allocated once, the collective run every step into it
+    buf = sharding.gather_buffer(la, world)
+    for _ in range(2):
+        ga = sharding.gather_results(la, dist, world, out=buf)
+    assert ga.data_ptr() == buf.data_ptr()
     dist.barrier()
     q.put((rank, gb.numpy(), ga.numpy()))
     dist.destroy_process_group()

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # tools/batch_plan_sweep.sh <B> <plans...>  with plan = W:SPLIT (strips per buffer : contraction splits; 0 = planner's own)
 B=$1; shift
 for plan in "$@"; do

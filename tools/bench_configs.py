@@ -2,6 +2,9 @@
 
     python tools/bench_configs.py [c1] [c2] [c3] [c4x1] [c5] [resynth] [--no-cpu] [--prof]
 
+(bench.py imports this module to run c2 / c3 / c5 behind its headline and put their driver-timed figures into the same
+JSON line: `configs`.  It lives under tools/, not in the package, because its cpu_baseline legs call the oracle.)
+
 The configs other than c4 are parity-test shapes, not bench.py lines; this tool is what DESIGN section 6 quotes for
 them and what the rocprofv3 summaries under profiles/ were taken on (tools/profile_configs.sh).  Work per unit is
 SURVEY 8(d)'s: one NMF iteration = 8 F T K flop and (2 F T + 4 (F K + K T)) 8 bytes; one STFT frame = hop 4 + F 8
@@ -159,7 +162,7 @@ def run_nmf_config(ctx, name, with_cpu):
         out["cpu_baseline"] = cpu_nmf(np.ascontiguousarray(mag), K, 42)
         out["cpu_baseline"]["gpu_speedup_per_channel_iteration"] = (1.0 / per_it) / out["cpu_baseline"]["value"]
     cor.close()
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def run_c5(ctx, with_cpu):
@@ -218,7 +221,7 @@ def run_c5(ctx, with_cpu):
         cpu = (time.perf_counter() - t0) / 32
         res["cpu_baseline"] = {"value": T / cpu, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": "32 of the 8192 slices, oracle BufMFCC, gcc -O3 -march=native"}
-    print(json.dumps(res), flush=True)
+    return res
 
 
 def run_resynth(ctx):
@@ -258,7 +261,33 @@ def run_resynth(ctx):
                         "per": "whole call (reciprocal V-hat pre-pass + the batched kernel)"},
            "device": device_line(ctx)}
     c.close()
-    print(json.dumps(res), flush=True)
+    return res
+
+
+def bench_line_configs(ctx, names=("c2", "c3", "c5")):
+    """What bench.py appends to its JSON line as `configs`: the BASELINE configs other than the headline, timed by the same
+    process right behind it (SURVEY 8(d) names c2 and c3 beside c4; c5 is the feature pipeline).  One compact entry per
+    config -- time per unit, the roofline that bounds it with the algorithmic work per unit -- or {"error": ...}."""
+    out = {}
+    for name in names:
+        t0 = time.perf_counter()
+        try:
+            if name == "c5":
+                r = run_c5(ctx, False)
+                e = {"workload": r["workload"], "ms": r.get("ms"), "value": r["value"], "unit": r["unit"],
+                     "kernel_ms": r.get("kernel_ms"), "roofline": r.get("roofline"), "shape": r["shape"]}
+            else:
+                r = run_nmf_config(ctx, name, False)
+                e = {"workload": r["workload"], "us_per_iteration": r["us_per_iteration"], "value": r["value"],
+                     "unit": r["unit"], "iterations_timed": r["shape"]["iterations_timed"],
+                     "roofline": r["roofline"], "kernel_ms_per_iteration": r["kernel_ms_per_iteration"],
+                     "stft_frames_per_s": r["stft_frames_per_s"], "roofline_stft": r["roofline_stft"],
+                     "schedule": r["schedule"], "shape": r["shape"]}
+        except Exception as ex:  # a config that fails must not take the headline line with it
+            e = {"error": f"{type(ex).__name__}: {ex}"}
+        e["wall_s"] = time.perf_counter() - t0
+        out[name] = e
+    return out
 
 
 def main():
@@ -268,11 +297,12 @@ def main():
     ctx = fluhip.Context(0)
     for name in names:
         if name == "c5":
-            run_c5(ctx, with_cpu)
+            res = run_c5(ctx, with_cpu)
         elif name == "resynth":
-            run_resynth(ctx)
+            res = run_resynth(ctx)
         else:
-            run_nmf_config(ctx, name, with_cpu)
+            res = run_nmf_config(ctx, name, with_cpu)
+        print(json.dumps(res), flush=True)
     ctx.close()
 
 

@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # equal-length corpora beyond two rounds of wavefronts (B x 10 s, rank 32): the planner's choice against the forced forms
 for B in 288 400 520 900 1000; do
   for v in "A=1" "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do

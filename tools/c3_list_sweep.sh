@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # c3 (2 x 10 min, rank 128) under schedule switches: bash tools/c3_list_sweep.sh
 run() { echo "== $*"; env "$@" python tools/bench_configs.py c3 --no-cpu 2>&1 | tail -1 | python -c "
 import sys,json

@@ -1,5 +1,6 @@
 """wall time of a mono 10 s rank-32 BufNMF job through the C++ client, without and with resynthesis: python tools/client_mono_timing.py"""
 import os, sys, subprocess, tempfile
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))

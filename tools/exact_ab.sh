@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 for B in 256 512 1024 128; do
   for v in "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do
     echo "B=$B $v: $(env $v timeout 400 python tools/batch_timing.py $B 10 32 40 2>/dev/null | python -c "

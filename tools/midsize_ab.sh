@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # equal-length corpora between one and two rounds of the 1024 SIMDs (10 s buffers, rank 32): the planner's choice (work lists), the
 # uniform schedule (FLUHIP_LIST_PLAN=0; with FLUHIP_TAIL_SPLIT=0 without the two-launch H update)
 for B in 144 176 200 232 250; do

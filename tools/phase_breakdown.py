@@ -1,5 +1,6 @@
 """Per-phase cycle breakdown of one wavefront of the W-update (FLUHIP_K5_INSTR=1 build path)."""
 import ctypes, os, sys
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd")); sys.path.insert(0, os.path.join(ROOT, "oracle"))

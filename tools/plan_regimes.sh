@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # the planner's choice against the forced forms over corpus shapes off the BASELINE configs: B buffers x seconds at rank K
 # (tools/batch_timing.py; us per iteration of the whole corpus, without / with a progress callback)
 while read B secs K it; do

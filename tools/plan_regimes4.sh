@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # rank 128, few buffers: uniform schedule (FLUHIP_LIST_PLAN=0) against work lists (=1)
 while read B secs K it; do
   for v in "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do

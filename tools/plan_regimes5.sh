@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # other transform sizes: uniform schedule (FLUHIP_LIST_PLAN=0) against the planner's choice (A=1) and forced lists (=1)
 while read B secs K it fft hop; do
   for v in "A=1" "FLUHIP_LIST_PLAN=0" "FLUHIP_LIST_PLAN=1"; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 export TMPDIR=/tmp
 cfg=$1; shift
 for plan in "$@"; do

@@ -3,6 +3,7 @@
 wall time of the job; FLUHIP_POOL_SLICES=0 runs a device's share as one corpus (upload, then compute) instead of slices whose
 uploads overlap the previous slice's iterations."""
 import sys, os, time, json
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))

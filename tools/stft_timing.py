@@ -1,6 +1,7 @@
 """STFT phase time for corpus shapes (both magnitude layouts written): python tools/stft_timing.py
 FLUHIP_STFT_BLOCK selects the block-kernel variant (0 = the round-1 wave kernel + transposing copy)."""
 import sys, time, numpy as np, os
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))
 import fluhip, synth

@@ -2,6 +2,7 @@
 the phase stamps of workgroup 0 (FLUHIP_STRIP_INSTR=1: shader-clock and 100 MHz stamps around staging / H phase /
 combine / W phase / partial stores).   usage: python tools/strip_timing.py [seconds=60] [rank=16] [fft=2048]"""
 import ctypes, os, sys, time
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "flucoma-core_amd"))

@@ -2,6 +2,7 @@
 single buffers of several lengths / fft sizes / ranks <= 16: where the planner's threshold comes from.
 usage: python tools/strip_vs_split.py"""
 import os, subprocess, sys
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CHILD = r'''
 import os, sys, time

@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 # config 3 with the H update as one launch (FLUHIP_TAIL_SPLIT=0) against two (api.hip plan_tail; =3 / =5 force the pieces), alternating on one box
 set -x
 cd /root/repo

@@ -3,6 +3,7 @@ one launch of 1024 in lock step?  Two contexts (= two streams), one 64-buffer co
 one 128-buffer corpus.  Run with FLUHIP_LIST_PLAN=0 FLUHIP_PLAN_SPLIT=1 (whole contractions, the uniform kernel):
     FLUHIP_LIST_PLAN=0 FLUHIP_PLAN_SPLIT=1 python tools/two_stream_probe.py [iters]"""
 import os
+os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import sys
 import threading
 import time

@@ -1,3 +1,4 @@
+export FLUHIP_AB=1   # the build whose experiment switches are live (flucoma-core_amd/build.py --ab)
 for K in 64 128; do for v in 0 1; do
 echo "K=$K FLUHIP_LIST_PLAN=$v: $(FLUHIP_LIST_PLAN=$v timeout 200 python tools/batch_timing.py 128 1.6 $K 8 2>&1 | tail -1 | python -c "
 import sys, json
