@@ -129,6 +129,10 @@ def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
     procs = max(1, min(64, (os.cpu_count() or 1) // 4))
     all_rate = cpu_all_cores(mag, wl, procs, max(3, int(4.0 / max(per_iter, 1e-9)))) if procs > 1 else None
     executed_flop = 14.0 * F * T * wl["rank"] * iters
+    try:
+        core_peak = o.fma_peak_gflops()
+    except Exception:
+        core_peak = None
     cpu_model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -140,10 +144,16 @@ def cpu_baseline(audio_one, wl, budget_s, gpu_bases0=None, gpu_acts0=None):
     return {
         "value": iters / t_nmf, "unit": "iterations/s", "cores": 1, "kind": "port",
         "sample": f"1 buffer ({n} samples, T={T}, F={F}), rank {wl['rank']}, {iters} of {wl['iters']} "
-                  f"iterations, oracle faithful mode (7 GEMMs/iter like alg/NMF.hpp), gcc -O3 -march=native",
+                  f"iterations, oracle faithful mode (7 GEMMs/iter like alg/NMF.hpp), gcc -O3 -march=native "
+                  f"(AVX-512 micro-kernels where the host has them)",
         "stft_frames_per_s": T / t_stft,
         "value_sse4_build": sse4_rate,
         "executed_gflops": executed_flop / t_nmf / 1e9,
+        # the same core's FMA rate measured with nothing but register FMAs in the loop (oracle/fluid_oracle.c fo_fma_burst):
+        # how much of the core the restatement's GEMMs use -- Eigen's would sit somewhere above it, the GPU / CPU ratio
+        # is only as meaningful as this fraction is high
+        "core_fma_peak_gflops": core_peak,
+        "frac_of_core_peak": executed_flop / t_nmf / 1e9 / core_peak if core_peak else None,
         "bufnmf_wall_s_200iter_est": t_stft + t_nmf / iters * wl["iters"],
         "value_many_jobs": all_rate, "many_jobs_processes": procs, "parity_vs_gpu": parity,
         "cpu_model": cpu_model, "host_cores_available": os.cpu_count(),
@@ -291,13 +301,13 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     # which global buffers every rank held (rank r must hold shard_range(world * B, world, r): the rehearsal test checks it)
-    rng = torch.tensor([g_begin, g_end], dtype=torch.int64, device=tmax.device)
+    rng = torch.tensor([[g_begin, g_end]], dtype=torch.int64, device=tmax.device)
     ranges = torch.empty((world, 2), dtype=torch.int64, device=tmax.device)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_gather_into_tensor(ranges, rng)
     else:
-        ranges[0] = rng
+        ranges.copy_(rng)
     elapsed_max = float(tmax.item())
     shard_ranges = [[int(a), int(b)] for a, b in ranges.cpu().tolist()]
 

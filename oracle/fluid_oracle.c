@@ -179,8 +179,8 @@ void fo_rng_uniform01(uint64_t seed, int64_t count, double* out)
 
 /* C(MxN) = A(MxK) * B(KxN); A, C column-major contiguous over rows; B(k,j) = B[k*sbk + j*sbj].
  * Register-blocked 32x4 micro-kernel, auto-vectorised over rows. */
-static void gemm_nn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
-                    const double* B, int64_t sbk, int64_t sbj, double* C, int64_t ldc)
+static void gemm_nn_generic(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                            const double* B, int64_t sbk, int64_t sbj, double* C, int64_t ldc)
 {
   enum { MB = 32, NB = 4 };
   for (int64_t j0 = 0; j0 < N; j0 += NB)
@@ -227,8 +227,8 @@ static void gemm_nn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t l
 
 /* C(MxN) = A^T * B with A (Kd x M) and B (Kd x N) column-major (contraction over rows).
  * 4x4 blocked dot products, vectorised over the contraction index. */
-static void gemm_tn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
-                    const double* B, int64_t ldb, double* C, int64_t ldc)
+static void gemm_tn_generic(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                            const double* B, int64_t ldb, double* C, int64_t ldc)
 {
   enum { IB = 4, JB = 4 };
   for (int64_t j0 = 0; j0 < N; j0 += JB)
@@ -275,6 +275,179 @@ static void gemm_tn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t l
     }
   }
 }
+
+#if defined(__AVX512F__) && !defined(FO_NO_AVX512)
+/* The -march=native build on a host with AVX-512 (the GPU box's EPYC 9575F; bench.py's cpu_baseline): register-blocked
+ * micro-kernels written out with intrinsics, so that the baseline the GPU is held against is not a slow GEMM (VERDICT r03
+ * item 9: the auto-vectorised loops above reached 18 % of that core's FMA peak).  The -msse4 build (the reference's shipped
+ * default, script/flucoma_simdcmd.cmake) keeps the plain loops.  Same products, different summation order: results move
+ * at rounding level only (tests/test_oracle.py holds both builds against the numpy restatement). */
+#include <immintrin.h>
+#define FO_AVX512 1
+
+/* 24 rows (three zmm, row masks for the last panel) x 8 columns; panels outermost so that A's 24 x Kd panel stays in
+ * the L1 / L2 while all column blocks pass over it */
+static void gemm_nn_avx512(int64_t M, int64_t N8, int64_t Kd, const double* A, int64_t lda,
+                           const double* B, int64_t sbk, int64_t sbj, double* C, int64_t ldc)
+{
+  for (int64_t i0 = 0; i0 < M; i0 += 24)
+  {
+    const int64_t left = M - i0;
+    const __mmask8 m0 = (__mmask8) (left >= 8 ? 0xff : (1u << left) - 1);
+    const __mmask8 m1 = (__mmask8) (left >= 16 ? 0xff : left > 8 ? (1u << (left - 8)) - 1 : 0);
+    const __mmask8 m2 = (__mmask8) (left >= 24 ? 0xff : left > 16 ? (1u << (left - 16)) - 1 : 0);
+    for (int64_t j0 = 0; j0 < N8; j0 += 8)
+    {
+      __m512d c00 = _mm512_setzero_pd(), c01 = c00, c02 = c00, c03 = c00, c04 = c00, c05 = c00, c06 = c00, c07 = c00;
+      __m512d c10 = c00, c11 = c00, c12 = c00, c13 = c00, c14 = c00, c15 = c00, c16 = c00, c17 = c00;
+      __m512d c20 = c00, c21 = c00, c22 = c00, c23 = c00, c24 = c00, c25 = c00, c26 = c00, c27 = c00;
+      const double* b = B + j0 * sbj;
+      for (int64_t k = 0; k < Kd; k++)
+      {
+        const double* a = A + i0 + k * lda;
+        const __m512d a0 = _mm512_maskz_loadu_pd(m0, a), a1 = _mm512_maskz_loadu_pd(m1, a + 8), a2 = _mm512_maskz_loadu_pd(m2, a + 16);
+        const double* bk = b + k * sbk;
+        __m512d v;
+#define FO_NN_COL(J, C0, C1, C2)                                                     \
+        v = _mm512_set1_pd(bk[(J) * sbj]);                                            \
+        C0 = _mm512_fmadd_pd(a0, v, C0); C1 = _mm512_fmadd_pd(a1, v, C1); C2 = _mm512_fmadd_pd(a2, v, C2);
+        FO_NN_COL(0, c00, c10, c20) FO_NN_COL(1, c01, c11, c21) FO_NN_COL(2, c02, c12, c22) FO_NN_COL(3, c03, c13, c23)
+        FO_NN_COL(4, c04, c14, c24) FO_NN_COL(5, c05, c15, c25) FO_NN_COL(6, c06, c16, c26) FO_NN_COL(7, c07, c17, c27)
+#undef FO_NN_COL
+      }
+      double* c = C + i0 + j0 * ldc;
+#define FO_NN_ST(J, C0, C1, C2)                                                      \
+      _mm512_mask_storeu_pd(c + (J) * ldc, m0, C0); _mm512_mask_storeu_pd(c + (J) * ldc + 8, m1, C1);                  \
+      _mm512_mask_storeu_pd(c + (J) * ldc + 16, m2, C2);
+      FO_NN_ST(0, c00, c10, c20) FO_NN_ST(1, c01, c11, c21) FO_NN_ST(2, c02, c12, c22) FO_NN_ST(3, c03, c13, c23)
+      FO_NN_ST(4, c04, c14, c24) FO_NN_ST(5, c05, c15, c25) FO_NN_ST(6, c06, c16, c26) FO_NN_ST(7, c07, c17, c27)
+#undef FO_NN_ST
+    }
+  }
+}
+
+/* 4 columns of A x 6 columns of B, eight contraction rows per step (masked tail), 24 vertical accumulators reduced at the
+ * end; B's six columns stay in the L1 while A's columns pass */
+static void gemm_tn_avx512(int64_t M4, int64_t N6, int64_t Kd, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, double* C, int64_t ldc)
+{
+  const int64_t K8 = Kd & ~(int64_t) 7;
+  const __mmask8 mt = (__mmask8) ((1u << (Kd - K8)) - 1);
+  for (int64_t j0 = 0; j0 < N6; j0 += 6)
+  {
+    const double *b0 = B + (j0 + 0) * ldb, *b1 = B + (j0 + 1) * ldb, *b2 = B + (j0 + 2) * ldb;
+    const double *b3 = B + (j0 + 3) * ldb, *b4 = B + (j0 + 4) * ldb, *b5 = B + (j0 + 5) * ldb;
+    for (int64_t i0 = 0; i0 < M4; i0 += 4)
+    {
+      const double *a0 = A + (i0 + 0) * lda, *a1 = A + (i0 + 1) * lda, *a2 = A + (i0 + 2) * lda, *a3 = A + (i0 + 3) * lda;
+      __m512d s00 = _mm512_setzero_pd(), s01 = s00, s02 = s00, s03 = s00, s04 = s00, s05 = s00;
+      __m512d s10 = s00, s11 = s00, s12 = s00, s13 = s00, s14 = s00, s15 = s00;
+      __m512d s20 = s00, s21 = s00, s22 = s00, s23 = s00, s24 = s00, s25 = s00;
+      __m512d s30 = s00, s31 = s00, s32 = s00, s33 = s00, s34 = s00, s35 = s00;
+#define FO_TN_STEP(LD)                                                                                        \
+      {                                                                                                       \
+        const __m512d x0 = LD(a0 + k), x1 = LD(a1 + k), x2 = LD(a2 + k), x3 = LD(a3 + k);                      \
+        __m512d y;                                                                                            \
+        y = LD(b0 + k); s00 = _mm512_fmadd_pd(x0, y, s00); s10 = _mm512_fmadd_pd(x1, y, s10); s20 = _mm512_fmadd_pd(x2, y, s20); s30 = _mm512_fmadd_pd(x3, y, s30); \
+        y = LD(b1 + k); s01 = _mm512_fmadd_pd(x0, y, s01); s11 = _mm512_fmadd_pd(x1, y, s11); s21 = _mm512_fmadd_pd(x2, y, s21); s31 = _mm512_fmadd_pd(x3, y, s31); \
+        y = LD(b2 + k); s02 = _mm512_fmadd_pd(x0, y, s02); s12 = _mm512_fmadd_pd(x1, y, s12); s22 = _mm512_fmadd_pd(x2, y, s22); s32 = _mm512_fmadd_pd(x3, y, s32); \
+        y = LD(b3 + k); s03 = _mm512_fmadd_pd(x0, y, s03); s13 = _mm512_fmadd_pd(x1, y, s13); s23 = _mm512_fmadd_pd(x2, y, s23); s33 = _mm512_fmadd_pd(x3, y, s33); \
+        y = LD(b4 + k); s04 = _mm512_fmadd_pd(x0, y, s04); s14 = _mm512_fmadd_pd(x1, y, s14); s24 = _mm512_fmadd_pd(x2, y, s24); s34 = _mm512_fmadd_pd(x3, y, s34); \
+        y = LD(b5 + k); s05 = _mm512_fmadd_pd(x0, y, s05); s15 = _mm512_fmadd_pd(x1, y, s15); s25 = _mm512_fmadd_pd(x2, y, s25); s35 = _mm512_fmadd_pd(x3, y, s35); \
+      }
+#define FO_LD_FULL(p) _mm512_loadu_pd(p)
+#define FO_LD_TAIL(p) _mm512_maskz_loadu_pd(mt, p)
+      int64_t k = 0;
+      for (; k < K8; k += 8) FO_TN_STEP(FO_LD_FULL)
+      if (mt) FO_TN_STEP(FO_LD_TAIL)
+#undef FO_TN_STEP
+#undef FO_LD_FULL
+#undef FO_LD_TAIL
+      double* c = C + i0 + j0 * ldc;
+      c[0] = _mm512_reduce_add_pd(s00); c[1] = _mm512_reduce_add_pd(s10); c[2] = _mm512_reduce_add_pd(s20); c[3] = _mm512_reduce_add_pd(s30);
+      c += ldc;
+      c[0] = _mm512_reduce_add_pd(s01); c[1] = _mm512_reduce_add_pd(s11); c[2] = _mm512_reduce_add_pd(s21); c[3] = _mm512_reduce_add_pd(s31);
+      c += ldc;
+      c[0] = _mm512_reduce_add_pd(s02); c[1] = _mm512_reduce_add_pd(s12); c[2] = _mm512_reduce_add_pd(s22); c[3] = _mm512_reduce_add_pd(s32);
+      c += ldc;
+      c[0] = _mm512_reduce_add_pd(s03); c[1] = _mm512_reduce_add_pd(s13); c[2] = _mm512_reduce_add_pd(s23); c[3] = _mm512_reduce_add_pd(s33);
+      c += ldc;
+      c[0] = _mm512_reduce_add_pd(s04); c[1] = _mm512_reduce_add_pd(s14); c[2] = _mm512_reduce_add_pd(s24); c[3] = _mm512_reduce_add_pd(s34);
+      c += ldc;
+      c[0] = _mm512_reduce_add_pd(s05); c[1] = _mm512_reduce_add_pd(s15); c[2] = _mm512_reduce_add_pd(s25); c[3] = _mm512_reduce_add_pd(s35);
+    }
+  }
+}
+#endif
+
+static void gemm_nn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                    const double* B, int64_t sbk, int64_t sbj, double* C, int64_t ldc)
+{
+#ifdef FO_AVX512
+  const int64_t N8 = N & ~(int64_t) 7;
+  if (N8 > 0 && M >= 8) gemm_nn_avx512(M, N8, Kd, A, lda, B, sbk, sbj, C, ldc);
+  else { gemm_nn_generic(M, N, Kd, A, lda, B, sbk, sbj, C, ldc); return; }
+  if (N > N8) gemm_nn_generic(M, N - N8, Kd, A, lda, B + N8 * sbj, sbk, sbj, C + N8 * ldc, ldc);
+#else
+  gemm_nn_generic(M, N, Kd, A, lda, B, sbk, sbj, C, ldc);
+#endif
+}
+
+static void gemm_tn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t lda,
+                    const double* B, int64_t ldb, double* C, int64_t ldc)
+{
+#ifdef FO_AVX512
+  const int64_t M4 = M & ~(int64_t) 3, N6 = N - N % 6;
+  if (M4 > 0 && N6 > 0 && Kd >= 8)
+  {
+    gemm_tn_avx512(M4, N6, Kd, A, lda, B, ldb, C, ldc);
+    if (M > M4) gemm_tn_generic(M - M4, N6, Kd, A + M4 * lda, lda, B, ldb, C + M4, ldc);       /* leftover columns of A */
+    if (N > N6) gemm_tn_generic(M, N - N6, Kd, A, lda, B + N6 * ldb, ldb, C + N6 * ldc, ldc);  /* leftover columns of B */
+    return;
+  }
+#endif
+  gemm_tn_generic(M, N, Kd, A, lda, B, ldb, C, ldc);
+}
+
+/* The host core's FMA rate, measured: `reps` rounds of 24 independent vector FMAs on registers (nothing else in the
+ * loop), 24 x FO_VL x 2 flop per round.  bench.py times the call and prices the oracle's executed GFLOP/s against it
+ * (cpu_baseline.frac_of_core_peak) -- the flags x nominal-clock product would guess both the pipe count and the clock. */
+#ifdef FO_AVX512
+#define FO_VL 8
+double fo_fma_burst(int64_t reps, int64_t* flop_per_rep)
+{
+  __m512d a[24];
+  const __m512d x = _mm512_set1_pd(1.0000001), y = _mm512_set1_pd(1e-9);
+  for (int i = 0; i < 24; i++) a[i] = _mm512_set1_pd(1.0 + i);
+  for (int64_t r = 0; r < reps; r++)
+  {
+#pragma GCC unroll 24
+    for (int i = 0; i < 24; i++) a[i] = _mm512_fmadd_pd(a[i], x, y);
+    __asm__ volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+  }
+  __m512d t = a[0];
+  for (int i = 1; i < 24; i++) t = _mm512_add_pd(t, a[i]);
+  *flop_per_rep = 24 * FO_VL * 2;
+  return _mm512_reduce_add_pd(t);
+}
+#else
+#define FO_VL 4
+double fo_fma_burst(int64_t reps, int64_t* flop_per_rep)
+{
+  double a[24][FO_VL];
+  const double x = 1.0000001, y = 1e-9;
+  for (int i = 0; i < 24; i++)
+    for (int l = 0; l < FO_VL; l++) a[i][l] = 1.0 + i + l;
+  for (int64_t r = 0; r < reps; r++)
+    for (int i = 0; i < 24; i++)
+      for (int l = 0; l < FO_VL; l++) a[i][l] = a[i][l] * x + y;
+  double t = 0;
+  for (int i = 0; i < 24; i++)
+    for (int l = 0; l < FO_VL; l++) t += a[i][l];
+  *flop_per_rep = 24 * FO_VL * 2;
+  return t;
+}
+#endif
 
 static void normalize_cols(double* W, int64_t F, int64_t K)
 {

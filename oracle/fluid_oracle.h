@@ -59,6 +59,9 @@ int64_t fo_stft_f32(const float* audio, int64_t n, int64_t stride, int64_t win, 
  * std::mt19937_64{seed}: out[i] = double(g())/2^64 (clamped below 1). */
 void fo_rng_uniform01(uint64_t seed, int64_t count, double* out);
 
+/* `reps` rounds of independent register FMAs (*flop_per_rep flop each): the caller times it -> the core's measured FMA peak */
+double fo_fma_burst(int64_t reps, int64_t* flop_per_rep);
+
 typedef int (*fo_progress_fn)(int64_t iteration, void* user); /* return 0 => cancel */
 
 /* alg/NMF.hpp:91-134 (process) + :144-183 (multiplicativeUpdates).

@@ -136,6 +136,21 @@ class Oracle:
         self.lib.fo_stft_f32(_f(audio), n, 1, win, fft, hop, _d(spec), _d(mag))
         return spec[..., 0] + 1j * spec[..., 1], mag
 
+    def fma_peak_gflops(self, seconds=0.2):
+        """the host core's FMA rate as this build reaches it with nothing but register FMAs in the loop (best of three)"""
+        import time
+        fpr = _i64(0)
+        self.lib.fo_fma_burst.restype = ctypes.c_double
+        self.lib.fo_fma_burst.argtypes = [_i64, ctypes.POINTER(_i64)]
+        reps, best = 1 << 20, 0.0
+        for _ in range(4):
+            t0 = time.perf_counter()
+            self.lib.fo_fma_burst(reps, ctypes.byref(fpr))
+            dt = time.perf_counter() - t0
+            best = max(best, reps * fpr.value / dt / 1e9)
+            reps = int(max(1 << 18, reps * (seconds / 3) / max(dt, 1e-6)))
+        return best
+
     def rng_uniform01(self, seed, count):
         out = np.empty(count)
         self.lib.fo_rng_uniform01(seed, count, _d(out))
