@@ -1486,16 +1486,29 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
       {
         enqueue_iteration(c, updateW, updateH, false);
         i = 1;
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
+        // whatever fails in here, the stream leaves capture mode and the graph objects are released (an early
+        // return between Begin- and EndCapture left the context's stream capturing, and every later call on it failed)
+        struct Capture
+        {
+          hipStream_t s;
+          hipGraph_t graph = nullptr;
+          hipGraphExec_t exec = nullptr;
+          bool capturing = false;
+          ~Capture()
+          {
+            if (capturing) (void) hipStreamEndCapture(s, &graph);
+            if (exec) (void) hipGraphExecDestroy(exec);
+            if (graph) (void) hipGraphDestroy(graph);
+          }
+        } cap{ctx->stream};
         HIPCHK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        cap.capturing = true;
         for (int g = 0; g < graphN; g++) enqueue_iteration(c, updateW, updateH, false);
-        HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &graph));
-        HIPCHK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-        for (; i + graphN < iters; i += graphN) HIPCHK(ctx, hipGraphLaunch(exec, ctx->stream));
+        cap.capturing = false;
+        HIPCHK(ctx, hipStreamEndCapture(ctx->stream, &cap.graph));
+        HIPCHK(ctx, hipGraphInstantiate(&cap.exec, cap.graph, nullptr, nullptr, 0));
+        for (; i + graphN < iters; i += graphN) HIPCHK(ctx, hipGraphLaunch(cap.exec, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); // (experiment: the graph is dropped right away)
-        (void) hipGraphExecDestroy(exec);
-        (void) hipGraphDestroy(graph);
       }
       for (; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
     }

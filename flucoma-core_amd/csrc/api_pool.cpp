@@ -358,7 +358,10 @@ int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* p, const float* const* audio, con
         RaggedWorker w;
         w.cancel = &cancel;
         if (rc == FLUHIP_OK)
-          rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? sd.data() : nullptr, ragged_progress, &w);
+          // the per-iteration callback (one host round trip per iteration, no round-major / graph scheduling) only where a
+          // refusal can arrive: without a caller's callback the cancel flag can never be set
+          rc = fluhip_corpus_nmf(c, iters, update_w, update_h, seed, seeds ? sd.data() : nullptr,
+                                 progress ? ragged_progress : nullptr, progress ? &w : nullptr);
         if (rc == FLUHIP_OK) rc = fluhip_corpus_writeback_ragged_host(c, bases ? bp.data() : nullptr, acts ? cp.data() : nullptr);
         if (rc != FLUHIP_OK) errs[(size_t) r] = fluhip_last_error(ctx);
         if (c) fluhip_corpus_destroy(c);

@@ -367,10 +367,13 @@ typedef struct fluhip_bufnmf_job
 int fluhip_pool_bufnmf_job_f32(fluhip_pool* pool, const fluhip_bufnmf_job* job, fluhip_progress_fn progress, void* user);
 /* The same over buffers of DIFFERENT lengths (a folder of sound files): audio[i] = n[i] host floats; bases[i] receives
  * K x F, acts[i] K x T_i floats with T_i = fluhip_stft_num_frames(n[i], win, hop) (either array, or single entries, may be
- * NULL).  Buffers are dealt by fluhip_balanced_assignment over their frame counts; on its device every run of
- * equal-length buffers is processed as one corpus, the others one by one.  progress (may be NULL) is called on the
- * calling thread with the number of buffers finished so far, 1..count in order; returning 0 stops every device after
- * the group it is working on (FLUHIP_CANCELLED; the outputs of unfinished buffers are not written). */
+ * NULL).  Buffers are dealt by fluhip_balanced_assignment over their frame counts; a device's share runs as ONE ragged
+ * corpus (all its buffers advance together, iteration by iteration); shapes the ragged form does not cover are
+ * processed run by run of equal length.  progress (may be NULL) is called on the calling thread with the number of
+ * buffers finished so far, ascending up to count -- in the ragged form a device's whole share finishes at once, so the
+ * count moves in steps of a share, not buffer by buffer; returning 0 stops every device at its next iteration
+ * (FLUHIP_CANCELLED; the outputs of unfinished buffers are not written).  Without a callback the iterations are
+ * enqueued without the per-iteration host round trip a cancellable job needs. */
 int fluhip_pool_bufnmf_ragged_f32(fluhip_pool* pool, const float* const* audio, const int64_t* n, int64_t count, int64_t win,
                                   int64_t fft, int64_t hop, int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
                                   const int64_t* seeds, float* const* bases, float* const* acts, fluhip_progress_fn progress,

@@ -242,13 +242,19 @@ private:
     mWrite = false;
     if (mValid)
     {
+      const bool sameShape = mFrames == src.numFrames() && mChans == src.numChans() &&
+                             mData.size() == static_cast<size_t>(mFrames * mChans);
       mFrames = src.numFrames();
       mChans = src.numChans();
       // block by block of frames (cc/MemoryBufferAdaptor.hpp:125-131 copies channel by channel: on two interleaved buffers
       // that is numChans strided passes over both)
       index        stride = 0;
       const float* base = contents ? interleavedBase(src, stride) : nullptr;
-      if (!contents) mData.resize(static_cast<size_t>(mFrames * mChans));
+      if (!contents) // shape only (a buffer the job writes and never reads): zeros unless the cached copy already has the shape
+      {
+        // (a cached copy of the same shape holds what the last job copied back to this very origin: the host's own content)
+        if (!sameShape) mData.assign(static_cast<size_t>(mFrames * mChans), 0.0f);
+      }
       else if (base && stride == mChans) // the same layout as this one: one pass, allocation and copy together
         mData.assign(base, base + mFrames * mChans);
       else
@@ -272,11 +278,14 @@ private:
   {
     mWrite = true;
     mSampleRate = sampleRate;
+    // (FluidTensor::resize, data/FluidTensor.hpp: the container is resized, not cleared -- a buffer that already has the
+    //  shape keeps its memory untouched; zero-filling 451 MB of resynthesis buffer per job was 40 ms of an 8-channel job.)
+    // A CHANGE of shape starts from zeros: the old samples would sit at other (frame, channel) positions, and a client
+    // that resizes an output without writing every sample of it (a warning path, fewer frames written than sized) must not
+    // hand the previous job's data back to the host.  Same for a shape-only copy, copyFrom(contents = false).
+    if (frames != mFrames || channels != mChans) mData.assign(static_cast<size_t>(frames * channels), 0.0f);
     mFrames = frames;
     mChans = channels;
-    // (FluidTensor::resize, data/FluidTensor.hpp: the container is resized, not cleared -- a buffer that already has the
-    //  size keeps its memory untouched; zero-filling 451 MB of resynthesis buffer per job was 40 ms of an 8-channel job)
-    mData.resize(static_cast<size_t>(frames * channels));
     return {};
   }
   VectorView<float>       samps(index c) override { return {mData.data() + c, mFrames, mChans}; }

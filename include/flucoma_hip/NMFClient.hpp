@@ -14,6 +14,7 @@
 #include "BufferAdaptor.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -416,6 +417,9 @@ public:
                                  perChannelSeeds.empty() ? nullptr : perChannelSeeds.data(), cb, &prog);      // :268-271
         lap("nmf");
         if (rc == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""};        // :273-274
+#ifdef FLUHIP_AB_SWITCHES // tests: a failure of the batched block behind the iterations (as an allocation of the resynthesis would be)
+        if (rc == FLUHIP_OK && std::getenv("FLUHIP_CLIENT_FAIL_BATCHED")) rc = FLUHIP_ERROR;
+#endif
         std::vector<float> outWAll, outHAll, outRAll;
         if (hasFilters && !fixFilters) outWAll.resize(nc * static_cast<size_t>(rank * nBins));
         if (hasEnvelopes && !fixEnvelopes) outHAll.resize(nc * static_cast<size_t>(rank * nWindows));
@@ -443,7 +447,13 @@ public:
             rc = fluhip_corpus_resynth_host(cor, outRAll.data());
           }
         }
-        if (rc != FLUHIP_OK) return {S::kError, "BufNMF: ", fluhip_last_error(mCtx)};
+        // Any failure of the batched block other than a cancellation -- the kept spectrum (as large as both magnitude
+        // copies), the resynthesis output and its transposed copy (2 x channels x nFrames floats), the mask workspace: all
+        // sized for every channel at once -- sends the job to the channel-by-channel loop below, which needs one channel's
+        // worth of each and rewrites every output buffer from scratch (nothing of this block's results has been handed
+        // to the host's buffers as a finished channel yet).  If one channel does not fit either, that loop reports it.
+        if (rc == FLUHIP_OK)
+        {
         lap("write-back");
         for (index i = 0; i < nChannels; ++i) // buffer writes in channel order, as the reference's loop leaves them
         {
@@ -475,8 +485,11 @@ public:
         }
         lap("scatter to buffers");
         return {S::kOk, ""};
+        }
+        batchedFallbacks() += 1; // (read by tests: the batched block failed and the sequential loop took the job)
       }
-      // the corpus could not be created (device memory): the channel-by-channel loop below needs one channel at a time
+      // the corpus could not be created, or a later allocation of the batched block failed (device memory): the
+      // channel-by-channel loop below needs one channel at a time
     }
 
     mono.resize(static_cast<size_t>(nFrames));
@@ -551,6 +564,15 @@ private:
     return false;
 #endif
   }
+public:
+  // jobs (of this process) whose batched block failed and that the channel-by-channel loop then ran
+  static std::atomic<int>& batchedFallbacks()
+  {
+    static std::atomic<int> n{0};
+    return n;
+  }
+
+private:
   NMFParams*  mParams;
   fluhip_ctx* mCtx{nullptr};
   int         mDevice{-1};

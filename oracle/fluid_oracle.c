@@ -416,18 +416,26 @@ static void gemm_tn(int64_t M, int64_t N, int64_t Kd, const double* A, int64_t l
 #define FO_VL 8
 double fo_fma_burst(int64_t reps, int64_t* flop_per_rep)
 {
-  __m512d a[24];
+  /* 24 named accumulators (an array would be spilled and the loop would time the stack) */
   const __m512d x = _mm512_set1_pd(1.0000001), y = _mm512_set1_pd(1e-9);
-  for (int i = 0; i < 24; i++) a[i] = _mm512_set1_pd(1.0 + i);
+#define FO_DECL(n) __m512d a##n = _mm512_set1_pd(1.0 + n);
+#define FO_STEP(n) a##n = _mm512_fmadd_pd(a##n, x, y);
+#define FO_ALL(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23)
+  FO_ALL(FO_DECL)
   for (int64_t r = 0; r < reps; r++)
   {
-#pragma GCC unroll 24
-    for (int i = 0; i < 24; i++) a[i] = _mm512_fmadd_pd(a[i], x, y);
-    __asm__ volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]));
+    FO_ALL(FO_STEP)
+    FO_ALL(FO_STEP)
+    __asm__ volatile("" : "+v"(a0), "+v"(a12)); /* keep the loop a loop */
   }
-  __m512d t = a[0];
-  for (int i = 1; i < 24; i++) t = _mm512_add_pd(t, a[i]);
-  *flop_per_rep = 24 * FO_VL * 2;
+  __m512d t = _mm512_setzero_pd();
+#define FO_SUM(n) t = _mm512_add_pd(t, a##n);
+  FO_ALL(FO_SUM)
+#undef FO_DECL
+#undef FO_STEP
+#undef FO_SUM
+#undef FO_ALL
+  *flop_per_rep = 2 * 24 * FO_VL * 2;
   return _mm512_reduce_add_pd(t);
 }
 #else

@@ -482,6 +482,7 @@ int main(int argc, char** argv)
       std::printf("max_progress|%d|%g\n", maxProgress <= 1.0 ? 1 : 0, maxProgress);
     }
     report("result", r);
+    std::printf("fallbacks|%d|\n", fluhip::bufnmf::NMFClient::batchedFallbacks().load());
     writeBuffer(prefix + "_bases.bin", bases);
     writeBuffer(prefix + "_acts.bin", acts);
     if (p.resynthMode) writeBuffer(prefix + "_resynth.bin", resynth);

@@ -233,6 +233,30 @@ def test_client_eight_channels_run_as_one_corpus(driver, oracle, onp, tmp_path, 
 
 
 @pytest.mark.gpu
+def test_client_batched_failure_falls_back_to_the_channel_loop(driver, tmp_path, ctx):
+    """every allocation of the batched multi-channel block is sized for all channels at once (kept spectrum,
+    resynthesis output + its transposed copy, mask workspace); a failure anywhere in it -- injected here behind the
+    iterations, where an out-of-memory resynthesis would sit -- must hand the job to the channel-by-channel loop instead of
+    returning kError: same status, same floats in all three output buffers as the job that never failed."""
+    frames, chans = 20000, 3
+    win, hop, fft, K, iters, seed = 1024, 256, 1024, 4, 12, 42
+    rs = np.random.RandomState(11)
+    audio = rs.uniform(-0.5, 0.5, (frames, chans)).astype(np.float32)
+    inp = tmp_path / "in.f32"
+    audio.tofile(inp)
+    outs = {}
+    for tag, env in (("batched", {}), ("failed", {"FLUHIP_CLIENT_FAIL_BATCHED": "1"})):
+        prefix = str(tmp_path / tag)
+        r = run(driver, "run", inp, frames, chans, win, hop, fft, K, iters, seed, 0, 0, 1, 0, -1, 0, -1, prefix,
+                env=dict(env, CLIENT_RESYNTH="1"))
+        assert r["result"] == (OK, ""), r
+        assert r["fallbacks"][0] == (1 if env else 0), r
+        outs[tag] = [read_buffer(prefix + s)[0] for s in ("_bases.bin", "_acts.bin", "_resynth.bin")]
+    for a, b in zip(outs["batched"], outs["failed"]):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-6
+
+
+@pytest.mark.gpu
 def test_pool_from_a_cpp_host(driver, ctx):
     """fluhip_pool_bufnmf_f32 called from C++ (tests/cpp/client_driver.cpp): 7 buffers over two contexts on device 0 give
     the floats of the one-context run (the schedules differ by the number of buffers per launch: rounding only)"""
