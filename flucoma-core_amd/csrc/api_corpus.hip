@@ -1,469 +1,14 @@
-// api.hip -- the C ABI of libflucoma_hip.so (include/flucoma_hip.h) over the gfx950 kernels.
-//
-// Host-side control flow mirrors the reference call sites it replaces:
-//   algorithm::STFT::process / magnitude   include/flucoma/algorithms/public/STFT.hpp:90-108,61-66
-//   algorithm::NMF::process                include/flucoma/algorithms/public/NMF.hpp:91-134
+// api_corpus.hip -- the corpus level of the C ABI: B equal-shape (or ragged) buffers resident in HBM, the planner that picks
+// the schedule of the factor updates for a shape, the iteration loop, and the fluhip_corpus_* entry points.
 //   NMF::multiplicativeUpdates             include/flucoma/algorithms/public/NMF.hpp:144-183
 //   bufnmf::NMFClient::process write-back  include/flucoma/clients/nrt/NMFClient.hpp:277-300
-// There is no CPU fallback anywhere in this file: every compute path launches HIP kernels and
-// fails with FLUHIP_ERROR when the device is unusable.
-#include "../../include/flucoma_hip.h"
-#include "fluhip_kernels.h"
-
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <memory>
-#include <mutex>
-#include <optional>
-#include <random>
-#include <string>
-#include <tuple>
-#include <utility>
-#include <vector>
-
-using namespace fluhip;
-
-// ---------------------------------------------------------------------------------------
-// context
-// ---------------------------------------------------------------------------------------
-struct ProfRec
-{
-  int cls;
-  hipEvent_t start, stop;
-};
-
-struct fluhip_ctx
-{
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t copyStream = nullptr; // host -> device audio uploads run beside the compute stream (created on first use)
-  std::string err;
-  std::map<std::tuple<int64_t, int64_t, int>, double*> windows; // (win, fft, type) -> device table
-  std::map<int, double*> twiddles;                // fft -> device table
-  bool prof = false;
-  std::vector<ProfRec> profRecs;
-  std::vector<hipEvent_t> eventPool;
-  hipDeviceProp_t props;
-  int progressLag = 8;        // iterations the device may run ahead of the last progress report (fluhip_ctx_set_progress_lag)
-  void* bigFft = nullptr;     // workspace of the global-memory FFT passes (fft > 8192), grown on demand
-  size_t bigFftBytes = 0;
-  void* stage[2] = {nullptr, nullptr}; // pinned staging blocks of large device -> host copies (copy_to_host)
-  hipEvent_t stageEv[2] = {nullptr, nullptr};
-};
-
-static int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERROR);
-// workspace for transforms whose frame does not fit the LDS; null (with the error set) when it cannot be had
-static double* big_fft_scratch(fluhip_ctx* ctx, int64_t win, int64_t fft, int64_t frames)
-{
-  if (!stft_needs_scratch(win, fft)) return nullptr;
-  const size_t need = (size_t) big_fft_scratch_bytes(fft, frames, nullptr);
-  if (need > ctx->bigFftBytes)
-  {
-    (void) hipStreamSynchronize(ctx->stream);
-    if (ctx->bigFft) (void) hipFree(ctx->bigFft);
-    ctx->bigFft = nullptr;
-    ctx->bigFftBytes = 0;
-    if (hipMalloc(&ctx->bigFft, need) != hipSuccess) { fail(ctx, "out of device memory for the FFT workspace"); return nullptr; }
-    ctx->bigFftBytes = need;
-  }
-  return static_cast<double*>(ctx->bigFft);
-}
-
-static int fail(fluhip_ctx* ctx, const std::string& msg, int status)
-{
-  if (ctx) ctx->err = msg;
-  return status;
-}
-
-#define HIPCHK(ctx, expr)                                                                        \
-  do                                                                                             \
-  {                                                                                              \
-    hipError_t e__ = (expr);                                                                     \
-    if (e__ != hipSuccess)                                                                       \
-      return fail(ctx, std::string("HIP error: ") + hipGetErrorString(e__) + " in " #expr);      \
-  } while (0)
-
-// Large results to pageable host memory: a plain hipMemcpy stages them through the runtime's small pinned buffers (measured
-// 4.7 - 5.3 GB/s: 85 - 95 ms for the 451 MB of an 8-channel x 32-component resynthesis).  Here: two pinned blocks of 8 MiB,
-// the DMA of block i + 1 running while the host copies block i to its place.  `rows` rows of `width` bytes, source rows
-// spitch and destination rows dpitch bytes apart (a contiguous copy: rows = 1).  Work queued on `s` before the call is
-// complete when it returns.  Small copies take the plain path.
-static int copy_to_host(fluhip_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows,
-                        hipStream_t s)
-{
-  constexpr size_t kStage = (size_t) 8 << 20;
-  const size_t total = width * rows;
-  static const int off = [] { const char* e = fluhip::ab_getenv("FLUHIP_PINNED_D2H"); return e && std::atoi(e) == 0 ? 1 : 0; }();
-  if (off || total < 2 * kStage || width > kStage)
-  {
-    HIPCHK(ctx, hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-    return FLUHIP_OK;
-  }
-  for (int i = 0; i < 2; i++)
-  {
-    if (!ctx->stage[i]) HIPCHK(ctx, hipHostMalloc(&ctx->stage[i], kStage, hipHostMallocDefault));
-    if (!ctx->stageEv[i]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->stageEv[i], hipEventDisableTiming));
-  }
-  // units: whole rows per block when there are several rows, byte ranges of the one row otherwise
-  const bool byRows = rows > 1;
-  const size_t unit = byRows ? width : 1;
-  const size_t unitsPerBlock = kStage / unit;
-  const size_t units = byRows ? rows : width;
-  auto issue = [&](size_t u0, int slot) -> hipError_t {
-    const size_t nu = std::min(unitsPerBlock, units - u0);
-    hipError_t e = byRows ? hipMemcpy2DAsync(ctx->stage[slot], width, static_cast<const char*>(src) + u0 * spitch, spitch, width, nu,
-                                             hipMemcpyDeviceToHost, s)
-                          : hipMemcpyAsync(ctx->stage[slot], static_cast<const char*>(src) + u0, nu, hipMemcpyDeviceToHost, s);
-    if (e != hipSuccess) return e;
-    return hipEventRecord(ctx->stageEv[slot], s);
-  };
-  size_t u = 0;
-  int slot = 0;
-  HIPCHK(ctx, issue(0, 0));
-  while (u < units)
-  {
-    const size_t nu = std::min(unitsPerBlock, units - u);
-    const size_t next = u + nu;
-    if (next < units) HIPCHK(ctx, issue(next, slot ^ 1));
-    HIPCHK(ctx, hipEventSynchronize(ctx->stageEv[slot]));
-    if (byRows)
-      for (size_t r = 0; r < nu; r++)
-        std::memcpy(static_cast<char*>(dst) + (u + r) * dpitch, static_cast<const char*>(ctx->stage[slot]) + r * width, width);
-    else
-      std::memcpy(static_cast<char*>(dst) + u, ctx->stage[slot], nu);
-    u = next;
-    slot ^= 1;
-  }
-  return FLUHIP_OK;
-}
-
-
-// Device allocations go through a small caching pool: a BufNMF call allocates and frees a dozen buffers, and
-// hipMalloc / the device-synchronising hipFree each time were a millisecond or two of a 2-15 ms call.  Freed blocks
-// are kept per device (up to kPoolCap bytes) and handed out again to requests of about their size; a block is
-// returned to the pool only after the stream it was used on has drained.  (HIP's own stream-ordered pool --
-// hipMallocAsync -- was tried first and returned corrupted tails of result buffers from the third call of a
-// shape on; not pursued.)  FLUHIP_NO_POOL=1 goes back to plain hipMalloc / hipFree.
-struct BlockPool
-{
-  static constexpr size_t kPoolCap = (size_t) 8 << 30;
-  std::mutex m;
-  std::multimap<size_t, void*> freeBlocks[16];
-  size_t cached[16] = {}; // per device
-  static bool enabled()
-  {
-    static const bool on = [] { const char* e = std::getenv("FLUHIP_NO_POOL"); return !(e && std::atoi(e)); }();
-    return on;
-  }
-  void* take(int dev, size_t n, size_t* got)
-  {
-    std::lock_guard<std::mutex> g(m);
-    auto& f = freeBlocks[dev & 15];
-    auto it = f.lower_bound(n);
-    if (it == f.end() || it->first > 2 * n + ((size_t) 1 << 20)) return nullptr;
-    void* p = it->second;
-    *got = it->first;
-    cached[dev & 15] -= it->first;
-    f.erase(it);
-    return p;
-  }
-  bool give(int dev, size_t n, void* p)
-  {
-    std::lock_guard<std::mutex> g(m);
-    if (cached[dev & 15] + n > kPoolCap) return false;
-    freeBlocks[dev & 15].emplace(n, p);
-    cached[dev & 15] += n;
-    return true;
-  }
-  void trim(int dev)
-  {
-    std::lock_guard<std::mutex> g(m);
-    for (auto& kv : freeBlocks[dev & 15]) { (void) hipFree(kv.second); cached[dev & 15] -= kv.first; }
-    freeBlocks[dev & 15].clear();
-  }
-};
-static BlockPool g_pool;
-
-struct DevBuf
-{
-  void* p = nullptr;
-  size_t bytes = 0;     // requested
-  size_t capacity = 0;  // of the block behind it
-  int dev = 0;
-  hipStream_t owner = nullptr;
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { release(); }
-  // FLUHIP_CANARY=1 (debugging): every buffer gets a 64 KiB guard band behind the requested bytes, filled with a
-  // pattern at allocation and checked when the buffer is released; a kernel that writes past its buffer aborts
-  // the process with the size of the buffer it trampled.
-  static bool canary()
-  {
-    static const bool on = [] { const char* e = std::getenv("FLUHIP_CANARY"); return e && std::atoi(e); }();
-    return on;
-  }
-  void check_canary()
-  {
-    if (!canary() || !p) return;
-    std::vector<unsigned char> h(65536);
-    (void) hipStreamSynchronize(owner);
-    if (hipMemcpy(h.data(), static_cast<char*>(p) + bytes, 65536, hipMemcpyDeviceToHost) != hipSuccess) return;
-    for (size_t i = 0; i < h.size(); i++)
-      if (h[i] != 0xA5)
-      {
-        std::fprintf(stderr, "fluhip: write past the end of a %zu-byte device buffer (offset +%zu)\n", bytes, i);
-        std::abort();
-      }
-  }
-  void release()
-  {
-    if (p)
-    {
-      check_canary();
-      bool kept = false;
-      if (BlockPool::enabled() && hipStreamSynchronize(owner) == hipSuccess) kept = g_pool.give(dev, capacity, p);
-      if (!kept) (void) hipFree(p);
-    }
-    p = nullptr;
-    bytes = capacity = 0;
-  }
-  hipError_t alloc(size_t n, bool zero, hipStream_t s)
-  {
-    release();
-    if (n == 0) n = 16;
-    const size_t want = ((n + 65535) & ~(size_t) 65535) + (canary() ? 131072 : 0); // 64 KiB granules: near-equal requests share blocks
-    (void) hipGetDevice(&dev);
-    hipError_t e = hipSuccess;
-    capacity = want;
-    if (BlockPool::enabled()) p = g_pool.take(dev, want, &capacity);
-    if (!p)
-    {
-      e = hipMalloc(&p, want);
-      if (e != hipSuccess && BlockPool::enabled())
-      {
-        g_pool.trim(dev); // the cache may be what stands in the way
-        e = hipMalloc(&p, want);
-      }
-      if (e != hipSuccess) { p = nullptr; return e; }
-    }
-    bytes = n;
-    owner = s;
-    if (canary()) (void) hipMemsetAsync(static_cast<char*>(p) + n, 0xA5, 65536, s);
-    if (zero) e = hipMemsetAsync(p, 0, n, s);
-    return e;
-  }
-  template <typename T> T* as() const { return static_cast<T*>(p); }
-};
-
-static hipEvent_t take_event(fluhip_ctx* ctx)
-{
-  if (!ctx->eventPool.empty())
-  {
-    hipEvent_t e = ctx->eventPool.back();
-    ctx->eventPool.pop_back();
-    return e;
-  }
-  hipEvent_t e = nullptr;
-  (void) hipEventCreate(&e);
-  return e;
-}
-
-struct ProfScope
-{
-  fluhip_ctx* ctx;
-  ProfRec rec;
-  bool on;
-  ProfScope(fluhip_ctx* c, int cls) : ctx(c), on(c->prof)
-  {
-    if (!on) return;
-    rec.cls = cls;
-    rec.start = take_event(ctx);
-    rec.stop = take_event(ctx);
-    (void) hipEventRecord(rec.start, ctx->stream);
-  }
-  ~ProfScope()
-  {
-    if (!on) return;
-    (void) hipEventRecord(rec.stop, ctx->stream);
-    ctx->profRecs.push_back(rec);
-  }
-};
-
-// Strided host view -> contiguous device copy (clients/nrt/NMFClient.hpp:240 `tmp <<= samps(...)`).
-// A contiguous source is one plain copy; a strided one (a channel of a frame-interleaved host buffer) is gathered
-// on the host first -- a 2-D copy with element-sized rows would be issued row by row.
-static hipError_t upload_strided(void* dst, const void* src, size_t n, size_t stride, size_t esz, hipStream_t s)
-{
-  if (stride == 1)
-  {
-    hipError_t e = hipMemcpyAsync(dst, src, n * esz, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(s);
-  }
-  std::vector<char> tmp(n * esz);
-  const char* p = static_cast<const char*>(src);
-  if (esz == 4)
-    for (size_t i = 0; i < n; i++) reinterpret_cast<float*>(tmp.data())[i] = reinterpret_cast<const float*>(p)[i * stride];
-  else
-    for (size_t i = 0; i < n; i++) reinterpret_cast<double*>(tmp.data())[i] = reinterpret_cast<const double*>(p)[i * stride];
-  hipError_t e = hipMemcpyAsync(dst, tmp.data(), n * esz, hipMemcpyHostToDevice, s);
-  if (e != hipSuccess) return e;
-  return hipStreamSynchronize(s); // tmp goes out of scope
-}
-
-// ---------------------------------------------------------------------------------------
-// tables: window (alg/WindowFuncs.hpp:38-72) and FFT twiddles, computed on the host in f64
-// ---------------------------------------------------------------------------------------
-static bool make_window(int type, int64_t size, std::vector<double>& out)
-{
-  const double pi = M_PI; // util/AlgorithmUtils.hpp:21
-  out.resize((size_t) size);
-  switch (type)
-  {
-  case FLUHIP_WINDOW_HANN: // alg/WindowFuncs.hpp:41-45
-    for (int64_t i = 0; i < size; i++) out[(size_t) i] = 0.5 - 0.5 * std::cos((pi * 2 * i) / size);
-    return true;
-  case FLUHIP_WINDOW_HANND: // :46-51
-  {
-    double norm = pi / size;
-    for (int64_t i = 0; i < size; i++) out[(size_t) i] = norm * std::sin((2 * pi * i) / size);
-    return true;
-  }
-  case FLUHIP_WINDOW_HAMMING: // :52-56
-    for (int64_t i = 0; i < size; i++) out[(size_t) i] = 0.54 - 0.46 * std::cos((pi * 2 * i) / size);
-    return true;
-  case FLUHIP_WINDOW_BLACKMANHARRIS: // :57-65 (all three cosines share one argument, as written there)
-    for (int64_t i = 0; i < size; i++)
-      out[(size_t) i] = 0.35875 - 0.48829 * std::cos((pi * 2 * i) / size) +
-                        0.14128 * std::cos((pi * 2 * i) / size) +
-                        0.01168 * std::cos((pi * 2 * i) / size);
-    return true;
-  case FLUHIP_WINDOW_GAUSSIAN: // :66-72 (requires odd size; sigma = size / 3 in integer arithmetic)
-  {
-    if (size % 2 == 0) return false;
-    double sigma = (double) (size / 3);
-    int64_t h = (size - 1) / 2;
-    for (int64_t i = -h; i <= h; i++) out[(size_t) (i + h)] = std::exp(-i * i / (2 * sigma * sigma));
-    return true;
-  }
-  default: return false;
-  }
-}
-
-// device table of `fft` doubles: the window followed by zeros (a frame shorter than the transform
-// is zero-padded at its tail, util/FFT.hpp:97-98)
-static int get_window(fluhip_ctx* ctx, int64_t win, int64_t fft, int type, const double** out)
-{
-  auto key = std::make_tuple(win, fft, type);
-  auto it = ctx->windows.find(key);
-  if (it == ctx->windows.end())
-  {
-    std::vector<double> w;
-    if (!make_window(type, win, w)) return fail(ctx, "unsupported window type / size");
-    w.resize((size_t) std::max(win, fft), 0.0);
-    double* d = nullptr;
-    HIPCHK(ctx, hipMalloc(&d, w.size() * sizeof(double)));
-    HIPCHK(ctx, hipMemcpy(d, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
-    it = ctx->windows.emplace(key, d).first;
-  }
-  *out = it->second;
-  return FLUHIP_OK;
-}
-
-static int get_twiddle(fluhip_ctx* ctx, int64_t fft, const double** out)
-{
-  auto it = ctx->twiddles.find((int) fft);
-  if (it == ctx->twiddles.end())
-  {
-    const size_t nc = (size_t) fft / 2;
-    std::vector<double> t(2 * nc);
-    for (size_t j = 0; j < nc; j++)
-    {
-      const double ang = -2.0 * M_PI * (double) j / (double) fft;
-      t[2 * j] = std::cos(ang);
-      t[2 * j + 1] = std::sin(ang);
-    }
-    double* d = nullptr;
-    HIPCHK(ctx, hipMalloc(&d, std::max<size_t>(16, t.size() * sizeof(double))));
-    HIPCHK(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
-    it = ctx->twiddles.emplace((int) fft, d).first;
-  }
-  *out = it->second;
-  return FLUHIP_OK;
-}
-
-// ---------------------------------------------------------------------------------------
-// corpus
-// ---------------------------------------------------------------------------------------
-struct fluhip_corpus
-{
-  fluhip_ctx* ctx = nullptr;
-  int64_t B = 0, n = 0, win = 0, fft = 0, hop = 0, K = 0;
-  int64_t T = 0, F = 0, Tp = 0, Fp = 0, Kp = 0;
-  int windowType = FLUHIP_WINDOW_HANN;
-  bool keepSpec = false;
-  const float* audioDev = nullptr; // borrowed or owned (audioOwn)
-  DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
-  int nsplitW = 1, nsplitH = 1;
-  // H update in two launches (plan_tail): the first tailStripsH strips of every buffer (tailColsH frames) as whole
-  // contractions, the rest (tailRestH strips) with the contraction cut into tailSplitH pieces; 0 = one launch
-  int tailSplitH = 0, tailStripsH = 0, tailRestH = 0, tailColsH = 0;
-  // deferred normalisation of W inside the iteration loop (fluhip_kernels.h UpdateArgs::nrm)
-  bool lazy = false;     // the shape takes the two-launch-per-factor fast path
-  bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
-  bool wPending = false; // W in memory is W' = W diag(wnorm)
-  int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
-  DevBuf wnorm, wscratch, csumScratch, wideScratch;
-  DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's
-  // frame-strip schedule of a single large buffer at rank <= 16 (kernels_nmf_strip.hip)
-  bool strip = false;
-  bool stripReady = false;     // the numerator partials of the next W update are in stripPart
-  bool stripNormFresh = false; // wnorm holds the column norms of the W' in memory
-  bool stripStatsValid = false; // the column-statistics records of generation stripGen describe the W in memory
-  int stripGen = 0;
-  DevBuf stripPart;
-  bool haveMag = false, haveFactors = false;
-  bool touched = false; // work that reads the audio has been enqueued on the compute stream
-  // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats
-  std::vector<float> seedW32, seedH32;
-  // ragged corpus (fluhip_corpus_create_ragged): buffers of different lengths in ONE set of launches.  n / T are those of
-  // the longest buffer (the strides of every array); frames past a buffer's own count are zero padding that stays zero.
-  // The factor updates run kernels_nmf5.hip in work-list mode: one WaveDesc per wavefront, dealt by work.
-  bool ragged = false;
-  bool useLists = false; // the factor updates run from work lists (ragged corpora; small equal-length ones)
-  // window of buffers the next enqueue_iteration works on (0 buffers = all): corpora of several rounds of wavefronts
-  // run their iterations round by round (corpus_iterate_loop)
-  int64_t winB0 = 0, winB = 0;
-  int winStripsW = 0, winStripsH = 0;
-  std::vector<int64_t> nOf; // samples per buffer
-  std::vector<int> tOf;     // frames per buffer
-  DevBuf nTab, tTab;        // the same on the device
-  struct WorkList
-  {
-    DevBuf list, splitTab;
-    int wgs = 0, ng = 0, partial = 0, maxSplit = 1;
-    int64_t nPartials = 0;
-    int statParts = 0; // column-statistics parts per buffer (W update)
-  } listW, listH;
-  int64_t device_bytes() const
-  {
-    return (int64_t) (audioOwn.bytes + mag.bytes + magT.bytes + Wf.bytes + H1.bytes + spec.bytes +
-                      part.bytes + dpart.bytes + stage.bytes + hmax.bytes + normScratch.bytes);
-  }
-};
+#include "api_internal.h"
 
 // which factor-update path runs:
 //   5 = v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming (kernels_nmf5.hip): every rank up to 128, padded to 16 / 32 / 64 / 128
 //   0 = un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip): any rank, used above 128
 //       (FLUHIP_NMF_KERNEL=-1 forces it: an independent second implementation for the tests)
-static int update_variant(int Kp)
+int update_variant(int Kp)
 {
   if (Kp > 128) return 0;
   static const int forced = [] {
@@ -475,7 +20,7 @@ static int update_variant(int Kp)
 }
 // padded rank: the 4x4x4 kernel is built for 16 / 32 / 64 / 128 (components up to the padded rank are zero and stay zero);
 // above 128 the any-rank path takes multiples of 16
-static int64_t padded_rank(int64_t K)
+int64_t padded_rank(int64_t K)
 {
   if (K <= 16) return 16;
   if (K <= 32) return 32;
@@ -606,7 +151,7 @@ static bool list_plan_pays(const PlanShape* c)
 
 // how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
 // workspaces; needs B, T, F, Tp, Fp, Kp
-static int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
+int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   const size_t B = (size_t) c->B;
@@ -1045,7 +590,7 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
   return FLUHIP_OK;
 }
 
-static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
+int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
 {
   hipStream_t s = ctx->stream;
   c->T = (c->n + c->hop) / c->hop; // alg/STFT.hpp:98-99; nrt/NMFClient.hpp:111-112
@@ -1075,7 +620,7 @@ static int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
 // launch-geometry limits of the factor-update paths, refused up front with a message instead of surfacing as an
 // "invalid configuration" launch error: the normalisation kernels put the padded rank in one workgroup (<= 1024
 // threads), and the any-rank path (rank above 128, kernels_nmf_wide.hip) puts frames / bins in gridDim.y (<= 65535)
-static int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K)
+int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K)
 {
   if (padded_rank(K) > 1024) return fail(ctx, "ranks above 1024 are not supported");
   if (padded_rank(K) > 128 && std::max(T, F) > 65535)
@@ -1083,7 +628,7 @@ static int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K)
   return FLUHIP_OK;
 }
 
-static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t K)
+int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t K)
 {
   if (n <= 0) return fail(ctx, "not enough frames");
   if (win < 1 || hop < 1) return fail(ctx, "window and hop sizes must be positive");
@@ -1096,7 +641,7 @@ static int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int
   return check_rank(ctx, (n + hop) / hop, fft / 2 + 1, K);
 }
 
-static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride)
+int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride)
 {
   fluhip_ctx* ctx = c->ctx;
   const double *wtab = nullptr, *ttab = nullptr;
@@ -1142,7 +687,7 @@ static int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, in
 // util/EigenRandom.hpp:73-101: std::mt19937_64 g{seed ? *seed : rd()} +
 // std::uniform_real_distribution<double>{0, 1}; one draw per coefficient in Eigen's column-major
 // linear order.  libstdc++'s <random> is used verbatim, exactly as the reference does.
-static void draw_uniform(int64_t seed, size_t count, std::vector<double>& out)
+void draw_uniform(int64_t seed, size_t count, std::vector<double>& out)
 {
   std::random_device rd;
   std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
@@ -1151,17 +696,8 @@ static void draw_uniform(int64_t seed, size_t count, std::vector<double>& out)
   for (size_t i = 0; i < count; i++) out[i] = d(g);
 }
 
-struct FactorInit
-{
-  // device sources already in the padded layout are marked by null here
-  const double* W0host = nullptr; // [B or 1][K][F] f64
-  const double* H0host = nullptr; // [B or 1][T][K] f64
-  const float* W0f32 = nullptr;   // [B][K][F] f32 channel-major seeds
-  const float* H0f32 = nullptr;   // [B][K][T] f32 channel-major seeds
-  bool sharedW = false, sharedH = false;
-};
 
-static int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds,
+int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds,
                                const FactorInit& fi)
 {
   fluhip_ctx* ctx = c->ctx;
@@ -1550,7 +1086,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
   return FLUHIP_OK;
 }
 
-static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
+int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
                           fluhip_progress_fn progress, void* user)
 {
   const int rc = corpus_iterate_loop(c, iters, updateW, updateH, progress, user);
@@ -1584,119 +1120,8 @@ static int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool up
 
 // ---------------------------------------------------------------------------------------
 // C ABI
-// ---------------------------------------------------------------------------------------
 extern "C" {
 
-int fluhip_abi_version(void) { return FLUHIP_ABI_VERSION; }
-
-int fluhip_device_count(void)
-{
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
-  return n;
-}
-
-int fluhip_ctx_create(int device, fluhip_ctx** out)
-{
-  if (!out) return FLUHIP_ERROR;
-  *out = nullptr;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return FLUHIP_ERROR;
-  std::unique_ptr<fluhip_ctx> ctx(new fluhip_ctx);
-  ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess) return FLUHIP_ERROR;
-  if (hipGetDeviceProperties(&ctx->props, device) != hipSuccess) return FLUHIP_ERROR;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return FLUHIP_ERROR;
-  *out = ctx.release();
-  return FLUHIP_OK;
-}
-
-void fluhip_ctx_destroy(fluhip_ctx* ctx)
-{
-  if (!ctx) return;
-  (void) hipSetDevice(ctx->device);
-  if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
-  if (ctx->bigFft) (void) hipFree(ctx->bigFft);
-  for (int i = 0; i < 2; i++)
-  {
-    if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]);
-    if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]);
-  }
-  for (auto& kv : ctx->windows) (void) hipFree(kv.second);
-  for (auto& kv : ctx->twiddles) (void) hipFree(kv.second);
-  for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
-  for (auto e : ctx->eventPool) (void) hipEventDestroy(e);
-  if (ctx->copyStream) (void) hipStreamDestroy(ctx->copyStream);
-  if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
-  g_pool.trim(ctx->device); // cached device blocks go with the context
-  delete ctx;
-}
-
-const char* fluhip_last_error(const fluhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-int fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char* arch,
-                           int arch_len, int* compute_units)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (name && name_len > 0) { std::snprintf(name, (size_t) name_len, "%s", ctx->props.name); }
-  if (arch && arch_len > 0) { std::snprintf(arch, (size_t) arch_len, "%s", ctx->props.gcnArchName); }
-  if (compute_units) *compute_units = ctx->props.multiProcessorCount;
-  return FLUHIP_OK;
-}
-
-void* fluhip_ctx_stream(const fluhip_ctx* ctx) { return ctx ? (void*) ctx->stream : nullptr; }
-
-int fluhip_ctx_trim(fluhip_ctx* ctx)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  g_pool.trim(ctx->device);
-  return FLUHIP_OK;
-}
-
-int fluhip_ctx_set_progress_lag(fluhip_ctx* ctx, int lag)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (lag < 1 || lag > 64) return fail(ctx, "progress lag must be 1 .. 64");
-  ctx->progressLag = lag;
-  return FLUHIP_OK;
-}
-
-int fluhip_ctx_synchronize(fluhip_ctx* ctx)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FLUHIP_OK;
-}
-
-int fluhip_fft_params(int64_t win, int64_t hop, int64_t fft, int64_t* win_out, int64_t* hop_out,
-                      int64_t* fft_out, int64_t* bins_out)
-{
-  // clients/common/ParameterTypes.hpp:295-312
-  if (win < 4) return FLUHIP_ERROR;
-  int64_t h = hop > 0 ? hop : win >> 1;
-  int64_t f = fft;
-  if (f < 0)
-  {
-    f = 1;
-    while (f < win) f <<= 1; // nextPow2(win, up)
-  }
-  if ((f & (f - 1)) || f < win) return FLUHIP_ERROR;
-  if (win_out) *win_out = win;
-  if (hop_out) *hop_out = h;
-  if (fft_out) *fft_out = f;
-  if (bins_out) *bins_out = (f >> 1) + 1;
-  return FLUHIP_OK;
-}
-
-int64_t fluhip_stft_num_frames(int64_t n, int64_t win, int64_t hop)
-{
-  (void) win;
-  return hop > 0 ? (n + hop) / hop : 0;
-}
-
-// ---- corpus ---------------------------------------------------------------------------
 int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
                          int64_t hop, int64_t K, fluhip_corpus** out)
 {
@@ -2099,981 +1524,6 @@ int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1
 }
 
 // ---- algorithm-level single-buffer entry points -----------------------------------------
-static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int64_t n, int64_t stride,
-                       int64_t win, int64_t fft, int64_t hop, int window_type, double* spec,
-                       double* mag, int64_t* frames_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!a32 && !a64) return fail(ctx, "null audio");
-  if (stride < 1) return fail(ctx, "stride must be >= 1");
-  int rc = check_shape(ctx, n, win, fft, hop, 1);
-  if (rc) return rc;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = 1;
-  c.windowType = window_type;
-  c.keepSpec = spec != nullptr;
-  rc = corpus_alloc(ctx, &c);
-  if (rc) return rc;
-  // strided host view -> contiguous device copy (clients/nrt/NMFClient.hpp:240 `tmp <<= samps(...)`)
-  DevBuf in;
-  const size_t esz = a32 ? sizeof(float) : sizeof(double);
-  HIPCHK(ctx, in.alloc((size_t) n * esz, false, ctx->stream));
-  HIPCHK(ctx, upload_strided(in.p, a32 ? (const void*) a32 : (const void*) a64, (size_t) n, (size_t) stride, esz,
-                             ctx->stream));
-  rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n);
-  if (rc) return rc;
-  if (frames_out) *frames_out = c.T;
-  // (long buffers: through the pinned staging blocks -- a minute of audio at fft 2048 is 42 + 85 MB)
-  if (mag && (rc = copy_to_host(ctx, mag, (size_t) c.F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
-                                (size_t) c.F * sizeof(double), (size_t) c.T, ctx->stream)))
-    return rc;
-  if (spec)
-  {
-    const size_t nb = (size_t) c.T * c.F * 2 * sizeof(double);
-    if ((rc = copy_to_host(ctx, spec, nb, c.spec.p, nb, nb, 1, ctx->stream))) return rc;
-  }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return FLUHIP_OK;
-}
-
-int fluhip_stft_f64(fluhip_ctx* ctx, const double* audio, int64_t n, int64_t stride, int64_t win,
-                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
-                    int64_t* frames_out)
-{
-  return stft_common(ctx, nullptr, audio, n, stride, win, fft, hop, window_type, spec, mag, frames_out);
-}
-
-int fluhip_stft_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
-                    int64_t fft, int64_t hop, int window_type, double* spec, double* mag,
-                    int64_t* frames_out)
-{
-  return stft_common(ctx, audio, nullptr, n, stride, win, fft, hop, window_type, spec, mag, frames_out);
-}
-
-// ---- two-stride views at the algorithm boundary (data/FluidTensor_Support.hpp:260-420, util/FluidEigenMappings.hpp:35-225)
-} // extern "C" (the helpers below are C++)
-namespace {
-inline bool view_empty(const fluhip_matrix_view* v) { return !v || !v->data || v->rows == 0 || v->cols == 0; }
-// contiguous row-major host copy of a view (small matrices: seeds)
-std::vector<double> view_gather(const fluhip_matrix_view& v)
-{
-  std::vector<double> out((size_t) (v.rows * v.cols));
-  for (int64_t r = 0; r < v.rows; r++)
-    for (int64_t c = 0; c < v.cols; c++) out[(size_t) (r * v.cols + c)] = v.data[r * v.row_stride + c * v.col_stride];
-  return out;
-}
-void view_scatter(const fluhip_matrix_view& v, const double* src)
-{
-  for (int64_t r = 0; r < v.rows; r++)
-    for (int64_t c = 0; c < v.cols; c++) v.data[r * v.row_stride + c * v.col_stride] = src[r * v.cols + c];
-}
-} // namespace
-extern "C" {
-
-int fluhip_nmf_process_views_f64(fluhip_ctx* ctx, const fluhip_matrix_view* Xv, int64_t K, int64_t iters, int update_w,
-                                 int update_h, int64_t seed, const fluhip_matrix_view* W0v, const fluhip_matrix_view* H0v,
-                                 const fluhip_matrix_view* W1v, const fluhip_matrix_view* H1v, const fluhip_matrix_view* V1v,
-                                 fluhip_progress_fn progress, void* user)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (view_empty(Xv)) return fail(ctx, "bad input matrix");
-  const int64_t T = Xv->rows, F = Xv->cols;
-  if (K < 1) return fail(ctx, "rank must be >= 1");
-  if (iters < 0) return fail(ctx, "negative iteration count");
-  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
-  if ((Xv->col_stride == 1 && Xv->row_stride < F) || (Xv->row_stride == 1 && Xv->col_stride < T && Xv->col_stride != 1))
-    return fail(ctx, "bad input matrix");
-  // alg/NMF.hpp:109-110, 121-122 assert these shapes
-  if (!view_empty(W0v) && (W0v->rows != K || W0v->cols != F)) return fail(ctx, "W0 must be rank x bins");
-  if (!view_empty(H0v) && (H0v->rows != T || H0v->cols != K)) return fail(ctx, "H0 must be frames x rank");
-  if (!view_empty(W1v) && (W1v->rows != K || W1v->cols != F)) return fail(ctx, "W1 must be rank x bins");
-  if (!view_empty(H1v) && (H1v->rows != T || H1v->cols != K)) return fail(ctx, "H1 must be frames x rank");
-  if (!view_empty(V1v) && (V1v->rows != T || V1v->cols != F)) return fail(ctx, "V1 must be frames x bins");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.K = K;
-  // shape the corpus directly from the matrix extents (no audio behind it)
-  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
-  c.T = T; c.F = F;
-  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
-  {
-    HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
-    HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
-    HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
-    HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
-    HIPCHK(ctx, c.hmax.alloc(sizeof(double), true, s));
-    if (int rc2 = plan_updates(ctx, &c)) return rc2;
-  }
-  // alg/NMF.hpp:125  V = X^T.  A view with unit column stride is the T x F row-major image the frame-major copy wants;
-  // a view with unit ROW stride (FluidTensorView::transpose() of an F x T matrix) is byte for byte the bin-major copy:
-  // either goes up as one strided 2-D copy and the other layout is made on the device.  Anything else (both strides
-  // non-unit) is gathered on the host first.
-  // (a one-row view with a non-unit column stride is NOT a contiguous row: the frame-major path needs unit column stride
-  //  or a single column; such a view is byte for byte a bin-major image of one frame and takes the second path)
-  std::vector<double> xtmp;
-  if (Xv->col_stride == 1 || F == 1)
-  {
-    HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), Xv->data, (size_t) Xv->row_stride * sizeof(double),
-                                 (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
-    launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T, (int) F, 1, s);
-  }
-  else if (Xv->row_stride == 1 || T == 1)
-  {
-    HIPCHK(ctx, hipMemcpy2DAsync(c.magT.p, (size_t) c.Tp * sizeof(double), Xv->data, (size_t) Xv->col_stride * sizeof(double),
-                                 (size_t) T * sizeof(double), (size_t) F, hipMemcpyHostToDevice, s));
-    launch_transpose(c.magT.as<double>(), c.Tp, c.Fp * c.Tp, c.mag.as<double>(), c.Fp, c.Tp * c.Fp, (int) F, (int) T, 1, s);
-  }
-  else
-  {
-    xtmp = view_gather(*Xv);
-    HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), xtmp.data(), (size_t) F * sizeof(double),
-                                 (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
-    launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T, (int) F, 1, s);
-  }
-  c.haveMag = true;
-  // seeds are small (K x F, T x K): contiguous host images whatever their strides
-  std::vector<double> w0tmp, h0tmp;
-  FactorInit fi;
-  fi.sharedW = fi.sharedH = true;
-  if (!view_empty(W0v))
-  {
-    if (W0v->col_stride == 1 && W0v->row_stride == F) fi.W0host = W0v->data;
-    else { w0tmp = view_gather(*W0v); fi.W0host = w0tmp.data(); }
-  }
-  if (!view_empty(H0v))
-  {
-    if (H0v->col_stride == 1 && H0v->row_stride == K) fi.H0host = H0v->data;
-    else { h0tmp = view_gather(*H0v); fi.H0host = h0tmp.data(); }
-  }
-  int rc = corpus_init_factors(&c, seed, nullptr, fi);
-  if (rc) return rc;
-  rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user);
-  if (rc != FLUHIP_OK && rc != FLUHIP_CANCELLED) return rc;
-  const bool cancelled = rc == FLUHIP_CANCELLED;
-  // alg/NMF.hpp:127-133 outputs; :182 V = W*H only when the loop ran to completion
-  DevBuf dw, dh, dv, dvt;
-  std::vector<double> w1tmp, h1tmp, v1tmp;
-  if (!view_empty(W1v))
-  {
-    const bool direct = W1v->col_stride == 1 && W1v->row_stride == F;
-    if (!direct) w1tmp.resize((size_t) (K * F));
-    HIPCHK(ctx, dw.alloc((size_t) K * F * sizeof(double), false, s));
-    launch_gather_w_f64(c.Wf.as<double>(), 0, dw.as<double>(), 0, (int) F, (int) K, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(direct ? W1v->data : w1tmp.data(), dw.p, (size_t) K * F * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  if (!view_empty(H1v))
-  {
-    const bool direct = H1v->col_stride == 1 && H1v->row_stride == K;
-    if (!direct) h1tmp.resize((size_t) (T * K));
-    HIPCHK(ctx, dh.alloc((size_t) T * K * sizeof(double), false, s));
-    launch_gather_h_f64(c.H1.as<double>(), 0, dh.as<double>(), 0, (int) T, (int) K, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(direct ? H1v->data : h1tmp.data(), dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  if (!view_empty(V1v) && !cancelled)
-  {
-    HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
-    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F,
-                (int) c.Kp, 1, s);
-    if (V1v->col_stride == 1 || F == 1)
-      HIPCHK(ctx, hipMemcpy2DAsync(V1v->data, (size_t) V1v->row_stride * sizeof(double), dv.p, (size_t) F * sizeof(double),
-                                   (size_t) F * sizeof(double), (size_t) T, hipMemcpyDeviceToHost, s));
-    else if (V1v->row_stride == 1 || T == 1)
-    {
-      // a transposed view: the F x T image, made on the device
-      HIPCHK(ctx, dvt.alloc((size_t) F * T * sizeof(double), false, s));
-      launch_transpose(dv.as<double>(), F, 0, dvt.as<double>(), T, 0, (int) T, (int) F, 1, s);
-      HIPCHK(ctx, hipMemcpy2DAsync(V1v->data, (size_t) V1v->col_stride * sizeof(double), dvt.p, (size_t) T * sizeof(double),
-                                   (size_t) T * sizeof(double), (size_t) F, hipMemcpyDeviceToHost, s));
-    }
-    else
-    {
-      v1tmp.resize((size_t) (T * F));
-      HIPCHK(ctx, hipMemcpyAsync(v1tmp.data(), dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
-    }
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(s));
-  if (!w1tmp.empty()) view_scatter(*W1v, w1tmp.data());
-  if (!h1tmp.empty()) view_scatter(*H1v, h1tmp.data());
-  if (!v1tmp.empty()) view_scatter(*V1v, v1tmp.data());
-  return cancelled ? FLUHIP_CANCELLED : FLUHIP_OK;
-}
-
-int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
-                           int64_t K, int64_t iters, int update_w, int update_h, int64_t seed,
-                           const double* W0, const double* H0, double* W1, double* H1,
-                           double* V1, fluhip_progress_fn progress, void* user)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
-  const fluhip_matrix_view xv{const_cast<double*>(X), T, F, ldx, 1};
-  const fluhip_matrix_view w0{const_cast<double*>(W0), K, F, F, 1}, h0{const_cast<double*>(H0), T, K, K, 1};
-  const fluhip_matrix_view w1{W1, K, F, F, 1}, h1{H1, T, K, K, 1}, v1{V1, T, F, F, 1};
-  return fluhip_nmf_process_views_f64(ctx, &xv, K, iters, update_w, update_h, seed, W0 ? &w0 : nullptr, H0 ? &h0 : nullptr,
-                                      W1 ? &w1 : nullptr, H1 ? &h1 : nullptr, V1 ? &v1 : nullptr, progress, user);
-}
-
-int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
-                                  const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
-  if (!W0 || K < 1) return fail(ctx, "bad dictionary");
-  if (iters < 0) return fail(ctx, "negative iteration count");
-  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.K = K;
-  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
-  c.T = T; c.F = F;
-  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
-  HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
-  HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
-  HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
-  HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
-  if (int rc2 = plan_updates(ctx, &c)) return rc2;
-  // :57-58, 61  v0 = max(x, eps)
-  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
-                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
-  launch_clamp_eps(c.mag.as<double>(), c.Fp, 0, (int) T, (int) F, 1, s);
-  launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T,
-                   (int) F, 1, s);
-  // :59, 64-65  W = max(W, eps), every component divided by its L2 norm over the bins
-  HIPCHK(ctx, c.stage.alloc((size_t) K * F * sizeof(double), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(c.stage.p, W0, (size_t) K * F * sizeof(double), hipMemcpyHostToDevice, s));
-  launch_scatter_factor(c.stage.as<double>(), 0, c.Wf.as<double>(), c.Fp * c.Kp, (int) F, (int) K, (int) c.Kp, 1,
-                        true, s);
-  HIPCHK(ctx, c.normScratch.alloc((size_t) colnorm_scratch_doubles((int) F, (int) c.Kp, 1) * sizeof(double), false, s));
-  launch_colnorm(c.Wf.as<double>(), c.Fp * c.Kp, (int) F, (int) K, (int) c.Kp, 1, true, false,
-                 c.normScratch.as<double>(), s);
-  // :55-56, 60  h = max(uniform(0,1)^K, eps): the same K draws for every frame when seeded
-  std::vector<double> h0, rows((size_t) T * K);
-  if (seed >= 0)
-  {
-    draw_uniform(seed, (size_t) K, h0);
-    for (int64_t t = 0; t < T; t++) std::memcpy(&rows[(size_t) t * K], h0.data(), (size_t) K * sizeof(double));
-  }
-  else
-    draw_uniform(seed, (size_t) T * K, rows);
-  DevBuf hs;
-  HIPCHK(ctx, hs.alloc((size_t) T * K * sizeof(double), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(hs.p, rows.data(), (size_t) T * K * sizeof(double), hipMemcpyHostToDevice, s));
-  launch_scatter_factor(hs.as<double>(), 0, c.H1.as<double>(), c.Tp * c.Kp, (int) T, (int) K, (int) c.Kp, 1, false, s);
-  launch_clamp_eps(c.H1.as<double>(), c.Kp, 0, (int) T, (int) K, 1, s);
-  HIPCHK(ctx, hipStreamSynchronize(s)); // host staging vectors go out of use
-  c.haveMag = c.haveFactors = true;
-  // :71-79  nIterations of the H update
-  int rc = corpus_iterate(&c, iters, false, true, nullptr, nullptr);
-  if (rc != FLUHIP_OK) return rc;
-  DevBuf dh, dv;
-  if (H)
-  {
-    HIPCHK(ctx, dh.alloc((size_t) T * K * sizeof(double), false, s));
-    launch_gather_h_f64(c.H1.as<double>(), 0, dh.as<double>(), 0, (int) T, (int) K, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(H, dh.p, (size_t) T * K * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  if (V) // :87  v = W^T h
-  {
-    HIPCHK(ctx, dv.alloc((size_t) T * F * sizeof(double), false, s));
-    launch_vhat(c.Wf.as<double>(), 0, c.H1.as<double>(), 0, dv.as<double>(), F, 0, (int) T, (int) F, (int) c.Kp, 1, s);
-    HIPCHK(ctx, hipMemcpyAsync(V, dv.p, (size_t) T * F * sizeof(double), hipMemcpyDeviceToHost, s));
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipStreamSynchronize(s));
-  return FLUHIP_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------
-// NNDSVD (alg/NNDSVD.hpp) -- the SVD by one-sided Jacobi on the device (kernels_svd.hip), the O(k (F + T))
-// construction on the host
-// ---------------------------------------------------------------------------------------
-// G: device [F][ldg], row f = bin f over the T frames (the transposed magnitude copy; destroyed).  Top factors
-// to the host: s [min(F,T)] descending, U [k][F] (row j = u_j), VT [k][T]; k from the coverage rule.
-static int nndsvd_device(fluhip_ctx* ctx, double* G, int64_t F, int64_t T, int64_t ldg, int64_t minRank, int64_t maxRank,
-                         double amount, std::vector<double>& s, std::vector<double>& U, std::vector<double>& VT,
-                         int64_t* kOut)
-{
-  hipStream_t st = ctx->stream;
-  DevBuf dJ, dN, dFlag;
-  HIPCHK(ctx, dJ.alloc((size_t) F * F * sizeof(double), false, st));
-  HIPCHK(ctx, dN.alloc((size_t) F * sizeof(double), false, st));
-  HIPCHK(ctx, dFlag.alloc(sizeof(unsigned), true, st));
-  const int sweeps = launch_jacobi_svd(G, ldg, (int) F, (int) T, dJ.as<double>(), dN.as<double>(), dFlag.as<unsigned>(),
-                                       40, st);
-  HIPCHK(ctx, hipGetLastError());
-  if (sweeps < 0) return fail(ctx, "the SVD did not converge");
-  std::vector<double> norms((size_t) F);
-  HIPCHK(ctx, hipMemcpyAsync(norms.data(), dN.p, (size_t) F * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  std::vector<int64_t> order((size_t) F);
-  for (int64_t i = 0; i < F; i++) order[(size_t) i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return norms[(size_t) a] > norms[(size_t) b]; });
-  const int64_t r = std::min(F, T);
-  s.resize((size_t) r);
-  for (int64_t i = 0; i < r; i++) s[(size_t) i] = norms[(size_t) order[(size_t) i]];
-  // alg/NNDSVD.hpp:47-58
-  int64_t k = 0;
-  if (amount == 0) k = minRank;
-  else
-  {
-    double current = 0, total = 0;
-    for (double v : s) total += v;
-    while ((current / total) < amount && k < r) current += s[(size_t) k++];
-  }
-  if (k < minRank) k = minRank;
-  if (k > maxRank) k = maxRank;
-  if (k > r) return fail(ctx, "rank above min(bins, frames)");
-  *kOut = k;
-  U.assign((size_t) std::max<int64_t>(k, 1) * F, 0.0);
-  VT.assign((size_t) std::max<int64_t>(k, 1) * T, 0.0);
-  for (int64_t j = 0; j < k; j++)
-  {
-    const int64_t row = order[(size_t) j];
-    HIPCHK(ctx, hipMemcpyAsync(&U[(size_t) j * F], dJ.as<double>() + row * F, (size_t) F * sizeof(double),
-                               hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipMemcpyAsync(&VT[(size_t) j * T], G + row * ldg, (size_t) T * sizeof(double), hipMemcpyDeviceToHost, st));
-  }
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  for (int64_t j = 0; j < k; j++)
-  {
-    const double sj = s[(size_t) j];
-    if (sj > 0)
-      for (int64_t t = 0; t < T; t++) VT[(size_t) j * T + t] /= sj;
-  }
-  return FLUHIP_OK;
-}
-
-// alg/NNDSVD.hpp:60-129 from (U, s, V^T).  W: wRows x F row-major, H: T x wRows row-major.
-static void nndsvd_construct(const std::vector<double>& s, const std::vector<double>& U, const std::vector<double>& VT,
-                             int64_t F, int64_t T, int64_t k, int64_t wRows, int method, int64_t seed, double mean,
-                             double* W, double* H)
-{
-  const double eps = kEpsilon;
-  std::fill(W, W + wRows * F, 0.0);
-  std::fill(H, H + T * wRows, 0.0);
-  auto u = [&](int64_t j) { return &U[(size_t) j * F]; };
-  auto v = [&](int64_t j) { return &VT[(size_t) j * T]; };
-  if (method == 0)
-  {
-    for (int64_t j = 0; j < k; j++)
-    {
-      for (int64_t f = 0; f < F; f++) W[j * F + f] = std::fabs(u(j)[f]);
-      for (int64_t t = 0; t < T; t++) H[t * wRows + j] = std::fabs(s[(size_t) j] * v(j)[t]);
-    }
-    return;
-  }
-  if (k > 0)
-  {
-    for (int64_t f = 0; f < F; f++) W[f] = std::fabs(u(0)[f]);                                  // :68
-    const double sq = std::sqrt(s[0]);
-    for (int64_t t = 0; t < T; t++) H[t * wRows] = sq * std::fabs(v(0)[t]);                       // :69
-  }
-  for (int64_t j = 1; j < k; j++)
-  {
-    double xP = 0, yP = 0, xN = 0;
-    for (int64_t f = 0; f < F; f++) { const double x = u(j)[f]; if (x > 0) xP += x * x; else xN += x * x; }
-    for (int64_t t = 0; t < T; t++) { const double y = v(j)[t]; if (y > 0) yP += y * y; }
-    const double xPn = std::sqrt(xP), yPn = std::sqrt(yP), xNn = std::sqrt(xN);
-    const double yNn = xNn;                                                                       // :85 as written
-    const double mP = xPn * yPn, mN = xNn * yNn;
-    const bool pos = mP > mN;
-    const double sigma = pos ? mP : mN;
-    const double lbd = std::sqrt(s[(size_t) j] * sigma);
-    const double xn = pos ? xPn : xNn, yn = pos ? yPn : yNn; // :90-100 (yNn is ||xN||, see above)
-    for (int64_t f = 0; f < F; f++)
-    {
-      const double x = u(j)[f];
-      W[j * F + f] = (pos ? std::max(x, 0.0) : std::fabs(std::min(x, 0.0))) / xn;
-    }
-    for (int64_t t = 0; t < T; t++)
-    {
-      const double y = v(j)[t];
-      H[t * wRows + j] = lbd * ((pos ? std::max(y, 0.0) : std::fabs(std::min(y, 0.0))) / yn);
-    }
-  }
-  if (method == 1)
-  {
-    // :107-116: the lazily evaluated random matrix is only sampled where the condition holds, in the assignment's
-    // column-major traversal (WT is F x wRows, HT is wRows x T); a fresh generator of the same seed for each
-    std::random_device rd;
-    const double lo = eps, hi = mean * 0.001;
-    {
-      std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
-      std::uniform_real_distribution<double> d{lo, hi};
-      for (int64_t j = 0; j < wRows; j++)
-        for (int64_t f = 0; f < F; f++)
-          if (W[j * F + f] < eps) W[j * F + f] = d(g);
-    }
-    {
-      std::mt19937_64 g{seed >= 0 ? (size_t) seed : (size_t) rd()};
-      std::uniform_real_distribution<double> d{lo, hi};
-      for (int64_t t = 0; t < T; t++)
-        for (int64_t j = 0; j < wRows; j++)
-          if (H[t * wRows + j] < eps) H[t * wRows + j] = d(g);
-    }
-  }
-  else if (method == 2)
-  {
-    for (int64_t i = 0; i < wRows * F; i++) if (W[i] < eps) W[i] = mean;
-    for (int64_t i = 0; i < T * wRows; i++) if (H[i] < eps) H[i] = mean;
-  }
-}
-
-int fluhip_nndsvd_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx, int64_t w_rows,
-                      int64_t min_rank, int64_t max_rank, double amount, int method, int64_t seed, double* W,
-                      double* H, int64_t* rank_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!X || !W || !H || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad matrix arguments");
-  if (method < 0 || method > 3) return fail(ctx, "method must be 0..3");
-  if (!(amount > 0 || min_rank > 0)) return fail(ctx, "coverage or minimum rank must be positive"); // :40 assert
-  if (amount > 1) return fail(ctx, "coverage must be <= 1");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  DevBuf A, G;
-  HIPCHK(ctx, A.alloc((size_t) T * F * sizeof(double), false, st));
-  HIPCHK(ctx, G.alloc((size_t) F * T * sizeof(double), false, st));
-  HIPCHK(ctx, hipMemcpy2DAsync(A.p, (size_t) F * sizeof(double), X, (size_t) ldx * sizeof(double),
-                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, st));
-  launch_transpose(A.as<double>(), F, 0, G.as<double>(), T, 0, (int) T, (int) F, 1, st); // one bin per row
-  std::vector<double> s, U, VT;
-  int64_t k = 0;
-  if (int rc = nndsvd_device(ctx, G.as<double>(), F, T, T, min_rank, max_rank, amount, s, U, VT, &k)) return rc;
-  if (k > w_rows) return fail(ctx, "rank exceeds the rows of W");
-  double mean = 0;
-  for (int64_t t = 0; t < T; t++)
-    for (int64_t f = 0; f < F; f++) mean += X[t * ldx + f];
-  mean /= (double) (T * F);
-  nndsvd_construct(s, U, VT, F, T, k, w_rows, method, seed, mean, W, H);
-  if (rank_out) *rank_out = k;
-  return FLUHIP_OK;
-}
-
-int fluhip_bufnmfseed_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
-                          int64_t fft, int64_t hop, int64_t min_rank, int64_t max_rank, double coverage,
-                          int method, int64_t seed, float* bases_out, float* acts_out, int64_t* rank_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!audio) return fail(ctx, "null audio");
-  if (stride < 1) return fail(ctx, "stride must be >= 1");
-  if (max_rank < 1) return fail(ctx, "maximum rank must be >= 1");
-  int rc = check_shape(ctx, n, win, fft, hop, 1);
-  if (rc) return rc;
-  if (method < 0 || method > 3) return fail(ctx, "method must be 0..3");
-  if (!(coverage > 0 || min_rank > 0)) return fail(ctx, "coverage or minimum rank must be positive");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = 1;
-  rc = corpus_alloc(ctx, &c);
-  if (rc) return rc;
-  DevBuf in;
-  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, st));
-  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), st));
-  rc = corpus_stft(&c, in.as<float>(), nullptr, n); // NMFSeedClient.hpp:97-98
-  if (rc) return rc;
-  const int64_t T = c.T, F = c.F;
-  // mean of the magnitudes for methods 1 and 2 (alg/NNDSVD.hpp:105): on the host from a copy of the
-  // spectrogram (it is small next to the SVD)
-  std::vector<double> mag((size_t) T * F);
-  HIPCHK(ctx, hipMemcpy2DAsync(mag.data(), (size_t) F * sizeof(double), c.mag.p, (size_t) c.Fp * sizeof(double),
-                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyDeviceToHost, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  double mean = 0;
-  for (double v : mag) mean += v;
-  mean /= (double) (T * F);
-  std::vector<double> s, U, VT;
-  int64_t k = 0;
-  // the transposed copy holds one bin per row, as the Jacobi kernels want it; they work in place
-  rc = nndsvd_device(ctx, c.magT.as<double>(), F, T, c.Tp, min_rank, max_rank, coverage, s, U, VT, &k);
-  if (rc) return rc;
-  std::vector<double> W((size_t) max_rank * F), H((size_t) T * max_rank);
-  nndsvd_construct(s, U, VT, F, T, k, max_rank, method, seed, mean, W.data(), H.data());
-  // NMFSeedClient.hpp:108-128
-  if (bases_out)
-    for (int64_t i = 0; i < max_rank * F; i++) bases_out[i] = i < k * F ? (float) W[(size_t) i] : 0.f;
-  if (acts_out)
-  {
-    double maxH = H[0];
-    for (double v : H) maxH = std::max(maxH, v);
-    const float scale = (float) (1.0 / maxH);
-    for (int64_t j = 0; j < max_rank; j++)
-      for (int64_t t = 0; t < T; t++)
-        acts_out[j * T + t] = j < k ? (float) H[(size_t) t * max_rank + j] * scale : 0.f;
-  }
-  if (rank_out) *rank_out = k;
-  return FLUHIP_OK;
-}
-
-int fluhip_bufnmf_channel_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride,
-                              int64_t win, int64_t fft, int64_t hop, int64_t K, int64_t iters,
-                              int update_w, int update_h, int64_t seed, const float* bases_seed,
-                              const float* acts_seed, float* bases_out, float* acts_out,
-                              float* resynth_out, fluhip_progress_fn progress, void* user)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!audio) return fail(ctx, "null audio");
-  if (stride < 1) return fail(ctx, "stride must be >= 1");
-  int rc = check_shape(ctx, n, win, fft, hop, K);
-  if (rc) return rc;
-  if (iters < 0) return fail(ctx, "negative iteration count");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = K;
-  c.keepSpec = resynth_out != nullptr; // the complex spectrogram is only needed for resynthesis
-  rc = corpus_alloc(ctx, &c);
-  if (rc) return rc;
-  DevBuf in;
-  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
-  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), s));
-  rc = corpus_stft(&c, in.as<float>(), nullptr, n); // nrt/NMFClient.hpp:240-242
-  if (rc) return rc;
-  FactorInit fi;
-  fi.W0f32 = bases_seed; // :246-258 seeds gathered channel by channel
-  fi.H0f32 = acts_seed;
-  rc = corpus_init_factors(&c, seed, nullptr, fi);
-  if (rc) return rc;
-  rc = corpus_iterate(&c, iters, update_w != 0, update_h != 0, progress, user); // :268-271
-  if (rc) return rc;                                                             // :273-274
-  rc = fluhip_corpus_writeback_host(&c, bases_out, acts_out);                    // :277-300
-  if (rc) return rc;
-  if (resynth_out) // :302-334  estimate -> ratio mask -> ISTFT per component (the corpus form, one buffer)
-  {
-    DevBuf out32;
-    HIPCHK(ctx, out32.alloc((size_t) K * n * sizeof(float), false, s));
-    c.haveFactors = true;
-    rc = fluhip_corpus_resynth_dev(&c, out32.as<float>());
-    if (rc) return rc;
-    const size_t nbytes = (size_t) K * n * sizeof(float);
-    rc = copy_to_host(ctx, resynth_out, nbytes, out32.p, nbytes, nbytes, 1, s);
-    if (rc) return rc;
-  }
-  return FLUHIP_OK;
-}
-
-// ---- BufSTFT ------------------------------------------------------------------
-static int64_t bufstft_padding(int64_t win, int64_t hop, int mode)
-{
-  return mode == 0 ? 0 : (mode == 1 ? win >> 1 : win - hop); // cc/ParameterTypes.hpp:315-323
-}
-
-int fluhip_bufstft_forward_f32(fluhip_ctx* ctx, const float* audio, int64_t n, int64_t stride, int64_t win,
-                               int64_t fft, int64_t hop, int padding_mode, float* mag, float* phase,
-                               int64_t* hops_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!audio) return fail(ctx, "No input buffer supplied");
-  if (!mag && !phase) return fail(ctx, "Neither magnitude nor phase buffer supplied");
-  if (padding_mode < 0 || padding_mode > 2) return fail(ctx, "padding mode must be 0, 1 or 2");
-  if (stride < 1) return fail(ctx, "stride must be >= 1");
-  int rc = check_shape(ctx, n, win, fft, hop, 1);
-  if (rc) return rc;
-  if (fft / 2 + 1 >= 65536) // nrt/BufSTFTClient.hpp:135-138
-    return fail(ctx, "Can produce up to 65536 channels. Split your data up and try again");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int64_t F = fft / 2 + 1, pad = bufstft_padding(win, hop, padding_mode);
-  int64_t padded = n + 2 * pad;                                      // :121-124
-  if (padding_mode == 2) padded = ((padded + hop - 1) / hop) * hop;   // :125-127
-  if (padded < win) return fail(ctx, "not enough frames");
-  const int64_t T = 1 + (padded - win) / hop;                         // :129-130
-  if (hops_out) *hops_out = T;
-  const double *wtab = nullptr, *ttab = nullptr;
-  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
-  if (rc) return rc;
-  rc = get_twiddle(ctx, fft, &ttab);
-  if (rc) return rc;
-  DevBuf in, spec, dm, dp;
-  HIPCHK(ctx, in.alloc((size_t) n * sizeof(float), false, s));
-  HIPCHK(ctx, upload_strided(in.p, audio, (size_t) n, (size_t) stride, sizeof(float), s));
-  HIPCHK(ctx, spec.alloc((size_t) T * F * 2 * sizeof(double), false, s));
-  if (mag) HIPCHK(ctx, dm.alloc((size_t) T * F * sizeof(float), false, s));
-  if (phase) HIPCHK(ctx, dp.alloc((size_t) T * F * sizeof(float), false, s));
-  StftArgs sa;
-  sa.audio = in.as<float>(); sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
-  sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = 1;
-  sa.window = wtab; sa.twiddle = ttab; sa.mag = nullptr; sa.magStride = 0; sa.ldMag = 0;
-  sa.spec = spec.as<double>(); sa.specStride = 0;
-  sa.frameOffset = (int) (win / 2 - pad); // frame i starts at sample i*hop - padding (:151-162)
-  sa.bigScratch = big_fft_scratch(ctx, win, fft, T);
-  if (stft_needs_scratch(win, fft) && !sa.bigScratch) return FLUHIP_ERROR;
-  launch_stft(sa, s);
-  launch_spec_to_magphase(spec.as<double>(), (int) T, (int) F, mag ? dm.as<float>() : nullptr,
-                          phase ? dp.as<float>() : nullptr, s);
-  HIPCHK(ctx, hipGetLastError());
-  if (mag) HIPCHK(ctx, hipMemcpyAsync(mag, dm.p, (size_t) T * F * sizeof(float), hipMemcpyDeviceToHost, s));
-  if (phase) HIPCHK(ctx, hipMemcpyAsync(phase, dp.p, (size_t) T * F * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(ctx, hipStreamSynchronize(s));
-  return FLUHIP_OK;
-}
-
-int fluhip_bufstft_inverse_f32(fluhip_ctx* ctx, const float* mag, const float* phase, int64_t hops, int64_t win,
-                               int64_t fft, int64_t hop, int padding_mode, float* out, int64_t* n_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!mag || !phase) return fail(ctx, "Need both magnutude and phase buffers for inverse transform");
-  if (padding_mode < 0 || padding_mode > 2) return fail(ctx, "padding mode must be 0, 1 or 2");
-  if (hops < 1) return fail(ctx, "not enough frames");
-  int rc = check_shape(ctx, 1, win, fft, hop, 1);
-  if (rc) return rc;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int64_t F = fft / 2 + 1, T = hops, pad = bufstft_padding(win, hop, padding_mode);
-  const int64_t paddedOut = (T - 1) * hop + win; // nrt/BufSTFTClient.hpp:233
-  const int64_t finalOut = paddedOut - pad;      // :234
-  if (n_out) *n_out = finalOut;
-  if (!out) return FLUHIP_OK;                    // size query
-  const double *wtab = nullptr, *ttab = nullptr;
-  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
-  if (rc) return rc;
-  rc = get_twiddle(ctx, fft, &ttab);
-  if (rc) return rc;
-  DevBuf dm, dp, spec, frames, dout;
-  HIPCHK(ctx, dm.alloc((size_t) T * F * sizeof(float), false, s));
-  HIPCHK(ctx, dp.alloc((size_t) T * F * sizeof(float), false, s));
-  HIPCHK(ctx, spec.alloc((size_t) T * F * 2 * sizeof(double), false, s));
-  HIPCHK(ctx, frames.alloc((size_t) T * win * sizeof(double), false, s));
-  HIPCHK(ctx, dout.alloc((size_t) finalOut * sizeof(float), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(dm.p, mag, (size_t) T * F * sizeof(float), hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, hipMemcpyAsync(dp.p, phase, (size_t) T * F * sizeof(float), hipMemcpyHostToDevice, s));
-  launch_polar_to_spec(dm.as<float>(), dp.as<float>(), (int) T, (int) F, spec.as<double>(), s);
-  ResynthArgs ra;
-  ra.spec = spec.as<double>(); ra.Wf = nullptr; ra.H1 = nullptr; ra.Vhat = nullptr; ra.ldV = 0; ra.Kp = 0; ra.k = 0;
-  ra.win = (int) win; ra.fft = (int) fft; ra.hop = (int) hop; ra.T = (int) T; ra.F = (int) F;
-  ra.window = wtab; ra.twiddle = ttab; ra.frames = frames.as<double>(); ra.out = nullptr;
-  ra.out32 = dout.as<float>(); ra.n = finalOut; ra.trim = pad;
-  ra.bigScratch = big_fft_scratch(ctx, ra.win, ra.fft, ra.T);
-  if (stft_needs_scratch(ra.win, ra.fft) && !ra.bigScratch) return FLUHIP_ERROR;
-  launch_resynth(ra, s);
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(out, dout.p, (size_t) finalOut * sizeof(float), hipMemcpyDeviceToHost, s));
-  HIPCHK(ctx, hipStreamSynchronize(s));
-  return FLUHIP_OK;
-}
-
-// ---- feature pipeline -------------------------------------------------------
-static int features_common(fluhip_ctx* ctx, bool mfcc, const float* audio, int64_t count, int64_t n, int64_t win,
-                           int64_t fft, int64_t hop, int64_t nBands, int64_t nCoefs, int64_t startCoeff,
-                           double minFreq, double maxFreq, double sampleRate, int normalize, int scaleDb,
-                           int paddingMode, float* out, int64_t* frames_out)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  if (!audio || !out) return fail(ctx, "null buffer");
-  if (paddingMode < 0 || paddingMode > 2) return fail(ctx, "padding mode must be 0 (None), 1 (Default) or 2 (Full)");
-  if (count < 1) return fail(ctx, "need at least one buffer");
-  int rc = check_shape(ctx, n, win, fft, hop, 1);
-  if (rc) return rc;
-  if (nBands < 2 || nBands > fft / 2 + 1) return fail(ctx, "numBands must be in [2, fft/2 + 1]");
-  if (!(maxFreq > minFreq)) return fail(ctx, "maxFreq must be above minFreq");
-  if (mfcc && (nCoefs < 2 || nCoefs > nBands || startCoeff < 0 || startCoeff > 1))
-    return fail(ctx, "numCoeffs must be in [2, numBands] and startCoeff in [0, 1]");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t s = ctx->stream;
-  const int64_t F = fft / 2 + 1;
-  // StreamingControl bookkeeping (cc/FluidNRTClientWrapper.hpp:564-579, 642-644)
-  // userPadding.first = FFTParams::padding (cc/ParameterTypes.hpp:315-323): 0 / win/2 / win - hop; the input sits that
-  // far into the padded signal, the client's latency (= win) is added in front of the analysis, the padded length is
-  // rounded up to whole hops in Full mode (:572-574), and the first latency / hop output frames are dropped (:643-656)
-  const int64_t latencyHops = win / hop;
-  const int64_t userPad = paddingMode == 0 ? 0 : paddingMode == 1 ? win / 2 : win - hop;
-  int64_t paddedLength = n + win + 2 * userPad;
-  if (paddingMode == 2) paddedLength = ((paddedLength + hop - 1) / hop) * hop;
-  const int64_t T = 1 + (paddedLength - win) / hop - latencyHops;
-  // kept frame k starts at sample latencyHops hop - win - userPad + k hop; the kernels place frame t at
-  // t hop - win/2 + frameOffset
-  const int64_t frameOffset = latencyHops * hop - win + win / 2 - userPad;
-  if (T < 1) return fail(ctx, "not enough frames");
-  if (frames_out) *frames_out = T;
-  const int64_t Tp = round_up(T, 32), Fp = round_up(F, 32);
-  const int64_t bandsPad = round_up(nBands, 64);
-  // mel filter bank (alg/MelBands.hpp:53-73), bin-major and zero padded; f64 on the host like the reference
-  std::vector<double> filtT((size_t) F * bandsPad, 0.0);
-  {
-    auto hz2mel = [](double x) { return 1127.01048 * std::log(x / 700.0 + 1.0); };
-    const int64_t nc = nBands + 2;
-    std::vector<double> centres((size_t) nc);
-    const double mlo = hz2mel(minFreq), mhi = hz2mel(maxFreq);
-    for (int64_t i = 0; i < nc; i++)
-      centres[(size_t) i] = 700.0 * (std::exp((mlo + (double) i * (mhi - mlo) / (double) (nc - 1)) / 1127.01048) - 1.0);
-    for (int64_t b = 0; b < nBands; b++)
-    {
-      const double d0 = std::fabs(centres[(size_t) b] - centres[(size_t) b + 1]);
-      const double d1 = std::fabs(centres[(size_t) b + 1] - centres[(size_t) b + 2]);
-      for (int64_t f = 0; f < F; f++)
-      {
-        const double hz = (double) f * (sampleRate / 2.0) / (double) (F - 1);
-        const double lower = -(centres[(size_t) b] - hz) / d0, upper = (centres[(size_t) b + 2] - hz) / d1;
-        filtT[(size_t) (f * bandsPad + b)] = std::max(0.0, std::min(lower, upper));
-      }
-    }
-  }
-  // the filter bank over each band's support only (kernels_feat.hip): first non-zero bin and packed weights
-  std::vector<int> bandLo((size_t) bandsPad, 0);
-  int64_t maxLen = 1;
-  {
-    std::vector<int64_t> hi((size_t) bandsPad, -1);
-    for (int64_t b = 0; b < nBands; b++)
-    {
-      int64_t lo = -1;
-      for (int64_t f = 0; f < F; f++)
-        if (filtT[(size_t) (f * bandsPad + b)] != 0.0) { if (lo < 0) lo = f; hi[(size_t) b] = f; }
-      bandLo[(size_t) b] = (int) std::max<int64_t>(lo, 0);
-      if (lo >= 0) maxLen = std::max(maxLen, hi[(size_t) b] - lo + 1);
-    }
-  }
-  std::vector<double> wpack((size_t) maxLen * bandsPad, 0.0);
-  for (int64_t b = 0; b < nBands; b++)
-    for (int64_t j = 0; j < maxLen; j++)
-    {
-      const int64_t f = bandLo[(size_t) b] + j;
-      if (f < F) wpack[(size_t) (j * bandsPad + b)] = filtT[(size_t) (f * bandsPad + b)];
-    }
-  const int64_t nDct = mfcc ? std::min(nCoefs + startCoeff, nBands) : 0; // rt/MFCCClient.hpp:104-105
-  std::vector<double> dct((size_t) std::max<int64_t>(1, nDct * nBands));
-  for (int64_t i = 0; i < nDct; i++) // alg/DCT.hpp:53-61
-  {
-    const double scale = i == 0 ? 1.0 / std::sqrt((double) nBands) : std::sqrt(2.0 / (double) nBands);
-    for (int64_t j = 0; j < nBands; j++)
-      dct[(size_t) (i * nBands + j)] = std::cos((M_PI / (double) nBands) * (double) i * (0.5 + (double) j)) * scale;
-  }
-  const int64_t nOut = mfcc ? nCoefs : nBands;
-  const double *wtab = nullptr, *ttab = nullptr;
-  rc = get_window(ctx, win, fft, FLUHIP_WINDOW_HANN, &wtab);
-  if (rc) return rc;
-  rc = get_twiddle(ctx, fft, &ttab);
-  if (rc) return rc;
-  DevBuf dFilt, dDct, dAudio, dMag, dOut, dLo, dPack;
-  HIPCHK(ctx, dLo.alloc(bandLo.size() * sizeof(int), false, s));
-  HIPCHK(ctx, dPack.alloc(wpack.size() * sizeof(double), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(dLo.p, bandLo.data(), bandLo.size() * sizeof(int), hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, hipMemcpyAsync(dPack.p, wpack.data(), wpack.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, dFilt.alloc(filtT.size() * sizeof(double), false, s));
-  HIPCHK(ctx, dDct.alloc(dct.size() * sizeof(double), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(dFilt.p, filtT.data(), filtT.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  HIPCHK(ctx, hipMemcpyAsync(dDct.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
-  // ---- fused form (kernels_stft2.hip stft_feat_kernel): the magnitudes never leave the chip --------------------------
-  // Every bin must lie on the rising edge of at most one band and the falling edge of the band below it, with the
-  // bins of each edge contiguous: then band b = (sum of up[f] m[f] over interval b) + (sum of dn[f] m[f] over interval
-  // b + 1), interval s = the bins between centres s and s + 1.  True of any filter bank whose triangles are wider than
-  // a bin; checked here against the dense matrix, coefficient by coefficient, and anything else takes the two-kernel path.
-  {
-    const int CH = stft_features_bins_per_lane((int) fft);
-    std::vector<double> up((size_t) 64 * CH, 0.0), dn((size_t) 64 * CH, 0.0);
-    std::vector<short> slot((size_t) 64 * CH, (short) -1);
-    std::vector<int64_t> interval((size_t) F, -1); // interval of bin f, -1: no band touches it
-    bool ok = nBands <= 64 && (!mfcc || nDct * nBands <= 4096) && !stft_needs_scratch(win, fft) && (fft == 1024 || fft == 2048) &&
-              (win % 2) == 0;
-    if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_FUSED")) // A/B and tests: 0 forces the two-kernel form
-      if (std::atoi(e) == 0) ok = false;
-    std::vector<int64_t> peak((size_t) nBands, 0);
-    for (int64_t b = 0; ok && b < nBands; b++)
-    {
-      double best = -1.0;
-      for (int64_t f = 0; f < F; f++)
-        if (filtT[(size_t) (f * bandsPad + b)] > best) { best = filtT[(size_t) (f * bandsPad + b)]; peak[(size_t) b] = f; }
-      if (best <= 0.0) ok = false; // a band no bin falls into
-    }
-    for (int64_t f = 0; ok && f < F; f++)
-    {
-      int64_t b1 = -1, b2 = -1, cnt = 0;
-      for (int64_t b = 0; b < nBands; b++)
-        if (filtT[(size_t) (f * bandsPad + b)] != 0.0) { if (cnt == 0) b1 = b; else b2 = b; cnt++; }
-      if (cnt == 0) continue;
-      if (cnt > 2 || (cnt == 2 && b2 != b1 + 1)) { ok = false; break; }
-      if (cnt == 2)
-      {
-        interval[(size_t) f] = b2;
-        up[(size_t) f] = filtT[(size_t) (f * bandsPad + b2)];
-        dn[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)];
-      }
-      else if (f <= peak[(size_t) b1]) { interval[(size_t) f] = b1; up[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)]; }
-      else { interval[(size_t) f] = b1 + 1; dn[(size_t) f] = filtT[(size_t) (f * bandsPad + b1)]; }
-    }
-    // interval s starts at bin g[s].  The touched bins must be one contiguous run whose intervals ascend one at a time
-    // from some i0 up to nBands (the falling edge of the last band); intervals below i0 are empty and the running
-    // sums are still 0 at their boundaries, which therefore publish nothing.
-    std::vector<int64_t> g((size_t) nBands + 2, -1);
-    if (ok)
-    {
-      int64_t prev = -1, first = -1, last = -1;
-      bool ended = false;
-      for (int64_t f = 0; f < F && ok; f++)
-      {
-        const int64_t iv = interval[(size_t) f];
-        if (iv < 0) { if (first >= 0) ended = true; continue; }
-        if (ended) { ok = false; break; }              // touched bins are not one contiguous run
-        if (first < 0) first = f;
-        else if (iv != prev && iv != prev + 1) { ok = false; break; }
-        if (iv != prev) g[(size_t) iv] = f;
-        prev = iv;
-        last = f;
-      }
-      if (first < 0 || prev != nBands) ok = false;
-      if (ok)
-      {
-        int64_t i0 = 0;
-        while (g[(size_t) i0] < 0) i0++;
-        for (int64_t sI = 0; sI < i0; sI++) g[(size_t) sI] = first;
-        g[(size_t) nBands + 1] = last + 1;
-        for (int64_t sI = i0 + 1; sI <= nBands + 1; sI++) slot[(size_t) (g[(size_t) sI] - 1)] = (short) sI;
-      }
-      // reconstruction: the segment sums must give back the dense matrix exactly
-      for (int64_t b = 0; ok && b < nBands; b++)
-        for (int64_t f = 0; f < F; f++)
-        {
-          double w = 0.0;
-          if (f >= g[(size_t) b] && f < g[(size_t) b + 1]) w += up[(size_t) f];
-          if (f >= g[(size_t) b + 1] && f < g[(size_t) b + 2]) w += dn[(size_t) f];
-          if (w != filtT[(size_t) (f * bandsPad + b)]) { ok = false; break; }
-        }
-    }
-    if (ok)
-    {
-      DevBuf dUp, dDn, dSlot, dDct2, dAud, dOutF;
-      HIPCHK(ctx, dUp.alloc(up.size() * sizeof(double), false, s));
-      HIPCHK(ctx, dDn.alloc(dn.size() * sizeof(double), false, s));
-      HIPCHK(ctx, dSlot.alloc(slot.size() * sizeof(short), false, s));
-      HIPCHK(ctx, dDct2.alloc(dct.size() * sizeof(double), false, s));
-      HIPCHK(ctx, hipMemcpyAsync(dUp.p, up.data(), up.size() * sizeof(double), hipMemcpyHostToDevice, s));
-      HIPCHK(ctx, hipMemcpyAsync(dDn.p, dn.data(), dn.size() * sizeof(double), hipMemcpyHostToDevice, s));
-      HIPCHK(ctx, hipMemcpyAsync(dSlot.p, slot.data(), slot.size() * sizeof(short), hipMemcpyHostToDevice, s));
-      HIPCHK(ctx, hipMemcpyAsync(dDct2.p, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice, s));
-      // device-resident audio / output are used in place; host buffers go through staging chunks of bounded size
-      hipPointerAttribute_t pa;
-      const bool audDev = hipPointerGetAttributes(&pa, audio) == hipSuccess && pa.type == hipMemoryTypeDevice;
-      const bool outDev = hipPointerGetAttributes(&pa, out) == hipSuccess && pa.type == hipMemoryTypeDevice;
-      (void) hipGetLastError();
-      int64_t chunkBytes = (int64_t) 1 << 31;
-      if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CHUNK_BYTES")) chunkBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
-      const int64_t chunkB = (audDev && outDev) ? count
-                                                : std::max<int64_t>(1, std::min<int64_t>(count, chunkBytes / (n * (int64_t) sizeof(float))));
-      if (!audDev) HIPCHK(ctx, dAud.alloc((size_t) chunkB * n * sizeof(float), false, s));
-      if (!outDev) HIPCHK(ctx, dOutF.alloc((size_t) chunkB * nOut * T * sizeof(float), false, s));
-      for (int64_t b0 = 0; b0 < count; b0 += chunkB)
-      {
-        const int64_t nb = std::min(chunkB, count - b0);
-        const float* aPtr = audio + b0 * n;
-        if (!audDev)
-        {
-          HIPCHK(ctx, hipMemcpyAsync(dAud.p, aPtr, (size_t) nb * n * sizeof(float), hipMemcpyDefault, s));
-          aPtr = dAud.as<float>();
-        }
-        float* oPtr = outDev ? out + b0 * nOut * T : dOutF.as<float>();
-        StftArgs sa;
-        sa.audio = aPtr; sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
-        sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = (int) nb;
-        sa.window = wtab; sa.twiddle = ttab;
-        sa.mag = nullptr; sa.magStride = 0; sa.ldMag = 0; sa.spec = nullptr; sa.specStride = 0;
-        sa.frameOffset = (int) frameOffset; sa.bigScratch = nullptr;
-        FeatArgs fa;
-        fa.mag = nullptr; fa.magStride = 0; fa.ldMag = 0;
-        fa.T = (int) T; fa.F = (int) F; fa.B = (int) nb; fa.win = (int) win;
-        fa.filtT = nullptr; fa.nBands = (int) nBands; fa.bandsPad = (int) bandsPad;
-        fa.bandLo = nullptr; fa.wpack = nullptr; fa.maxLen = 0;
-        fa.magNorm = mfcc ? 0 : (normalize ? 1 : 0); fa.usePower = 0; fa.logOutput = mfcc ? 1 : (scaleDb ? 1 : 0);
-        fa.dct = mfcc ? dDct2.as<double>() : nullptr; fa.nDct = (int) nDct; fa.startCoeff = (int) startCoeff;
-        fa.nOut = (int) nOut; fa.out = oPtr;
-        bool launched;
-        {
-          ProfScope p(ctx, 2);
-          launched = launch_stft_features(sa, fa, dUp.as<double>(), dDn.as<double>(), dSlot.as<short>(), s);
-        }
-        if (!launched) { ok = false; break; }
-        HIPCHK(ctx, hipGetLastError());
-        if (!outDev)
-          HIPCHK(ctx, hipMemcpyAsync(out + b0 * nOut * T, oPtr, (size_t) nb * nOut * T * sizeof(float), hipMemcpyDefault, s));
-        if (!audDev || !outDev) HIPCHK(ctx, hipStreamSynchronize(s));   // the staging buffers are reused by the next chunk
-      }
-      if (ok)
-      {
-        HIPCHK(ctx, hipStreamSynchronize(s));
-        return FLUHIP_OK;
-      }
-    }
-  }
-  // ---- two-kernel form: magnitudes through HBM, any filter bank / fft size -------------------------------------------
-  // buffers are processed in chunks that keep the magnitude scratch around 2 GiB
-  const int64_t perBuf = Tp * Fp * (int64_t) sizeof(double);
-  int64_t scratchBytes = 2LL << 30;
-  if (const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CHUNK_BYTES")) scratchBytes = std::max<int64_t>(1, std::atoll(e)); // tests: force several chunks
-  const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(count, 65535), scratchBytes / perBuf));
-  HIPCHK(ctx, dAudio.alloc((size_t) chunk * n * sizeof(float), false, s));
-  HIPCHK(ctx, dMag.alloc((size_t) chunk * perBuf, true, s));
-  HIPCHK(ctx, dOut.alloc((size_t) chunk * nOut * T * sizeof(float), false, s));
-  for (int64_t b0 = 0; b0 < count; b0 += chunk)
-  {
-    const int64_t nb = std::min(chunk, count - b0);
-    // hipMemcpyDefault: `audio` and `out` may be host or device pointers (a corpus already resident in HBM skips PCIe)
-    HIPCHK(ctx, hipMemcpyAsync(dAudio.p, audio + b0 * n, (size_t) nb * n * sizeof(float), hipMemcpyDefault, s));
-    StftArgs sa;
-    sa.audio = dAudio.as<float>(); sa.audio64 = nullptr; sa.n = n; sa.audioStride = n;
-    sa.win = (int) win; sa.fft = (int) fft; sa.hop = (int) hop; sa.T = (int) T; sa.F = (int) F; sa.B = (int) nb;
-    sa.window = wtab; sa.twiddle = ttab;
-    sa.mag = dMag.as<double>(); sa.magStride = Tp * Fp; sa.ldMag = Fp;
-    sa.spec = nullptr; sa.specStride = 0; sa.frameOffset = (int) frameOffset;
-    sa.bigScratch = big_fft_scratch(ctx, win, fft, nb * T);
-    if (stft_needs_scratch(win, fft) && !sa.bigScratch) return FLUHIP_ERROR;
-    {
-      ProfScope p(ctx, 0);
-      launch_stft(sa, s);
-    }
-    FeatArgs fa;
-    fa.mag = dMag.as<double>(); fa.magStride = Tp * Fp; fa.ldMag = Fp;
-    fa.T = (int) T; fa.F = (int) F; fa.B = (int) nb; fa.win = (int) win;
-    fa.filtT = dFilt.as<double>(); fa.nBands = (int) nBands; fa.bandsPad = (int) bandsPad;
-    fa.bandLo = dLo.as<int>(); fa.wpack = dPack.as<double>(); fa.maxLen = (int) maxLen;
-    // rt/MFCCClient.hpp:123-124 (false, false, true); rt/MelBandsClient.hpp:106-108 (normalize, false, scale == dB)
-    fa.magNorm = mfcc ? 0 : (normalize ? 1 : 0); fa.usePower = 0; fa.logOutput = mfcc ? 1 : (scaleDb ? 1 : 0);
-    fa.dct = mfcc ? dDct.as<double>() : nullptr; fa.nDct = (int) nDct; fa.startCoeff = (int) startCoeff;
-    fa.nOut = (int) nOut; fa.out = dOut.as<float>();
-    {
-      ProfScope p(ctx, 2);
-      launch_features(fa, s);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(out + b0 * nOut * T, dOut.p, (size_t) nb * nOut * T * sizeof(float),
-                               hipMemcpyDefault, s));
-    HIPCHK(ctx, hipStreamSynchronize(s));
-  }
-  return FLUHIP_OK;
-}
-
-int fluhip_bufmelbands_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
-                                  int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
-                                  double sample_rate, int normalize, int scale_db, int padding_mode, float* out,
-                                  int64_t* frames_out)
-{
-  return features_common(ctx, false, audio, count, n, win, fft, hop, n_bands, 0, 0, min_freq, max_freq,
-                         sample_rate, normalize, scale_db, padding_mode, out, frames_out);
-}
-int fluhip_bufmelbands_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win,
-                           int64_t fft, int64_t hop, int64_t n_bands, double min_freq, double max_freq,
-                           double sample_rate, int normalize, int scale_db, float* out, int64_t* frames_out)
-{
-  return fluhip_bufmelbands_padded_f32(ctx, audio, count, n, win, fft, hop, n_bands, min_freq, max_freq, sample_rate,
-                                       normalize, scale_db, 1, out, frames_out);
-}
-
-int fluhip_bufmfcc_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
-                              int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
-                              double max_freq, double sample_rate, int padding_mode, float* out, int64_t* frames_out)
-{
-  return features_common(ctx, true, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
-                         max_freq, sample_rate, 0, 0, padding_mode, out, frames_out);
-}
-int fluhip_bufmfcc_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
-                       int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
-                       double max_freq, double sample_rate, float* out, int64_t* frames_out)
-{
-  return fluhip_bufmfcc_padded_f32(ctx, audio, count, n, win, fft, hop, n_bands, n_coefs, start_coeff, min_freq,
-                                   max_freq, sample_rate, 1, out, frames_out);
-}
-
 int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,
                                 int64_t cap, int32_t* info8)
 {
@@ -3165,45 +1615,6 @@ int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset)
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (out8) HIPCHK(ctx, hipMemcpy(out8, c->clk.p, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (reset) HIPCHK(ctx, hipMemset(c->clk.p, 0, 8 * sizeof(int64_t)));
-  return FLUHIP_OK;
-}
-
-int fluhip_prof_enable(fluhip_ctx* ctx, int on)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  ctx->prof = on != 0;
-  return FLUHIP_OK;
-}
-
-int fluhip_prof_reset(fluhip_ctx* ctx)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  for (auto& r : ctx->profRecs)
-  {
-    ctx->eventPool.push_back(r.start);
-    ctx->eventPool.push_back(r.stop);
-  }
-  ctx->profRecs.clear();
-  return FLUHIP_OK;
-}
-
-int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, double* total_ms)
-{
-  if (!ctx) return FLUHIP_ERROR;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  int64_t n = 0;
-  double tot = 0.0;
-  for (auto& r : ctx->profRecs)
-  {
-    if (r.cls != kernel_class) continue;
-    float ms = 0.f;
-    HIPCHK(ctx, hipEventElapsedTime(&ms, r.start, r.stop));
-    tot += ms;
-    n++;
-  }
-  if (launches) *launches = n;
-  if (total_ms) *total_ms = tot;
   return FLUHIP_OK;
 }
 

@@ -738,6 +738,11 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
 
   Core core;
   core.init(xb, tw2, twg, lane);
+  // FLUHIP_FEAT_PRIO (A/B): the wavefronts of a SIMD (wave, wave + 4, ...) at different issue priorities.  They run the same
+  // instruction stream from the same start; under fair round-robin issue they stay in phase -- all in their LDS exchanges,
+  // then all in their butterflies -- and the two pipes take turns instead of overlapping (PMC: VALU busy 46 % + LDS active
+  // 42 % of the launch).  With strict priorities the first one runs ahead and the others fill its waits.
+  if (a.prefetch & 2) { const int pr = (wave ^ (wave >> 2)) & 3; if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
   const double scale1 = 1.0 / ((double) a.win / 4.0);                          // alg/MelBands.hpp:49
   const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
 
@@ -760,7 +765,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     if (t >= a.T) continue;
     {
       cx pts[PPL];
-      gather_points<R1, N>(a, b, t, lane, wl, pts, a.n);
+      gather_points<R1, N>(a, b, t, lane, (a.prefetch & 1) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
       SCHED_FENCE();
       core.template run<false>(pts, nullptr);
     }
@@ -877,11 +882,26 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
   k.mag = nullptr; k.magStride = 0; k.ldMag = 0; k.magT = nullptr; k.magTStride = 0; k.ldMagT = 0;
   k.spec = nullptr; k.specStride = 0; k.frameOffset = a.frameOffset; k.blocksPerBuf = 0; k.totalBlocks = 0;
   k.nTab = nullptr; k.prefetch = 0;
+  if constexpr (kAbSwitches) // FLUHIP_FEAT_WINDOW_GLOBAL=1: the window pairs through the L1 instead of the LDS (A/B; `prefetch` is unused by this kernel)
+  {
+    static const int wg = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_WINDOW_GLOBAL"); return e ? std::atoi(e) : 0; }();
+    static const int pr = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_PRIO"); return e ? std::atoi(e) : 0; }();
+    k.prefetch = (wg ? 1 : 0) | (pr ? 2 : 0);
+  }
   FeatFusedArgs fa;
   fa.up = up; fa.dn = dn; fa.slot = slot; fa.dct = f.dct;
   fa.nBands = f.nBands; fa.nDct = f.nDct; fa.startCoeff = f.startCoeff; fa.nOut = f.nOut;
   fa.magNorm = f.magNorm; fa.usePower = f.usePower; fa.logOutput = f.logOutput; fa.out = f.out;
-  if (a.fft == 1024) return launch_feat_t<8, 8, 8, 16>(k, fa, s);
+  if (a.fft == 1024)
+  {
+    if constexpr (kAbSwitches) // FLUHIP_FEAT_NW=8|12: wavefronts per workgroup of the fused feature kernel (A/B; production 16)
+    {
+      static const int nw = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_NW"); return e ? std::atoi(e) : 16; }();
+      if (nw == 8) return launch_feat_t<8, 8, 8, 8>(k, fa, s);
+      if (nw == 12) return launch_feat_t<8, 8, 8, 12>(k, fa, s);
+    }
+    return launch_feat_t<8, 8, 8, 16>(k, fa, s);
+  }
   if (a.fft == 2048) return launch_feat_t<16, 8, 8, 8>(k, fa, s);
   return false;
 }
