@@ -224,35 +224,26 @@ int fluhip_nmf_process_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t 
                                       W1 ? &w1 : nullptr, H1 ? &h1 : nullptr, V1 ? &v1 : nullptr, progress, user);
 }
 
-int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
-                                  const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V)
+} // extern "C"
+
+// NMF::processFrame (alg/NMF.hpp:45-89) over the rows of a magnitude matrix that is ALREADY ON THE DEVICE: c->mag holds
+// T rows of F magnitudes (row stride c->Fp, allocated with the padding zero), c->T / F / K / Tp / Fp / Kp are set.  Leaves
+// the clamped, row-normalised dictionary in c->Wf and the activations of every frame in c->H1 ([Tp][Kp]).
+int process_frames_on_device(fluhip_ctx* ctx, fluhip_corpus& c, const double* W0host, int64_t iters, int64_t seed)
 {
-  if (!ctx) return FLUHIP_ERROR;
-  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
-  if (!W0 || K < 1) return fail(ctx, "bad dictionary");
-  if (iters < 0) return fail(ctx, "negative iteration count");
-  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   hipStream_t s = ctx->stream;
-  fluhip_corpus c;
-  c.ctx = ctx; c.B = 1; c.K = K;
-  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
-  c.T = T; c.F = F;
-  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
-  HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
+  const int64_t T = c.T, F = c.F, K = c.K;
   HIPCHK(ctx, c.magT.alloc((size_t) c.Fp * c.Tp * sizeof(double), true, s));
   HIPCHK(ctx, c.Wf.alloc((size_t) c.Fp * c.Kp * sizeof(double), true, s));
   HIPCHK(ctx, c.H1.alloc((size_t) c.Tp * c.Kp * sizeof(double), true, s));
   if (int rc2 = plan_updates(ctx, &c)) return rc2;
   // :57-58, 61  v0 = max(x, eps)
-  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
-                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
   launch_clamp_eps(c.mag.as<double>(), c.Fp, 0, (int) T, (int) F, 1, s);
   launch_transpose(c.mag.as<double>(), c.Fp, c.Tp * c.Fp, c.magT.as<double>(), c.Tp, c.Fp * c.Tp, (int) T,
                    (int) F, 1, s);
   // :59, 64-65  W = max(W, eps), every component divided by its L2 norm over the bins
   HIPCHK(ctx, c.stage.alloc((size_t) K * F * sizeof(double), false, s));
-  HIPCHK(ctx, hipMemcpyAsync(c.stage.p, W0, (size_t) K * F * sizeof(double), hipMemcpyHostToDevice, s));
+  HIPCHK(ctx, hipMemcpyAsync(c.stage.p, W0host, (size_t) K * F * sizeof(double), hipMemcpyHostToDevice, s));
   launch_scatter_factor(c.stage.as<double>(), 0, c.Wf.as<double>(), c.Fp * c.Kp, (int) F, (int) K, (int) c.Kp, 1,
                         true, s);
   HIPCHK(ctx, c.normScratch.alloc((size_t) colnorm_scratch_doubles((int) F, (int) c.Kp, 1) * sizeof(double), false, s));
@@ -275,7 +266,30 @@ int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, i
   HIPCHK(ctx, hipStreamSynchronize(s)); // host staging vectors go out of use
   c.haveMag = c.haveFactors = true;
   // :71-79  nIterations of the H update
-  int rc = corpus_iterate(&c, iters, false, true, nullptr, nullptr);
+  return corpus_iterate(&c, iters, false, true, nullptr, nullptr);
+}
+
+extern "C" {
+
+int fluhip_nmf_process_frames_f64(fluhip_ctx* ctx, const double* X, int64_t T, int64_t F, int64_t ldx,
+                                  const double* W0, int64_t K, int64_t iters, int64_t seed, double* H, double* V)
+{
+  if (!ctx) return FLUHIP_ERROR;
+  if (!X || T < 1 || F < 1 || ldx < F) return fail(ctx, "bad input matrix");
+  if (!W0 || K < 1) return fail(ctx, "bad dictionary");
+  if (iters < 0) return fail(ctx, "negative iteration count");
+  if (int rcr = check_rank(ctx, T, F, K)) return rcr;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  fluhip_corpus c;
+  c.ctx = ctx; c.B = 1; c.K = K;
+  c.hop = 1; c.n = T - 1; c.fft = (F - 1) * 2; c.win = c.fft;
+  c.T = T; c.F = F;
+  c.Tp = round_up(T, 32); c.Fp = round_up(F, 32); c.Kp = padded_rank(K);
+  HIPCHK(ctx, c.mag.alloc((size_t) c.Tp * c.Fp * sizeof(double), true, s));
+  HIPCHK(ctx, hipMemcpy2DAsync(c.mag.p, (size_t) c.Fp * sizeof(double), X, (size_t) ldx * sizeof(double),
+                               (size_t) F * sizeof(double), (size_t) T, hipMemcpyHostToDevice, s));
+  int rc = process_frames_on_device(ctx, c, W0, iters, seed);
   if (rc != FLUHIP_OK) return rc;
   DevBuf dh, dv;
   if (H)

@@ -294,4 +294,7 @@ void draw_uniform(int64_t seed, size_t count, std::vector<double>& out);
 int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds, const FactorInit& fi);
 int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH, fluhip_progress_fn progress, void* user);
 
+// api_algorithms.hip
+int process_frames_on_device(fluhip_ctx* ctx, fluhip_corpus& c, const double* W0host, int64_t iters, int64_t seed);
+
 #pragma GCC visibility pop

@@ -66,7 +66,7 @@ EXPORTS = [
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_debug_plan_lists", "fluhip_debug_plan_tail", "fluhip_debug_plan_kind",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
     "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_pool_bufmfcc_f32",
-    "fluhip_pool_bufmelbands_f32", "fluhip_shard_range", "fluhip_balanced_assignment",
+    "fluhip_pool_bufmelbands_f32", "fluhip_shard_range", "fluhip_balanced_assignment", "fluhip_nmfmatch_f32", "fluhip_nmffilter_f32",
 ]
 
 
@@ -392,6 +392,32 @@ class Context:
         return out
 
     # ---- BufSTFT ----------------------------------------------------------------------------
+    def nmfmatch(self, audio, bases, win, fft, hop, seed=42, padding_mode=1):
+        """NMFMatch over a buffer (fluhip_nmfmatch_f32): audio [channels, n] or [n] floats, bases [K, F] -> [channels, K, T]"""
+        a = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        b = np.ascontiguousarray(bases, dtype=np.float32)
+        count, n = a.shape
+        K = b.shape[0]
+        T = _i64(0)
+        f = self.lib.fluhip_nmfmatch_f32
+        f.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _fp, _i64, _i64, ctypes.c_int, _fp, _ip]
+        self._check(f(self.h, _f(a), count, n, win, fft, hop, _f(b), K, seed, padding_mode, None, ctypes.byref(T)))
+        out = np.empty((count, K, T.value), dtype=np.float32)
+        self._check(f(self.h, _f(a), count, n, win, fft, hop, _f(b), K, seed, padding_mode, _f(out), ctypes.byref(T)))
+        return out
+
+    def nmffilter(self, audio, bases, win, fft, hop, iters=10, seed=42):
+        """NMFFilter over a buffer (fluhip_nmffilter_f32): -> [channels, K, n] floats"""
+        a = np.ascontiguousarray(np.atleast_2d(audio), dtype=np.float32)
+        b = np.ascontiguousarray(bases, dtype=np.float32)
+        count, n = a.shape
+        K = b.shape[0]
+        out = np.empty((count, K, n), dtype=np.float32)
+        f = self.lib.fluhip_nmffilter_f32
+        f.argtypes = [_vp, _fp, _i64, _i64, _i64, _i64, _i64, _fp, _i64, _i64, _i64, _fp]
+        self._check(f(self.h, _f(a), count, n, win, fft, hop, _f(b), K, iters, seed, _f(out)))
+        return out
+
     def bufstft_forward(self, audio, win, fft, hop, padding_mode=1):
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         n = audio.shape[0]

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define FLUHIP_ABI_VERSION 3
+#define FLUHIP_ABI_VERSION 4
 
 /* clients/common/Result.hpp:24  enum class Status { kOk, kWarning, kError, kCancelled } */
 enum fluhip_status
@@ -234,6 +234,31 @@ int fluhip_bufmelbands_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t c
 int fluhip_bufmfcc_padded_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft,
                               int64_t hop, int64_t n_bands, int64_t n_coefs, int64_t start_coeff, double min_freq,
                               double max_freq, double sample_rate, int padding_mode, float* out, int64_t* frames_out);
+
+/* ---- the users of NMF::processFrame: NMFMatch and NMFFilter ------------------------------------------------------------
+ * clients/rt/NMFMatchClient.hpp:76-118 and clients/rt/NMFFilterClient.hpp:69-118 are real-time clients: a host vector in, a
+ * host vector out, one NMF::processFrame per hop against the dictionary in the `bases` buffer.  These two calls are those
+ * clients over a whole buffer, as the reference's offline wrapper templates drive a real-time client
+ * (clients/common/FluidNRTClientWrapper.hpp: StreamingControl :551-660, Streaming :466-547) -- every frame of every channel
+ * in one batch.  audio: count x n host floats (channels of one job; the client is reset per channel, :602 / :515).
+ * bases: K x F host floats, F = fft/2 + 1 (the filter buffer's channels, K = min(channels, maxComponents)).
+ *
+ * fluhip_nmfmatch_f32 -- the control output of NMFMatch per hop: out[channel][component][T], T as for the feature clients
+ * (fluhip_bufmfcc_padded_f32; *frames_out, also with out == NULL as a size query).  The client writes its output BEFORE
+ * it processes the call's frame (:104 against :108-117), so column k holds the activations of the frame at audio sample
+ * (k + win/hop - 1) hop - win - userPadding: one hop behind the frame BufMFCC analyses for that column (zeros where no
+ * frame precedes it).  processFrame runs TEN iterations there whatever the client's `iterations` parameter says (:113-116);
+ * seed >= 0: every frame starts from the same K draws (a fresh generator of the seed per call), seed < 0: random_device.
+ *
+ * fluhip_nmffilter_f32 -- the audio outputs of NMFFilter: out[channel][component][n].  Per frame: processFrame (`iters`
+ * iterations), the estimate W^T h as the ratio mask's denominator, component i's rank-one estimate through the mask
+ * (exponent 1), inverse transform, window, overlap-add, division by the overlap-added squared window; the ring buffers'
+ * delay of one window is removed as the wrapper removes it (frame m = 1, 2, ... covers samples [m hop - win, m hop)).
+ * hop <= win. */
+int fluhip_nmfmatch_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                        const float* bases, int64_t K, int64_t seed, int padding_mode, float* out, int64_t* frames_out);
+int fluhip_nmffilter_f32(fluhip_ctx* ctx, const float* audio, int64_t count, int64_t n, int64_t win, int64_t fft, int64_t hop,
+                         const float* bases, int64_t K, int64_t iters, int64_t seed, float* out);
 
 /* ---- corpus: many independent equal-shape buffers, resident in HBM --------------------- */
 /* The data-parallel form of the same path (BASELINE config 4): `count` mono buffers of n

@@ -552,3 +552,197 @@ def streaming_control_frame_starts(n, win, hop, padding_mode=1):
         # a frame lying wholly in the padding carries no index; callers only compare frames that touch the audio
         starts.append(int(f[nz[0]] - 1 - nz[0]) if nz.size else None)
     return n_analysis - latency_hops, starts
+
+
+# --------------------------------------------------------------------------------------
+# The users of NMF::processFrame: the real-time clients NMFMatch and NMFFilter (clients/rt/NMFMatchClient.hpp:76-118,
+# NMFFilterClient.hpp:69-118), restated LITERALLY -- host vector in, host vector out, FluidSource / FluidSink rings,
+# one processFrame per hop -- and driven offline the way the reference's own wrapper templates drive a real-time client
+# (cc/FluidNRTClientWrapper.hpp: StreamingControl :551-660 for control-rate outputs, Streaming :466-547 for audio
+# outputs).  The closed forms below them are what the HIP entry points (fluhip_nmfmatch_f32 / fluhip_nmffilter_f32)
+# compute in one batch; tests/test_oracle.py holds the two against each other.
+# --------------------------------------------------------------------------------------
+def _stft_frame(frame, w, fft):
+    """STFT::processFrame (alg/STFT.hpp:110-121): window, zero-pad to the transform size, real FFT (util/FFT.hpp:92-108)"""
+    X = np.fft.rfft(frame * w, n=fft)
+    X[0] = X[0].real
+    X[-1] = X[-1].real
+    return X
+
+
+def _process_frame_w(W0):
+    """the dictionary as processFrame leaves it (NMF.hpp:59, 64-65): clamped, every component divided by its L2 norm"""
+    W = np.maximum(np.asarray(W0, dtype=np.float64), EPS)
+    return W / np.sqrt((W * W).sum(axis=1, keepdims=True))
+
+
+class NMFMatchClientModel:
+    """rt/NMFMatchClient.hpp.  process(block) -> the control output of this call: the activations AS THEY STAND WHEN THE
+    CALL STARTS (:104, written before processInput runs), zeros beyond the rank; then every frame the block completes
+    updates them by processFrame with TEN iterations (:113-116: the literal 10, the `iterations` parameter is not read)."""
+
+    def __init__(self, bases, max_rank, win, fft, hop, seed, host_size):
+        self.bases = np.asarray(bases, dtype=np.float32)         # [K, F] as the filter buffer's channels hold them
+        self.max_rank, self.win, self.fft, self.hop, self.seed = max_rank, win, fft, hop, seed
+        self.w = hann(win)
+        self.host = host_size
+        self.reset()
+        self.act = np.zeros(max_rank)                            # mActivations(maxRank): value-initialised
+
+    def reset(self):                                             # :74 mSTFTProcessor.reset(): the ring and the frame clock
+        self.src = FluidSourceModel(self.win, self.host)
+        self.frame_time = 0
+
+    def process(self, block):
+        F = self.fft // 2 + 1
+        out = np.zeros(self.max_rank)
+        if self.bases.shape[1] != F:                             # :91 wrong frame size: nothing happens
+            return out
+        rank = min(self.bases.shape[0], self.max_rank)
+        out[:rank] = self.act[:rank]                             # :104-105
+        self.src.push(np.asarray(block, dtype=np.float64))
+        while self.frame_time < self.host:                       # BufferedProcess::processInput
+            X = _stft_frame(self.src.pull(self.win, self.frame_time), self.w, self.fft)
+            h, _ = nmf_process_frame(np.abs(X), self.bases[:rank].astype(np.float64), 10, self.seed)
+            self.act[:rank] = h
+            self.frame_time += self.hop
+        self.frame_time -= self.host
+        return out
+
+
+def nmfmatch_streaming_control(audio_f32, bases, win, fft, hop, seed, padding_mode=1, max_rank=None):
+    """NMFMatch behind StreamingControl, literally: padded copy, one client call per hop (host vector = hop, :580), column j of
+    the output = what call j returned, the first latency / hop columns dropped.  -> float32 [rank, keepHops]."""
+    audio = np.asarray(audio_f32, dtype=np.float64)
+    n = audio.shape[0]
+    K = np.asarray(bases).shape[0]
+    max_rank = K if max_rank is None else max_rank
+    pad = feature_padding(win, hop, padding_mode)
+    padded_len = n + win + 2 * pad
+    if padding_mode == 2:
+        padded_len = -(-padded_len // hop) * hop
+    n_analysis = 1 + (padded_len - win) // hop
+    padded = np.zeros(padded_len + hop)
+    padded[pad:pad + n] = audio
+    client = NMFMatchClientModel(bases, max_rank, win, fft, hop, seed, hop)
+    cols = [client.process(padded[j * hop:(j + 1) * hop]) for j in range(n_analysis)]
+    rank = min(K, max_rank)
+    lat = win // hop
+    return np.stack(cols[lat:], axis=1)[:rank].astype(np.float32) if n_analysis > lat else np.zeros((rank, 0), np.float32)
+
+
+def nmfmatch_channel(audio_f32, bases, win, fft, hop, seed, padding_mode=1, max_rank=None):
+    """The same in closed form: kept column k is processFrame (10 iterations) of the frame at audio sample
+    (k + latencyHops - 1) hop - win - userPadding -- ONE HOP BEHIND the frame the analysis clients (BufMFCC) put in that
+    column, because the output is written before the call's frame is processed; a column with no frame behind it yet
+    (k + latencyHops = 0) holds the initial zeros."""
+    audio = np.asarray(audio_f32, dtype=np.float64)
+    n = audio.shape[0]
+    bases = np.asarray(bases, dtype=np.float32)
+    K = bases.shape[0]
+    rank = min(K, K if max_rank is None else max_rank)
+    T, _ = feature_frames(n, win, hop, padding_mode)
+    pad = feature_padding(win, hop, padding_mode)
+    lat = win // hop
+    w = hann(win)
+    out = np.zeros((rank, max(T, 0)), dtype=np.float32)
+    for k in range(T):
+        f = k + lat - 1
+        if f < 0:
+            continue
+        idx = f * hop - win - pad + np.arange(win)
+        ok = (idx >= 0) & (idx < n)
+        frame = np.where(ok, audio[np.clip(idx, 0, n - 1)], 0.0)
+        h, _ = nmf_process_frame(np.abs(_stft_frame(frame, w, fft)), bases[:rank].astype(np.float64), 10, seed)
+        out[:, k] = h
+    return out
+
+
+class NMFFilterClientModel:
+    """rt/NMFFilterClient.hpp.  process(block) -> [rank, len(block)]: per completed frame, processFrame (`iterations`),
+    the estimate W^T h as the ratio mask's denominator (:104), component i's rank-one estimate through the mask
+    (alg/RatioMask.hpp:39-56, exponent 1), inverse frame (ISTFT::processFrame: inverse FFT, 1 / fft, window), overlap-add;
+    an extra channel overlap-adds window^2 and normalises the pulled block (BufferedProcess.hpp:219-239: x /= g where
+    x != 0, g > 0)."""
+
+    def __init__(self, bases, win, fft, hop, iters, seed, host_size):
+        self.bases = np.asarray(bases, dtype=np.float32)
+        self.win, self.fft, self.hop, self.iters, self.seed, self.host = win, fft, hop, iters, seed, host_size
+        self.w = hann(win)
+        self.reset()
+
+    def reset(self):
+        K = self.bases.shape[0]
+        self.src = FluidSourceModel(self.win, self.host)
+        self.sinks = [FluidSinkModel(self.win, self.host) for _ in range(K + 1)]
+        self.frame_time = 0
+
+    def process(self, block):
+        K, F = self.bases.shape
+        nb = len(block)
+        if F != self.fft // 2 + 1:
+            return np.zeros((K, nb))
+        self.src.push(np.asarray(block, dtype=np.float64))
+        while self.frame_time < self.host:                       # BufferedProcess::process
+            X = _stft_frame(self.src.pull(self.win, self.frame_time), self.w, self.fft)
+            h, vhat = nmf_process_frame(np.abs(X), self.bases.astype(np.float64), self.iters, self.seed)
+            Wn = _process_frame_w(self.bases)                    # processFrame normalised tmpFilt in place (:50-65)
+            mult = 1.0 / np.maximum(vhat, EPS)                   # RatioMask::init
+            for i in range(K):
+                Y = X * np.minimum(1.0, Wn[i] * h[i] * mult)     # NMF::estimate + RatioMask::process
+                y = np.fft.irfft(Y, n=self.fft)[:self.win] * self.w
+                self.sinks[i].push(y, self.frame_time)
+            self.sinks[K].push(self.w * self.w, self.frame_time)
+            self.frame_time += self.hop
+        self.frame_time -= self.host
+        g = self.sinks[K].pull(nb)
+        out = np.empty((K, nb))
+        for i in range(K):
+            x = self.sinks[i].pull(nb)
+            out[i] = np.where(x != 0, x / np.where(g > 0, g, 1.0), x)
+        return out
+
+
+def nmffilter_streaming(audio_f32, bases, win, fft, hop, iters, seed, host=64):
+    """NMFFilter behind Streaming (cc/FluidNRTClientWrapper.hpp:466-547), literally: host vectors of 64 samples
+    (NRTClientWrapper::VectorSize, :195), the input followed by zeros up to a whole number of vectors covering
+    nFrames + latency, the first `latency` = win output samples dropped.  -> float32 [K, n]."""
+    audio = np.asarray(audio_f32, dtype=np.float64)
+    n = audio.shape[0]
+    K = np.asarray(bases).shape[0]
+    n_hops = -(-(n + win) // host)
+    inp = np.zeros(host * n_hops)
+    inp[:n] = audio
+    client = NMFFilterClientModel(bases, win, fft, hop, iters, seed, host)
+    out = np.concatenate([client.process(inp[j * host:(j + 1) * host]) for j in range(n_hops)], axis=1)
+    return out[:, win:win + n].astype(np.float32)
+
+
+def nmffilter_channel(audio_f32, bases, win, fft, hop, iters, seed):
+    """The same in closed form: frames m = 1, 2, ... at audio samples m hop - win (the ring's delay of one window), each
+    masked per component and overlap-added where it came from; divided by the sum of window^2 over the frames covering a
+    sample (which is never zero where the numerator is not).  -> float32 [K, n]."""
+    audio = np.asarray(audio_f32, dtype=np.float64)
+    n = audio.shape[0]
+    bases = np.asarray(bases, dtype=np.float32)
+    K = bases.shape[0]
+    w = hann(win)
+    Wn = _process_frame_w(bases)
+    acc = np.zeros((K, n + 2 * win))
+    nrm = np.zeros(n + 2 * win)
+    m = 1
+    while m * hop - win < n:
+        s = m * hop - win
+        idx = s + np.arange(win)
+        ok = (idx >= 0) & (idx < n)
+        frame = np.where(ok, audio[np.clip(idx, 0, n - 1)], 0.0)
+        X = _stft_frame(frame, w, fft)
+        h, vhat = nmf_process_frame(np.abs(X), bases.astype(np.float64), iters, seed)
+        mult = 1.0 / np.maximum(vhat, EPS)
+        for i in range(K):
+            y = np.fft.irfft(X * np.minimum(1.0, Wn[i] * h[i] * mult), n=fft)[:win] * w
+            acc[i, s + win:s + 2 * win] += y
+        nrm[s + win:s + 2 * win] += w * w
+        m += 1
+    out = acc / np.maximum(nrm, EPS)[None, :]
+    return out[:, win:win + n].astype(np.float32)

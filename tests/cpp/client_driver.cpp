@@ -18,7 +18,13 @@
 //                      <startFrame> <numFrames> <startChan> <numChans> <async> <outprefix>
 //   client_driver melbands <in.f32> <frames> <chans> <win> <hop> <fft> <padding> <nBands> <normalize> <scale>
 //                      <startFrame> <numFrames> <startChan> <numChans> <async> <outprefix>
+//   client_driver nmfmatch <in.f32> <frames> <chans> <win> <hop> <fft> <padding> <maxComponents> <seed> <bases.f32|-> <K>
+//                      <async> <outprefix>          (bases file: K x (fft/2 + 1) floats, channel-major; "-" = no buffer)
+//   client_driver nmffilter <in.f32> <frames> <chans> <win> <hop> <fft> <maxComponents> <iterations> <seed> <bases.f32|->
+//                      <K> <async> <outprefix>
 #include "../../include/flucoma_hip/BufSTFTClient.hpp"
+#include "../../include/flucoma_hip/NMFFilterClient.hpp"
+#include "../../include/flucoma_hip/NMFMatchClient.hpp"
 #include "../../include/flucoma_hip/MFCCClient.hpp"
 #include "../../include/flucoma_hip/MelBandsClient.hpp"
 #include "../../include/flucoma_hip/NMFSeedClient.hpp"
@@ -152,6 +158,25 @@ static int runErrors2()
   // the validation branches of nrt/BufSTFTClient.hpp:84-107,189-216, nrt/NMFSeedClient.hpp:75-88 and
   // cc/FluidNRTClientWrapper.hpp:313-328 that need no device
   FluidContext ctx;
+  {
+    // the wrapper's checks in front of NMFMatch / NMFFilter (cc/FluidNRTClientWrapper.hpp:313-328)
+    fluhip::nmfmatch::NRTNMFMatchParams p;
+    fluhip::NRTNMFMatchClient           client(p, ctx);
+    report("match_no_source", client.process<float>(ctx));
+    p.source = makeBuffer(1, 4096);
+    report("match_no_output", client.process<float>(ctx));
+    p.maxComponents = 0; p.iterations = 0; p.startFrame = -3; p.padding = 7;
+    p.constrain();
+    std::printf("match_constraints|%d|\n", (p.maxComponents == 1 && p.iterations == 1 && p.startFrame == 0 && p.padding == 2) ? 1 : 0);
+    fluhip::nmffilter::NRTNMFFilterParams q;
+    fluhip::NRTNMFFilterClient            filt(q, ctx);
+    report("filter_no_source", filt.process<float>(ctx));
+    q.source = makeBuffer(2, 4096);
+    q.startChan = 2;
+    report("filter_bad_start_chan", filt.process<float>(ctx));
+    q.startChan = 0;
+    report("filter_no_output", filt.process<float>(ctx));
+  }
   {
     fluhip::bufstft::BufSTFTParams    p;
     fluhip::bufstft::BufferSTFTClient client(p, ctx);
@@ -315,6 +340,57 @@ int main(int argc, char** argv)
     }
     report("result", r);
     writeBuffer(prefix + "_features.bin", features);
+    return 0;
+  }
+
+  if (mode == "nmfmatch" || mode == "nmffilter")
+  {
+    if (argc < 15) return 2;
+    auto      in = readFile(argv[2]);
+    const idx frames = std::atol(argv[3]), chans = std::atol(argv[4]);
+    const FFTParams fft(std::atol(argv[5]), std::atol(argv[6]), std::atol(argv[7]));
+    auto      output = makeBuffer(1, 1);
+    auto      loadBases = [&](const char* path, idx K) -> std::shared_ptr<MemoryBufferAdaptor> {
+      if (std::string(path) == "-") return nullptr;
+      auto      sb = readFile(path);
+      const idx F = (idx) sb.size() / K;      // (a wrong frame count is one of the cases: take what the file holds)
+      auto      b = makeBuffer(K, F);
+      for (idx c = 0; c < K; ++c)
+        for (idx f = 0; f < F; ++f) b->raw()[f * K + c] = sb[(size_t) (c * F + f)];
+      return b;
+    };
+    Result r;
+    if (mode == "nmfmatch")
+    {
+      fluhip::nmfmatch::NRTNMFMatchParams p;
+      p.source = makeBuffer(chans, frames, in.data());
+      p.features = output;
+      p.fftSettings = fft;
+      p.padding = std::atol(argv[8]);
+      p.maxComponents = std::atol(argv[9]);
+      p.seed = std::atol(argv[10]);
+      p.bases = loadBases(argv[11], std::atol(argv[12]));
+      p.constrain();
+      r = runJob<fluhip::NRTThreadedNMFMatchClient>(p, std::atoi(argv[13]) != 0);
+      report("result", r);
+      writeBuffer(std::string(argv[14]) + "_features.bin", output);
+    }
+    else
+    {
+      if (argc < 16) return 2;
+      fluhip::nmffilter::NRTNMFFilterParams p;
+      p.source = makeBuffer(chans, frames, in.data());
+      p.resynth = output;
+      p.fftSettings = fft;
+      p.maxComponents = std::atol(argv[8]);
+      p.iterations = std::atol(argv[9]);
+      p.seed = std::atol(argv[10]);
+      p.bases = loadBases(argv[11], std::atol(argv[12]));
+      p.constrain();
+      r = runJob<fluhip::NRTThreadedNMFFilterClient>(p, std::atoi(argv[13]) != 0);
+      report("result", r);
+      writeBuffer(std::string(argv[14]) + "_resynth.bin", output);
+    }
     return 0;
   }
 

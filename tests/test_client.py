@@ -445,3 +445,76 @@ def test_bufmfcc_client_reproduces_the_references_corpus_rows(driver, tmp_path, 
         got = np.concatenate([m.mean(axis=1), m.std(axis=1)])
         assert feat.shape[0] == 13 and np.abs(got - g["expected"][j]).max() < 2e-5, (j, np.abs(got - g["expected"][j]).max())
 
+
+
+def test_validation_of_nmfmatch_and_nmffilter(driver):
+    """the wrapper's checks in front of the two processFrame clients (cc/FluidNRTClientWrapper.hpp:313-328) and the
+    constraints of their parameter tables (rt/NMFMatchClient.hpp:32-38, rt/NMFFilterClient.hpp:34-38): no device needed"""
+    r = run(driver, "errors2")
+    assert r["match_no_source"] == (ERROR, "Input buffer not set")
+    assert r["match_no_output"] == (ERROR, "No valid output has been set")
+    assert r["match_constraints"][0] == 1
+    assert r["filter_no_source"] == (ERROR, "Input buffer not set")
+    assert r["filter_bad_start_chan"] == (ERROR, "Input buffer  invalid start channel 2")
+    assert r["filter_no_output"] == (ERROR, "No valid output has been set")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+def test_nmfmatch_client(driver, onp, tmp_path, use_async, ctx):
+    """NRTThreadedNMFMatchClient (include/flucoma_hip/NMFMatchClient.hpp): NMFMatch behind the reference's StreamingControl
+    wrapper -- two channels, a bases buffer with MORE channels than maxComponents (rank = min of the two,
+    rt/NMFMatchClient.hpp:93), sync and on the adaptor's own thread: features buffer of keepHops x (channels * rank) at
+    sampleRate / hop, feature i of channel j in buffer channel i + j * rank (cc/FluidNRTClientWrapper.hpp:636-656), every
+    channel against the numpy restatement; and the no-filters case (zeros, maxComponents features)"""
+    frames, chans, win, hop, fft, K, max_rank, seed = 20000, 2, 1024, 256, 1024, 6, 4, 42
+    F = fft // 2 + 1
+    rs = np.random.RandomState(9)
+    audio = np.stack([onp.synth_audio(frames, 8300 + c) for c in range(chans)], axis=1)      # frames x chans
+    bases = (np.abs(rs.standard_normal((K, F))) + 0.01).astype(np.float32)
+    inp, bf = tmp_path / "in.f32", tmp_path / "bases.f32"
+    audio.astype(np.float32).tofile(inp); bases.tofile(bf)
+    prefix = str(tmp_path / "m")
+    r = run(driver, "nmfmatch", inp, frames, chans, win, hop, fft, 1, max_rank, seed, bf, K, use_async, prefix)
+    assert r["result"] == (OK, "")
+    feats, sr = read_buffer(prefix + "_features.bin")
+    T = onp.feature_frames(frames, win, hop, 1)[0]
+    assert feats.shape == (chans * max_rank, T) and sr == pytest.approx(44100.0 / hop)
+    for c in range(chans):
+        ref = onp.nmfmatch_channel(np.ascontiguousarray(audio[:, c]), bases[:max_rank], win, fft, hop, seed, 1)
+        assert rel_err(feats[c * max_rank:(c + 1) * max_rank], ref) < 1e-5, c
+    r = run(driver, "nmfmatch", inp, frames, chans, win, hop, fft, 1, max_rank, seed, "-", 1, use_async, prefix + "0")
+    assert r["result"] == (OK, "")
+    feats0, _ = read_buffer(prefix + "0_features.bin")
+    assert feats0.shape == (chans * max_rank, T) and not feats0.any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_async", [0, 1])
+def test_nmffilter_client(driver, onp, tmp_path, use_async, ctx):
+    """NRTThreadedNMFFilterClient (include/flucoma_hip/NMFFilterClient.hpp): NMFFilter behind the reference's Streaming
+    wrapper -- two channels, three components, sync and async: resynth buffer of frames x (channels * rank) at the source's
+    sample rate, component j of channel i in buffer channel i * rank + j, against the numpy restatement; the components of
+    a channel add back up to it; a bases buffer of the wrong frame count leaves zeros (rt/NMFFilterClient.hpp:93)"""
+    frames, chans, win, hop, fft, K, iters, seed = 15000, 2, 1024, 512, 1024, 3, 10, 42
+    F = fft // 2 + 1
+    rs = np.random.RandomState(10)
+    audio = np.stack([onp.synth_audio(frames, 8400 + c) for c in range(chans)], axis=1)
+    bases = (np.abs(rs.standard_normal((K, F))) + 0.01).astype(np.float32)
+    inp, bf = tmp_path / "in.f32", tmp_path / "bases.f32"
+    audio.astype(np.float32).tofile(inp); bases.tofile(bf)
+    prefix = str(tmp_path / "f")
+    r = run(driver, "nmffilter", inp, frames, chans, win, hop, fft, 20, iters, seed, bf, K, use_async, prefix)
+    assert r["result"] == (OK, "")
+    out, sr = read_buffer(prefix + "_resynth.bin")
+    assert out.shape == (chans * K, frames) and sr == pytest.approx(44100.0)
+    for c in range(chans):
+        x = np.ascontiguousarray(audio[:, c]).astype(np.float32)
+        ref = onp.nmffilter_channel(x, bases, win, fft, hop, iters, seed)
+        assert np.abs(out[c * K:(c + 1) * K] - ref).max() / np.abs(ref).max() < 1e-5, c
+        assert np.abs(out[c * K:(c + 1) * K].sum(axis=0) - x).max() < 1e-4
+    bases[:, :100].tofile(tmp_path / "short.f32")                 # 100 frames instead of 513
+    r = run(driver, "nmffilter", inp, frames, chans, win, hop, fft, 2, iters, seed, tmp_path / "short.f32", K, use_async, prefix + "0")
+    assert r["result"] == (OK, "")
+    out0, _ = read_buffer(prefix + "0_resynth.bin")
+    assert out0.shape == (chans * 2, frames) and not out0.any()

@@ -1310,3 +1310,46 @@ def test_reference_testbufferedprocess_cola_through_bufstft(ctx, frame):
     y = ctx.bufstft_inverse(mag, ph, frame, frame, hop, 1)
     m = min(len(y), n)
     assert np.abs(y[:m - frame] - x[:m - frame]).max() < 5e-6
+
+
+@pytest.mark.parametrize("n,win,fft,hop,K,mode", [(30000, 1024, 1024, 512, 5, 1), (12345, 1000, 1024, 300, 3, 0),
+                                                  (9000, 512, 1024, 128, 20, 2), (5000, 256, 256, 384, 2, 1),
+                                                  (20000, 2048, 2048, 512, 33, 1)])
+def test_nmfmatch_vs_oracle(ctx, onp, n, win, fft, hop, K, mode):
+    """fluhip_nmfmatch_f32 = NMFMatch (clients/rt/NMFMatchClient.hpp:76-118) behind StreamingControl: every frame of every
+    channel as one batch of the H update, against the numpy restatement (itself held against a literal model of the client
+    on the CPU): two channels, the three padding modes, hop not dividing the window, hop above the window, win < fft,
+    ranks on both sides of the 16 / 32 paddings"""
+    rs = np.random.RandomState(K)
+    audio = np.stack([onp.synth_audio(n, 8100 + c) for c in range(2)])
+    bases = (np.abs(rs.standard_normal((K, fft // 2 + 1))) + 0.01).astype(np.float32)
+    got = ctx.nmfmatch(audio, bases, win, fft, hop, seed=42, padding_mode=mode)
+    T = onp.feature_frames(n, win, hop, mode)[0]
+    assert got.shape == (2, K, T)
+    for c in range(2):
+        ref = onp.nmfmatch_channel(audio[c], bases, win, fft, hop, 42, mode)
+        assert rel_err(got[c], ref) < 1e-5, c
+    if win // hop == 0:
+        assert not got[:, :, 0].any()
+
+
+@pytest.mark.parametrize("n,win,fft,hop,K,iters", [(30000, 1024, 1024, 512, 4, 10), (12345, 1000, 1024, 300, 3, 5),
+                                                   (9000, 512, 1024, 128, 9, 12), (6000, 256, 256, 256, 2, 3),
+                                                   (20000, 2048, 2048, 512, 20, 10)])
+def test_nmffilter_vs_oracle(ctx, onp, n, win, fft, hop, K, iters):
+    """fluhip_nmffilter_f32 = NMFFilter (clients/rt/NMFFilterClient.hpp:69-118) behind Streaming: processFrame per frame,
+    ratio mask per component, inverse frames overlap-added at the ring buffers' positions -- against the numpy
+    restatement (held against the literal client model on the CPU); and the components add back up to the input"""
+    rs = np.random.RandomState(K + n)
+    audio = np.stack([onp.synth_audio(n, 8200 + c) for c in range(2)])
+    bases = (np.abs(rs.standard_normal((K, fft // 2 + 1))) + 0.01).astype(np.float32)
+    got = ctx.nmffilter(audio, bases, win, fft, hop, iters=iters, seed=42)
+    assert got.shape == (2, K, n)
+    for c in range(2):
+        ref = onp.nmffilter_channel(audio[c], bases, win, fft, hop, iters, 42)
+        scale = max(np.abs(ref).max(), 1e-12)
+        assert np.abs(got[c] - ref).max() / scale < 1e-5, c
+        if hop < win and win % hop == 0:
+            assert np.abs(got[c].sum(axis=0) - audio[c]).max() < 1e-4
+    with pytest.raises(Exception):
+        ctx.nmffilter(audio, bases, 256, 256, 300)

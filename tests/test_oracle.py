@@ -481,3 +481,33 @@ def test_reference_corpus_fixture_is_what_the_oracles_give(oracle, onp):
         for o in (onp, oracle):
             assert np.abs(_mfcc_stats(o.bufmfcc_channel(seg, 1024, 1024, 512, 40, 13, 1)) - g["expected"][j]).max() < 2e-5
 
+
+
+@pytest.mark.parametrize("n,win,fft,hop,K,mode", [(3000, 256, 256, 64, 3, 1), (2500, 256, 512, 100, 2, 0),
+                                                  (4100, 128, 128, 128, 4, 2), (1000, 64, 64, 96, 2, 1), (700, 255, 256, 60, 2, 1)])
+def test_nmfmatch_and_nmffilter_closed_forms_against_the_literal_clients(onp, n, win, fft, hop, K, mode):
+    """The users of NMF::processFrame (clients/rt/NMFMatchClient.hpp:76-118, NMFFilterClient.hpp:69-118): oracle_np holds a
+    LITERAL model of each real-time client -- host vector in, host vector out, FluidSource / FluidSink rings, the output
+    written before the call's frame is processed (NMFMatch), the window^2 normalisation channel (NMFFilter) -- driven the
+    way the reference's offline wrappers drive a real-time client (StreamingControl with host vectors of one hop;
+    Streaming with host vectors of 64 samples), and the closed forms the HIP entry points compute in one batch.  They must
+    be the same floats: hop dividing the window or not, hop = window, hop > window (NMFMatch), odd window, win < fft."""
+    rs = np.random.RandomState(n)
+    x = onp.synth_audio(n, 5).astype(np.float32)
+    bases = rs.uniform(0.01, 1, (K, fft // 2 + 1)).astype(np.float32)
+    a = onp.nmfmatch_streaming_control(x, bases, win, fft, hop, 42, mode)
+    b = onp.nmfmatch_channel(x, bases, win, fft, hop, 42, mode)
+    assert a.shape == b.shape == (K, onp.feature_frames(n, win, hop, mode)[0]) and np.array_equal(a, b)
+    if win // hop >= 1:
+        assert np.any(a[:, 0] != 0)            # a frame precedes the first kept column
+    else:
+        assert not a[:, 0].any()               # ... or it holds the activations as constructed
+    if hop <= win:
+        c = onp.nmffilter_streaming(x, bases, win, fft, hop, 7, 42)
+        d = onp.nmffilter_channel(x, bases, win, fft, hop, 7, 42)
+        assert c.shape == d.shape == (K, n) and np.array_equal(c, d)
+        if hop < win and win % hop == 0:
+            assert np.abs(c.sum(axis=0) - x).max() < 1e-5   # the masks add up to one: the components add up to the input
+    # a maxComponents below the buffer's channel count takes the first components only (:93)
+    a2 = onp.nmfmatch_streaming_control(x, bases, win, fft, hop, 42, mode, max_rank=1)
+    assert a2.shape[0] == 1 and np.array_equal(a2, onp.nmfmatch_channel(x, bases[:1], win, fft, hop, 42, mode))
