@@ -211,6 +211,16 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     {
       c->sideW = false;
       HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), false, s));
+      // FLUHIP_STRIP_BIN=1 (A/B build only): the W update as its own launch over bin strips instead of the fused form (W
+      // partials behind the H phase + the reduce launch).  Built and measured in round 4 (profiles/r04/c2_forms.md): 45.1 us
+      // per iteration against 40.3 at config 2 -- a tenth of the partial bytes, but the last arriver's chain of cross-XCD
+      // round trips (ticket, partials in two rounds, update) costs what the reduce launch cost.  Not adopted.
+      static const int binEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_BIN"); return e ? std::atoi(e) : 0; }();
+      c->stripBin = kAbSwitches && binEnv != 0;
+#ifdef FLUHIP_AB_SWITCHES
+      if (c->stripBin)
+        HIPCHK(ctx, c->binWork.alloc((size_t) nmf_binstrip_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), true, s));
+#endif
     }
     // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
     // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
@@ -836,7 +846,23 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       launch_nmf_strip_wstats(a, s);
       c->stripStatsValid = true;
     }
-    if (updateW)
+    if (updateW && c->stripBin)
+    {
+      // alg/NMF.hpp:158-161 as one launch over bin strips: reads W', its records and the H in memory, leaves the new W' and
+      // its records (other generation); :162 stays deferred as in the fused form
+      a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
+      {
+        ProfScope p(ctx, 1);
+#ifdef FLUHIP_AB_SWITCHES
+        launch_nmf_binstrip(a, c->binWork.as<double>(), s);
+#endif
+      }
+      c->stripGen ^= 1;
+      c->wPending = true;
+      c->stripReady = false;
+      c->stripNormFresh = false;
+    }
+    else if (updateW)
     {
       // alg/NMF.hpp:158-161; :162 is implicit in the next staging of W'
       if (!c->stripReady)
@@ -858,7 +884,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     if (updateH)
     {
       // :165-170, and behind it the numerator of the next iteration's W update while the new H is at hand
-      a.doH = 1; a.doW = (updateW && !last) ? 1 : 0; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
+      a.doH = 1; a.doW = (updateW && !last && !c->stripBin) ? 1 : 0; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
       ProfScope p(ctx, 1);
       launch_nmf_strip(a, s);
       c->stripReady = a.doW != 0;
@@ -1585,7 +1611,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
   out8[4] = c->sideW ? 1 : 0;
   out8[5] = c->stripsW;
   out8[6] = c->Kp;
-  out8[7] = c->strip ? 1 : 0;
+  out8[7] = c->strip ? (c->stripBin ? 2 : 1) : 0; // 2: the W update as a bin-strip launch
   return FLUHIP_OK;
 }
 

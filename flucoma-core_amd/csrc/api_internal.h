@@ -242,6 +242,10 @@ struct fluhip_corpus
   bool stripStatsValid = false; // the column-statistics records of generation stripGen describe the W in memory
   int stripGen = 0;
   DevBuf stripPart;
+  // ... with the W update as its own launch over bin strips (kernels_nmf_strip.hip nmf_binstrip_kernel; round 4): no
+  // numerator partials of the whole matrix, no reduce launch, the strip kernel runs its H phase only
+  bool stripBin = false;
+  DevBuf binWork;
   bool haveMag = false, haveFactors = false;
   bool touched = false; // work that reads the audio has been enqueued on the compute stream
   // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats

@@ -207,6 +207,10 @@ int64_t nmf_strip_part_doubles(int F, int T, int B);
 void launch_nmf_strip(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_wstats(const StripArgs& a, hipStream_t s);
+// the W update of the frame-strip schedule as its own launch over bin strips (no numerator partials of the whole matrix, no
+// reduce launch); `work`: nmf_binstrip_doubles() doubles, zeroed once
+int64_t nmf_binstrip_doubles(int F, int T, int B);
+void launch_nmf_binstrip(const StripArgs& a, double* work, hipStream_t s);
 
 // dst[b][row][k] = src[b or 0][k*rows + row] (colMajorSrc) or src[row*K + k]
 // rowsTab (device, [B] ints; ragged corpora): only rows < rowsTab[b] of buffer b are written

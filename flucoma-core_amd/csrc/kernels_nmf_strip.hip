@@ -659,6 +659,323 @@ __global__ __launch_bounds__(64) void nmf_strip_wstats_kernel(StripK a)
   strip_block_stats(v, a.statOut + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, r, lane);
 }
 
+#ifdef FLUHIP_AB_SWITCHES // (measured slower than the fused form: compiled into the A/B build only)
+// ---------------------------------------------------------------------------------------------------------------
+// W update of the frame-strip schedule as its OWN launch, bin strips (round 4).
+//
+// The fused form above hands the W update's numerator from 256 frame strips to the reduce launch as 256 partials of the
+// whole F x 16 matrix (34 MB written write-through and read back per iteration at config 2, 11.4 us of reduce launch
+// behind a 10 us W phase).  Here the decomposition of the W update is turned by 90 degrees against the H update's:
+// a workgroup owns PP bin pairs (96 bins: its rows of W' stay in registers as MFMA operands) and one of nSlices slices
+// of the frames, whose rows of the NEW H and tiles of V it streams; the partial numerators of a bin strip are nSlices x
+// 12 KB (3 MB in all), and the LAST workgroup of a strip to arrive adds them in slice order, forms
+// W' <- (W' / nrm) * num / max(den, eps) (alg/NMF.hpp:158-161) and leaves the statistics records of its pairs -- no
+// reduce launch.  One iteration = this launch + the strip kernel with its H phase only (which then needs no W phase,
+// no partial stores, no second use of its V registers).  V is read twice per iteration instead of once (from `mag`
+// both times, in the W-phase arrangement: sixteen lanes read 256 contiguous bytes of a frame).
+//
+// Tiles and operand roles are those of the strip kernel's W phase: a tile is 16 bins x 4 frames, lane (x, blk, y);
+//   Q[t][f]   = sum_k (H / nrm)[k][t] W'[f][k]     A = H rows (frame x, k = 4 y + m), B = W rows   -> D lane = Q[t_y][f_x]
+//   num[f][k] += sum_t (V / Q)[t][f] H[k][t]        A = the quotient as it lies,       B = H rows (frame y, k = 4 x + m)
+// Determinism: a wavefront adds its quads in order, the four wavefronts of a workgroup and then the slices of a strip are
+// added in fixed order by whoever arrives last -- the arrival order decides WHO adds, never in which order.
+// Cross-workgroup visibility (MI355X guide, "inter-workgroup visibility"): partials leave write-through (sc0 sc1), every
+// thread waits for its stores, one agent-scope ticket per strip; the last arriver reads the partials with sc1 loads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kBinPP = 3; // bin pairs per workgroup
+
+struct BinK
+{
+  const double* V;
+  int64_t strideV;
+  int ldv;
+  double* W;
+  int64_t strideW;
+  const double* H;
+  int64_t strideH;
+  double* part;   // [B][nStrips][nSlices][PP * 8][64] numerator partials
+  double* dpart;  // [B][nStrips][nSlices][16] row sums of H over the slice
+  int* ticket;    // [B][nStrips], zero between launches
+  const double* statIn;
+  double* statOut;
+  int F, T, K, nPairs, nBlk, nq, nStrips, nSlices, qBase, qRem, wPend;
+  long long* dbg; // FLUHIP_STRIP_INSTR: 100 MHz stamps of workgroup 0 ([0..7]) and of strip 0's last arriver ([8..15])
+};
+
+// a load that bypasses this CU's L1 (global_load ... sc1): the compiler's own relaxed agent-scope load, so that its wait
+// counters know about it (an inline-asm load returns into registers the compiler believes free)
+__device__ __forceinline__ double load_sc1(const double* p)
+{
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define BIN_STAMP(i)                                                                                       \
+  if constexpr (INSTR)                                                                                   \
+  {                                                                                                      \
+    if (tid == 0 && blockIdx.y == 0)                                                                     \
+    {                                                                                                    \
+      if (blockIdx.x == 0 && (i) < 8) a.dbg[(i)] = (long long) wall_clock64();                          \
+      if ((i) >= 8 && strip == 0) a.dbg[(i)] = (long long) wall_clock64();                               \
+    }                                                                                                    \
+  }
+
+template <int PP, bool INSTR = false>
+__global__ __launch_bounds__(256) void nmf_binstrip_kernel(BinK a)
+{
+  __shared__ double red[4][PP * 8][64]; // the wavefronts' numerators; the statistics scratch before that
+  __shared__ double nrmL[16], csL[16], denW[4][16], denL[16];
+  __shared__ int lastFlag;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
+  const int b = blockIdx.y;
+  const int strip = blockIdx.x % a.nStrips, slice = blockIdx.x / a.nStrips;
+  const int jp0 = strip * PP, jpLast = a.nPairs - 1;
+  const double* Vb = a.V + (int64_t) b * a.strideV;
+  double* Wg = a.W + (int64_t) b * a.strideW;
+  const double* Hg = a.H + (int64_t) b * a.strideH;
+
+  BIN_STAMP(0)
+  // the requests of the prologue first: statistics records, then this lane's rows of W' (B operand of the first product:
+  // W'[f][4 y + m], f = 32 jp + 8 blk + 2 x + e -- 32 contiguous bytes per (pair, e))
+  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, tid);
+  d2 wB[PP][2][2];
+#pragma unroll
+  for (int p = 0; p < PP; p++)
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+    {
+      const double* wp = Wg + (int64_t) (32 * min(jp0 + p, jpLast) + 8 * blk + 2 * x + e) * 16 + 4 * y;
+      wB[p][e][0] = *reinterpret_cast<const d2*>(wp);
+      wB[p][e][1] = *reinterpret_cast<const d2*>(wp + 2);
+    }
+  // this wavefront's quads of the slice: q = qBeg + wv, + 4, ...
+  const int qBeg = slice * a.qBase + min(slice, a.qRem), qEnd = qBeg + a.qBase + (slice < a.qRem ? 1 : 0);
+  const int nMine = (qEnd - qBeg - wv + 3) >> 2; // (may be <= 0)
+  const unsigned vLane = (unsigned) (y * a.ldv + 8 * blk + 2 * x);
+  struct Ops
+  {
+    d2 ha[2], hb[2], v[PP];
+  };
+  auto request = [&](int q, Ops& o) {
+    const int t0 = 4 * q;
+    const double* ha = Hg + (int64_t) (t0 + x) * 16 + 4 * y;
+    const double* hb = Hg + (int64_t) (t0 + y) * 16 + 4 * x;
+    o.ha[0] = *reinterpret_cast<const d2*>(ha); o.ha[1] = *reinterpret_cast<const d2*>(ha + 2);
+    o.hb[0] = *reinterpret_cast<const d2*>(hb); o.hb[1] = *reinterpret_cast<const d2*>(hb + 2);
+    const double* vp = Vb + (int64_t) t0 * a.ldv + vLane;
+#pragma unroll
+    for (int p = 0; p < PP; p++) o.v[p] = *reinterpret_cast<const d2*>(vp + 32 * min(jp0 + p, jpLast));
+  };
+  // Operands are requested kDepth - 1 quads ahead: one wavefront per SIMD (a round of workgroups is one per CU) has nobody to
+  // hide a memory round trip behind, and a quad is ~1 100 cycles of work against ~2 000 of latency (first version, one quad
+  // ahead: 25 us for config 2's launch, most of it waiting).
+  constexpr int kDepth = 3;
+  Ops ops[kDepth];
+  // (rows of H and V past the buffer's frames are allocated and zero: a quad index past the end re-reads the last one)
+  const int qLastValid = max(qEnd - 1, qBeg);
+#pragma unroll
+  for (int d = 0; d < kDepth - 1; d++) request(min(qBeg + wv + 4 * d, qLastValid), ops[d]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  strip_column_stats(straw, a.nBlk / 4, a.K, a.wPend, &red[0][0][0], nrmL, csL, tid, true);
+  double rn[4];
+#pragma unroll
+  for (int m = 0; m < 4; m++) rn[m] = 1.0 / nrmL[4 * y + m];
+  // pairs past the last one: zero rows (their numerators are never stored)
+#pragma unroll
+  for (int p = 0; p < PP; p++)
+    if (jp0 + p > jpLast)
+#pragma unroll
+      for (int e = 0; e < 2; e++) wB[p][e][0] = wB[p][e][1] = d2{0.0, 0.0};
+
+  double num[PP][2][4];
+#pragma unroll
+  for (int p = 0; p < PP; p++)
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int m = 0; m < 4; m++) num[p][e][m] = 0.0;
+  double dacc[4] = {0.0, 0.0, 0.0, 0.0};
+
+  BIN_STAMP(1)
+  constexpr int NQ = PP * 2; // quotients per quad (the staging macro's width)
+  auto compute = [&](const Ops& cur) {
+    double Ha[4], Hb[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+      Ha[m] = cur.ha[m >> 1][m & 1] * rn[m];
+      Hb[m] = cur.hb[m >> 1][m & 1];
+      dacc[m] += Hb[m];
+    }
+    double Q[NQ], Vt[NQ], R[NQ];
+#pragma unroll
+    for (int j = 0; j < NQ; j++) { Q[j] = 0.0; Vt[j] = cur.v[j >> 1][j & 1]; }
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int j = 0; j < NQ; j++) Q[j] = MFMA44(Ha[m], wB[j >> 1][j & 1][m >> 1][m & 1], Q[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    STRIP_QUOT(R, Vt, Q)
+#pragma unroll
+    for (int j = 0; j < NQ; j++)
+#pragma unroll
+      for (int m = 0; m < 4; m++) num[j >> 1][j & 1][m] = MFMA44(R[j], Hb[m], num[j >> 1][j & 1][m]);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int i = 0; i < nMine; i += kDepth)
+  {
+#pragma unroll
+    for (int d = 0; d < kDepth; d++)
+    {
+      // (the request is unconditional -- a clamped index -- so that no load sits behind a branch; the work is)
+      request(min(qBeg + wv + 4 * (i + d + kDepth - 1), qLastValid), ops[(d + kDepth - 1) % kDepth]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + d < nMine) compute(ops[d]);
+    }
+  }
+
+  BIN_STAMP(2)
+  // ---- the four wavefronts, in fixed order ----------------------------------------------------------------------------
+  // row sums of H over the wavefront's frames: lane (x, y) holds frames y of every quad, columns 4 x + m
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+  {
+    double v = dacc[m];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 4) denW[wv][4 * lane + m] = v;
+  }
+  __syncthreads(); // (the statistics scratch in red is free)
+#pragma unroll
+  for (int p = 0; p < PP; p++)
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+#pragma unroll
+      for (int m = 0; m < 4; m++) red[wv][(p * 2 + e) * 4 + m][lane] = num[p][e][m];
+  __syncthreads();
+  const int64_t slot = ((int64_t) b * a.nStrips + strip) * a.nSlices + slice;
+  double* P = a.part + slot * (PP * 8 * 64);
+#pragma unroll
+  for (int u = 0; u < PP * 2; u++)
+  {
+    const int r = wv + 4 * u; // block r of the strip, this thread's lane of it
+    const double s4 = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    double* dst = P + r * 64 + lane;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(s4) : "memory");
+  }
+  if (tid < 16)
+  {
+    const double d = ((denW[0][tid] + denW[1][tid]) + denW[2][tid]) + denW[3][tid];
+    double* dst = a.dpart + slot * 16 + tid;
+    asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(d) : "memory");
+  }
+  BIN_STAMP(3)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  BIN_STAMP(4)
+  if (tid == 0)
+  {
+    const int old = __hip_atomic_fetch_add(a.ticket + b * a.nStrips + strip, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lastFlag = old == a.nSlices - 1;
+  }
+  __syncthreads();
+  BIN_STAMP(5)
+  if (!lastFlag) return;
+  BIN_STAMP(8)
+
+  // ---- the last workgroup of the strip: the slices in a fixed order, the update, the statistics of the new W' -----------
+  // Everything below is latency: the partials come from other XCDs' stores (sc1 loads, ~1.5 us a round trip), so every
+  // round trip carries as many independent loads as the wait counter holds, 16 bytes each.
+  const int64_t slot0 = ((int64_t) b * a.nStrips + strip) * a.nSlices;
+  // the old values of the elements this thread will write, requested ahead of the partials (one round trip less at the end)
+  double wold[PP * 2];
+#pragma unroll
+  for (int u = 0; u < PP * 2; u++)
+  {
+    const int rl = wv + 4 * u;
+    const int f = 32 * min(jp0 + (rl >> 3), jpLast) + 8 * blk + 2 * y + ((rl >> 2) & 1), k = 4 * x + (rl & 3);
+    wold[u] = Wg[(int64_t) min(f, a.F - 1) * 16 + k];
+  }
+  {
+    // row sums of H: thread (k = tid & 15, g = tid >> 4) adds the slices g, g + 16, ... in that order; the 16 group sums
+    // are then added in group order
+    const int k = tid & 15, g = tid >> 4;
+    double d = 0.0;
+    for (int j0 = g; j0 < a.nSlices; j0 += 64)
+    {
+      double v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) v[u] = load_sc1(a.dpart + (slot0 + min(j0 + 16 * u, a.nSlices - 1)) * 16 + k);
+#pragma unroll
+      for (int u = 0; u < 4; u++) d += j0 + 16 * u < a.nSlices ? v[u] : 0.0;
+    }
+    red[0][0][tid] = d; // [g][k] as tid = g * 16 + k (this workgroup's own partials left the array before the ticket)
+  }
+  __syncthreads();
+  if (tid < 16)
+  {
+    double d = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; g++) d += red[0][0][g * 16 + tid];
+    denL[tid] = fmax(d, kEpsilon);
+  }
+  BIN_STAMP(9)
+  // numerators: the strip's PP * 8 blocks of 64 doubles = PP * 256 pairs of doubles per slice; thread tid takes the pairs
+  // tid, tid + 256, ... of every slice (16-byte loads), the slices in ascending order
+  const double* P0 = a.part + slot0 * (PP * 8 * 64);
+  d2 tot[PP];
+#pragma unroll
+  for (int u = 0; u < PP; u++) tot[u] = d2{0.0, 0.0};
+  constexpr int JB = 24 / PP < 1 ? 1 : 24 / PP; // slices per round trip: 2 * PP * JB eight-byte loads in flight (<= 48)
+  for (int j0 = 0; j0 < a.nSlices; j0 += JB)
+  {
+    d2 v[JB][PP];
+#pragma unroll
+    for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+      for (int u = 0; u < PP; u++)
+      {
+        const double* src = P0 + (int64_t) min(j0 + jj, a.nSlices - 1) * (PP * 8 * 64) + 2 * (tid + 256 * u);
+        v[jj][u][0] = load_sc1(src);
+        v[jj][u][1] = load_sc1(src + 1);
+      }
+#pragma unroll
+    for (int jj = 0; jj < JB; jj++)
+#pragma unroll
+      for (int u = 0; u < PP; u++)
+        if (j0 + jj < a.nSlices) { tot[u][0] += v[jj][u][0]; tot[u][1] += v[jj][u][1]; }
+  }
+  BIN_STAMP(10)
+  __syncthreads(); // denL complete, red free again
+  double* totL = &red[0][0][0]; // [PP * 8][64]
+#pragma unroll
+  for (int u = 0; u < PP; u++) *reinterpret_cast<d2*>(totL + 2 * (tid + 256 * u)) = tot[u];
+  __syncthreads();
+  const int nStep = a.nBlk / 4;
+#pragma unroll
+  for (int u = 0; u < PP * 2; u++)
+  {
+    const int rl = wv + 4 * u;                       // block of the strip: (pair p, e, m)
+    const int p = rl >> 3, e = (rl >> 2) & 1, m = rl & 3;
+    const int jp = jp0 + p;
+    if (jp > jpLast) continue;                       // (wave-uniform)
+    const int f = 32 * jp + 8 * blk + 2 * y + e, k = 4 * x + m;
+    double wnew = 0.0;
+    if (f < a.F && k < a.K)
+    {
+      wnew = (wold[u] / nrmL[k]) * totL[rl * 64 + lane] / denL[k];
+      Wg[(int64_t) f * 16 + k] = wnew;
+    }
+    strip_block_stats(wnew, a.statOut + (int64_t) b * a.nBlk * kStatW, nStep, (jp * 2 + e) * 4 + m, lane);
+  }
+  BIN_STAMP(11)
+  if (tid == 0) a.ticket[b * a.nStrips + strip] = 0; // for the next launch (kernel boundaries order it)
+}
+
+#endif // FLUHIP_AB_SWITCHES
+
 int strip_pairs(int F) { return (F + 31) / 32; }
 
 } // namespace strip
@@ -748,6 +1065,46 @@ void launch_nmf_strip(const StripArgs& a, hipStream_t s)
   else if (npw <= 5) launch_strip_q<5>(k, a.B, s);
   else launch_strip_q<9>(k, a.B, s);
 }
+
+#ifdef FLUHIP_AB_SWITCHES
+// bin-strip W update: workgroups = strips of kBinPP pairs x slices of the frames, at most one round of the chip
+static void binstrip_shape(int F, int T, int* nStrips, int* nSlices)
+{
+  const int nPairs = strip_pairs(F), nq = (T + 3) / 4;
+  *nStrips = (nPairs + kBinPP - 1) / kBinPP;
+  // a slice of at least 8 quads (two per wavefront): below that the launch is all prologue and hand-off
+  *nSlices = std::max(1, std::min(std::max(1, nq / 8), 256 / *nStrips));
+}
+int64_t nmf_binstrip_doubles(int F, int T, int B)
+{
+  int nStrips, nSlices;
+  binstrip_shape(F, T, &nStrips, &nSlices);
+  return (int64_t) B * nStrips * ((int64_t) nSlices * (kBinPP * 8 * 64 + 16) + 1) + 16;
+}
+// W' <- (W' / nrm) * (V / (W' (H / nrm))) H^T / rowsum(H) from the records of generation statGen, records of the new W'
+// into the other generation; `work` = nmf_binstrip_doubles() of workspace whose ticket words are zero (they return to zero)
+void launch_nmf_binstrip(const StripArgs& s0, double* work, hipStream_t s)
+{
+  const StripK k = make_k(s0);
+  BinK a;
+  a.V = s0.V; a.strideV = s0.strideV; a.ldv = (int) s0.ldv;
+  a.W = s0.W; a.strideW = s0.strideW; a.H = s0.H; a.strideH = s0.strideH;
+  a.statIn = k.statIn; a.statOut = k.statOut;
+  a.F = s0.F; a.T = s0.T; a.K = s0.K; a.nPairs = k.nPairs; a.nBlk = k.nBlk; a.nq = k.nq; a.wPend = s0.wPend;
+  binstrip_shape(s0.F, s0.T, &a.nStrips, &a.nSlices);
+  a.qBase = a.nq / a.nSlices; a.qRem = a.nq % a.nSlices;
+  a.part = work;
+  a.dpart = a.part + (int64_t) s0.B * a.nStrips * a.nSlices * (kBinPP * 8 * 64);
+  a.ticket = reinterpret_cast<int*>(a.dpart + (int64_t) s0.B * a.nStrips * a.nSlices * 16);
+  a.dbg = k.dbg;
+  static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
+  if (instr)
+    hipLaunchKernelGGL((nmf_binstrip_kernel<kBinPP, true>), dim3((unsigned) (a.nStrips * a.nSlices), (unsigned) s0.B), dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL((nmf_binstrip_kernel<kBinPP, false>), dim3((unsigned) (a.nStrips * a.nSlices), (unsigned) s0.B), dim3(256), 0, s, a);
+}
+
+#endif // FLUHIP_AB_SWITCHES
 
 // reads the records of generation statGen, leaves those of the new W' in the other generation
 void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s)

@@ -377,7 +377,6 @@ int main(int argc, char** argv)
     }
     else
     {
-      if (argc < 16) return 2;
       fluhip::nmffilter::NRTNMFFilterParams p;
       p.source = makeBuffer(chans, frames, in.data());
       p.resynth = output;

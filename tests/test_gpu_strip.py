@@ -67,7 +67,7 @@ assert rc == fluhip.CANCELLED and seen == [1, 2, 3, 4, 5], (rc, seen)
 # a corpus of several buffers on the strip schedule
 audio = np.stack([oracle_np.synth_audio(30000, 1000 + b) for b in range(5)])
 c = fluhip.Corpus(ctx, 5, 30000, 1024, 1024, 256, 8)
-assert c.plan()["strip"] == 1, c.plan()
+assert c.plan()["strip"] == (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1), c.plan()   # 2: bin strips for W
 c.set_audio(audio); c.stft(); c.nmf(10, seed=42)
 mag, W1, H1 = c.read_f64()
 for b in (0, 4):
@@ -79,7 +79,7 @@ for b in (0, 4):
 # ... and at fft 2048 (nine bin pairs per wavefront), three buffers, seeds per buffer
 audio = np.stack([oracle_np.synth_audio(40000, 2000 + b) for b in range(3)])
 c = fluhip.Corpus(ctx, 3, 40000, 2048, 2048, 512, 16)
-assert c.plan()["strip"] == 1, c.plan()
+assert c.plan()["strip"] == (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1), c.plan()   # 2: bin strips for W
 c.set_audio(audio); c.stft(); c.nmf(6, seeds=[5, 6, 5])
 mag, W1, H1 = c.read_f64()
 for b in range(3):
@@ -93,9 +93,13 @@ assert worst < 1e-9, worst
 '''
 
 
-def test_strip_schedule_against_the_oracle(ab_lib_paths):
+@pytest.mark.parametrize("bin_launch", ["0", "1"])
+def test_strip_schedule_against_the_oracle(ab_lib_paths, bin_launch):
+    """bin_launch 0: the fused form, W partials behind the H phase + the reduce launch (production); 1: the W update as its
+    own launch over bin strips (FLUHIP_STRIP_BIN=1, A/B build: measured slower, kept as a tested alternative)"""
     e = dict(os.environ)
     e["FLUHIP_STRIP"] = "1"
+    e["FLUHIP_STRIP_BIN"] = bin_launch
     e["FLUHIP_LIB"] = ab_lib_paths[0]
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
