@@ -26,6 +26,9 @@
 // the pace: tools/hbm_write_probe.hip reproduces the figure with a plain FMA loop and the same two store patterns.
 #include "fluhip_kernels.h"
 
+#include <algorithm>
+#include <cstdio>
+#include <vector>
 #include <cstdlib>
 
 namespace fluhip {
@@ -699,6 +702,7 @@ struct FeatFusedArgs
   int nBands, nDct, startCoeff, nOut;
   int magNorm, usePower, logOutput;
   float* out;          // [B][nOut][T]
+  long long* dbg = nullptr; // FLUHIP_FEAT_CLOCK (A/B build): shader-cycle and 100 MHz stamps of workgroup 0's first wavefront
 };
 
 template <int R1, int R2, int R3, int NW>
@@ -736,6 +740,11 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
   __syncthreads();
 
+  if (fa.dbg && threadIdx.x == 0)
+  {
+    if (blockIdx.x == 0) fa.dbg[0] = (long long) __builtin_readcyclecounter();
+    fa.dbg[4 + 2 * blockIdx.x] = (long long) wall_clock64();
+  }
   Core core;
   core.init(xb, tw2, twg, lane);
   // FLUHIP_FEAT_PRIO (A/B): the wavefronts of a SIMD (wave, wave + 4, ...) at different issue priorities.  They run the same
@@ -847,6 +856,11 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       }
     }
   }
+  if (fa.dbg && threadIdx.x == 0)
+  {
+    if (blockIdx.x == 0) fa.dbg[2] = (long long) __builtin_readcyclecounter();
+    fa.dbg[5 + 2 * blockIdx.x] = (long long) wall_clock64();
+  }
 }
 
 template <int R1, int R2, int R3, int NW>
@@ -866,6 +880,36 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
   if (grid > 256) grid = 256;
+  if constexpr (kAbSwitches)
+  {
+    static const int clk = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CLOCK"); return e ? std::atoi(e) : 0; }();
+    if (clk)
+    {
+      FeatFusedArgs f2 = fa;
+      long long* d = nullptr;
+      if (hipMalloc(&d, (4 + 2 * 256) * 8) == hipSuccess)
+      {
+        f2.dbg = d;
+        hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(64 * NW), shmem, s, k, f2);
+        std::vector<long long> h(4 + 2 * 256, 0);
+        (void) hipStreamSynchronize(s);
+        (void) hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+        (void) hipFree(d);
+        long long t0 = h[4], t1 = h[5];
+        for (int g = 0; g < (int) grid; g++) { t0 = std::min(t0, h[4 + 2 * g]); t1 = std::max(t1, h[5 + 2 * g]); }
+        const double us = (h[5] - h[4]) / 100.0;
+        std::fprintf(stderr, "stft_feat_kernel: workgroup 0 alive %.1f us, %lld shader cycles -> %.0f MHz; all %d workgroups: %.1f us first start to last end\n",
+                     us, h[2] - h[0], (h[2] - h[0]) / us, (int) grid, (t1 - t0) / 100.0);
+        std::fprintf(stderr, "  start offsets / lifetimes (us) of workgroups 0, 1, 8, 9, 64, 128, 255:");
+        for (int g : {0, 1, 8, 9, 64, 128, 255})
+          if (g < (int) grid) std::fprintf(stderr, "  %.0f/%.0f", (h[4 + 2 * g] - t0) / 100.0, (h[5 + 2 * g] - h[4 + 2 * g]) / 100.0);
+        int late = 0;
+        for (int g = 0; g < (int) grid; g++) late += (h[4 + 2 * g] - t0) > 10000 ? 1 : 0;   // started more than 100 us after the first
+        std::fprintf(stderr, "\n  workgroups that started more than 100 us after the first: %d\n", late);
+        return true;
+      }
+    }
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(64 * NW), shmem, s, k, fa);
   return true;
 }
