@@ -399,6 +399,132 @@ struct FftCore
     if constexpr (SPEC) specRow[N] = d2{xr, 0.0};
   }
   }
+
+  // ---- NF frames at once (round 4, the fused feature kernel) ---------------------------------------------------------
+  // The same passes with NF independent frames between the same fences: frame f stages through the buffer f * BUFD doubles
+  // behind xb.  One frame's chain -- pass, exchange (write, read, wait), pass, ... -- leaves the wavefront waiting on the
+  // LDS most of its life (a single wavefront at top priority needs 11.8 k cycles per frame for 2 760 cycles of VALU issue,
+  // and four of them per SIMD fill the VALU to a half); two frames in one instruction stream give the scheduler something
+  // to put into every one of those waits.
+  template <int NF>
+  __device__ __forceinline__ void passesN(cx (&pts)[NF][PPL], cx (&p3)[NF][PPL])
+  {
+  SCHED_FENCE();
+#pragma unroll
+  for (int f = 0; f < NF; f++)
+#pragma unroll
+    for (int bb = 0; bb < NB1; bb++)
+    {
+      cx v[R1];
+#pragma unroll
+      for (int r = 0; r < R1; r++) v[r] = pts[f][bb * R1 + r];
+      bfr<R1>(v);
+#pragma unroll
+      for (int r = 0; r < R1; r++) pts[f][bb * R1 + r] = v[r];
+    }
+  SCHED_FENCE();
+  cx p2[NF][PPL];
+#pragma unroll
+  for (int f = 0; f < NF; f++)
+  {
+#pragma unroll
+    for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+      for (int r = 0; r < R1; r++) w1p[f * BUFD + (64 * R1 + 4 * R1) * bb + ((R1 == 8 && r >= 8) ? 0 : r)] = pts[f][bb * R1 + r].re;
+#pragma unroll
+    for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+      for (int r = 0; r < R2; r++) p2[f][bb * R2 + r].re = r2p[f * BUFD + 68 * bb + (N / R2 + N / R2 / 16) * r];
+#pragma unroll
+    for (int bb = 0; bb < NB1; bb++)
+#pragma unroll
+      for (int r = 0; r < R1; r++) w1p[f * BUFD + (64 * R1 + 4 * R1) * bb + ((R1 == 8 && r >= 8) ? 0 : r)] = pts[f][bb * R1 + r].im;
+#pragma unroll
+    for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+      for (int r = 0; r < R2; r++) p2[f][bb * R2 + r].im = r2p[f * BUFD + 68 * bb + (N / R2 + N / R2 / 16) * r];
+  }
+  SCHED_FENCE();
+#pragma unroll
+  for (int bb = 0; bb < NB2; bb++)
+  {
+    // (one read of a pass-2 twiddle serves every frame)
+    cx tw[R2];
+#pragma unroll
+    for (int r = 1; r < R2; r++) tw[r] = tocx(tw2p[(r - 1) * NS2]);
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+    {
+      cx v[R2];
+      v[0] = p2[f][bb * R2];
+#pragma unroll
+      for (int r = 1; r < R2; r++) v[r] = cmul2(p2[f][bb * R2 + r], tw[r]);
+      bfr<R2>(v);
+#pragma unroll
+      for (int r = 0; r < R2; r++) p2[f][bb * R2 + r] = v[r];
+    }
+  }
+  SCHED_FENCE();
+  auto in3 = [&](int f, int bb, int r) -> const double* {
+    return (LOCAL && bb == 1 ? r3pB : r3pA) + f * BUFD + (NS3 + NS3 / 16) * r;
+  };
+#pragma unroll
+  for (int f = 0; f < NF; f++)
+  {
+#pragma unroll
+    for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+      for (int r = 0; r < R2; r++)
+        w2p[f * BUFD + (64 * R2 + 4 * R2) * bb + NS2 * r + ((NS2 * r) >> 4)] = p2[f][bb * R2 + r].re;
+#pragma unroll
+    for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+      for (int r = 0; r < R3; r++) p3[f][bb * R3 + r].re = *in3(f, bb, r);
+#pragma unroll
+    for (int bb = 0; bb < NB2; bb++)
+#pragma unroll
+      for (int r = 0; r < R2; r++)
+        w2p[f * BUFD + (64 * R2 + 4 * R2) * bb + NS2 * r + ((NS2 * r) >> 4)] = p2[f][bb * R2 + r].im;
+#pragma unroll
+    for (int bb = 0; bb < NB3; bb++)
+#pragma unroll
+      for (int r = 0; r < R3; r++) p3[f][bb * R3 + r].im = *in3(f, bb, r);
+  }
+  SCHED_FENCE();
+#pragma unroll
+  for (int bb = 0; bb < NB3; bb++)
+  {
+    cx tw[R3];
+#pragma unroll
+    for (int r = 1; r < R3; r++) tw[r] = tocx((LOCAL && bb == 1 ? tw3pB : tw3pA)[(r - 1) * NS3]);
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+    {
+      cx v[R3];
+      v[0] = p3[f][bb * R3];
+#pragma unroll
+      for (int r = 1; r < R3; r++) v[r] = cmul2(p3[f][bb * R3 + r], tw[r]);
+      bfr<R3>(v);
+#pragma unroll
+      for (int r = 0; r < R3; r++) p3[f][bb * R3 + r] = v[r];
+    }
+  }
+  SCHED_FENCE();
+  }
+
+  // the split + magnitude of frame f of NF (staged at xb + f * BUFD); one frame's worth of the single-frame split()
+  template <int NF>
+  __device__ __forceinline__ void splitN(cx (&p3)[NF][PPL])
+  {
+    double* const xb0 = xb;
+#pragma unroll
+    for (int f = 0; f < NF; f++)
+    {
+      xb = xb0 + f * BUFD;
+      split<false>(p3[f], nullptr);
+    }
+    xb = xb0;
+  }
 };
 
 // gather + window of frame t of buffer b: point m = x[2m] + i x[2m+1], m = lane + 64 bb + r N/R1 (alg/STFT.hpp:94-105;
@@ -863,6 +989,205 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   }
 }
 
+#ifdef FLUHIP_AB_SWITCHES
+// The same kernel with FPW frames per wavefront in ONE instruction stream (FftCore::passesN): a block is NW * FPW
+// consecutive frames, wavefront w takes frames w FPW .. w FPW + FPW - 1 of it.  Half the wavefronts per SIMD (twice the
+// registers per wavefront), the same number of frames in flight -- but the frames of a wavefront are scheduled against each
+// other by the compiler instead of against the luck of the round-robin.
+template <int R1, int R2, int R3, int NW, int FPW>
+__global__ __launch_bounds__(64 * NW) void stft_feat2_kernel(StftBArgs a, FeatFusedArgs fa)
+{
+  using Core = FftCore<R1, R2, R3>;
+  constexpr int N = Core::N, PPL = Core::PPL, BUFD = Core::BUFD;
+  constexpr int CH = (N + 1 + 63) / 64;
+  constexpr int WS = 66 + 66 + 64;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  d2* tw2 = reinterpret_cast<d2*>(lds);
+  d2* wl = tw2 + Core::T2 + Core::T3;
+  double* xall = reinterpret_cast<double*>(wl + N);
+  double* scr = xall + NW * FPW * BUFD;           // [NW][FPW][WS]
+  double* upl = scr + NW * FPW * WS;
+  double* dnl = upl + 64 * CH;
+  double* dctl = dnl + 64 * CH;
+  const int dld = fa.nBands + 1;
+  short* slotl = reinterpret_cast<short*>(dctl + (fa.dct ? fa.nDct * dld : 0));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  double* xb = xall + wave * FPW * BUFD;
+  double* bu0 = scr + wave * FPW * WS;
+
+  const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
+  Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
+  for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
+  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
+  if (fa.dct)
+    for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[(i / fa.nBands) * dld + (i % fa.nBands)] = fa.dct[i];
+  for (int i = lane; i < FPW * WS; i += 64) bu0[i] = 0.0;
+  __syncthreads();
+
+  Core core;
+  core.init(xb, tw2, twg, lane);
+  const double scale1 = 1.0 / ((double) a.win / 4.0);
+  const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);
+
+  const int64_t chunk = (a.totalBlocks + 7) / 8;
+  for (int64_t L = blockIdx.x;; L += gridDim.x)
+  {
+    const int64_t slot8 = L >> 3;
+    if (slot8 >= chunk) break;
+    const int64_t blk = (L & 7) * chunk + slot8;
+    if (blk >= a.totalBlocks) continue;
+    const int b = (int) (blk / a.blocksPerBuf);
+    const int t0 = ((int) (blk % a.blocksPerBuf) * NW + wave) * FPW;
+    if (t0 >= a.T) continue;
+    {
+      cx pts[FPW][PPL], p3[FPW][PPL];
+#pragma unroll
+      for (int f = 0; f < FPW; f++) gather_points<R1, N>(a, b, min(t0 + f, a.T - 1), lane, wl, pts[f], a.n); // (a frame past the last repeats it; not stored)
+      SCHED_FENCE();
+      core.template passesN<FPW>(pts, p3);
+      core.template splitN<FPW>(p3);
+    }
+    SCHED_FENCE();
+    // ---- band sums of the FPW frames, stage by stage ----------------------------------------------------------------
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    double v[FPW];
+    {
+      double pu[FPW][CH], pd[FPW][CH];
+      double su[FPW], sd[FPW], en[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; f++) su[f] = sd[f] = en[f] = 0.0;
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        const int fb = CH * ln + i;
+        const double wu = upl[i * 64 + ln], wd = dnl[i * 64 + ln];
+#pragma unroll
+        for (int f = 0; f < FPW; f++)
+        {
+          double m = fb <= N ? xb[f * BUFD + fb] : 0.0;
+          if (fa.magNorm) { m *= scale1; en[f] += m; }
+          if (fa.usePower) m = m * m;
+          su[f] = __builtin_fma(wu, m, su[f]);
+          sd[f] = __builtin_fma(wd, m, sd[f]);
+          pu[f][i] = su[f];
+          pd[f][i] = sd[f];
+        }
+      }
+      double eu[FPW], ed[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; f++)
+      {
+        const double xu = wave_scan(su[f]), xd = wave_scan(sd[f]);
+        eu[f] = wave_shr1(xu);
+        ed[f] = wave_shr1(xd);
+      }
+#pragma unroll
+      for (int i = 0; i < CH; i++)
+      {
+        const int sl = slotl[i * 64 + ln];
+        if (sl >= 0)
+        {
+#pragma unroll
+          for (int f = 0; f < FPW; f++) { bu0[f * WS + sl] = eu[f] + pu[f][i]; bu0[f * WS + 66 + sl] = ed[f] + pd[f][i]; }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < FPW; f++)
+      {
+        const double* bu = bu0 + f * WS;
+        const double* bd = bu + 66;
+        double vv = 0.0;
+        if (lane < fa.nBands) vv = (bu[lane + 1] - bu[lane]) + (bd[lane + 2] - bd[lane + 1]);
+        if (fa.magNorm)
+        {
+          double bs = vv, e = en[f];
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) { bs += __shfl_xor(bs, off); e += __shfl_xor(e, off); }
+          vv = vv * (e * scale2) / fmax(kEpsilon, bs);
+        }
+        if (fa.logOutput) vv = (double) (6.020599913279624f * __log2f((float) fmax(vv, kEpsilon)));
+        v[f] = vv;
+      }
+    }
+    if (!fa.dct)
+    {
+#pragma unroll
+      for (int f = 0; f < FPW; f++)
+        if (lane < fa.nBands && t0 + f < a.T) fa.out[((int64_t) b * fa.nOut + lane) * a.T + t0 + f] = (float) v[f];
+      continue;
+    }
+#pragma unroll
+    for (int f = 0; f < FPW; f++) bu0[f * WS + 132 + lane] = v[f];
+    if (4 * fa.nOut <= 64)
+    {
+      const int j = lane >> 2, part = lane & 3;
+      const int q = (fa.nBands + 3) >> 2;
+      double sacc[FPW];
+#pragma unroll
+      for (int f = 0; f < FPW; f++) sacc[f] = 0.0;
+      if (j < fa.nOut && fa.startCoeff + j < fa.nDct)
+      {
+        const double* drow = dctl + (fa.startCoeff + j) * dld;
+        const int b1 = min((part + 1) * q, fa.nBands);
+        for (int band = part * q; band < b1; band++)
+        {
+          const double dv = drow[band];
+#pragma unroll
+          for (int f = 0; f < FPW; f++) sacc[f] = __builtin_fma(dv, bu0[f * WS + 132 + band], sacc[f]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < FPW; f++)
+      {
+        sacc[f] += __shfl_xor(sacc[f], 1);
+        sacc[f] += __shfl_xor(sacc[f], 2);
+        if (part == 0 && j < fa.nOut && t0 + f < a.T) fa.out[((int64_t) b * fa.nOut + j) * a.T + t0 + f] = (float) sacc[f];
+      }
+    }
+    else
+    {
+      for (int j = lane; j < fa.nOut; j += 64)
+#pragma unroll
+        for (int f = 0; f < FPW; f++)
+        {
+          double sacc = 0.0;
+          if (fa.startCoeff + j < fa.nDct)
+          {
+            const double* drow = dctl + (fa.startCoeff + j) * dld;
+            for (int band = 0; band < fa.nBands; band++) sacc = __builtin_fma(drow[band], bu0[f * WS + 132 + band], sacc);
+          }
+          if (t0 + f < a.T) fa.out[((int64_t) b * fa.nOut + j) * a.T + t0 + f] = (float) sacc;
+        }
+    }
+  }
+}
+
+template <int R1, int R2, int R3, int NW, int FPW>
+static bool launch_feat2_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStream_t s)
+{
+  using Core = FftCore<R1, R2, R3>;
+  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = 66 + 66 + 64;
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + N) * 16 + ((size_t) NW * FPW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
+                       (fa.dct ? (size_t) fa.nDct * (fa.nBands + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
+  if (shmem > 160 * 1024) return false;
+  StftBArgs k = k0;
+  k.blocksPerBuf = (k.T + NW * FPW - 1) / (NW * FPW);
+  k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
+  if (k.totalBlocks < 1) return true;
+  auto kern = stft_feat2_kernel<R1, R2, R3, NW, FPW>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem) != hipSuccess)
+    return false;
+  const int64_t chunk = (k.totalBlocks + 7) / 8;
+  int64_t grid = 8 * chunk;
+  if (grid > 256) grid = 256;
+  hipLaunchKernelGGL(kern, dim3((unsigned) grid), dim3(64 * NW), shmem, s, k, fa);
+  return true;
+}
+
+#endif // FLUHIP_AB_SWITCHES
+
 template <int R1, int R2, int R3, int NW>
 static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStream_t s)
 {
@@ -938,12 +1263,21 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
   fa.magNorm = f.magNorm; fa.usePower = f.usePower; fa.logOutput = f.logOutput; fa.out = f.out;
   if (a.fft == 1024)
   {
-    if constexpr (kAbSwitches) // FLUHIP_FEAT_NW=8|12: wavefronts per workgroup of the fused feature kernel (A/B; production 16)
+#ifdef FLUHIP_AB_SWITCHES // (forms measured no faster than the production one, profiles/r04/c5_experiments.md: compiled into the A/B build only)
+    // FLUHIP_FEAT_FPW=2: two frames per wavefront in one instruction stream, eight wavefronts per workgroup
+    {
+      static const int fpw = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_FPW"); return e ? std::atoi(e) : 1; }();
+      if (fpw == 2) return launch_feat2_t<8, 8, 8, 8, 2>(k, fa, s);
+      if (fpw == 22) return launch_feat2_t<8, 8, 8, 12, 2>(k, fa, s);
+      if (fpw == 3) return launch_feat2_t<8, 8, 8, 4, 3>(k, fa, s);
+    }
+    // FLUHIP_FEAT_NW=8|12: wavefronts per workgroup of the fused feature kernel (production 16)
     {
       static const int nw = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_NW"); return e ? std::atoi(e) : 16; }();
       if (nw == 8) return launch_feat_t<8, 8, 8, 8>(k, fa, s);
       if (nw == 12) return launch_feat_t<8, 8, 8, 12>(k, fa, s);
     }
+#endif
     return launch_feat_t<8, 8, 8, 16>(k, fa, s);
   }
   if (a.fft == 2048) return launch_feat_t<16, 8, 8, 8>(k, fa, s);
