@@ -346,15 +346,28 @@ def main():
         ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
         # gfx950 rocprofv3 correction + WRITE_SIZE); only quoted for the workload they were taken on
+        # ... and only while the kernel source still hashes to what the counters were taken on (a kernel change must not
+        # keep quoting the old kernel's traffic: null until tools/pmc_bench.sh + tools/pmc_summary.py are re-run)
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        import hashlib
+        try:
+            ksha = hashlib.sha256(open(os.path.join(ROOT, "flucoma-core_amd", "csrc", "kernels_nmf5.hip"), "rb").read()).hexdigest()
+        except OSError:
+            ksha = None
+        for rnd in ("r04", "r03", "r02", "r01"):
             try:
                 path = os.path.join("profiles", rnd, "pmc_update_kernel.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))
-                if (B, K, T, F) == (128, 32, 862, 1025):
-                    traffic = pmc["hbm_bytes_per_launch"]
-                    traffic_src = f"{path}: separate rocprofv3 --pmc passes of this command, not measured in this run"
+                if (B, K, T, F) != (128, 32, 862, 1025):
                     break
+                if pmc.get("kernel_source_sha256") == ksha:
+                    traffic = pmc["hbm_bytes_per_launch"]
+                    traffic_src = (f"{path}: separate rocprofv3 --pmc passes of this command, not measured in this run; taken on "
+                                   f"kernels_nmf5.hip sha256 {ksha[:16]} = the source of this build")
+                else:
+                    traffic_src = (f"{path} was taken on another state of kernels_nmf5.hip "
+                                   f"({str(pmc.get('kernel_source_sha256'))[:16]} against {str(ksha)[:16]}): traffic withheld")
+                break
             except (OSError, KeyError, ValueError):
                 pass
         # shader cycles per launch and the clock the part sustained while it ran them (s_memtime / s_memrealtime stamps of

@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdio>
 
 #include "fluhip_env.h"
 
@@ -12,6 +13,16 @@ namespace fluhip {
 constexpr double kEpsilon = 2.220446049250313e-16; // util/AlgorithmUtils.hpp:19
 
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Dynamic LDS above the default limit for `kern`.  A refusal is not dropped: the call leaves its error in the runtime's
+// last-error slot (as does the launch that follows and cannot get its LDS), and every C-ABI entry point reads that slot behind
+// its launches -- HIPCHK(ctx, hipGetLastError()) -- and returns FLUHIP_ERROR with the HIP message.
+template <class Kern>
+inline void request_dynamic_lds(Kern kern, size_t bytes)
+{
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes) != hipSuccess)
+    std::fprintf(stderr, "fluhip: %zu bytes of dynamic LDS refused for a kernel\n", bytes);
+}
 
 // ---------------------------------------------------------------------------------------
 // HBM layout of one corpus (B equal-shape buffers); everything f64 unless noted.

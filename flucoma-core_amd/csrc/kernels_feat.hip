@@ -141,8 +141,7 @@ void launch_features(const FeatArgs& a, hipStream_t s)
   int nw = 4;
   while (nw > 1 && (size_t) nw * kFT * (a.bandsPad + a.F) * sizeof(double) > 144 * 1024) nw >>= 1;
   const size_t shmem = (size_t) nw * kFT * (a.bandsPad + a.F) * sizeof(double);
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(mel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             160 * 1024);
+  request_dynamic_lds(mel_kernel, (size_t) (160 * 1024));
   dim3 grid((unsigned) ((a.T + nw * kFT - 1) / (nw * kFT)), (unsigned) a.B);
   hipLaunchKernelGGL(mel_kernel, grid, dim3((unsigned) (64 * nw)), shmem, s, a);
 }

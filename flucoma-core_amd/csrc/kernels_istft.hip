@@ -242,8 +242,7 @@ void launch_resynth(const ResynthArgs& a, hipStream_t s)
 {
   if (a.bigScratch) { launch_resynth_big(a, s); return; }
   const size_t shmem = (size_t) a.fft * 2 * sizeof(double); // two complex buffers of fft/2 points
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(resynth_frames_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  request_dynamic_lds(resynth_frames_kernel, (size_t) (160 * 1024));
   int threads = a.fft / 8;
   if (threads < 64) threads = 64;
   if (threads > 256) threads = 256;

@@ -1065,8 +1065,7 @@ static void launch5_list(const UpdateArgs& a, hipStream_t s)
   constexpr size_t shmem = 4 * ((stg > ring && 4 * stg <= 160 * 1024) ? stg : ring);
   static_assert(shmem <= 160 * 1024, "LDS");
   auto kern = nmf_update5_kernel<M, NG, NS, 1, 0, MODE, 1, 1>;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   hipLaunchKernelGGL(kern, dim3((unsigned) a.listWGs), dim3(256), shmem, s, k);
 }
 
@@ -1098,8 +1097,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
   auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS>;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
   if (k.nsplit > 1)
     launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, k.nsplit, a.B, s, a.nrm, a.nrmMode,

@@ -1034,7 +1034,7 @@ static void launch_strip_t(const StripK& k, int B, hipStream_t s)
 {
   const size_t shmem = strip_shmem(k.nPairs); // <= 160 KiB: nmf_strip_supported() is what the planner asks
   auto kern = nmf_strip_kernel<NPW, NQ, INSTR>;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   const unsigned grid = (k.doH || k.doW) ? (unsigned) k.nWG : 1u;
   hipLaunchKernelGGL(kern, dim3(grid, (unsigned) B), dim3(256), shmem, s, k);
 }

@@ -502,8 +502,7 @@ static void launch_stft_wave(const StftKArgs& k, hipStream_t s)
   if (waves > MAXW) waves = MAXW;
   const size_t shmem = ((size_t) (TW + N) + (size_t) waves * BUF) * 16;
   auto kern = stft_wave_kernel<R1, R2, R3, MAXW>;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   int64_t wgs = (k.totalFrames + waves - 1) / waves;
   if (wgs > 256 * 4) wgs = 256 * 4;
   if (wgs < 1) return;
@@ -705,8 +704,7 @@ void launch_stft(const StftArgs& a, hipStream_t s)
   int threads = k.nc / 4;
   if (threads < 64) threads = 64;
   if (threads > 256) threads = 256;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(stft_r2c_mag_kernel),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  request_dynamic_lds(stft_r2c_mag_kernel, (size_t) (160 * 1024));
   int64_t grid = k.totalFrames;
   const int64_t cap = 256 * 8; // persistent-ish: each workgroup strides over frames
   if (grid > cap) grid = cap;

@@ -866,18 +866,22 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
   __syncthreads();
 
+#ifdef FLUHIP_AB_SWITCHES
   if (fa.dbg && threadIdx.x == 0)
   {
     if (blockIdx.x == 0) fa.dbg[0] = (long long) __builtin_readcyclecounter();
     fa.dbg[4 + 2 * blockIdx.x] = (long long) wall_clock64();
   }
+#endif
   Core core;
   core.init(xb, tw2, twg, lane);
   // FLUHIP_FEAT_PRIO (A/B): the wavefronts of a SIMD (wave, wave + 4, ...) at different issue priorities.  They run the same
   // instruction stream from the same start; under fair round-robin issue they stay in phase -- all in their LDS exchanges,
   // then all in their butterflies -- and the two pipes take turns instead of overlapping (PMC: VALU busy 46 % + LDS active
   // 42 % of the launch).  With strict priorities the first one runs ahead and the others fill its waits.
+#ifdef FLUHIP_AB_SWITCHES
   if (a.prefetch & 2) { const int pr = (wave ^ (wave >> 2)) & 3; if (pr == 0) __builtin_amdgcn_s_setprio(0); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+#endif
   const double scale1 = 1.0 / ((double) a.win / 4.0);                          // alg/MelBands.hpp:49
   const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
 
@@ -900,7 +904,11 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     if (t >= a.T) continue;
     {
       cx pts[PPL];
+#ifdef FLUHIP_AB_SWITCHES
       gather_points<R1, N>(a, b, t, lane, (a.prefetch & 1) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
+#else
+      gather_points<R1, N>(a, b, t, lane, wl, pts, a.n);
+#endif
       SCHED_FENCE();
       core.template run<false>(pts, nullptr);
     }
@@ -982,11 +990,13 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       }
     }
   }
+#ifdef FLUHIP_AB_SWITCHES
   if (fa.dbg && threadIdx.x == 0)
   {
     if (blockIdx.x == 0) fa.dbg[2] = (long long) __builtin_readcyclecounter();
     fa.dbg[5 + 2 * blockIdx.x] = (long long) wall_clock64();
   }
+#endif
 }
 
 #ifdef FLUHIP_AB_SWITCHES
@@ -1201,7 +1211,7 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
   auto kern = stft_feat_kernel<R1, R2, R3, NW>;
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
   if (grid > 256) grid = 256;
@@ -1300,7 +1310,7 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
   auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true, FPW> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false, FPW>;   // the complex spectrum is kept for resynthesis / BufSTFT only
-  (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) shmem);
+  request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
   const int perCu = (int) ((160 * 1024) / shmem);
@@ -1696,7 +1706,7 @@ static bool launch_resynth_batch_t(const ResynthBatchArgs& a, hipStream_t s)
   const bool shared = sharedEnv != 0 && a.K >= NW;
   const size_t shmemS = shmem + (size_t) (2 * (Core::N + 2) * 2 + 2 * (Core::N + 2)) * 8;
   auto go = [&](auto kern, size_t sh) {
-    (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int) sh);
+    request_dynamic_lds(kern, (size_t) (sh));
     hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3(64 * NW), sh, s, a, runSlots, runsPerBuf, kGroups);
   };
   if (shared && shmemS <= 160 * 1024)

@@ -16,7 +16,7 @@ run sq2 SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INST_CYCLES_VMEM SQ_ACTIV
 python - "$out" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]
-for f in sorted(glob.glob(out + "/*counter_collection.csv")):
+for f in sorted(glob.glob(out + "/**/*counter_collection.csv", recursive=True)):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0][:60]

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes of tools/pmc_bench.sh for one kernel into the JSON bench.py quotes.
 usage: tools/pmc_summary.py <pmc dir> <kernel-name substring> <out.json>"""
-import collections, csv, glob, json, sys
+import collections, csv, glob, hashlib, json, os, sys
 d, sub, outp = sys.argv[1:4]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KSRC = os.path.join(ROOT, "flucoma-core_amd", "csrc", "kernels_nmf5.hip")
 agg = collections.defaultdict(list)
-for f in sorted(glob.glob(d + "/*counter_collection.csv")):
+for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         if sub in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -14,6 +16,9 @@ alg = (F * T + 2 * (F * K + K * T)) * 8 * B
 out = {
     "source": "rocprofv3 --pmc, separate passes (tools/pmc_bench.sh), MI355X, bench.py workload (128 x (862 x 1025), K = 32)",
     "kernel": sub + " (one factor update of 128 buffers)",
+    # the counters describe THIS source state of the kernel: bench.py quotes `traffic` only while the file still hashes to it
+    "kernel_source": "flucoma-core_amd/csrc/kernels_nmf5.hip",
+    "kernel_source_sha256": hashlib.sha256(open(KSRC, "rb").read()).hexdigest(),
     "launches_averaged": {k: len(v) for k, v in agg.items()},
     "FETCH_SIZE_KB_raw": m.get("FETCH_SIZE"),
     "fetch_correction": "x2: gfx950 rocprofv3 reports half the bytes of 16-byte-per-lane streaming loads "
