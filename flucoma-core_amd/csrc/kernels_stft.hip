@@ -312,6 +312,8 @@ __device__ __forceinline__ void stockham_pass(d2 (&pts)[NB * R], d2* buf, const 
   }
 }
 
+#ifdef FLUHIP_AB_SWITCHES // round 1's wave-per-frame kernel: production reaches it for no shape any more (the block form of
+                         // kernels_stft2.hip covers fft 1024 / 2048 / 4096 with an even window); kept for the A/B build (FLUHIP_STFT_BLOCK=0)
 template <int R1, int R2, int R3, int MAXW>
 __global__ __launch_bounds__(64 * MAXW) void stft_wave_kernel(StftKArgs a)
 {
@@ -508,6 +510,7 @@ static void launch_stft_wave(const StftKArgs& k, hipStream_t s)
   if (wgs < 1) return;
   hipLaunchKernelGGL(kern, dim3((unsigned) wgs), dim3((unsigned) (64 * waves)), shmem, s, k);
 }
+#endif // FLUHIP_AB_SWITCHES
 
 // ---------------------------------------------------------------------------------------
 // fft sizes whose frame does not fit the LDS (above 8192): the same Stockham passes through global memory, a
@@ -693,8 +696,10 @@ void launch_stft(const StftArgs& a, hipStream_t s)
     {
       // the block form (kernels_stft2.hip) without its bin-major output is the faster wave-per-frame kernel
       if (launch_stft_block(a, nullptr, 0, 0, s)) return;
+#ifdef FLUHIP_AB_SWITCHES // (only with FLUHIP_STFT_BLOCK=0: the block form takes these sizes)
       if (a.fft == 2048) { launch_stft_wave<16, 8, 8, 8>(k, s); return; }
       if (a.fft == 1024) { launch_stft_wave<8, 8, 8, 8>(k, s); return; }
+#endif
     }
   }
   // window table in LDS when it keeps >= 2 workgroups per CU
