@@ -1,4 +1,4 @@
-// fluhip_kernels.h -- internal launch interface between the C-ABI layer (api.hip) and the
+// fluhip_kernels.h -- internal launch interface between the C-ABI layer (api_*.hip) and the
 // gfx950 kernels (kernels_stft.hip, kernels_nmf.hip).  Not installed; not part of the ABI.
 #pragma once
 

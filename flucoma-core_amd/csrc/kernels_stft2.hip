@@ -816,7 +816,7 @@ __device__ __forceinline__ double wave_shr1(double x) { return dpp_f64<0x138, 0x
 // two segment sums of two running sums over the bins: lane l forms the running sums of its CH consecutive bins, a
 // wavefront scan gives each lane its offset, the lanes holding the last bin before an interval boundary publish the
 // running sums there, and lane b takes band b as two differences.  (The host checks that the filter bank at hand has
-// this shape -- api.hip features_common -- and falls back to the two-kernel path otherwise.)
+// this shape -- api_features.hip features_common -- and falls back to the two-kernel path otherwise.)
 // No workgroup barrier anywhere in the frame loop: wavefronts are independent.
 // ---------------------------------------------------------------------------------------------------------------
 struct FeatFusedArgs

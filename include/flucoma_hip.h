@@ -343,13 +343,13 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8);
 int64_t fluhip_debug_plan_lists(int64_t count, const int64_t* frames, int64_t bins, int64_t K, int which, int32_t* desc,
                                 int64_t cap, int32_t* info8);
 
-/* Likewise for the two-launch form of the H update (api.hip plan_tail): `count` equal-length buffers of `frames` frames and
+/* Likewise for the two-launch form of the H update (api_corpus.hip plan_tail): `count` equal-length buffers of `frames` frames and
  * `bins` bins at rank K.  out4 = {pieces of the tail launch's contraction (0: the update stays one launch), strips per buffer
  * of the first launch, strips per buffer of the tail launch, frames per buffer in the first launch}. */
 int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4);
 /* Which schedule family an equal-length corpus of that shape gets when nothing else decides first (a single buffer of rank <= 16
  * that fits the frame-strip schedule never asks): 1 = the work lists, 0 = the uniform schedule; -1: bad arguments.  The rules are
- * measured ones (api.hip list_plan_pays, profiles/r03/plan_regimes.txt); the CPU tests pin them for the BASELINE shapes. */
+ * measured ones (api_corpus.hip list_plan_pays, profiles/r03/plan_regimes.txt); the CPU tests pin them for the BASELINE shapes. */
 int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t K);
 
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */

@@ -156,7 +156,7 @@ def test_wide_rank_batches(ctx, oracle, onp, K, B, frames, fft):
                                            (128, 18000, "fixed_w"), (128, 18000, "progress"), (32, 74000, "both")])
 def test_two_launch_h_update(ctx, oracle, onp, K, frames, mode):
     """two long buffers at a wide rank: the H update's wavefronts need a poorly filled last round, so it goes out as two
-    launches -- whole contractions for the frames that fill whole rounds, split ones for the rest (api.hip plan_tail);
+    launches -- whole contractions for the frames that fill whole rounds, split ones for the rest (api_corpus.hip plan_tail);
     also with the bases fixed (no deferred normalisation in the H update) and with a progress callback per iteration"""
     import fluhip
     fft, hop, B, iters = 1024, 256, 2, 3
@@ -181,7 +181,7 @@ def test_two_launch_h_update(ctx, oracle, onp, K, frames, mode):
 
 @pytest.mark.parametrize("K,B,seconds", [(32, 1, 100), (20, 1, 70), (64, 1, 60), (32, 2, 40)])
 def test_long_buffers_on_the_work_lists(ctx, oracle, onp, K, B, seconds):
-    """one or two long buffers at ranks up to 64: past ~45 s of frames in all the planner hands them to the work lists (api.hip
+    """one or two long buffers at ranks up to 64: past ~45 s of frames in all the planner hands them to the work lists (api_corpus.hip
     list_plan_pays, profiles/r03/plan_regimes.txt) -- the contraction of every strip cut into pieces added up inside a workgroup"""
     import fluhip
     fft, hop, iters = 2048, 512, 4

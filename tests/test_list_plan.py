@@ -1,4 +1,4 @@
-"""The work lists of the factor updates (api.hip build_list_plan, reached through fluhip_debug_plan_lists: pure host code,
+"""The work lists of the factor updates (api_corpus.hip build_list_plan, reached through fluhip_debug_plan_lists: pure host code,
 no GPU): whatever strip width, cutting and grouping the planner picks, the lists must be a valid schedule --
 every (buffer, column group) covered over exactly its contraction range, once; the wavefronts that split a strip
 consecutive in ONE workgroup with one leader; output slots (result / partial / denominator / statistics) each written by
@@ -132,7 +132,7 @@ def _tail(lib, count, frames, bins, K):
 
 
 def test_two_launch_plan_of_the_h_update(fluhip_lib_path):
-    """api.hip plan_tail (pure host code): a whole-contraction H update whose wavefronts leave a poorly filled last round of the
+    """api_corpus.hip plan_tail (pure host code): a whole-contraction H update whose wavefronts leave a poorly filled last round of the
     1024 SIMDs is cut into a launch of whole rounds and a split tail; exact fills and single rounds stay one launch"""
     import fluhip
     lib = fluhip.load_library(fluhip_lib_path)
@@ -158,7 +158,7 @@ def test_two_launch_plan_of_the_h_update(fluhip_lib_path):
 
 
 def test_schedule_family_of_the_baseline_shapes(fluhip_lib_path):
-    """api.hip list_plan_pays (pure host code): the measured rules, pinned for the shapes whose records are under profiles/r03/"""
+    """api_corpus.hip list_plan_pays (pure host code): the measured rules, pinned for the shapes whose records are under profiles/r03/"""
     import fluhip
     lib = fluhip.load_library(fluhip_lib_path)
     kind = lambda B, T, F, K: lib.fluhip_debug_plan_kind(B, T, F, K)  # noqa: E731

@@ -1,5 +1,5 @@
 """us per NMF iteration of the single-buffer BASELINE shapes with the iteration loop enqueued launch by launch or replayed from
-a hipGraph (FLUHIP_GRAPH_ITERS=n, api.hip corpus_iterate_loop): python tools/graph_ab.py [iters]"""
+a hipGraph (FLUHIP_GRAPH_ITERS=n, api_corpus.hip corpus_iterate_loop): python tools/graph_ab.py [iters]"""
 import os
 os.environ.setdefault("FLUHIP_AB", "1")   # the build whose experiment switches are live (build.py --ab)
 import sys
