@@ -210,7 +210,9 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     if (c->strip)
     {
       c->sideW = false;
-      HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), false, s));
+      // (zeroed once: with the Nyquist bin as a side column only 16 values of its partial blocks are ever written, and the
+      //  reduce launch adds the whole blocks before it masks the bins that do not exist)
+      HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), true, s));
       // FLUHIP_STRIP_BIN=1 (A/B build only): the W update as its own launch over bin strips instead of the fused form (W
       // partials behind the H phase + the reduce launch).  Built and measured in round 4 (profiles/r04/c2_forms.md): 45.1 us
       // per iteration against 40.3 at config 2 -- a tenth of the partial bytes, but the last arriver's chain of cross-XCD

@@ -198,7 +198,14 @@ __device__ __forceinline__ void strip_column_stats(const StripStatRaw& w, int nS
   __syncthreads();
 }
 
-template <int NPW, int NQ, bool INSTR>
+// SIDE (round 4): every power-of-two transform has F = 32 j + 1 bins, so the last bin pair holds the Nyquist bin alone and
+// costs every wavefront a whole pair slot (9 instead of 8 at fft 2048, 5 instead of 4 at fft 1024: the pairs are dealt
+// round-robin and a wavefront without a pair works against zeros).  With SIDE the MFMA loops run over the pairs below it
+// and bin F - 1 is a side column of the combine step: thread (frame, k) already holds H[frame][k]; sixteen lanes form
+// Q_N = sum_k W'_N[k] H[frame][k] / nrm[k], the quotient V[frame][F - 1] / max(Q_N, eps) times W'_N[k] joins the numerator of
+// the H update (alg/NMF.hpp:165-170), and the same with the NEW H gives the strip's share of bin F - 1's row of the next W
+// update's numerator (:158-160), which leaves in the partial slots that bin has in the layout of the reduce launch.
+template <int NPW, int NQ, bool INSTR, bool SIDE = false>
 __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -213,6 +220,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   double* nrmL = hn + kNQ * 64;                             // [16] column norms of W' (1 when W is normalised)
   double* csL = nrmL + 16;                                  // [16] column sums of W'
   unsigned char* zeroPage = reinterpret_cast<unsigned char*>(csL + 16); // 4 KB
+  double* nyq = reinterpret_cast<double*>(zeroPage + 4096);             // [kNQ * 64] SIDE: bin F - 1's numerator terms per (frame, k)
 
   const double* Vb = a.V + (int64_t) b * a.strideV;
   const double* Wg = a.W + (int64_t) b * a.strideW;
@@ -221,7 +229,7 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 
   // quads dealt evenly (host-side quotient and remainder: a 64-bit division here is 300 instructions of cold code)
   const int qBeg = g * a.qBase + min(g, a.qRem), qEnd = qBeg + a.qBase + (g < a.qRem ? 1 : 0);
-  const int jpLast = a.nPairs - 1;
+  const int jpLast = a.nPairs - 1 - (SIDE ? 1 : 0); // last pair of the MFMA loops
   const int nql = min(NQ, qEnd - qBeg);
   const int t0 = 4 * qBeg;
 
@@ -291,6 +299,14 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   double hold[2];
 #pragma unroll
   for (int i = 0; i < 2; i++) hold[i] = Hg[(int64_t) t0 * 16 + min(tid + 256 * i, nql * 64 - 1)];
+  // side column: bin F - 1 of this thread's frames, and the bin's row of W' (column tid & 15)
+  double vN[2] = {0.0, 0.0}, wN = 0.0;
+  if constexpr (SIDE)
+  {
+#pragma unroll
+    for (int i = 0; i < 2; i++) vN[i] = Vb[(int64_t) (t0 + (min(tid + 256 * i, nql * 64 - 1) >> 4)) * a.ldv + a.F - 1];
+    wN = Wg[(int64_t) (a.F - 1) * 16 + (tid & 15)];
+  }
   __builtin_amdgcn_sched_barrier(0);
   STRIP_STAMP(9)
   *reinterpret_cast<d2*>(zeroPage + tid * 16) = d2{0.0, 0.0};
@@ -319,6 +335,14 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 #pragma unroll
   for (int m = 0; m < 4; m++) rn[m] = 1.0 / nrmL[4 * y + m];
 
+  // SIDE: this thread's term of bin F - 1's row of the next W update's numerator, (V / max(W'_N (H / nrm), eps))[frame] H[frame][k]
+  // with the H that the W update will see (the 16 lanes of a frame form the product; frames past the strip give 0)
+  auto side_share = [&](int i, double hv, bool valid, int k) -> double {
+    double qn = valid ? wN * (hv / nrmL[k]) : 0.0;
+#pragma unroll
+    for (int sh = 1; sh < 16; sh <<= 1) qn += __shfl_xor(qn, sh);
+    return valid ? (vN[i] / fmax(qn, kEpsilon)) * hv : 0.0;
+  };
   double wdenAcc = 0.0;
   const int srcLane4 = 4 * (y + 4 * blk + 16 * x);
   if (a.doH)
@@ -438,12 +462,21 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         if (q < nql)
         {
           const int ix = (q * 4 + (k & 3)) * 16 + (k >> 2) + 4 * yy;
-          const double s = ((red[ix] + red[kNQ * 64 + ix]) + red[2 * kNQ * 64 + ix]) + red[3 * kNQ * 64 + ix];
+          double s = ((red[ix] + red[kNQ * 64 + ix]) + red[2 * kNQ * 64 + ix]) + red[3 * kNQ * 64 + ix];
+          if constexpr (SIDE)
+          {
+            // bin F - 1 joins the numerator behind the MFMA bins (the 16 lanes of a frame: the same butterfly in each)
+            double qn = wN * (hold[i] / nrmL[k]);
+#pragma unroll
+            for (int sh = 1; sh < 16; sh <<= 1) qn += __shfl_xor(qn, sh);
+            s += (vN[i] / fmax(qn, kEpsilon)) * wN;
+          }
           // :170  H * (W^T (V / V2)) / max(W^T 1, eps) with W = W' / nrm
           hv = hold[i] * (s / nrmL[k]) / fmax(csL[k] / nrmL[k], kEpsilon);
           Hg[(int64_t) t0 * 16 + o] = hv;
         }
         hn[o] = hv;
+        if constexpr (SIDE) nyq[o] = side_share(i, hv, q < nql, k);
       }
     }
   }
@@ -459,7 +492,12 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
     }
 #pragma unroll
     for (int i = 0; i < 2; i++)
-      if (tid + 256 * i < NQ * 64) hn[tid + 256 * i] = ((tid + 256 * i) >> 6) < nql ? hold[i] : 0.0;
+      if (tid + 256 * i < NQ * 64)
+      {
+        const bool valid = ((tid + 256 * i) >> 6) < nql;
+        hn[tid + 256 * i] = valid ? hold[i] : 0.0;
+        if constexpr (SIDE) nyq[tid + 256 * i] = side_share(i, hold[i], valid, tid & 15);
+      }
   }
   __syncthreads();
   STRIP_STAMP(3)
@@ -467,6 +505,18 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   {
     if (tid < 16)
       for (int t = 0; t < 4 * nql; t++) wdenAcc += hn[t * 16 + tid]; // :160 row sums of H, this strip's share
+    if constexpr (SIDE)
+    {
+      if (tid < 16)
+      {
+        // bin F - 1's share: its 16 values sit in blocks m = k & 3 of step (last pair, e = 0) at lane x = k >> 2
+        double sN = 0.0;
+        for (int t = 0; t < 4 * nql; t++) sN += nyq[t * 16 + tid];
+        double* dst = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + ((int64_t) ((a.nPairs - 1) * 2) * a.nWG * 4 + (tid & 3)) * 64 + (tid >> 2);
+        if (kWriteThrough) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(sN) : "memory");
+        else *dst = sN;
+      }
+    }
     // ---- W phase: the strip's share of the next W update's numerator (alg/NMF.hpp:158-160), on the tiles the H phase
     // used (no second read of V).
     double Ha[NQ][4], Hb[NQ][4];
@@ -984,7 +1034,7 @@ using namespace strip;
 // LDS of a strip workgroup: the W image (4 KiB per bin pair), the H / partial staging and a page of zeros
 static size_t strip_shmem(int nPairs)
 {
-  return (size_t) nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double) + 4096;
+  return (size_t) nPairs * 4096 + (size_t) (4 * kNQ * 4 * 16 + kNQ * 64 + 32) * sizeof(double) + 4096 + (size_t) kNQ * 64 * sizeof(double);
 }
 // the W image of all bin pairs must fit the 160 KiB of a CU next to the staging: 35 pairs, F <= 1120
 bool nmf_strip_supported(int F, int T, int Kp)
@@ -1029,41 +1079,56 @@ static StripK make_k(const StripArgs& s)
   return k;
 }
 
-template <int NPW, int NQ, bool INSTR = false>
+template <int NPW, int NQ, bool INSTR = false, bool SIDE = false>
 static void launch_strip_t(const StripK& k, int B, hipStream_t s)
 {
   const size_t shmem = strip_shmem(k.nPairs); // <= 160 KiB: nmf_strip_supported() is what the planner asks
-  auto kern = nmf_strip_kernel<NPW, NQ, INSTR>;
+  auto kern = nmf_strip_kernel<NPW, NQ, INSTR, SIDE>;
   request_dynamic_lds(kern, (size_t) (shmem));
   const unsigned grid = (k.doH || k.doW) ? (unsigned) k.nWG : 1u;
   hipLaunchKernelGGL(kern, dim3(grid, (unsigned) B), dim3(256), shmem, s, k);
 }
 
-template <int NPW>
+template <int NPW, bool SIDE>
 static void launch_strip_q(const StripK& k, int B, hipStream_t s)
 {
   // widest strip of the launch, in frame quads: the tile loops are built for 2, 4 or 6
   const int widest = (k.nq + k.nWG - 1) / k.nWG;
-  if (widest <= 2) launch_strip_t<NPW, 2>(k, B, s);
-  else if (widest <= 4) launch_strip_t<NPW, 4>(k, B, s);
+  if (widest <= 2) launch_strip_t<NPW, 2, false, SIDE>(k, B, s);
+  else if (widest <= 4) launch_strip_t<NPW, 4, false, SIDE>(k, B, s);
   else
   {
-    if constexpr (NPW == 9)
+    if constexpr (NPW == 9 && !SIDE)
     {
       static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
       if (instr && k.doH && k.doW) { launch_strip_t<9, kNQ, true>(k, B, s); return; }
     }
-    launch_strip_t<NPW, kNQ>(k, B, s);
+    launch_strip_t<NPW, kNQ, false, SIDE>(k, B, s);
   }
+}
+
+// the Nyquist bin as a side column of the combine step: F = 32 j + 1 (every power-of-two transform from fft 64 on)
+static bool strip_side(const StripK& k)
+{
+  static const int off = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_SIDE"); return e && std::atoi(e) == 0 ? 1 : 0; }(); // A/B: 0 = all pairs in the MFMA loops
+  return !off && k.nPairs >= 2 && (k.F - 1) % 32 == 0;
 }
 
 void launch_nmf_strip(const StripArgs& a, hipStream_t s)
 {
   const StripK k = make_k(a);
+  if (strip_side(k))
+  {
+    const int npw = (k.nPairs - 1 + 3) / 4; // pair slots per wavefront without the Nyquist pair: 8 at fft 2048, 4 at fft 1024
+    if (npw <= 2) launch_strip_q<2, true>(k, a.B, s);
+    else if (npw <= 4) launch_strip_q<4, true>(k, a.B, s);
+    else launch_strip_q<8, true>(k, a.B, s);
+    return;
+  }
   const int npw = (k.nPairs + 3) / 4;
-  if (npw <= 3) launch_strip_q<3>(k, a.B, s);
-  else if (npw <= 5) launch_strip_q<5>(k, a.B, s);
-  else launch_strip_q<9>(k, a.B, s);
+  if (npw <= 3) launch_strip_q<3, false>(k, a.B, s);
+  else if (npw <= 5) launch_strip_q<5, false>(k, a.B, s);
+  else launch_strip_q<9, false>(k, a.B, s);
 }
 
 #ifdef FLUHIP_AB_SWITCHES
