@@ -831,7 +831,12 @@ struct FeatFusedArgs
   long long* dbg = nullptr; // FLUHIP_FEAT_CLOCK (A/B build): shader-cycle and 100 MHz stamps of workgroup 0's first wavefront
 };
 
-template <int R1, int R2, int R3, int NW>
+// DYN (round 4): the wavefronts of a workgroup take their frames from a counter in the LDS instead of a fixed share.  The issue
+// arbiter of a SIMD serves its oldest wavefront first: with equal shares the first wavefront of every SIMD was done after
+// 2.0 ms of a 3.86 ms launch (config 5, per-wavefront stamps) and the youngest ran the last third of the launch alone, at a
+// quarter of the VALU's rate -- the counters show the VALU 87 % busy while four wavefronts are alive and 64 % over the launch.
+// Handing out frames as wavefronts come free makes them finish together.
+template <int R1, int R2, int R3, int NW, bool DYN = true>
 __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFusedArgs fa)
 {
   using Core = FftCore<R1, R2, R3>;
@@ -864,6 +869,8 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   if (fa.dct)
     for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[(i / fa.nBands) * dld + (i % fa.nBands)] = fa.dct[i];
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
+  __shared__ unsigned nextFrame;                      // DYN: frames of this workgroup handed out so far
+  if (threadIdx.x == 0) nextFrame = 0;
   __syncthreads();
 
 #ifdef FLUHIP_AB_SWITCHES
@@ -886,6 +893,7 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
 
   const int64_t chunk = (a.totalBlocks + 7) / 8;
+  // (Round 4: what these measurements were really showing is in the DYN comment at the head of the kernel.)
   // Round 3 measurements of this loop (config 5, 1.417 M frames, one box; profiles/r03/c5_breakdown.txt), parts switched off
   // one at a time: everything 3.93 ms; without the sample gather 3.38; without the transform 1.92; without the band sums /
   // DCT / stores 2.95 (the stores alone: 0.05); the loop with nothing in it 0.38.  Alone, the gather takes 0.82 ms (the HBM
@@ -893,15 +901,47 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   // (transform exchanges 32, twiddles 14, window 8, staging 8 + 8, weights and DCT rows 23) keep the LDS pipe busy through
   // all three.  Requesting the next frame's samples ahead of the feature stores (as stft_block_kernel does) changes
   // nothing here (3.94 / 3.94 ms without, 3.92 / 3.92 with): four wavefronts per SIMD cover that wait.
-  for (int64_t L = blockIdx.x;; L += gridDim.x)
+  // Block index -> (buffer, frame block) WITHOUT a division per frame: the workgroup's blocks are blk0, blk0 + step, ...
+  // (step = gridDim.x / 8 inside its XCD's chunk), so (buffer, frame block) advance by (step / blocksPerBuf, step %
+  // blocksPerBuf) with a carry -- scalar adds.  The 64-bit blk / blocksPerBuf, blk % blocksPerBuf of rounds 2 - 3 ran on the
+  // VALU (quarter-rate v_mul_hi / v_mul_lo sequences) once per frame and wavefront: most of the 0.38 ms the EMPTY frame
+  // loop measured at config 5 (profiles/r03/c5_breakdown.txt).
+  const int64_t blk0 = (int64_t) (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const int step = (int) (gridDim.x >> 3);                      // (launch_feat_t: the grid is a multiple of 8)
+  const int stepB = step / a.blocksPerBuf, stepF = step % a.blocksPerBuf;
+  int bCur = __builtin_amdgcn_readfirstlane((int) (blk0 / a.blocksPerBuf));
+  int fCur = __builtin_amdgcn_readfirstlane((int) (blk0 % a.blocksPerBuf));
+  int64_t slot8 = blockIdx.x >> 3, blk = blk0;
+  // DYN: unit u of the workgroup = wavefront slot u % NW of its block u / NW (block i of the workgroup is block blk0 + i step of
+  // the launch); the division by blocksPerBuf is a multiplication by its reciprocal on the scalar unit
+  const unsigned bpb = (unsigned) a.blocksPerBuf, bpbInv = (unsigned) (((unsigned long long) 1 << 32) / bpb);
+  for (;; slot8 += step, blk += step, bCur += stepB, fCur += stepF)
   {
-    const int64_t slot8 = L >> 3;
-    if (slot8 >= chunk) break;
-    const int64_t blk = (L & 7) * chunk + slot8;
-    if (blk >= a.totalBlocks) continue;
-    const int b = (int) (blk / a.blocksPerBuf);
-    const int t = (int) (blk % a.blocksPerBuf) * NW + wave;
-    if (t >= a.T) continue;
+    int b, t;
+    if constexpr (DYN)
+    {
+      unsigned u = 0;
+      if (lane == 0) u = atomicAdd(&nextFrame, 1u);
+      u = (unsigned) __builtin_amdgcn_readfirstlane((int) u);
+      const unsigned i = u / NW, slot = u % NW;
+      const int64_t bl = blk0 + (int64_t) i * step;
+      if ((int64_t) (blockIdx.x >> 3) + (int64_t) i * step >= chunk || bl >= a.totalBlocks) break; // (blocks ascend: nothing behind this one either)
+      const unsigned x = (unsigned) bl;               // (totalBlocks < 2^31: launch_feat_t)
+      unsigned q = __umulhi(x, bpbInv), r = x - q * bpb;
+      while (r >= bpb) { q++; r -= bpb; }
+      b = (int) q;
+      t = (int) (r * NW + slot);
+      if (t >= a.T) continue;
+    }
+    else
+    {
+      if (fCur >= a.blocksPerBuf) { fCur -= a.blocksPerBuf; bCur += 1; }
+      if (slot8 >= chunk) break;
+      if (blk >= a.totalBlocks) continue;
+      b = bCur;
+      t = fCur * NW + wave;
+      if (t >= a.T) continue;
+    }
     {
       cx pts[PPL];
 #ifdef FLUHIP_AB_SWITCHES
@@ -1210,7 +1250,12 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
   k.blocksPerBuf = (k.T + NW - 1) / NW;
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
+  if (k.totalBlocks >= ((int64_t) 1 << 31)) return false; // (the kernel's block arithmetic is 32-bit; the two-kernel path takes it)
   auto kern = stft_feat_kernel<R1, R2, R3, NW>;
+#ifdef FLUHIP_AB_SWITCHES // FLUHIP_FEAT_DYN=0: a fixed share of the frames per wavefront (rounds 2 - 3)
+  static const int dynOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_DYN"); return e && std::atoi(e) == 0 ? 1 : 0; }();
+  if (dynOff) kern = stft_feat_kernel<R1, R2, R3, NW, false>;
+#endif
   request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
