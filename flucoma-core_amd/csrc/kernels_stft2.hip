@@ -851,8 +851,9 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   double* upl = scr + NW * WS;                    // [64 CH]
   double* dnl = upl + 64 * CH;                    // [64 CH]
   double* dctl = dnl + 64 * CH;                   // [nDct * nBands]
-  const int dld = fa.nBands + 1;                  // DCT rows one double apart in bank phase: the four lanes of eight coefficients
-                                                  // read eight rows at once, and rows of 40 doubles would put rows j and j + 4 on one bank
+  const int dq = (fa.nBands + 3) >> 2;            // bands per quarter row (four lanes share a coefficient)
+  const int dld = 4 * dq + 1;                     // DCT rows: four quarters, zero-padded past nBands, one double apart in bank phase
+                                                  // (rows of 40 doubles would put rows j and j + 4 on one bank)
   short* slotl = reinterpret_cast<short*>(dctl + (fa.dct ? fa.nDct * dld : 0));   // [64 CH]
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -867,7 +868,11 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   // (per-lane tables lie [i][lane] in the LDS: a lane's CH consecutive bins are CH rows apart, a row is read without bank conflicts)
   for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
   if (fa.dct)
-    for (int i = threadIdx.x; i < fa.nDct * fa.nBands; i += 64 * NW) dctl[(i / fa.nBands) * dld + (i % fa.nBands)] = fa.dct[i];
+    for (int i = threadIdx.x; i < fa.nDct * dld; i += 64 * NW)
+    {
+      const int row = i / dld, col = i % dld;
+      dctl[i] = col < fa.nBands ? fa.dct[row * fa.nBands + col] : 0.0;
+    }
   for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
   __shared__ unsigned nextFrame;                      // DYN: frames of this workgroup handed out so far
   if (threadIdx.x == 0) nextFrame = 0;
@@ -962,8 +967,9 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     for (int i = 0; i < CH; i++)
     {
       const int f = CH * ln + i;
-      double m = f <= N ? xb[f] : 0.0;
-      if (fa.magNorm) { m *= scale1; en += m; }     // :86-90
+      // (bins past N have zero weights: the clamped read costs a v_min where the select cost a compare and two v_cndmask)
+      double m = xb[min(f, N)];
+      if (fa.magNorm) { m = f <= N ? m * scale1 : 0.0; en += m; }     // :86-90
       if (fa.usePower) m = m * m;
       su = __builtin_fma(upl[i * 64 + ln], m, su);
       sd = __builtin_fma(dnl[i * 64 + ln], m, sd);
@@ -998,23 +1004,27 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       if (lane < fa.nBands) fa.out[((int64_t) b * fa.nOut + lane) * a.T + t] = (float) v;
       continue;
     }
-    bands[lane] = v;                                         // bands beyond nBands hold 0 / log(eps): never read
+    bands[lane] = lane < fa.nBands ? v : 0.0;                // (the DCT rows are zero there too: the quarters need no bounds)
     // ---- DCT-II rows startCoeff .. startCoeff + nOut - 1 (alg/DCT.hpp:73-75) -----------------------------------------
     if (4 * fa.nOut <= 64)
     {
-      // four lanes per coefficient, a quarter of the bands each (ascending), then two exchange-adds
+      // four lanes per coefficient, a quarter of the bands each (ascending), then two exchange-adds.  Every lane walks dq
+      // products -- a wave-uniform trip count, positions past nBands multiply zeros, lanes without a coefficient walk row 0
+      // and store nothing -- instead of a loop whose bounds depend on the lane (exec-mask bookkeeping per product).
       const int j = lane >> 2, part = lane & 3;
-      const int q = (fa.nBands + 3) >> 2;
+      const bool live = j < fa.nOut && fa.startCoeff + j < fa.nDct;
+      const double* drow = dctl + (live ? fa.startCoeff + j : 0) * dld + part * dq;
+      const double* bq = bands + part * dq;
       double sacc = 0.0;
-      if (j < fa.nOut && fa.startCoeff + j < fa.nDct)
+#pragma unroll
+      for (int i = 0; i < 16; i++)                            // (nBands <= 64: dq <= 16)
       {
-        const double* drow = dctl + (fa.startCoeff + j) * dld;
-        const int b1 = min((part + 1) * q, fa.nBands);
-        for (int band = part * q; band < b1; band++) sacc = __builtin_fma(drow[band], bands[band], sacc);
+        if (i >= dq) break;
+        sacc = __builtin_fma(drow[i], bq[i], sacc);
       }
       sacc += __shfl_xor(sacc, 1);
       sacc += __shfl_xor(sacc, 2);
-      if (part == 0 && j < fa.nOut) fa.out[((int64_t) b * fa.nOut + j) * a.T + t] = (float) sacc;
+      if (part == 0 && j < fa.nOut) fa.out[((int64_t) b * fa.nOut + j) * a.T + t] = (float) (live ? sacc : 0.0);
     }
     else
     {
@@ -1244,7 +1254,7 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
   using Core = FftCore<R1, R2, R3>;
   constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = 66 + 66 + 64;
   const size_t shmem = ((size_t) Core::T2 + Core::T3 + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
-                       (fa.dct ? (size_t) fa.nDct * (fa.nBands + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
+                       (fa.dct ? (size_t) fa.nDct * (4 * ((fa.nBands + 3) / 4) + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
   if (shmem > 160 * 1024) return false;
   StftBArgs k = k0;
   k.blocksPerBuf = (k.T + NW - 1) / NW;
