@@ -337,11 +337,19 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 
   // SIDE: this thread's term of bin F - 1's row of the next W update's numerator, (V / max(W'_N (H / nrm), eps))[frame] H[frame][k]
   // with the H that the W update will see (the 16 lanes of a frame form the product; frames past the strip give 0)
-  auto side_share = [&](int i, double hv, bool valid, int k) -> double {
-    double qn = valid ? wN * (hv / nrmL[k]) : 0.0;
+  // (the quotient as the tile loops take it: reciprocal seed + one Newton step; the norms enter as reciprocals like rn[])
+  auto side_quot = [](double v, double q) -> double {
+    const double d = fmax(q, kEpsilon);
+    double yq = __builtin_amdgcn_rcp(d);
+    yq = __builtin_fma(yq, __builtin_fma(-d, yq, 1.0), yq);
+    return v * yq;
+  };
+  const double rnk = SIDE ? 1.0 / nrmL[tid & 15] : 1.0; // this thread's column in the combine step
+  auto side_share = [&](int i, double hv, bool valid, int) -> double {
+    double qn = valid ? wN * (hv * rnk) : 0.0;
 #pragma unroll
     for (int sh = 1; sh < 16; sh <<= 1) qn += __shfl_xor(qn, sh);
-    return valid ? (vN[i] / fmax(qn, kEpsilon)) * hv : 0.0;
+    return valid ? side_quot(vN[i], qn) * hv : 0.0;
   };
   double wdenAcc = 0.0;
   const int srcLane4 = 4 * (y + 4 * blk + 16 * x);
@@ -466,10 +474,10 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
           if constexpr (SIDE)
           {
             // bin F - 1 joins the numerator behind the MFMA bins (the 16 lanes of a frame: the same butterfly in each)
-            double qn = wN * (hold[i] / nrmL[k]);
+            double qn = wN * (hold[i] * rnk);
 #pragma unroll
             for (int sh = 1; sh < 16; sh <<= 1) qn += __shfl_xor(qn, sh);
-            s += (vN[i] / fmax(qn, kEpsilon)) * wN;
+            s += side_quot(vN[i], qn) * wN;
           }
           // :170  H * (W^T (V / V2)) / max(W^T 1, eps) with W = W' / nrm
           hv = hold[i] * (s / nrmL[k]) / fmax(csL[k] / nrmL[k], kEpsilon);
@@ -503,16 +511,32 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   STRIP_STAMP(3)
   if (a.doW)
   {
-    if (tid < 16)
-      for (int t = 0; t < 4 * nql; t++) wdenAcc += hn[t * 16 + tid]; // :160 row sums of H, this strip's share
+    // :160 row sums of H, this strip's share: wavefront 0, lane (part = lane >> 4, k = lane & 15) adds the frames part, part + 4,
+    // ..., the four parts are then added in a fixed order (a single lane per column walked 24 dependent LDS reads here)
+    if (wv == 0)
+    {
+      const int part = lane >> 4, k = lane & 15;
+      double d = 0.0;
+      for (int t = part; t < 4 * nql; t += 4) d += hn[t * 16 + k];
+      d += __shfl_xor(d, 16);
+      d += __shfl_xor(d, 32);
+      wdenAcc = d;
+    }
     if constexpr (SIDE)
     {
-      if (tid < 16)
+      double sN = 0.0;
+      if (wv == 1) // (beside the row sums, on another SIMD)
       {
+        const int part = lane >> 4, k = lane & 15;
+        for (int t = part; t < 4 * nql; t += 4) sN += nyq[t * 16 + k];
+        sN += __shfl_xor(sN, 16);
+        sN += __shfl_xor(sN, 32);
+      }
+      if (wv == 1 && lane < 16)
+      {
+        const int tidk = lane;
         // bin F - 1's share: its 16 values sit in blocks m = k & 3 of step (last pair, e = 0) at lane x = k >> 2
-        double sN = 0.0;
-        for (int t = 0; t < 4 * nql; t++) sN += nyq[t * 16 + tid];
-        double* dst = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + ((int64_t) ((a.nPairs - 1) * 2) * a.nWG * 4 + (tid & 3)) * 64 + (tid >> 2);
+        double* dst = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + ((int64_t) ((a.nPairs - 1) * 2) * a.nWG * 4 + (tidk & 3)) * 64 + (tidk >> 2);
         if (kWriteThrough) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(sN) : "memory");
         else *dst = sN;
       }
