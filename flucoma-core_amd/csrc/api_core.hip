@@ -246,6 +246,9 @@ void fluhip_ctx_destroy(fluhip_ctx* ctx)
   for (auto& kv : ctx->twiddles) (void) hipFree(kv.second);
   for (auto& r : ctx->profRecs) { (void) hipEventDestroy(r.start); (void) hipEventDestroy(r.stop); }
   for (auto e : ctx->eventPool) (void) hipEventDestroy(e);
+  if (ctx->sideStream) (void) hipStreamSynchronize(ctx->sideStream);
+  for (auto e : ctx->sideEv) if (e) (void) hipEventDestroy(e);
+  if (ctx->sideStream) (void) hipStreamDestroy(ctx->sideStream);
   if (ctx->copyStream) (void) hipStreamDestroy(ctx->copyStream);
   if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
   g_pool.trim(ctx->device); // cached device blocks go with the context

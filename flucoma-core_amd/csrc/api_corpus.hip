@@ -827,6 +827,17 @@ int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds,
   return FLUHIP_OK;
 }
 
+// the second stream and the fork / join events of the W update's side column (created on first use; false: stay on one stream)
+constexpr bool kSideBesideDefault = false;
+static bool side_stream_ready(fluhip_ctx* ctx)
+{
+  if (ctx->sideStream) return ctx->sideEv[7] != nullptr;
+  if (hipStreamCreateWithFlags(&ctx->sideStream, hipStreamNonBlocking) != hipSuccess) { ctx->sideStream = nullptr; return false; }
+  for (auto& e : ctx->sideEv)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+  return true;
+}
+
 static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool last)
 {
   fluhip_ctx* ctx = c->ctx;
@@ -924,6 +935,21 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // and its per-wavefront column statistics; [side column ->] new wnorm.  alg/NMF.hpp:162 is then
       // implicit in every later use of (W', wnorm).
       a.nrm = wnormW; a.nrmMode = 1; a.statPart = c->wscratch.as<double>();
+      SideColumn sc{magTW + (c->F - 1) * c->Tp, c->Fp * c->Tp, H1W, c->Tp * c->Kp, (int) c->T};
+      // The side column (bin F-1 of W, scalar FMAs) reads H, V, the old W row and the old norms -- nothing the update launch
+      // writes -- so it runs BESIDE that launch on a second stream: forked behind the H update in front, joined before the norm
+      // combine.  The update launch is enqueued first; its wavefronts are the older ones on every SIMD and are served first.
+      static const bool sideBeside = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_STREAM"); return e ? std::atoi(e) != 0 : kSideBesideDefault; }();
+      const bool sideReady = c->sideFromH;
+      c->sideFromH = false;
+      hipEvent_t join = nullptr;
+      if (c->sideW && !sideReady && sideBeside && side_stream_ready(ctx))
+      {
+        hipEvent_t fork = ctx->sideEv[(ctx->sideTurn * 2) % 8];
+        join = ctx->sideEv[(ctx->sideTurn * 2 + 1) % 8];
+        ctx->sideTurn++;
+        if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(ctx->sideStream, fork, 0) != hipSuccess) join = nullptr;
+      }
       {
         ProfScope p(ctx, 1);
         launch_nmf_update5(a, s);
@@ -931,10 +957,20 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
           launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listW.maxSplit, a.B, s, a.nrm, a.nrmMode,
                                  a.statPart, c->listW.splitTab.as<int>());
       }
+      if (join)
+      {
+        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                             c->wscratch.as<double>(), wnormW, &sc, ctx->sideStream, 1);
+        (void) hipEventRecord(join, ctx->sideStream);
+        (void) hipStreamWaitEvent(s, join, 0);
+      }
       ProfScope p(ctx, 3);
-      SideColumn sc{magTW + (c->F - 1) * c->Tp, c->Fp * c->Tp, H1W, c->Tp * c->Kp, (int) c->T};
-      launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
-                           c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s);
+      if (c->sideW && sideReady)   // the H update in front left the side column's partials: the norm combine is all that is due
+        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                             c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices);
+      else
+        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                             c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s, join ? 2 : 0);
       c->wPending = true;
     }
     else
@@ -986,7 +1022,25 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       a2.clk = nullptr;                         // the clock stamps stay those of the whole-contraction wavefront
       launch_nmf_update5(a2, s);
     }
-    else if (uv == 5) launch_nmf_update5(a, s);
+    else if (uv == 5)
+    {
+      // a W update follows (same call, same window) and keeps bin F - 1 as a side column: this launch, which holds the new H
+      // in registers at its end, leaves that side column's contraction as per-wavefront partials (UpdateArgs::sideOut) and the
+      // side-column launch -- a second pass over H, 10 us per iteration of the bench shard -- is not needed.
+      // FLUHIP_SIDE_FROM_H=0 (A/B build): the side-column launch as before.
+      static const bool fromH = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FROM_H"); return e ? std::atoi(e) != 0 : true; }();
+      if (fromH && updateW && !last && c->lazy && c->sideW && c->wPending && c->nsplitH == 1)
+      {
+        a.sideOut = wnorm_side_part(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW);
+        a.sideWold = wnorm_side_wold(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW);
+      }
+      c->sideFromH = launch_nmf_update5(a, s);
+      if (c->sideFromH)
+      {
+        const int G = ((int) c->T + 15) / 16;
+        c->sideFromHSlices = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips((int) c->T, (int) c->Kp, Bw);
+      }
+    }
     else launch_nmf_update_wide(a, c->wideScratch.as<double>(), s);
   }
 }
@@ -998,6 +1052,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
                                fluhip_progress_fn progress, void* user)
 {
   fluhip_ctx* ctx = c->ctx;
+  c->sideFromH = false; // (side-column partials an H update leaves are only ever used by the W update enqueued right behind it)
   if (!progress)
   {
     // Corpora of several rounds of wavefronts (more than 1024 / strips buffers) run ROUND-MAJOR: all iterations of the
@@ -1035,6 +1090,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
       {
         c->winB0 = b0;
         c->winB = std::min(chunk, c->B - b0);
+        c->sideFromH = false;
         for (int64_t i = 0; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
       }
       c->winB0 = c->winB = 0;

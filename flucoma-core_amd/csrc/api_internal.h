@@ -40,6 +40,9 @@ struct fluhip_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t copyStream = nullptr; // host -> device audio uploads run beside the compute stream (created on first use)
+  hipStream_t sideStream = nullptr; // the W update's side column runs beside the update launch (created on first use)
+  hipEvent_t sideEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // fork / join pairs, in rotation
+  unsigned sideTurn = 0;
   std::string err;
   std::map<std::tuple<int64_t, int64_t, int>, double*> windows; // (win, fft, type) -> device table
   std::map<int, double*> twiddles;                // fft -> device table
@@ -232,6 +235,8 @@ struct fluhip_corpus
   bool lazy = false;     // the shape takes the two-launch-per-factor fast path
   bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
   bool wPending = false; // W in memory is W' = W diag(wnorm)
+  bool sideFromH = false; // the H update enqueued last left the next W update's side-column partials (sideFromHSlices per buffer)
+  int sideFromHSlices = 0;
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
   DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's

@@ -132,6 +132,12 @@ struct UpdateArgs
   // > 0: strips (wavefronts) per buffer instead of the planner's choice for a.B buffers (windows of a larger corpus keep
   // the schedule of one round)
   int stripsOverride = 0;
+  // H update of a corpus whose W update keeps its last bin as a side column (SideColumn): leave, beside the new H, every
+  // wavefront's share of that side column's contraction for the W update that follows -- sideOut [B][strips][2][Kp] in the
+  // layout of the side-column slices (launch_wnorm_combine), sideWold [B][Kp] the old side row W'[R-1] / nrm.
+  // launch_nmf_update5 returns true when the launch it picked did so (else the side-column launch is still due).
+  double* sideOut = nullptr;
+  double* sideWold = nullptr;
 };
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine
@@ -155,7 +161,7 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
 // then the largest count
 int update_finalize_parts(int C, int Kp);
 int nmf_update5_waves_per_buffer(int C, int Kp, int B);          // the planner's strips per buffer
-void launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming
+bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming
 // any rank (used above Kp = 128): un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip)
 void launch_nmf_update_wide(const UpdateArgs& a, double* scratch, hipStream_t s);
 int64_t nmf_update_wide_scratch_doubles(int R, int C, int Kp, int B);
@@ -186,7 +192,10 @@ bool nmf_side_column_supported(int R, int C, int Kp);
 // [side column ->] new nrm [B][Kp] (1 where alg/NMF.hpp:162 would skip the normalisation)
 int wnorm_scratch_doubles(int Kp, int B, int nStrips);
 void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s);
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase = 0, int sideSlices = 0);
+// where the side-column slices / the old side row live inside `scratch` (an H update with UpdateArgs::sideOut fills them)
+double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips);
+double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips);
 // S = S / nrm in memory, nrm = 1
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);
 void launch_fill_ones(double* p, int64_t n, hipStream_t s);

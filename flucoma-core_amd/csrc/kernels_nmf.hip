@@ -612,6 +612,168 @@ __global__ __launch_bounds__(THREADS) void wnorm_combine_kernel(double* Sbase, i
                      shd);
 }
 
+// ---- side column and norm combine in ONE launch, one workgroup of 1024 threads per buffer (round 4) -----------------------
+// For corpora (many buffers of a few hundred frames) the two launches above cost 10 + 6 us per iteration of the bench shard,
+// most of it the latency of their dependent round trips: side-column slices -> partials in memory -> kernel boundary ->
+// combine.  Here one workgroup does a buffer's side column over ALL frames and then its norm, with nothing in between
+// leaving the CU.  Lane layout of the contraction: the Kp / 2 16-byte pieces of a row of the moving factor lie on adjacent
+// lanes (coalesced loads, every row read once), FPB = 1024 / (Kp / 2) rows per pass; a row's quotient is formed by a butterfly
+// of DPP exchange-adds inside its lane group (all lanes end up with the same bits: the operands of every add are the same
+// two numbers in either order), its contribution to num / den stays in the lane's registers, and the FPB row groups are
+// added in fixed order through the LDS at the end.  No atomics, no tickets: run-to-run bit-identical.
+template <int CTRL>
+__device__ __forceinline__ double side_dpp(double x)
+{
+  const long long b = __double_as_longlong(x);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffff), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+// sum over the PPR adjacent lanes of a row (PPR = 8 .. 64), every lane of the group receives it
+template <int PPR>
+__device__ __forceinline__ double side_group_sum(double q)
+{
+  q += side_dpp<0xB1>(q);                           // quad_perm [1,0,3,2]
+  q += side_dpp<0x4E>(q);                           // quad_perm [2,3,0,1]
+  q += side_dpp<0x141>(q);                          // row_half_mirror: the other quad of the half row
+  if constexpr (PPR >= 16) q += side_dpp<0x140>(q); // row_mirror: the other half row
+  if constexpr (PPR >= 32) q += __shfl_xor(q, 16);
+  if constexpr (PPR >= 64) q += __shfl_xor(q, 32);
+  return q;
+}
+// v / d for d >= eps: reciprocal seed, one Newton step, quotient, one residual correction (rounding error only)
+__device__ __forceinline__ double side_div(double v, double d)
+{
+  double y = __builtin_amdgcn_rcp(d);
+  y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+  const double r = v * y;
+  return __builtin_fma(__builtin_fma(-d, r, v), y, r);
+}
+constexpr int kSideNormUnr = 8; // rows per lane in flight
+
+template <int Kp>
+__global__ __launch_bounds__(1024) void side_norm_kernel(double* Sbase, int64_t strideS, int C, int K, SideColumn side,
+                                                         const double* statPart, int nParts, double* nrm)
+{
+  constexpr int PPR = Kp / 2, FPB = 1024 / PPR, NJ = 1024 / Kp; // FPB == 2 NJ
+  __shared__ double wsh[Kp], smax[Kp];
+  __shared__ double shN[FPB * Kp], shD[FPB * Kp];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  double* S = Sbase + (int64_t) b * strideS;
+  const double* Mv = side.Mv + (int64_t) b * side.strideM;
+  const double* vcol = side.vcol + (int64_t) b * side.strideV;
+  const int p = tid % PPR, g = tid / PPR;
+  // Requests first, arithmetic later: the old side row, its norm and the first pass of rows leave before anything waits;
+  // every further pass is requested before the one in hand is worked on, and the statistics parts the update launch left
+  // (one per wavefront; summed in index order) are requested ahead of the last pass, whose arithmetic covers their latency.
+  const int R = side.R;
+  auto request = [&](int r0, d2 (&h)[kSideNormUnr], double (&v)[kSideNormUnr]) {
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++)
+    {
+      const int r = r0 + u * FPB + g;
+      h[u] = d2{0.0, 0.0};
+      v[u] = 0.0;
+      if (r < R)
+      {
+        h[u] = *reinterpret_cast<const d2*>(Mv + (int64_t) r * Kp + 2 * p);
+        v[u] = vcol[r];
+      }
+    }
+  };
+  double sraw = 0.0, nr = 1.0;
+  if (tid < Kp)
+  {
+    sraw = S[(int64_t) (C - 1) * Kp + tid];
+    nr = nrm[(int64_t) b * Kp + tid];
+  }
+  d2 h[kSideNormUnr];
+  double v[kSideNormUnr];
+  request(0, h, v);
+  // the stationary row, normalised the way the update kernel normalises its rows (S = W' / nrm)
+  if (tid < Kp) wsh[tid] = sraw / nr;
+  __syncthreads();
+  const double w0 = wsh[2 * p], w1 = wsh[2 * p + 1];
+  double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
+  auto work = [&](const d2 (&h)[kSideNormUnr], const double (&v)[kSideNormUnr]) {
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++)
+    {
+      // (rows past the end: h = 0, v = 0 -> 0 / eps = 0, nothing added)
+      const double q = side_group_sum<PPR>(__builtin_fma(h[u][0], w0, h[u][1] * w1));
+      const double ratio = side_div(v[u], fmax(q, kEpsilon));
+      n0 = __builtin_fma(ratio, h[u][0], n0);
+      n1 = __builtin_fma(ratio, h[u][1], n1);
+      d0 += h[u][0];
+      d1 += h[u][1];
+    }
+  };
+#pragma unroll 1
+  for (int r0 = FPB * kSideNormUnr; r0 < R; r0 += FPB * kSideNormUnr)
+  {
+    d2 hn[kSideNormUnr];
+    double vn[kSideNormUnr];
+    request(r0, hn, vn);
+    work(h, v);
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++) { h[u] = hn[u]; v[u] = vn[u]; }
+  }
+  const double* pp = statPart + (int64_t) b * nParts * 2 * Kp;
+  double vs[8], vm[8];
+#pragma unroll
+  for (int u = 0; u < 8; u++)
+  {
+    vs[u] = 0.0;
+    vm[u] = -INFINITY;
+    if (tid < Kp && u < nParts) { vs[u] = pp[(int64_t) u * 2 * Kp + tid]; vm[u] = pp[(int64_t) u * 2 * Kp + Kp + tid]; }
+  }
+  work(h, v);
+  double st = 0.0, sm = -INFINITY;
+  if (tid < Kp)
+  {
+#pragma unroll
+    for (int u = 0; u < 8; u++) { st += vs[u]; sm = fmax(sm, vm[u]); }   // (parts past nParts: + 0, max with -inf)
+    for (int j = 8; j < nParts; j++) { st += pp[(int64_t) j * 2 * Kp + tid]; sm = fmax(sm, pp[(int64_t) j * 2 * Kp + Kp + tid]); }
+  }
+  shN[g * Kp + 2 * p] = n0; shN[g * Kp + 2 * p + 1] = n1;
+  shD[g * Kp + 2 * p] = d0; shD[g * Kp + 2 * p + 1] = d1;
+  __syncthreads();
+  {
+    // row groups j and j + NJ, then (below) the NJ sums in index order
+    const int k = tid % Kp, j = tid / Kp;
+    const double a = shN[j * Kp + k] + shN[(j + NJ) * Kp + k], c = shD[j * Kp + k] + shD[(j + NJ) * Kp + k];
+    shN[j * Kp + k] = a;
+    shD[j * Kp + k] = c;
+  }
+  __syncthreads();
+  if (tid < Kp)
+  {
+    double n = 0.0, d = 0.0;
+#pragma unroll
+    for (int j0 = 0; j0 < NJ; j0 += 8)
+    {
+      double pn[8], pd[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) { pn[j] = shN[(j0 + j) * Kp + tid]; pd[j] = shD[(j0 + j) * Kp + tid]; }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { n += pn[j]; d += pd[j]; }
+    }
+    // the side row (not normalised, like every other row of W') and alg/NMF.hpp:162 for the whole column
+    const double wnew = (tid < K) ? (wsh[tid] * n) / fmax(d, kEpsilon) : 0.0;
+    S[(int64_t) (C - 1) * Kp + tid] = wnew;
+    st += wnew * wnew;
+    sm = fmax(sm, wnew);
+    smax[tid] = (tid < K) ? sm : -INFINITY;
+  }
+  __syncthreads();
+  if (tid < Kp)
+  {
+    double gmax = -INFINITY;
+    for (int j = 0; j < Kp; j++) gmax = fmax(gmax, smax[j]);
+    nrm[(int64_t) b * Kp + tid] = (tid < K && gmax > kEpsilon) ? sqrt(st) : 1.0;
+  }
+}
+
 // W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
 // outside the two update kernels reads W)
 __global__ void wnorm_apply_kernel(double* Sbase, int64_t strideS, int C, int Kp, double* nrm)
@@ -655,14 +817,36 @@ bool nmf_side_column_supported(int R, int C, int Kp)
 }
 int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
 
-void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s)
+double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips) { return scratch + (int64_t) B * nStrips * 2 * Kp; }
+double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips)
 {
+  return wnorm_side_part(scratch, Kp, B, nStrips) + (int64_t) B * kSideSlices * 2 * Kp;
+}
+
+void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices)
+{
+  // sideSlices > 0 (with sidePhase 2): the side column's partials are there already, sideSlices per buffer, dense -- left by
+  // the H update in front (UpdateArgs::sideOut)
+  // sidePhase 0: side column launch, then the combine launch, both on s.  1: the side column launch alone (the caller runs
+  // it on a second stream beside the update launch -- it reads nothing the update writes).  2: the combine launch alone.
   double* statPart = scratch;
   double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;
   double* wold = sidePart + (int64_t) B * kSideSlices * 2 * Kp;
-  int nsl = 0;
-  if (side)
+  int nsl = side ? (sideSlices > 0 ? sideSlices : side_slices_for(side->R, Kp)) : 0;
+  // corpora: one launch, one workgroup per buffer (side_norm_kernel) -- enough buffers to occupy the part, few enough rows
+  // that a workgroup walks them in a few passes, few statistics parts.  FLUHIP_SIDE_NORM=0 (A/B build): the two launches.
+  static const bool oneLaunch = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_NORM"); return e ? std::atoi(e) != 0 : true; }();
+  if (side && sidePhase == 0 && oneLaunch && B >= 64 && nStrips <= 64 && (int64_t) side->R * Kp <= (int64_t) 64 * 2048)
+  {
+    const dim3 grid((unsigned) B), block(1024);
+    if (Kp == 16) hipLaunchKernelGGL(side_norm_kernel<16>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
+    else if (Kp == 32) hipLaunchKernelGGL(side_norm_kernel<32>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
+    else if (Kp == 64) hipLaunchKernelGGL(side_norm_kernel<64>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
+    else hipLaunchKernelGGL(side_norm_kernel<128>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
+    return;
+  }
+  if (side && sidePhase != 2)
   {
     const int nrg = 256 / Kp;
     nsl = side_slices_for(side->R, Kp);
@@ -683,6 +867,7 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     if (fused) return;
   }
+  if (sidePhase == 1) return;
   // one block per buffer sums nStrips statistics parts and nsl side slices per component: 1024 threads where that is long
   // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
   if (nStrips > 128 || nsl > 64)

@@ -56,6 +56,10 @@ struct Upd5Args
   // work-list mode (ragged corpora, fluhip_kernels.h WaveDesc): wavefront w of workgroup i takes list[4 i + w]; the uniform
   // mapping above (wavesPerBuf, nsplit, stepsPerSplit, xcdMap) is then unused
   const WaveDesc* list;
+  // SIDEQ instantiations (H update): per-wavefront partials of the NEXT W update's side column, [B][wavesPerBuf][2][KP], and the
+  // normalised old side row [B][KP] (UpdateArgs::sideOut / sideWold)
+  double* sidePart;
+  double* sideWold;
 };
 
 // The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
@@ -129,7 +133,21 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
   }
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0>
+// quad_perm exchange of a double (the four lanes x = 0 .. 3 of a result row)
+template <int CTRL>
+__device__ __forceinline__ double quad_dpp(double v)
+{
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffff), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+}
+
+// SIDEQ (round 4; H update of a corpus whose W update keeps bin C_w - 1 as a side column): the epilogue, which holds the new
+// rows of H in registers, also forms this wavefront's share of the side column's contraction for the W update that follows --
+// q_t = sum_k H[t][k] w_k with w = W'[R-1] / nrm, V[R-1][t] / max(q_t, eps), num_k, den_k over its frames -- so that no launch
+// has to read H again for it (side_slices_kernel: 10 us per iteration of the bench shard, all of it a second pass over H).
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0, int SIDEQ = 0>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
@@ -302,6 +320,24 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   };
   long long tP1 = 0, tP2 = 0, tP3 = 0;
   if constexpr (INSTR) tP1 = (long long) __builtin_amdgcn_s_memrealtime();
+  // SIDEQ: what the epilogue needs from memory -- row R - 1 of the moving factor (the W update's side row) and the side bin's
+  // magnitudes of this strip's frames -- is copied into the LDS behind the rings by the first DMAs of the launch: the oldest
+  // requests, landed long before the loop ends (fetched in the epilogue they cost the launch two memory latencies, 4.5 us)
+  constexpr int NJSV = SIDEQ ? (NG * 128 + 1023) / 1024 : 0;
+  [[maybe_unused]] char* sideL = nullptr;
+  if constexpr (SIDEQ)
+  {
+    sideL = lds + WPB * WAVE_REGION + wave * (1 + NJSV) * 1024;
+    const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KP) + min(lane, SPR - 1) * 16;
+    FLUHIP_GLDS(wsrc, sideL);
+#pragma unroll
+    for (int j = 0; j < NJSV; j++)
+    {
+      const int i = min(64 * j + lane, 8 * ng - 1);
+      const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) (a.R - 1) * a.ldv + (int64_t) g0 * 16) + i * 16;
+      FLUHIP_GLDS(vsrc, sideL + 1024 + j * 1024);
+    }
+  }
   if constexpr (MODE >= 1) fill_slots(0, 2);
 
   // ---- stationary operand + accumulators ------------------------------------------------------
@@ -899,6 +935,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   {
     double nrE[M], ss[M], mx[M];
     if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
+    [[maybe_unused]] double nrL = 1.0;   // SIDEQ: the norm of component `lane` (the old side row leaves normalised)
+    if constexpr (SIDEQ) if (strip == 0 && lane < KP) nrL = a.nrm[(int64_t) buf * KP + lane];
     if (a.nrmMode == 2)
     {
 #pragma unroll
@@ -935,6 +973,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     constexpr int CPR = KP / 2;            // 16-byte chunks per row
     constexpr int NST = 16 * CPR / 64;     // store instructions per group
     char* stg = lds + wave * WAVE_REGION;
+    [[maybe_unused]] double wsd[M], numS[M], denS[M], vsd[NG];
+    if constexpr (SIDEQ)
+    {
+      static_assert(KP <= 64 && LIST == 0, "side-column partials: one lane per component at the end");
+      // w_k = W'[R-1][k] / nrm_k for this lane's k = M x + m (nrE holds those norms), the side bin's magnitudes of this lane's frames
+      const double* wl = reinterpret_cast<const double*>(sideL);
+      const double* vl = reinterpret_cast<const double*>(sideL + 1024);
+#pragma unroll
+      for (int m = 0; m < M; m++) { wsd[m] = fdiv_pos(wl[M * x + m], nrE[m]); numS[m] = 0.0; denS[m] = 0.0; }
+#pragma unroll
+      for (int g = 0; g < NG; g++)
+      {
+        const int col = (g0 + g) * 16 + 4 * blk + y;
+        vsd[g] = (g < ng && col < a.C) ? vl[g * 16 + 4 * blk + y] : 0.0;
+      }
+    }
 #pragma unroll
     for (int gb = 0; gb < NG; gb += GB)
     {
@@ -944,6 +998,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         const int col = (g0 + g) * 16 + 4 * blk + y;
         const bool live = g < ng && col < a.C;
         char* row = stg + (g - gb) * GRPB + (4 * blk + y) * ROWB + (M * x) * 8;
+        [[maybe_unused]] double rr[M];
 #pragma unroll
         for (int m = 0; m < M; m += 2)
         {
@@ -956,6 +1011,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             const double r0 = v * dy[m + e];
             const double r = __builtin_fma(__builtin_fma(-dd[m + e], r0, v), dy[m + e], r0);
             r2[e] = r;
+            if constexpr (SIDEQ) rr[m + e] = r;
             if (live)
             {
               ss[m + e] = __builtin_fma(r, r, ss[m + e]);
@@ -963,6 +1019,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             }
           }
           *reinterpret_cast<d2*>(row + m * 8) = d2{r2[0], r2[1]};
+        }
+        if constexpr (SIDEQ)
+        {
+          // the four lanes x = 0 .. 3 of a frame hold its KP new activations: the dot product with w closes over the quad
+          double qs = 0.0;
+#pragma unroll
+          for (int m = 0; m < M; m++) qs = __builtin_fma(rr[m], wsd[m], qs);
+          qs += quad_dpp<0xB1>(qs);
+          qs += quad_dpp<0x4E>(qs);
+          const double ratio = live ? fdiv_pos(vsd[g], fmax(qs, kEpsilon)) : 0.0;
+#pragma unroll
+          for (int m = 0; m < M; m++)
+          {
+            numS[m] = __builtin_fma(ratio, rr[m], numS[m]);
+            denS[m] += live ? rr[m] : 0.0;
+          }
         }
       }
 #pragma unroll
@@ -980,6 +1052,34 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             if (col < a.C) store_result16(S + (int64_t) col * KP + piece * 2, t);
           }
         }
+      }
+    }
+    if constexpr (SIDEQ)
+    {
+      // the 16 lanes (blk, y) of equal x hold partial sums of the same components: added in fixed order through the (idle)
+      // ring, one lane per component; the wavefront's (num, den) go where side_slices_kernel would have left a slice's
+      double* red = reinterpret_cast<double*>(stg);          // [2][16][KP]
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the staged results have been read back
+      const int jr = 4 * blk + y;
+#pragma unroll
+      for (int m = 0; m < M; m++)
+      {
+        red[jr * KP + M * x + m] = numS[m];
+        red[(16 + jr) * KP + M * x + m] = denS[m];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < KP)
+      {
+        double pn[16], pd[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) { pn[j] = red[j * KP + lane]; pd[j] = red[(16 + j) * KP + lane]; }
+        double n = 0.0, d = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { n += pn[j]; d += pd[j]; }
+        double* sp = a.sidePart + ((int64_t) buf * a.wavesPerBuf + strip) * 2 * KP;
+        sp[lane] = n;
+        sp[KP + lane] = d;
+        if (strip == 0) a.sideWold[(int64_t) buf * KP + lane] = reinterpret_cast<const double*>(sideL)[lane] / nrL;
       }
     }
     if (a.statPart)
@@ -1069,10 +1169,11 @@ static void launch5_list(const UpdateArgs& a, hipStream_t s)
   hipLaunchKernelGGL(kern, dim3((unsigned) a.listWGs), dim3(256), shmem, s, k);
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int SIDEQ = 0>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
+  k.sidePart = SIDEQ ? a.sideOut : nullptr; k.sideWold = SIDEQ ? a.sideWold : nullptr;
   k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
   k.Mv = a.Mv; k.strideM = a.strideM;
   k.S = a.S; k.strideS = a.strideS;
@@ -1094,9 +1195,9 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
   constexpr int KP = 4 * M, SPR = KP / 2;
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
-  constexpr size_t shmem = (size_t) 4 * WPS * NS * (NJV + NJM) * 1024;
+  constexpr size_t shmem = (size_t) 4 * WPS * (NS * (NJV + NJM) + (SIDEQ ? 1 + (NG * 128 + 1023) / 1024 : 0)) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS>;
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS, 0, SIDEQ>;
   request_dynamic_lds(kern, (size_t) (shmem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
   if (k.nsplit > 1)
@@ -1152,12 +1253,16 @@ constexpr int ring_depth()
   return fit >= 6 ? 6 : (fit < 3 ? 3 : fit);
 }
 
+// true: the launch also left the side-column partials UpdateArgs::sideOut asks for (the SIDEQ instantiations: ranks up to
+// 64, the production pipeline form of the rank, strips of two groups or more, deferred normalisation, un-split)
 template <int M, int NG, int WPS>
-static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
+static bool launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 {
   if constexpr (NG == 1) launch5_t<M, 1, ring_depth<M, 1, WPS>(), WPS>(a, w, s);
   else
   {
+    const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1;
+    (void) sideq;
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, WPS>();
@@ -1166,8 +1271,8 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
         static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();
         static const int imode = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : 1; }();
-        if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return; }
-        if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return; }
+        if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return false; }
+        if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return false; }
       }
       if constexpr (WPS == 1 && NS >= 4 && NS % 2 == 0)
       {
@@ -1192,17 +1297,30 @@ static void launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
             if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
             else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
             launch5_t<M, NG, NS, WPS, 0, 2, 0>(a, w, s);
-            return;
+            return false;
           }
         }
-        else if (eff == 2) { launch5_t<M, NG, NS, WPS, 0, 2>(a, w, s); return; }
+        else if (eff == 2)
+        {
+          if constexpr (M == 16)
+            if (sideq) { launch5_t<M, NG, NS, WPS, 0, 2, 1, 1>(a, w, s); return true; }
+          launch5_t<M, NG, NS, WPS, 0, 2>(a, w, s);
+          return false;
+        }
         if constexpr (M <= 16)
-          if (eff == 1) { launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s); return; }
+          if (eff == 1)
+          {
+            if constexpr (M <= 8)
+              if (sideq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 1>(a, w, s); return true; }
+            launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s);
+            return false;
+          }
       }
       launch5_t<M, NG, NS, WPS>(a, w, s);
     }
-    else launch5_ng<M, NG - 1, WPS>(a, w, ng, s);
+    else return launch5_ng<M, NG - 1, WPS>(a, w, ng, s);
   }
+  return false;
 }
 
 // the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
@@ -1242,7 +1360,7 @@ int nmf_update5_strips(int C, int Kp, int B)
 
 // strips per buffer for WPS wavefronts per SIMD: WPS x the one-wave plan, as long as every strip
 // keeps at least one group
-void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
+bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
   if (a.list)
   {
@@ -1256,7 +1374,7 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     case 32: launch5_list_ng<32, 2>(a, a.listNG, s); break;
     default: break;
     }
-    return;
+    return false;
   }
   const int G = (a.C + 15) / 16;
   const int w = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips(a.C, a.Kp, a.B);
@@ -1266,8 +1384,8 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
   {
     switch (a.Kp / 4)
     {
-    case 4: launch5_ng<4, 4, 2>(a, w, ng, s); break;
-    case 8: launch5_ng<8, 4, 2>(a, w, ng, s); break;
+    case 4: return launch5_ng<4, 4, 2>(a, w, ng, s);
+    case 8: return launch5_ng<8, 4, 2>(a, w, ng, s);
     default: break;
     }
   }
@@ -1275,13 +1393,14 @@ void launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
   {
     switch (a.Kp / 4)
     {
-    case 4: launch5_ng<4, 9, 1>(a, w, ng, s); break;
-    case 8: launch5_ng<8, 9, 1>(a, w, ng, s); break;
-    case 16: launch5_ng<16, 4, 1>(a, w, ng, s); break;
-    case 32: launch5_ng<32, 2, 1>(a, w, ng, s); break;
+    case 4: return launch5_ng<4, 9, 1>(a, w, ng, s);
+    case 8: return launch5_ng<8, 9, 1>(a, w, ng, s);
+    case 16: return launch5_ng<16, 4, 1>(a, w, ng, s);
+    case 32: return launch5_ng<32, 2, 1>(a, w, ng, s);
     default: break;
     }
   }
+  return false;
 }
 
 } // namespace fluhip

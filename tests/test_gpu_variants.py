@@ -41,7 +41,7 @@ print("plan", c.plan()["kernel"], "worst", worst)
 assert worst < 1e-9, worst
 # the batched regime with the Nyquist side column (FLUHIP_SIDE_SLICES=2: its slices then go through the block in chunks,
 # as on buffers of more than 256 x 64 frames), ranks 32 and 128
-for K in (32, 64, 128):
+for K in (12, 32, 64, 128):
     audio = np.stack([oracle_np.synth_audio(70000, 1100 + (b % 3)) for b in range(128)])
     c = fluhip.Corpus(ctx, 128, 70000, 2048, 2048, 512, K)
     c.set_audio(audio); c.stft(); c.nmf(4, seed=42)
@@ -74,7 +74,7 @@ for k in range(9):
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "1"}, {"FLUHIP_TAIL_SPLIT": "0"}, {"FLUHIP_GRAPH_ITERS": "4"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"}, {"FLUHIP_STRIP_BIN": "1"}, {"FLUHIP_STRIP_SIDE": "0"},
                                  {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
-                                 {"FLUHIP_SIDE_SLICES": "2"}],
+                                 {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env, ab_lib_paths):
     e = dict(os.environ)
