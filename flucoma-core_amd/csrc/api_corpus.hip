@@ -913,6 +913,40 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
   double* const WfW = c->Wf.as<double>() + b0 * c->Fp * c->Kp;
   double* const H1W = c->H1.as<double>() + b0 * c->Tp * c->Kp;
   double* const wnormW = c->wnorm.p ? c->wnorm.as<double>() + b0 * c->Kp : nullptr;
+  // the H update's arguments (alg/NMF.hpp:165-170; V2 is formed from the already updated W) -- also wanted by the W update's
+  // step, which asks what the H launch behind it will take over (dryRun)
+  auto h_args = [&]() {
+    UpdateArgs a;
+    a.V = magTW; a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
+    a.Mv = WfW; a.strideM = c->Fp * c->Kp;
+    a.S = H1W; a.strideS = c->Tp * c->Kp;
+    a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp;
+    if (c->winB) a.stripsOverride = c->winStripsH;
+    a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
+    a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Tp; a.colsumScratch = c->csumScratch.as<double>();
+    a.clk = c->clk.as<long long>() + 4;
+    return a;
+  };
+  const int uvH = update_variant((int) c->Kp);
+  // (the plain one-launch form of the H update: no work lists, no second launch for a poorly filled last round)
+  const bool hPlain = !c->useLists && uvH == 5 && !(c->tailSplitH > 1 && !c->winB);
+  // FLUHIP_SIDE_FROM_H=0 (A/B build): side-column launch and norm-combine launch between the updates, as before round 4
+  static const bool fromH = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FROM_H"); return e ? std::atoi(e) != 0 : true; }();
+  static const bool normInH = [] { const char* e = fluhip::ab_getenv("FLUHIP_NORM_IN_H"); return e ? std::atoi(e) != 0 : true; }();
+  auto side_io = [&](UpdateArgs& a, bool wantNorm) {
+    double* scr = c->wscratch.as<double>();
+    const int outGen = c->sideGen ^ 1;
+    a.sideOut = wnorm_side_part(scr, (int) c->Kp, Bw, c->stripsW, outGen);
+    a.sideWold = wnorm_side_wold(scr, (int) c->Kp, Bw, c->stripsW, outGen);
+    if (wantNorm)
+    {
+      a.cmbStat = scr; a.cmbParts = c->stripsW;
+      a.cmbSide = wnorm_side_part(scr, (int) c->Kp, Bw, c->stripsW, c->sideGen);
+      a.cmbWold = wnorm_side_wold(scr, (int) c->Kp, Bw, c->stripsW, c->sideGen);
+      a.cmbSlices = c->sideFromHSlices; a.cmbK = (int) c->K;
+      a.cmbNrmOut = wnormW; a.cmbRowOut = WfW;
+    }
+  };
   if (updateW)
   {
     // alg/NMF.hpp:158-161
@@ -965,9 +999,20 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         (void) hipStreamWaitEvent(s, join, 0);
       }
       ProfScope p(ctx, 3);
-      if (c->sideW && sideReady)   // the H update in front left the side column's partials: the norm combine is all that is due
+      c->normDue = false;
+      if (c->sideW && sideReady && updateH && hPlain && normInH && c->stripsW <= 16 && c->sideFromHSlices <= 16)
+      {
+        // ... and the norm combine too can wait for the H update behind this launch, whose wavefronts then do it in their
+        // prologue -- if the form that launch will take does that (dryRun: nothing is launched)
+        UpdateArgs ah = h_args();
+        ah.nrm = wnormW; ah.nrmMode = 2; ah.dryRun = true;
+        side_io(ah, true);
+        c->normDue = (launch_nmf_update5(ah, s) & 2) != 0;
+      }
+      if (c->normDue) {}
+      else if (c->sideW && sideReady)   // the H update in front left the side column's partials: the norm combine is all that is due
         launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
-                             c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices);
+                             c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices, c->sideGen);
       else
         launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
                              c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s, join ? 2 : 0);
@@ -987,19 +1032,10 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
   }
   if (updateH)
   {
-    // alg/NMF.hpp:165-170 (V2 is formed from the already updated W)
-    UpdateArgs a;
-    a.V = magTW; a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
-    a.Mv = WfW; a.strideM = c->Fp * c->Kp;
-    a.S = H1W; a.strideS = c->Tp * c->Kp;
-    a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp;
-    if (c->winB) a.stripsOverride = c->winStripsH;
-    a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
-    a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Tp; a.colsumScratch = c->csumScratch.as<double>();
-    a.clk = c->clk.as<long long>() + 4;
+    UpdateArgs a = h_args();
     if (c->wPending) { a.nrm = wnormW; a.nrmMode = 2; }
     ProfScope p(ctx, 1);
-    const int uv = update_variant(a.Kp);
+    const int uv = uvH;
     if (c->useLists)
     {
       a.list = c->listH.list.as<WaveDesc>(); a.listWGs = c->listH.wgs; a.listNG = c->listH.ng; a.listPartial = c->listH.partial;
@@ -1028,16 +1064,17 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // in registers at its end, leaves that side column's contraction as per-wavefront partials (UpdateArgs::sideOut) and the
       // side-column launch -- a second pass over H, 10 us per iteration of the bench shard -- is not needed.
       // FLUHIP_SIDE_FROM_H=0 (A/B build): the side-column launch as before.
-      static const bool fromH = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FROM_H"); return e ? std::atoi(e) != 0 : true; }();
-      if (fromH && updateW && !last && c->lazy && c->sideW && c->wPending && c->nsplitH == 1)
-      {
-        a.sideOut = wnorm_side_part(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW);
-        a.sideWold = wnorm_side_wold(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW);
-      }
-      c->sideFromH = launch_nmf_update5(a, s);
-      if (c->sideFromH)
+      // (the norm combine of the W update in front, if that was left to this launch: c->normDue)
+      const bool wantNorm = c->normDue;
+      if (wantNorm || (fromH && updateW && !last && c->lazy && c->sideW && c->wPending && c->nsplitH == 1)) side_io(a, wantNorm);
+      const int did = launch_nmf_update5(a, s);
+      if (wantNorm && !(did & 2)) c->planError = true; // (cannot happen: the dry run in the W update's step took the same arguments)
+      c->normDue = false;
+      c->sideFromH = (did & 1) != 0 && updateW && !last;
+      if (did & 1)
       {
         const int G = ((int) c->T + 15) / 16;
+        c->sideGen ^= 1;
         c->sideFromHSlices = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips((int) c->T, (int) c->Kp, Bw);
       }
     }
@@ -1053,6 +1090,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
 {
   fluhip_ctx* ctx = c->ctx;
   c->sideFromH = false; // (side-column partials an H update leaves are only ever used by the W update enqueued right behind it)
+  c->normDue = false;
   if (!progress)
   {
     // Corpora of several rounds of wavefronts (more than 1024 / strips buffers) run ROUND-MAJOR: all iterations of the
@@ -1133,6 +1171,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
       for (; i < iters; i++) enqueue_iteration(c, updateW, updateH, i + 1 == iters);
     }
     HIPCHK(ctx, hipGetLastError());
+    if (c->planError) return fail(ctx, "internal error: an update launch did not take the form its dry run announced");
     return FLUHIP_OK;
   }
   // One event per iteration; callbacks are delivered in order as the events complete, and the host never runs more
@@ -1167,6 +1206,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
     }
   }
   give_back();
+  if (c->planError) return fail(ctx, "internal error: an update launch did not take the form its dry run announced");
   return FLUHIP_OK;
 }
 

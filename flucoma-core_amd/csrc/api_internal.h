@@ -237,6 +237,9 @@ struct fluhip_corpus
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   bool sideFromH = false; // the H update enqueued last left the next W update's side-column partials (sideFromHSlices per buffer)
   int sideFromHSlices = 0;
+  int sideGen = 0;        // which of the two side-partial areas of wscratch holds them (an H update reads one and fills the other)
+  bool normDue = false;   // the W update enqueued last left its norm combine to the H update behind it
+  bool planError = false; // a launch did not take the form its dry run announced (reported by corpus_iterate)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
   DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's

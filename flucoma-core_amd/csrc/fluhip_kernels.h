@@ -135,9 +135,20 @@ struct UpdateArgs
   // H update of a corpus whose W update keeps its last bin as a side column (SideColumn): leave, beside the new H, every
   // wavefront's share of that side column's contraction for the W update that follows -- sideOut [B][strips][2][Kp] in the
   // layout of the side-column slices (launch_wnorm_combine), sideWold [B][Kp] the old side row W'[R-1] / nrm.
-  // launch_nmf_update5 returns true when the launch it picked did so (else the side-column launch is still due).
   double* sideOut = nullptr;
   double* sideWold = nullptr;
+  // ... and, when the norm combine of the W update in front has not been launched (launch_wnorm_combine), do it in the
+  // prologue of every wavefront: cmbStat [B][cmbParts][2][Kp] the W update's column statistics, cmbSide [B][cmbSlices][2][Kp]
+  // and cmbWold [B][Kp] the side column's partials / old side row (an earlier launch's sideOut / sideWold), cmbK the rank;
+  // the new norms go to cmbNrmOut [B][Kp] (= nrm, which the launch then does not read), the new side row to row R - 1 of
+  // cmbRowOut (= Mv).  Return value of launch_nmf_update5: bit 0 side partials left, bit 1 norm combine done.
+  const double* cmbStat = nullptr;
+  const double* cmbSide = nullptr;
+  const double* cmbWold = nullptr;
+  double* cmbNrmOut = nullptr;
+  double* cmbRowOut = nullptr;
+  int cmbParts = 0, cmbSlices = 0, cmbK = 0;
+  bool dryRun = false; // nothing is launched: the return value says what a launch with these arguments would do
 };
 
 // out[b * outStride + k] = sum_r Mv[b][r][k], r < R: 256-row partials, then a fixed-order combine
@@ -161,7 +172,7 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
 // then the largest count
 int update_finalize_parts(int C, int Kp);
 int nmf_update5_waves_per_buffer(int C, int Kp, int B);          // the planner's strips per buffer
-bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming
+int launch_nmf_update5(const UpdateArgs& a, hipStream_t s);     // v_mfma_f64_4x4x4_4b + LDS-DMA operand streaming
 // any rank (used above Kp = 128): un-fused, over a materialised ratio matrix (kernels_nmf_wide.hip)
 void launch_nmf_update_wide(const UpdateArgs& a, double* scratch, hipStream_t s);
 int64_t nmf_update_wide_scratch_doubles(int R, int C, int Kp, int B);
@@ -192,10 +203,12 @@ bool nmf_side_column_supported(int R, int C, int Kp);
 // [side column ->] new nrm [B][Kp] (1 where alg/NMF.hpp:162 would skip the normalisation)
 int wnorm_scratch_doubles(int Kp, int B, int nStrips);
 void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase = 0, int sideSlices = 0);
-// where the side-column slices / the old side row live inside `scratch` (an H update with UpdateArgs::sideOut fills them)
-double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips);
-double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips);
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase = 0, int sideSlices = 0, int sideGen = -1);
+// Where the side-column partials / the old side row of an H update with UpdateArgs::sideOut live inside `scratch`: two
+// areas (gen 0 / 1) inside the slice region, up to 64 slices per buffer each -- an H update that does the norm combine reads
+// one generation in its prologue while its own epilogues fill the other.
+double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen);
+double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen);
 // S = S / nrm in memory, nrm = 1
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);
 void launch_fill_ones(double* p, int64_t n, hipStream_t s);

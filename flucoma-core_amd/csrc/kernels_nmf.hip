@@ -817,14 +817,18 @@ bool nmf_side_column_supported(int R, int C, int Kp)
 }
 int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
 
-double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips) { return scratch + (int64_t) B * nStrips * 2 * Kp; }
-double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips)
+static_assert(kSideSlices == 256, "two generations of 128 slices: 64 of partials, then the old side row");
+double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen)
 {
-  return wnorm_side_part(scratch, Kp, B, nStrips) + (int64_t) B * kSideSlices * 2 * Kp;
+  return scratch + (int64_t) B * nStrips * 2 * Kp + (int64_t) gen * B * 128 * 2 * Kp;
+}
+double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen)
+{
+  return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * 64 * 2 * Kp;
 }
 
 void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices)
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices, int sideGen)
 {
   // sideSlices > 0 (with sidePhase 2): the side column's partials are there already, sideSlices per buffer, dense -- left by
   // the H update in front (UpdateArgs::sideOut)
@@ -833,6 +837,11 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   double* statPart = scratch;
   double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;
   double* wold = sidePart + (int64_t) B * kSideSlices * 2 * Kp;
+  if (sideGen >= 0) // (sideSlices > 0: an H update's partials, in the generation it filled)
+  {
+    sidePart = wnorm_side_part(scratch, Kp, B, nStrips, sideGen);
+    wold = wnorm_side_wold(scratch, Kp, B, nStrips, sideGen);
+  }
   int nsl = side ? (sideSlices > 0 ? sideSlices : side_slices_for(side->R, Kp)) : 0;
   // corpora: one launch, one workgroup per buffer (side_norm_kernel) -- enough buffers to occupy the part, few enough rows
   // that a workgroup walks them in a few passes, few statistics parts.  FLUHIP_SIDE_NORM=0 (A/B build): the two launches.

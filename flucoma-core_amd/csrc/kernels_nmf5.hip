@@ -60,6 +60,13 @@ struct Upd5Args
   // normalised old side row [B][KP] (UpdateArgs::sideOut / sideWold)
   double* sidePart;
   double* sideWold;
+  // SIDEQ & 2: the norm combine of the W update in front, done by every wavefront in its prologue (UpdateArgs::cmb*)
+  const double* cmbStat;
+  const double* cmbSide;
+  const double* cmbWold;
+  double* cmbNrmOut;
+  double* cmbRowOut;
+  int cmbParts, cmbSlices, cmbK;
 };
 
 // The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
@@ -147,6 +154,12 @@ __device__ __forceinline__ double quad_dpp(double v)
 // rows of H in registers, also forms this wavefront's share of the side column's contraction for the W update that follows --
 // q_t = sum_k H[t][k] w_k with w = W'[R-1] / nrm, V[R-1][t] / max(q_t, eps), num_k, den_k over its frames -- so that no launch
 // has to read H again for it (side_slices_kernel: 10 us per iteration of the bench shard, all of it a second pass over H).
+// SIDEQ & 2 (H update right behind a W update whose norm combine is still due): every wavefront forms the new norms and
+// the new side row of W' itself, in its prologue, from the column statistics the W update's wavefronts left and the side-column
+// partials of the H update before that -- a few KB per wavefront, the same sums in the same order in all of them -- instead
+// of a launch in between (5.7 us + a kernel boundary per iteration of the bench shard).  The wavefronts of a buffer all store
+// the (identical) side row; strip 0 stores the norms.  Nothing in this launch reads either back from memory except each
+// wavefront's own last DMA stage (row R - 1 of W'), 270 us behind its own store.
 template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0, int SIDEQ = 0>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
@@ -324,12 +337,35 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // magnitudes of this strip's frames -- is copied into the LDS behind the rings by the first DMAs of the launch: the oldest
   // requests, landed long before the loop ends (fetched in the epilogue they cost the launch two memory latencies, 4.5 us)
   constexpr int NJSV = SIDEQ ? (NG * 128 + 1023) / 1024 : 0;
+  constexpr bool NORMQ = (SIDEQ & 2) != 0;
   [[maybe_unused]] char* sideL = nullptr;
+  // NORMQ: the requests of the norm combine leave first (lane k < KP holds component k)
+  [[maybe_unused]] double cs[8], cm[8], cn[8], cd[8], cwo = 0.0;
+  if constexpr (NORMQ)
+  {
+#pragma unroll
+    for (int u = 0; u < 8; u++) { cs[u] = 0.0; cm[u] = -INFINITY; cn[u] = 0.0; cd[u] = 0.0; }
+    if (lane < KP)
+    {
+      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KP + lane;
+      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KP + lane;
+      cwo = a.cmbWold[(int64_t) buf * KP + lane];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+      {
+        if (u < a.cmbParts) { cs[u] = sp[(int64_t) u * 2 * KP]; cm[u] = sp[(int64_t) u * 2 * KP + KP]; }
+        if (u < a.cmbSlices) { cn[u] = qp[(int64_t) u * 2 * KP]; cd[u] = qp[(int64_t) u * 2 * KP + KP]; }
+      }
+    }
+  }
   if constexpr (SIDEQ)
   {
     sideL = lds + WPB * WAVE_REGION + wave * (1 + NJSV) * 1024;
-    const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KP) + min(lane, SPR - 1) * 16;
-    FLUHIP_GLDS(wsrc, sideL);
+    if constexpr (!NORMQ)
+    {
+      const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KP) + min(lane, SPR - 1) * 16;
+      FLUHIP_GLDS(wsrc, sideL);
+    }
 #pragma unroll
     for (int j = 0; j < NJSV; j++)
     {
@@ -350,10 +386,48 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
     if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KP + M * y);
   }
+  if constexpr (NORMQ)
+  {
+    // sums in index order (parts / slices beyond eight: a second, dependent round -- corpora of few buffers per chip)
+    double t = 0.0, mv = -INFINITY, n = 0.0, d = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++) { t += cs[u]; mv = fmax(mv, cm[u]); n += cn[u]; d += cd[u]; }
+    if (lane < KP)
+    {
+      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KP + lane;
+      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KP + lane;
+      for (int j = 8; j < a.cmbParts; j++) { t += sp[(int64_t) j * 2 * KP]; mv = fmax(mv, sp[(int64_t) j * 2 * KP + KP]); }
+      for (int j = 8; j < a.cmbSlices; j++) { n += qp[(int64_t) j * 2 * KP]; d += qp[(int64_t) j * 2 * KP + KP]; }
+    }
+    // the side row (not normalised, like every other row of W') and alg/NMF.hpp:162 for the whole column
+    const bool liveK = lane < a.cmbK;
+    const double wnew = liveK ? (cwo * n) / fmax(d, kEpsilon) : 0.0;
+    t = __builtin_fma(wnew, wnew, t);
+    mv = liveK ? fmax(mv, wnew) : -INFINITY;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) mv = fmax(mv, __shfl_xor(mv, off));
+    const double nv = (liveK && mv > kEpsilon) ? sqrt(t) : 1.0;
+    double* ldsW = reinterpret_cast<double*>(sideL);
+    if (lane < KP)
+    {
+      ldsW[lane] = wnew;
+      ldsW[64 + lane] = nv;
+      a.cmbRowOut[(int64_t) buf * a.strideM + (int64_t) (a.R - 1) * KP + lane] = wnew;
+      if (strip == 0) a.cmbNrmOut[(int64_t) buf * KP + lane] = nv;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   if (a.nrmMode)
   {
     // deferred normalisation: W update -> the stationary rows are W' / nrm = W; H update -> Q = W' (H / nrm)^T
     double nr[M];
+    if constexpr (NORMQ)
+    {
+      const double* ldsN = reinterpret_cast<const double*>(sideL) + 64;
+#pragma unroll
+      for (int m = 0; m < M; m++) nr[m] = ldsN[M * y + m];
+    }
+    else
     load_vec5<M>(nr, a.nrm + (int64_t) buf * KP + M * y);
 #pragma unroll
     for (int g = 0; g < NG; g++)
@@ -934,9 +1008,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   if (whole())
   {
     double nrE[M], ss[M], mx[M];
-    if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
     [[maybe_unused]] double nrL = 1.0;   // SIDEQ: the norm of component `lane` (the old side row leaves normalised)
-    if constexpr (SIDEQ) if (strip == 0 && lane < KP) nrL = a.nrm[(int64_t) buf * KP + lane];
+    if constexpr (NORMQ)
+    {
+      const double* ldsN = reinterpret_cast<const double*>(sideL) + 64;
+#pragma unroll
+      for (int m = 0; m < M; m++) nrE[m] = ldsN[M * x + m];
+      if (lane < KP) nrL = ldsN[lane];
+    }
+    else
+    {
+      if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
+      if constexpr (SIDEQ) if (strip == 0 && lane < KP) nrL = a.nrm[(int64_t) buf * KP + lane];
+    }
     if (a.nrmMode == 2)
     {
 #pragma unroll
@@ -1173,7 +1257,10 @@ template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
+  if (a.dryRun) return;
   k.sidePart = SIDEQ ? a.sideOut : nullptr; k.sideWold = SIDEQ ? a.sideWold : nullptr;
+  k.cmbStat = a.cmbStat; k.cmbSide = a.cmbSide; k.cmbWold = a.cmbWold; k.cmbNrmOut = a.cmbNrmOut; k.cmbRowOut = a.cmbRowOut;
+  k.cmbParts = a.cmbParts; k.cmbSlices = a.cmbSlices; k.cmbK = a.cmbK;
   k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
   k.Mv = a.Mv; k.strideM = a.strideM;
   k.S = a.S; k.strideS = a.strideS;
@@ -1253,16 +1340,18 @@ constexpr int ring_depth()
   return fit >= 6 ? 6 : (fit < 3 ? 3 : fit);
 }
 
-// true: the launch also left the side-column partials UpdateArgs::sideOut asks for (the SIDEQ instantiations: ranks up to
-// 64, the production pipeline form of the rank, strips of two groups or more, deferred normalisation, un-split)
+// bit 0: the launch also left the side-column partials UpdateArgs::sideOut asks for; bit 1: it did the norm combine
+// UpdateArgs::cmb* describes (the SIDEQ instantiations: ranks up to 64, the production pipeline form of the rank, strips of
+// two groups or more, deferred normalisation, un-split)
 template <int M, int NG, int WPS>
-static bool launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
+static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 {
   if constexpr (NG == 1) launch5_t<M, 1, ring_depth<M, 1, WPS>(), WPS>(a, w, s);
   else
   {
     const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1;
-    (void) sideq;
+    const bool normq = sideq && a.cmbStat && a.cmbSide && a.cmbWold && a.cmbNrmOut && a.cmbRowOut && (a.R + 3) / 4 > 12;
+    (void) normq;
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, WPS>();
@@ -1271,8 +1360,8 @@ static bool launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         // FLUHIP_K5_INSTR=1: per-phase s_memtime breakdown of one wavefront (tools/phase_breakdown.py)
         static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_INSTR"); return e ? std::atoi(e) : 0; }();
         static const int imode = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : 1; }();
-        if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return false; }
-        if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return false; }
+        if (instr && imode == 1) { launch5_t<M, NG, NS, WPS, 1, 1>(a, w, s); return 0; }
+        if (instr) { launch5_t<M, NG, NS, WPS, 1>(a, w, s); return 0; }
       }
       if constexpr (WPS == 1 && NS >= 4 && NS % 2 == 0)
       {
@@ -1297,30 +1386,36 @@ static bool launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
             if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
             else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
             launch5_t<M, NG, NS, WPS, 0, 2, 0>(a, w, s);
-            return false;
+            return 0;
           }
         }
         else if (eff == 2)
         {
           if constexpr (M == 16)
-            if (sideq) { launch5_t<M, NG, NS, WPS, 0, 2, 1, 1>(a, w, s); return true; }
+          {
+            if (normq) { launch5_t<M, NG, NS, WPS, 0, 2, 1, 3>(a, w, s); return 3; }
+            if (sideq) { launch5_t<M, NG, NS, WPS, 0, 2, 1, 1>(a, w, s); return 1; }
+          }
           launch5_t<M, NG, NS, WPS, 0, 2>(a, w, s);
-          return false;
+          return 0;
         }
         if constexpr (M <= 16)
           if (eff == 1)
           {
             if constexpr (M <= 8)
-              if (sideq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 1>(a, w, s); return true; }
+            {
+              if (normq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 3>(a, w, s); return 3; }
+              if (sideq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 1>(a, w, s); return 1; }
+            }
             launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s);
-            return false;
+            return 0;
           }
       }
       launch5_t<M, NG, NS, WPS>(a, w, s);
     }
     else return launch5_ng<M, NG - 1, WPS>(a, w, ng, s);
   }
-  return false;
+  return 0;
 }
 
 // the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
@@ -1360,8 +1455,9 @@ int nmf_update5_strips(int C, int Kp, int B)
 
 // strips per buffer for WPS wavefronts per SIMD: WPS x the one-wave plan, as long as every strip
 // keeps at least one group
-bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
+int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
+  if (a.dryRun && (a.list || a.Kp > 64)) return 0; // (nothing but the plain un-split forms up to rank 64 take anything over)
   if (a.list)
   {
     // work-list mode: one wavefront per SIMD, the widest strip of the list picks the instantiation; the column sums
@@ -1374,7 +1470,7 @@ bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     case 32: launch5_list_ng<32, 2>(a, a.listNG, s); break;
     default: break;
     }
-    return false;
+    return 0;
   }
   const int G = (a.C + 15) / 16;
   const int w = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips(a.C, a.Kp, a.B);
@@ -1400,7 +1496,7 @@ bool launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     default: break;
     }
   }
-  return false;
+  return 0;
 }
 
 } // namespace fluhip

@@ -74,7 +74,7 @@ for k in range(9):
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "1"}, {"FLUHIP_TAIL_SPLIT": "0"}, {"FLUHIP_GRAPH_ITERS": "4"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_STRIP": "0"}, {"FLUHIP_STRIP_BIN": "1"}, {"FLUHIP_STRIP_SIDE": "0"},
                                  {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
-                                 {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}],
+                                 {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}, {"FLUHIP_NORM_IN_H": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env, ab_lib_paths):
     e = dict(os.environ)
