@@ -836,17 +836,21 @@ struct FeatFusedArgs
 // 2.0 ms of a 3.86 ms launch (config 5, per-wavefront stamps) and the youngest ran the last third of the launch alone, at a
 // quarter of the VALU's rate -- the counters show the VALU 87 % busy while four wavefronts are alive and 64 % over the launch.
 // Handing out frames as wavefronts come free makes them finish together.
-template <int R1, int R2, int R3, int NW, bool DYN = true>
-__global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFusedArgs fa)
+// SMALL (round 4): the layout for TWO workgroups per CU (20 wavefronts, five per SIMD, where one workgroup of 1024 threads stops
+// at four): the window pairs come through the L1 instead of the LDS and the per-wavefront scratch of the band stage lies in
+// the wavefront's staging buffer, which is idle by then -- 67 KB per workgroup of ten wavefronts at fft 1024.
+template <int R1, int R2, int R3, int NW, bool DYN = true, bool SMALL = false>
+__global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftBArgs a, FeatFusedArgs fa)
 {
   using Core = FftCore<R1, R2, R3>;
   constexpr int N = Core::N, PPL = Core::PPL, BUFD = Core::BUFD;
   constexpr int CH = (N + 1 + 63) / 64;           // consecutive bins per lane in the band sums
-  constexpr int WS = 66 + 66 + 64;                // per-wavefront scratch: boundary sums (rising, falling), band values
+  constexpr int WS = SMALL ? 0 : 66 + 66 + 64;    // per-wavefront scratch: boundary sums (rising, falling), band values
+  static_assert(!SMALL || BUFD >= 66 + 66 + 64, "the band stage's scratch inside the staging buffer");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   d2* tw2 = reinterpret_cast<d2*>(lds);
   d2* wl = tw2 + Core::T2 + Core::T3;             // [N] window pairs
-  double* xall = reinterpret_cast<double*>(wl + N);
+  double* xall = reinterpret_cast<double*>(wl + (SMALL ? 0 : N));
   double* scr = xall + NW * BUFD;                 // [NW][WS]
   double* upl = scr + NW * WS;                    // [64 CH]
   double* dnl = upl + 64 * CH;                    // [64 CH]
@@ -858,13 +862,14 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* xb = xall + wave * BUFD;
-  double* bu = scr + wave * WS;
+  double* bu = SMALL ? xb : scr + wave * WS;
   double* bd = bu + 66;
   double* bands = bd + 66;
 
   const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
   Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
-  for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
+  if constexpr (!SMALL)
+    for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
   // (per-lane tables lie [i][lane] in the LDS: a lane's CH consecutive bins are CH rows apart, a row is read without bank conflicts)
   for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
   if (fa.dct)
@@ -873,7 +878,8 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
       const int row = i / dld, col = i % dld;
       dctl[i] = col < fa.nBands ? fa.dct[row * fa.nBands + col] : 0.0;
     }
-  for (int i = lane; i < WS; i += 64) bu[i] = 0.0;    // boundaries nobody publishes (before the first bin) stay 0
+  if constexpr (!SMALL)
+    for (int i = lane; i < WS; i += 64) bu[i] = 0.0;  // boundaries nobody publishes (before the first bin) stay 0
   __shared__ unsigned nextFrame;                      // DYN: frames of this workgroup handed out so far
   if (threadIdx.x == 0) nextFrame = 0;
   __syncthreads();
@@ -950,9 +956,9 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     {
       cx pts[PPL];
 #ifdef FLUHIP_AB_SWITCHES
-      gather_points<R1, N>(a, b, t, lane, (a.prefetch & 1) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
+      gather_points<R1, N>(a, b, t, lane, (SMALL || (a.prefetch & 1)) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #else
-      gather_points<R1, N>(a, b, t, lane, wl, pts, a.n);
+      gather_points<R1, N>(a, b, t, lane, SMALL ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #endif
       SCHED_FENCE();
       core.template run<false>(pts, nullptr);
@@ -980,6 +986,13 @@ __global__ __launch_bounds__(64 * NW) void stft_feat_kernel(StftBArgs a, FeatFus
     // broadcast upwards), then shifted by one lane: what the lanes below contribute
     const double xu = wave_scan(su), xd = wave_scan(sd);
     const double eu = wave_shr1(xu), ed = wave_shr1(xd);
+    if constexpr (SMALL)
+    {
+      // the boundary sums live in the staging buffer (the magnitudes have been read: LDS operations of a wavefront complete
+      // in order): boundaries nobody publishes read 0
+      bu[lane] = 0.0; bd[lane] = 0.0;
+      if (lane < 2) { bu[64 + lane] = 0.0; bd[64 + lane] = 0.0; }
+    }
 #pragma unroll
     for (int i = 0; i < CH; i++)
     {
@@ -1248,28 +1261,28 @@ static bool launch_feat2_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStre
 
 #endif // FLUHIP_AB_SWITCHES
 
-template <int R1, int R2, int R3, int NW>
+template <int R1, int R2, int R3, int NW, bool SMALL = false>
 static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStream_t s)
 {
   using Core = FftCore<R1, R2, R3>;
-  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = 66 + 66 + 64;
-  const size_t shmem = ((size_t) Core::T2 + Core::T3 + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
+  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = SMALL ? 0 : 66 + 66 + 64;
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + (SMALL ? 0 : N)) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
                        (fa.dct ? (size_t) fa.nDct * (4 * ((fa.nBands + 3) / 4) + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
-  if (shmem > 160 * 1024) return false;
+  if (shmem > (SMALL ? 80 : 160) * 1024) return false;
   StftBArgs k = k0;
   k.blocksPerBuf = (k.T + NW - 1) / NW;
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
   if (k.totalBlocks >= ((int64_t) 1 << 31)) return false; // (the kernel's block arithmetic is 32-bit; the two-kernel path takes it)
-  auto kern = stft_feat_kernel<R1, R2, R3, NW>;
+  auto kern = stft_feat_kernel<R1, R2, R3, NW, true, SMALL>;
 #ifdef FLUHIP_AB_SWITCHES // FLUHIP_FEAT_DYN=0: a fixed share of the frames per wavefront (rounds 2 - 3)
   static const int dynOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_DYN"); return e && std::atoi(e) == 0 ? 1 : 0; }();
-  if (dynOff) kern = stft_feat_kernel<R1, R2, R3, NW, false>;
+  if (dynOff && !SMALL) kern = stft_feat_kernel<R1, R2, R3, NW, false>;
 #endif
   request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
-  if (grid > 256) grid = 256;
+  if (grid > (SMALL ? 512 : 256)) grid = SMALL ? 512 : 256;
   if constexpr (kAbSwitches)
   {
     static const int clk = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_CLOCK"); return e ? std::atoi(e) : 0; }();
@@ -1341,6 +1354,8 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
       static const int nw = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_NW"); return e ? std::atoi(e) : 16; }();
       if (nw == 8) return launch_feat_t<8, 8, 8, 8>(k, fa, s);
       if (nw == 12) return launch_feat_t<8, 8, 8, 12>(k, fa, s);
+      if (nw == 10) return launch_feat_t<8, 8, 8, 10, true>(k, fa, s);   // two workgroups per CU
+      if (nw == 9) return launch_feat_t<8, 8, 8, 9, true>(k, fa, s);
     }
 #endif
     return launch_feat_t<8, 8, 8, 16>(k, fa, s);
