@@ -1683,6 +1683,27 @@ int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t 
   return list_plan_pays(&ps) ? 1 : 0;
 }
 
+int fluhip_debug_plan_h_update(int64_t count, int64_t frames, int64_t bins, int64_t K)
+{
+  if (count < 1 || frames < 1 || bins < 1 || K < 1) return -1;
+  const int Kp = (int) padded_rank(K);
+  if (update_variant(Kp) != 5) return 0;
+  const PlanShape ps{count, frames, bins, Kp};
+  int wA = 0;
+  if (list_plan_pays(&ps) || plan_tail(count, (int) frames, (int) bins, Kp, &wA) > 1) return 0; // (work lists, two-launch H update: the plain forms only)
+  if (!nmf_side_column_supported((int) frames, (int) bins, Kp)) return 0;                       // no side column, nothing to take over
+  // the launcher's own answer for these arguments (nothing is launched, no device is touched: UpdateArgs::dryRun)
+  double dummy = 0.0;
+  UpdateArgs a;
+  a.R = (int) bins; a.C = (int) frames; a.B = (int) count; a.Kp = Kp;
+  a.nsplit = 1;
+  a.nrm = &dummy; a.nrmMode = 2;
+  a.sideOut = &dummy; a.sideWold = &dummy;
+  a.cmbStat = &dummy; a.cmbSide = &dummy; a.cmbWold = &dummy; a.cmbNrmOut = &dummy; a.cmbRowOut = &dummy;
+  a.dryRun = true;
+  return launch_nmf_update5(a, nullptr);
+}
+
 int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out4)
 {
   if (count < 1 || frames < 1 || bins < 1 || K < 1 || !out4) return FLUHIP_ERROR;

@@ -351,6 +351,11 @@ int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t 
  * that fits the frame-strip schedule never asks): 1 = the work lists, 0 = the uniform schedule; -1: bad arguments.  The rules are
  * measured ones (api_corpus.hip list_plan_pays, profiles/r03/plan_regimes.txt); the CPU tests pin them for the BASELINE shapes. */
 int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t K);
+/* What the H update of an equal-length corpus of that shape takes over from the launches that used to run between the two
+ * factor updates (kernels_nmf5.hip SIDEQ forms; no device needed): bit 0 = the next W update's side column (its last bin)
+ * comes out of this launch's epilogue, bit 1 = the norm combine of the W update in front is done in its prologue; 0 = neither
+ * (rank above 64, work lists, two-launch H update, no side column at this bin count); -1: bad arguments. */
+int fluhip_debug_plan_h_update(int64_t count, int64_t frames, int64_t bins, int64_t K);
 
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
 /* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of

@@ -173,3 +173,20 @@ def test_schedule_family_of_the_baseline_shapes(fluhip_lib_path):
     assert kind(100, 862, 1025, 64) == 1 and kind(1, 25840, 1025, 64) == 1
     assert kind(2, 40000, 513, 200) == 0        # above rank 128: the un-fused path, no lists
     assert kind(0, 1, 1, 1) == -1
+
+
+def test_what_the_h_update_takes_over(fluhip_lib_path):
+    """kernels_nmf5.hip SIDEQ forms, asked through the launcher's dry run (pure host code): in steady state an iteration of the
+    bench shard is two launches -- the H update forms the next W update's side column and does the norm combine in front"""
+    import fluhip
+    lib = fluhip.load_library(fluhip_lib_path)
+    form = lambda B, T, F, K: lib.fluhip_debug_plan_h_update(B, T, F, K)  # noqa: E731
+    assert form(128, 862, 1025, 32) == 3        # the bench shard (and every 128-buffer window of the config-4 corpus run round-major)
+    assert form(128, 862, 1025, 16) == 3 and form(128, 862, 1025, 12) == 3
+    assert form(128, 862, 1025, 64) == 0        # rank 64 at that size runs from the work lists
+    assert form(128, 862, 1025, 128) == 0       # rank 128: more components than lanes, the launches stay
+    assert form(1024, 862, 1025, 32) == 0       # work lists
+    assert form(2, 25840, 2049, 128) == 0       # config 3
+    assert form(128, 862, 1024, 32) == 0        # 1 024 bins: whole column groups, no side column
+    assert form(128, 137, 1025, 32) == 3        # 70 000 samples at hop 512 (the variants test's corpus)
+    assert form(0, 1, 1, 1) == -1
