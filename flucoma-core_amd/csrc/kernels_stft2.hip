@@ -165,6 +165,16 @@ __device__ __forceinline__ cx split_const(int r)
 // exchange, pass 2, exchange, pass 3, real-FFT split, |X|.  `pts` holds the windowed points m = lane + 64 bb + r N/R1
 // (x[2m], x[2m+1]); on return the wavefront's buffer xb holds |X[k]| at xb[k], k = 0 .. N (plain index), and the
 // complex bins have been written to specRow when that is not null.
+// One ds_read_b64 that stays one: the compiler pairs neighbouring loads off one base into ds_read2(st64)_b64, which the LDS
+// serves as two passes of 16-lane groups at 128 B per clock where two ds_read_b64 run at 256 (MI355X_MICROARCH.md, LDS
+// table) -- and whose lane groups are not the ones the swizzled layouts below are laid out for.
+__device__ __forceinline__ double lds_read1(const double* p)
+{
+  // (volatile keeps the load single; the explicit LDS address space keeps it a ds_read: address-space inference leaves
+  //  volatile accesses through generic pointers as flat loads)
+  return *(const volatile __attribute__((address_space(3))) double*) p;
+}
+
 template <int R1, int R2, int R3>
 struct FftCore
 {
@@ -175,6 +185,16 @@ struct FftCore
   static constexpr bool LOCAL = NB3 == 2;        // both bins of a split pair in one lane
   static constexpr int BUFD = N + N / 16 + 2;    // doubles per wavefront (the + 2 staggers the buffers over the banks)
   static constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
+  // SWZ (round 4, the 8 x 8 x 8 transform of fft 1024): the exchange buffer is addressed through bit swizzles instead of the
+  // one-in-sixteen padding.  The padding serves the first exchange's stores (ds_write_b64: groups of 16 lanes over 32 dword
+  // banks) and costs every read behind both exchanges a third cycle (ds_read_b64: groups of 32 lanes over 64 banks -- 32
+  // consecutive points span 33 slots) and the second exchange's stores a 2-way conflict: 19 % of the feature kernel's LDS
+  // cycles (profiles/r04/c5_experiments.md).  Point i of the first exchange sits at slot s with
+  //   s0 = i0 ^ i5, s1 = i1 ^ i6, s2 = i3, s3 = i4, s4 = i2, s5.. = i5..      (stores vary i3..i6, loads vary i0..i4)
+  // and point i of the second at i ^ (i6 << 3) (stores vary i0..i2 and i6, loads i0..i4): every lane group of either
+  // instruction meets every bank once.  Per lane that is four store bases + two load bases for the first exchange and two +
+  // two for the second, all loop invariant; the offsets stay compile-time immediates.
+  static constexpr bool SWZ = R1 == 8 && R2 == 8 && R3 == 8;
   static_assert(R1 == 16 || R1 == 8, "pass-1 radix");
   static_assert(NS2 % 8 == 0 && NS3 % 16 == 0 && (N / R2) % 16 == 0, "index arithmetic of the exchanges");
   int lane, jA, jB;
@@ -186,6 +206,11 @@ struct FftCore
   double* w2p;
   const double *r3pA, *r3pB;
   const d2 *tw2p, *tw3pA, *tw3pB;
+  // SWZ: store bases of the first exchange by r & 3, load bases by r & 1; second exchange: both by r & 1
+  double* w1q[4];
+  const double* r2q[2];
+  double* w2q[2];
+  const double* r3q[2];
 
   // the pass tables [R2-1][NS2] and [R3-1][NS3] from the natural table e^{-2 pi i m / fft} (m < fft/2)
   static __device__ __forceinline__ void fill_tables(d2* tw2, const d2* twg, int tid, int nthreads)
@@ -225,6 +250,25 @@ struct FftCore
     tw2p = tw2 + k2;
     tw3pA = tw3 + jA;
     tw3pB = tw3 + jB;
+    if constexpr (SWZ)
+    {
+      const int l = lane;
+      const int l0 = l & 1, l1 = (l >> 1) & 1, l2 = (l >> 2) & 1, l3 = (l >> 3) & 1, l4 = (l >> 4) & 1, l5 = (l >> 5) & 1;
+      // first exchange, stores: i = 8 l + r -> (q ^ c) + 16 (r >> 2) + L, q = r & 3, c = (l >> 2) & 3
+      const int c = (l >> 2) & 3, L = 4 * l0 + 8 * l1 + 32 * l2 + 64 * l3 + 128 * l4 + 256 * l5;
+      for (int q = 0; q < 4; q++) w1q[q] = xb + L + (q ^ c);
+      // first exchange, loads: i = l + 64 r -> (l0 ^ l5) + 2 (l1 ^ r0) + 4 l3 + 8 l4 + 16 l2 + 32 l5 + 64 r
+      const int A = (l0 ^ l5) + 4 * l3 + 8 * l4 + 16 * l2 + 32 * l5;
+      r2q[0] = xb + A + 2 * l1;
+      r2q[1] = xb + A + 2 * (l1 ^ 1);
+      // second exchange, stores: i = 64 a + k + 8 r (a = l >> 3, k = l & 7) -> i ^ (l3 << 3): r0 flips where l3 is set
+      const int E = 64 * (l >> 3) + (l & 7);
+      w2q[0] = xb + E + 8 * l3;
+      w2q[1] = xb + E + 8 * (l3 ^ 1) - 8;                 // (+ 8 r with r odd)
+      // second exchange, loads: i = l + 64 r -> i ^ ((r & 1) << 3)
+      r3q[0] = xb + l;
+      r3q[1] = xb + (l ^ 8);
+    }
   }
 
   // the same lane positions in another staging buffer `delta` doubles further on (a wavefront that transforms several
@@ -232,14 +276,22 @@ struct FftCore
   __device__ __forceinline__ void shift(int delta)
   {
     xb += delta; w1p += delta; r2p += delta; w2p += delta; r3pA += delta; r3pB += delta;
+    if constexpr (SWZ)
+    {
+      for (int q = 0; q < 4; q++) w1q[q] += delta;
+      for (int q = 0; q < 2; q++) { r2q[q] += delta; w2q[q] += delta; r3q[q] += delta; }
+    }
   }
 
-  template <bool SPEC>
+  // TAB: the split's twiddles e^{-2 pi i k / fft} / 2 come from a table in the LDS (splitTab[k], k < N) instead of being
+  // formed per frame as products of the lane's factor with compile-time constants (28 FP64 instructions at R3 = 8)
+  const d2* splitTab = nullptr;
+  template <bool SPEC, bool TAB = false>
   __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
   {
     cx p3[PPL];
     passes(pts, p3);
-    split<SPEC>(p3, specRow);
+    split<SPEC, TAB>(p3, specRow);
   }
 
   // the three passes of the complex transform: points m = lane + 64 bb + r N/R1 in, bins j + r NS3 out (j = lane, and for
@@ -261,6 +313,19 @@ struct FftCore
   SCHED_FENCE();
   cx p2[PPL];
   // exchange 1 -> distribution of pass 2 (butterfly j = lane + 64 bb reads j + r N/R2): real plane, then imaginary
+  if constexpr (SWZ)
+  {
+#pragma unroll
+    for (int r = 0; r < R1; r++) w1q[r & 3][16 * (r >> 2)] = pts[r].re;
+#pragma unroll
+    for (int r = 0; r < R2; r++) p2[r].re = lds_read1(r2q[r & 1] + 64 * r);
+#pragma unroll
+    for (int r = 0; r < R1; r++) w1q[r & 3][16 * (r >> 2)] = pts[r].im;
+#pragma unroll
+    for (int r = 0; r < R2; r++) p2[r].im = lds_read1(r2q[r & 1] + 64 * r);
+  }
+  else
+  {
 #pragma unroll
   for (int bb = 0; bb < NB1; bb++)
 #pragma unroll
@@ -277,6 +342,7 @@ struct FftCore
   for (int bb = 0; bb < NB2; bb++)
 #pragma unroll
     for (int r = 0; r < R2; r++) p2[bb * R2 + r].im = r2p[68 * bb + (N / R2 + N / R2 / 16) * r];
+  }
   SCHED_FENCE();
   // ---- pass 2 (Ns = R1): twiddle e^{-2 pi i k r / (R1 R2)}, k = j mod R1 = lane mod R1 -----------------
 #pragma unroll
@@ -295,6 +361,19 @@ struct FftCore
   auto in3 = [&](int bb, int r) -> const double* {
     return (LOCAL && bb == 1 ? r3pB : r3pA) + (NS3 + NS3 / 16) * r;
   };
+  if constexpr (SWZ)
+  {
+#pragma unroll
+    for (int r = 0; r < R2; r++) w2q[r & 1][8 * r] = p2[r].re;
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[r].re = lds_read1(r3q[r & 1] + 64 * r);
+#pragma unroll
+    for (int r = 0; r < R2; r++) w2q[r & 1][8 * r] = p2[r].im;
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[r].im = lds_read1(r3q[r & 1] + 64 * r);
+  }
+  else
+  {
 #pragma unroll
   for (int bb = 0; bb < NB2; bb++)
 #pragma unroll
@@ -313,6 +392,7 @@ struct FftCore
   for (int bb = 0; bb < NB3; bb++)
 #pragma unroll
     for (int r = 0; r < R3; r++) p3[bb * R3 + r].im = *in3(bb, r);
+  }
   SCHED_FENCE();
   // ---- pass 3 (Ns = R1 R2 = N / R3, so k = j): the outputs are the bins j + r NS3 and stay in registers -----
 #pragma unroll
@@ -329,7 +409,7 @@ struct FftCore
   SCHED_FENCE();
   }
 
-  template <bool SPEC>
+  template <bool SPEC, bool TAB = false>
   __device__ __forceinline__ void split(cx (&p3)[PPL], d2* specRow)
   {
   // ---- real-FFT split (util/FFT.hpp:99-106) + magnitude (alg/STFT.hpp:61-66) ------------------------------
@@ -380,7 +460,9 @@ struct FftCore
       const cx A = p3[i], Bc = partner(bb, r);
       const double er = A.re + Bc.re, ei = A.im - Bc.im;
       const double dr = A.re - Bc.re, di = A.im + Bc.im;
-      const cx w = r == 0 ? wj : cmul2(wj, split_const<R3>(r));
+      cx w;
+      if constexpr (TAB) w = tocx(splitTab[j + r * NS3]);
+      else w = r == 0 ? wj : cmul2(wj, split_const<R3>(r));
       const double xr = __builtin_fma(0.5, er, __builtin_fma(w.re, di, w.im * dr));
       double xi = __builtin_fma(0.5, ei, __builtin_fma(w.im, di, -(w.re * dr)));
       const int k = j + r * NS3;
@@ -850,7 +932,8 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
   extern __shared__ __attribute__((aligned(16))) double lds[];
   d2* tw2 = reinterpret_cast<d2*>(lds);
   d2* wl = tw2 + Core::T2 + Core::T3;             // [N] window pairs
-  double* xall = reinterpret_cast<double*>(wl + (SMALL ? 0 : N));
+  d2* tws = wl + (SMALL ? 0 : N);                 // [N] the split's twiddles, halved
+  double* xall = reinterpret_cast<double*>(tws + N);
   double* scr = xall + NW * BUFD;                 // [NW][WS]
   double* upl = scr + NW * WS;                    // [64 CH]
   double* dnl = upl + 64 * CH;                    // [64 CH]
@@ -870,6 +953,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
   Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
   if constexpr (!SMALL)
     for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
+  for (int m = threadIdx.x; m < N; m += 64 * NW) { const d2 w = twg[m]; tws[m] = d2{0.5 * w[0], 0.5 * w[1]}; }
   // (per-lane tables lie [i][lane] in the LDS: a lane's CH consecutive bins are CH rows apart, a row is read without bank conflicts)
   for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
   if (fa.dct)
@@ -893,6 +977,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
 #endif
   Core core;
   core.init(xb, tw2, twg, lane);
+  core.splitTab = tws;
   // FLUHIP_FEAT_PRIO (A/B): the wavefronts of a SIMD (wave, wave + 4, ...) at different issue priorities.  They run the same
   // instruction stream from the same start; under fair round-robin issue they stay in phase -- all in their LDS exchanges,
   // then all in their butterflies -- and the two pipes take turns instead of overlapping (PMC: VALU busy 46 % + LDS active
@@ -961,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       gather_points<R1, N>(a, b, t, lane, SMALL ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #endif
       SCHED_FENCE();
-      core.template run<false>(pts, nullptr);
+      core.template run<false, true>(pts, nullptr);
     }
     SCHED_FENCE();
     // ---- band sums ------------------------------------------------------------------------------------------
@@ -977,8 +1062,8 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       double m = xb[min(f, N)];
       if (fa.magNorm) { m = f <= N ? m * scale1 : 0.0; en += m; }     // :86-90
       if (fa.usePower) m = m * m;
-      su = __builtin_fma(upl[i * 64 + ln], m, su);
-      sd = __builtin_fma(dnl[i * 64 + ln], m, sd);
+      su = __builtin_fma(lds_read1(upl + i * 64 + ln), m, su);    // (single ds_read_b64s: paired they run at half the rate)
+      sd = __builtin_fma(lds_read1(dnl + i * 64 + ln), m, sd);
       pu[i] = su;
       pd[i] = sd;
     }
@@ -1033,7 +1118,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       for (int i = 0; i < 16; i++)                            // (nBands <= 64: dq <= 16)
       {
         if (i >= dq) break;
-        sacc = __builtin_fma(drow[i], bq[i], sacc);
+        sacc = __builtin_fma(lds_read1(drow + i), lds_read1(bq + i), sacc);
       }
       sacc += __shfl_xor(sacc, 1);
       sacc += __shfl_xor(sacc, 2);
@@ -1266,7 +1351,7 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
 {
   using Core = FftCore<R1, R2, R3>;
   constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = SMALL ? 0 : 66 + 66 + 64;
-  const size_t shmem = ((size_t) Core::T2 + Core::T3 + (SMALL ? 0 : N)) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + (SMALL ? 0 : N) + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
                        (fa.dct ? (size_t) fa.nDct * (4 * ((fa.nBands + 3) / 4) + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
   if (shmem > (SMALL ? 80 : 160) * 1024) return false;
   StftBArgs k = k0;
