@@ -417,7 +417,9 @@ struct FftCore
   // the products of the per-lane factors with the compile-time constants are loop invariant, and hoisted they
   // would sit in 56 registers for the whole frame loop: keep the factors opaque so they are formed where used
   asm volatile("" : "+v"(wA.re), "+v"(wA.im), "+v"(wB.re), "+v"(wB.im));
-  const bool l0 = lane == 0;
+  int lq = lane;
+  asm volatile("" : "+v"(lq));                    // (opaque: `lane == 0` is compared where it is used, not kept as a spilled exec mask)
+  const bool l0 = lq == 0;
   const int srcAddr = ((64 - lane) & 63) * 4;
   (void) srcAddr;
   auto partner = [&](int bb, int r) -> cx {
@@ -1085,7 +1087,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       if (sl >= 0) { bu[sl] = eu + pu[i]; bd[sl] = ed + pd[i]; }
     }
     double v = 0.0;
-    if (lane < fa.nBands) v = (bu[lane + 1] - bu[lane]) + (bd[lane + 2] - bd[lane + 1]);
+    if (ln < fa.nBands) v = (bu[ln + 1] - bu[ln]) + (bd[ln + 2] - bd[ln + 1]);   // (predicates from the opaque lane: recomputed per frame, not kept as spilled exec masks)
     if (fa.magNorm)
     {
       // :93  bands * energy / max(eps, sum of the bands), energy = sum_f (m scale1) * scale2 (:86-87)
@@ -1099,17 +1101,17 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
     if (fa.logOutput) v = (double) (6.020599913279624f * __log2f((float) fmax(v, kEpsilon)));
     if (!fa.dct)
     {
-      if (lane < fa.nBands) fa.out[((int64_t) b * fa.nOut + lane) * a.T + t] = (float) v;
+      if (ln < fa.nBands) fa.out[((int64_t) b * fa.nOut + ln) * a.T + t] = (float) v;
       continue;
     }
-    bands[lane] = lane < fa.nBands ? v : 0.0;                // (the DCT rows are zero there too: the quarters need no bounds)
+    bands[ln] = ln < fa.nBands ? v : 0.0;                // (the DCT rows are zero there too: the quarters need no bounds)
     // ---- DCT-II rows startCoeff .. startCoeff + nOut - 1 (alg/DCT.hpp:73-75) -----------------------------------------
     if (4 * fa.nOut <= 64)
     {
       // four lanes per coefficient, a quarter of the bands each (ascending), then two exchange-adds.  Every lane walks dq
       // products -- a wave-uniform trip count, positions past nBands multiply zeros, lanes without a coefficient walk row 0
       // and store nothing -- instead of a loop whose bounds depend on the lane (exec-mask bookkeeping per product).
-      const int j = lane >> 2, part = lane & 3;
+      const int j = ln >> 2, part = ln & 3;
       const bool live = j < fa.nOut && fa.startCoeff + j < fa.nDct;
       const double* drow = dctl + (live ? fa.startCoeff + j : 0) * dld + part * dq;
       const double* bq = bands + part * dq;
