@@ -402,6 +402,14 @@ def main():
                          "datasheet_mhz": PEAK_MHZ,
                          "frac_at_sustained_clock": (ach_tflops / (PEAK_FP64_MFMA_TFLOPS * sustained_mhz / PEAK_MHZ)
                                                      if sustained_mhz else None),
+                         # The event pair of a launch that sits right behind another launch also holds the boundary between the
+                         # two (drain of the slowest wavefronts, end-of-kernel release, dispatch): with two launches per iteration
+                         # and nothing else in the stream, avg_launch_ms is the iteration's whole period / 2.  The stamped
+                         # wavefront's own life (shader_cycles_per_launch at sustained_mhz) is the launch without that boundary:
+                         "stamped_wavefront_ms": (cycles_per_launch / (sustained_mhz * 1e3)
+                                                  if cycles_per_launch and sustained_mhz else None),
+                         "frac_of_stamped_wavefront": (flop_per_launch / (cycles_per_launch / (sustained_mhz * 1e6)) / 1e12
+                                                       / PEAK_FP64_MFMA_TFLOPS if cycles_per_launch and sustained_mhz else None),
                          "clock_stamps": clocks,
                          "flop_per_launch": flop_per_launch, "bytes_per_launch": bytes_per_launch,
                          "hbm_view": {"achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -414,7 +422,10 @@ def main():
                               "achieved": stft_bytes / (stft_ms * 1e-3) / 1e9 if stft_ms > 0 else None,
                               "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": (stft_bytes / (stft_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if stft_ms > 0 else None},
-            "schedule": dict(corpus.plan(), between_updates_ms_per_iteration=(ms_mid / max(n_mid, 1))),
+            # (launches between the two factor updates, summed over the profiled step and divided by its ITERATIONS: in the
+            #  two-launch steady state only the first iteration of a call has any)
+            "schedule": dict(corpus.plan(), between_updates_ms_per_iteration=(ms_mid / max(args.iters * (args.steps if args.prof_in_timed_region else 1), 1)),
+                             between_updates_launch_groups_per_step=n_mid),
             "device": {"name": name, "arch": arch, "compute_units": cus,
                        "corpus_device_bytes": corpus.device_bytes()},
             "result_finite": finite, "result_checksum": checksum, "total_buffers": world * B,

@@ -998,7 +998,6 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         (void) hipEventRecord(join, ctx->sideStream);
         (void) hipStreamWaitEvent(s, join, 0);
       }
-      ProfScope p(ctx, 3);
       c->normDue = false;
       if (c->sideW && sideReady && updateH && hPlain && normInH && c->stripsW <= 16 && c->sideFromHSlices <= 16)
       {
@@ -1009,13 +1008,16 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         side_io(ah, true);
         c->normDue = (launch_nmf_update5(ah, s) & 2) != 0;
       }
-      if (c->normDue) {}
-      else if (c->sideW && sideReady)   // the H update in front left the side column's partials: the norm combine is all that is due
-        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
-                             c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices, c->sideGen);
-      else
-        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
-                             c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s, join ? 2 : 0);
+      if (!c->normDue)   // (nothing between the updates otherwise: no event pair of the profiling aid there either)
+      {
+        ProfScope p(ctx, 3);
+        if (c->sideW && sideReady)   // the H update in front left the side column's partials: the norm combine is all that is due
+          launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                               c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices, c->sideGen);
+        else
+          launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                               c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s, join ? 2 : 0);
+      }
       c->wPending = true;
     }
     else
