@@ -1,3 +1,6 @@
+#!/bin/bash
+# round 4: the persistent form's two barriers (FLUHIP_PERSIST_LIGHT=1: no agent-scope fences) against two launches per iteration;
+# needs profiles/r04/persistent_form.patch applied (the form was measured and not adopted)
 for v in "FLUHIP_PERSIST=0" "FLUHIP_PERSIST_LIGHT=1" "FLUHIP_PERSIST_LIGHT=0" "FLUHIP_PERSIST=0" "FLUHIP_PERSIST_LIGHT=1"; do
   env FLUHIP_AB=1 $v timeout 300 python bench.py --no-cpu-baseline --configs none 2>/dev/null | python -c "
 import json,sys
