@@ -26,6 +26,8 @@
 // the pace: tools/hbm_write_probe.hip reproduces the figure with a plain FMA loop and the same two store patterns.
 #include "fluhip_kernels.h"
 
+#include <type_traits>
+
 #include <algorithm>
 #include <cstdio>
 #include <vector>
@@ -929,13 +931,18 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
   using Core = FftCore<R1, R2, R3>;
   constexpr int N = Core::N, PPL = Core::PPL, BUFD = Core::BUFD;
   constexpr int CH = (N + 1 + 63) / 64;           // consecutive bins per lane in the band sums
-  constexpr int WS = SMALL ? 0 : 66 + 66 + 64;    // per-wavefront scratch: boundary sums (rising, falling), band values
-  static_assert(!SMALL || BUFD >= 66 + 66 + 64, "the band stage's scratch inside the staging buffer");
+  // per-wavefront scratch: boundary sums (rising, falling) -- 66 boundary slots, then one DUMP slot per lane: bins that end no
+  // interval publish there, so that the publishing needs no compare, no exec mask and no select (36 v_cndmask + 9 v_cmp per
+  // frame as the compiler had if-converted it) -- and the band values
+  constexpr int WB = 66 + 64;
+  constexpr int WS = SMALL ? 0 : 2 * WB + 64;
+  static_assert(!SMALL || BUFD >= 2 * WB + 64, "the band stage's scratch inside the staging buffer");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   d2* tw2 = reinterpret_cast<d2*>(lds);
   d2* wl = tw2 + Core::T2 + Core::T3;             // [N] window pairs
+  constexpr bool TAB = R1 == 8;                   // (fft 2048 has no LDS to spare for the table)
   d2* tws = wl + (SMALL ? 0 : N);                 // [N] the split's twiddles, halved
-  double* xall = reinterpret_cast<double*>(tws + N);
+  double* xall = reinterpret_cast<double*>(tws + (TAB ? N : 0));
   double* scr = xall + NW * BUFD;                 // [NW][WS]
   double* upl = scr + NW * WS;                    // [64 CH]
   double* dnl = upl + 64 * CH;                    // [64 CH]
@@ -948,16 +955,23 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   double* xb = xall + wave * BUFD;
   double* bu = SMALL ? xb : scr + wave * WS;
-  double* bd = bu + 66;
-  double* bands = bd + 66;
+  double* bd = bu + WB;
+  double* bands = bd + WB;
 
   const d2* twg = reinterpret_cast<const d2*>(a.twiddle);
   Core::fill_tables(tw2, twg, threadIdx.x, 64 * NW);
   if constexpr (!SMALL)
     for (int m = threadIdx.x; m < N; m += 64 * NW) wl[m] = reinterpret_cast<const d2*>(a.window)[m];
-  for (int m = threadIdx.x; m < N; m += 64 * NW) { const d2 w = twg[m]; tws[m] = d2{0.5 * w[0], 0.5 * w[1]}; }
+  if constexpr (TAB)
+    for (int m = threadIdx.x; m < N; m += 64 * NW) { const d2 w = twg[m]; tws[m] = d2{0.5 * w[0], 0.5 * w[1]}; }
   // (per-lane tables lie [i][lane] in the LDS: a lane's CH consecutive bins are CH rows apart, a row is read without bank conflicts)
-  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW) { const int q = (i % CH) * 64 + i / CH; upl[q] = fa.up[i]; dnl[q] = fa.dn[i]; slotl[q] = fa.slot[i]; }
+  for (int i = threadIdx.x; i < 64 * CH; i += 64 * NW)
+  {
+    const int q = (i % CH) * 64 + i / CH;
+    upl[q] = fa.up[i]; dnl[q] = fa.dn[i];
+    const short sl = fa.slot[i];
+    slotl[q] = sl >= 0 ? sl : (short) (66 + i / CH);           // (the lane's dump slot)
+  }
   if (fa.dct)
     for (int i = threadIdx.x; i < fa.nDct * dld; i += 64 * NW)
     {
@@ -1048,7 +1062,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       gather_points<R1, N>(a, b, t, lane, SMALL ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #endif
       SCHED_FENCE();
-      core.template run<false, true>(pts, nullptr);
+      core.template run<false, TAB>(pts, nullptr);
     }
     SCHED_FENCE();
     // ---- band sums ------------------------------------------------------------------------------------------
@@ -1056,19 +1070,29 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
     asm volatile("" : "+v"(ln));                    // (opaque: per-bin LDS positions are recomputed, not kept)
     double pu[CH], pd[CH];
     double su = 0.0, sd = 0.0, en = 0.0;
+    // (the two options are launch-wide: a scalar branch around two copies of the loop -- if-converted they were two selects per
+    //  bin, 36 v_cndmask + 18 multiplications per frame that the MFCC / mel-band defaults never use)
+    auto band_sums = [&](auto plainTag) {
+      constexpr bool PLAIN = decltype(plainTag)::value;
 #pragma unroll
-    for (int i = 0; i < CH; i++)
-    {
-      const int f = CH * ln + i;
-      // (bins past N have zero weights: the clamped read costs a v_min where the select cost a compare and two v_cndmask)
-      double m = xb[min(f, N)];
-      if (fa.magNorm) { m = f <= N ? m * scale1 : 0.0; en += m; }     // :86-90
-      if (fa.usePower) m = m * m;
-      su = __builtin_fma(lds_read1(upl + i * 64 + ln), m, su);    // (single ds_read_b64s: paired they run at half the rate)
-      sd = __builtin_fma(lds_read1(dnl + i * 64 + ln), m, sd);
-      pu[i] = su;
-      pd[i] = sd;
-    }
+      for (int i = 0; i < CH; i++)
+      {
+        const int f = CH * ln + i;
+        // (bins past N have zero weights: the clamped read costs a v_min where the select cost a compare and two v_cndmask)
+        double m = xb[min(f, N)];
+        if constexpr (!PLAIN)
+        {
+          if (fa.magNorm) { m = f <= N ? m * scale1 : 0.0; en += m; }     // :86-90
+          if (fa.usePower) m = m * m;
+        }
+        su = __builtin_fma(lds_read1(upl + i * 64 + ln), m, su);    // (single ds_read_b64s: paired they run at half the rate)
+        sd = __builtin_fma(lds_read1(dnl + i * 64 + ln), m, sd);
+        pu[i] = su;
+        pd[i] = sd;
+      }
+    };
+    if (fa.magNorm | fa.usePower) band_sums(std::false_type{});
+    else band_sums(std::true_type{});
     // inclusive scan of the lane totals over the wavefront (DPP: four shifts inside a row of 16, then the row totals
     // broadcast upwards), then shifted by one lane: what the lanes below contribute
     const double xu = wave_scan(su), xd = wave_scan(sd);
@@ -1084,7 +1108,8 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
     for (int i = 0; i < CH; i++)
     {
       const int sl = slotl[i * 64 + ln];
-      if (sl >= 0) { bu[sl] = eu + pu[i]; bd[sl] = ed + pd[i]; }
+      bu[sl] = eu + pu[i];
+      bd[sl] = ed + pd[i];
     }
     double v = 0.0;
     if (ln < fa.nBands) v = (bu[ln + 1] - bu[ln]) + (bd[ln + 2] - bd[ln + 1]);   // (predicates from the opaque lane: recomputed per frame, not kept as spilled exec masks)
@@ -1352,8 +1377,8 @@ template <int R1, int R2, int R3, int NW, bool SMALL = false>
 static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStream_t s)
 {
   using Core = FftCore<R1, R2, R3>;
-  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = SMALL ? 0 : 66 + 66 + 64;
-  const size_t shmem = ((size_t) Core::T2 + Core::T3 + (SMALL ? 0 : N) + N) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
+  constexpr int N = Core::N, CH = (N + 1 + 63) / 64, WS = SMALL ? 0 : 2 * (66 + 64) + 64;
+  const size_t shmem = ((size_t) Core::T2 + Core::T3 + (SMALL ? 0 : N) + (R1 == 8 ? N : 0)) * 16 + ((size_t) NW * (Core::BUFD + WS) + 2 * 64 * CH) * 8 +
                        (fa.dct ? (size_t) fa.nDct * (4 * ((fa.nBands + 3) / 4) + 1) * 8 : 0) + (size_t) 64 * CH * 2 + 16;
   if (shmem > (SMALL ? 80 : 160) * 1024) return false;
   StftBArgs k = k0;
