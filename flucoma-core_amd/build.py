@@ -55,7 +55,7 @@ def _newer(target, sources):
 # per-file extras: the factor-update kernels never see NaNs by construction (every operand is
 # clamped to >= eps or is a finite product of finite inputs), and fmax() without the sNaN
 # canonicalisation saves one op per quotient on the FP64 datapath the MFMAs share.
-EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans"], "kernels_nmf.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"], "kernels_nmf.hip": ["-fno-honor-nans"]}
 
 
 def _compile(src, variant="default"):
