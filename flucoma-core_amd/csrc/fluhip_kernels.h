@@ -207,6 +207,7 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
 // Where the side-column partials / the old side row of an H update with UpdateArgs::sideOut live inside `scratch`: two
 // areas (gen 0 / 1) inside the slice region, up to 64 slices per buffer each -- an H update that does the norm combine reads
 // one generation in its prologue while its own epilogues fill the other.
+constexpr int kSideFromHSlots = 64; // slices of side-column partials per buffer and generation (H update's SIDEQ epilogue: one per strip)
 double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen);
 double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen);
 // S = S / nrm in memory, nrm = 1

@@ -817,14 +817,14 @@ bool nmf_side_column_supported(int R, int C, int Kp)
 }
 int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
 
-static_assert(kSideSlices == 256, "two generations of 128 slices: 64 of partials, then the old side row");
+static_assert(kSideSlices == 4 * kSideFromHSlots, "two generations of 128 slices: 64 of partials, then the old side row");
 double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen)
 {
-  return scratch + (int64_t) B * nStrips * 2 * Kp + (int64_t) gen * B * 128 * 2 * Kp;
+  return scratch + (int64_t) B * nStrips * 2 * Kp + (int64_t) gen * B * (2 * kSideFromHSlots) * 2 * Kp;
 }
 double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen)
 {
-  return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * 64 * 2 * Kp;
+  return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * kSideFromHSlots * 2 * Kp;
 }
 
 void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,

@@ -82,6 +82,14 @@ constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
 #define FLUHIP_SHARED_RECIPROCAL 1
 #endif
 constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
+// FLUHIP_M2_DBG (bisecting builds of the in-place pipeline form only, tools/mode2_bisect.sh): bit 0 = every ds_read drained before
+// a slot's refill is issued, bit 1 = every DMA landed at the head of a step, bit 2 = the in-place operand reads one chunk
+// later than the MFMAs that free their registers, bit 3 = nothing refilled in place in the out-phase (mb read at the head
+// of the next step instead), bit 4 = nothing refilled in place in the Q-phase (ma read after the phase)
+#ifndef FLUHIP_M2_DBG
+#define FLUHIP_M2_DBG 0
+#endif
+constexpr int kM2Dbg = FLUHIP_M2_DBG;
 // The results of a launch leave with write-through (sc1) stores: with plain stores the kernel ends on tens of MB of
 // dirty L2 lines that the end-of-kernel release has to write back before the next launch may start
 // (MI355X_MICROARCH.md "publish-large": 8.2 vs 3.0 us for 64 KB per workgroup).  -DFLUHIP_EPILOGUE_SC1=0: plain stores.
@@ -621,7 +629,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         // stages s+1, s+2 landed.  (Refills past the last step re-read the last step's rows -- L2 hits; skipping
         // them was measured slower both ways: a branch per DMA splits the MFMA stream into basic blocks, and
         // issuing them under EXEC = 0 stalls on every EXEC write.)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
+        if constexpr (kM2Dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
         ratio_phase(v, qc, ratio);
 #pragma unroll
         for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
@@ -648,13 +657,38 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
               if ((m & 1) && g == NG - 1) // chunk m/2 of ma(s+1) is spent: its registers take ma(s+2)
               {
-                __builtin_amdgcn_sched_barrier(0);
-                d2 t = *reinterpret_cast<const d2*>(maAddr[m / 2] + u2 * MSTAGE);
-                ma[m - 1] = t[0];
-                ma[m] = t[1];
-                __builtin_amdgcn_sched_barrier(0);
+                constexpr int lag = (kM2Dbg & 4) ? 1 : 0;
+                if constexpr (!(kM2Dbg & 16))
+                  if (m / 2 - lag >= 0)
+                  {
+                    __builtin_amdgcn_sched_barrier(0);
+                    d2 t = *reinterpret_cast<const d2*>(maAddr[m / 2 - lag] + u2 * MSTAGE);
+                    ma[m - 1 - 2 * lag] = t[0];
+                    ma[m - 2 * lag] = t[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
               }
             }
+          if constexpr ((kM2Dbg & 4) && !(kM2Dbg & 16))
+          {
+            __builtin_amdgcn_sched_barrier(0);
+            d2 t = *reinterpret_cast<const d2*>(maAddr[M / 2 - 1] + u2 * MSTAGE);
+            ma[M - 2] = t[0];
+            ma[M - 1] = t[1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr ((kM2Dbg & 16) != 0)
+          {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < M / 2; j++)
+            {
+              d2 t = *reinterpret_cast<const d2*>(maAddr[j] + u2 * MSTAGE);
+              ma[2 * j] = t[0];
+              ma[2 * j + 1] = t[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int g = 0; g < NG; g++)
           {
@@ -670,7 +704,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
           const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
           const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
           // every ds_read of slot u was issued in earlier steps; the Q-phase above issued QREADS newer ones
-          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
+          if constexpr (kM2Dbg & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
 #pragma unroll
           for (int m = 0; m < M; m++)
 #pragma unroll
@@ -687,13 +722,38 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
               if ((m & 1) && g == NG - 1) // chunk m/2 of mb(s) is spent: its registers take mb(s+1)
               {
-                __builtin_amdgcn_sched_barrier(0);
-                d2 t = *reinterpret_cast<const d2*>(mbAddr[m / 2] + u1 * MSTAGE);
-                mb[m - 1] = t[0];
-                mb[m] = t[1];
-                __builtin_amdgcn_sched_barrier(0);
+                constexpr int lag = (kM2Dbg & 4) ? 1 : 0;
+                if constexpr (!(kM2Dbg & 8))
+                  if (m / 2 - lag >= 0)
+                  {
+                    __builtin_amdgcn_sched_barrier(0);
+                    d2 t = *reinterpret_cast<const d2*>(mbAddr[m / 2 - lag] + u1 * MSTAGE);
+                    mb[m - 1 - 2 * lag] = t[0];
+                    mb[m - 2 * lag] = t[1];
+                    __builtin_amdgcn_sched_barrier(0);
+                  }
               }
             }
+          if constexpr ((kM2Dbg & 4) && !(kM2Dbg & 8))
+          {
+            __builtin_amdgcn_sched_barrier(0);
+            d2 t = *reinterpret_cast<const d2*>(mbAddr[M / 2 - 1] + u1 * MSTAGE);
+            mb[M - 2] = t[0];
+            mb[M - 1] = t[1];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if constexpr ((kM2Dbg & 8) != 0)
+          {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < M / 2; j++)
+            {
+              d2 t = *reinterpret_cast<const d2*>(mbAddr[j] + u1 * MSTAGE);
+              mb[2 * j] = t[0];
+              mb[2 * j + 1] = t[1];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -1095,6 +1155,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             const double r0 = v * dy[m + e];
             const double r = __builtin_fma(__builtin_fma(-dd[m + e], r0, v), dy[m + e], r0);
             r2[e] = r;
+            if constexpr (MODE == 2 && (kM2Dbg & 32) != 0) // (bisecting build: one lane's epilogue operands, 32 words of dpart)
+              if (g == 0 && blockIdx.x == 0 && wave == 0 && lane == 3 && a.dpart)
+              {
+                a.dpart[(m + e) * 4 + 0] = so; a.dpart[(m + e) * 4 + 1] = acc[g][m + e];
+                a.dpart[(m + e) * 4 + 2] = dy[m + e]; a.dpart[(m + e) * 4 + 3] = r;
+              }
             if constexpr (SIDEQ) rr[m + e] = r;
             if (live)
             {
@@ -1349,7 +1415,9 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
   if constexpr (NG == 1) launch5_t<M, 1, ring_depth<M, 1, WPS>(), WPS>(a, w, s);
   else
   {
-    const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1;
+    // (w <= kSideFromHSlots: the partials are laid out [B][strips][2][Kp] in an area that holds kSideFromHSlots slices per
+    //  buffer and generation, wnorm_side_part -- long buffers take more strips than that and keep the side-column launch)
+    const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1 && w <= kSideFromHSlots;
     const bool normq = sideq && a.cmbStat && a.cmbSide && a.cmbWold && a.cmbNrmOut && a.cmbRowOut && (a.R + 3) / 4 > 12;
     (void) normq;
     if (ng >= NG)

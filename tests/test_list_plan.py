@@ -189,4 +189,10 @@ def test_what_the_h_update_takes_over(fluhip_lib_path):
     assert form(2, 25840, 2049, 128) == 0       # config 3
     assert form(128, 862, 1024, 32) == 0        # 1 024 bins: whole column groups, no side column
     assert form(128, 137, 1025, 32) == 3        # 70 000 samples at hop 512 (the variants test's corpus)
+    # more than 64 strips per buffer in the H update (uniform plan, long buffers): the side-column partials have 64 slices per
+    # buffer, so the epilogue must not take the side column over (it wrote past the area)
+    kind = lambda B, T, F, K: lib.fluhip_debug_plan_kind(B, T, F, K)  # noqa: E731
+    assert kind(64, 5000, 1025, 64) == 0 and form(64, 5000, 1025, 64) == 0       # 80 strips
+    assert kind(64, 12800, 1025, 64) == 0 and form(64, 12800, 1025, 64) == 0     # 200 strips
+    assert kind(128, 9300, 1025, 32) == 0 and form(128, 9300, 1025, 32) == 0     # 65 strips
     assert form(0, 1, 1, 1) == -1
