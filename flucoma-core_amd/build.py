@@ -109,15 +109,6 @@ def build_ab(force: bool = False):
     return _build_variant("ab", LIB_AB, force), _build_variant("qc", LIB_QC, force)
 
 
-def build_m2dbg(bits: int, force: bool = False) -> str:
-    """lib_ab/libflucoma_hip_m2dbg<bits>.so: the A/B build with -DFLUHIP_M2_DBG=<bits> in kernels_nmf5.hip (bisecting builds of
-    the in-place pipeline form, tools/mode2_bisect.py; only that file is recompiled)"""
-    name = f"m2dbg{bits}"
-    VARIANTS[name] = (os.path.join(HERE, f"build_{name}"), ["-DFLUHIP_AB_SWITCHES", f"-DFLUHIP_M2_DBG={bits}"],
-                      ["kernels_nmf5.hip"], "ab")
-    return _build_variant(name, os.path.join(ABDIR, f"libflucoma_hip_{name}.so"), force)
-
-
 def build_host_tests() -> str:
     """g++ build of the C++ host-client test driver (plain C++17 above the C ABI)."""
     root = os.path.dirname(HERE)

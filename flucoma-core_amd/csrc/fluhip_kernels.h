@@ -234,6 +234,12 @@ struct StripArgs
   int F, T, K, B;
   int doH, doW;     // both 0: only nrm is produced
   int wPend;        // W in memory is the un-normalised W' of the last reduce launch
+  // round 5, the W update as a bin-tiled launch (kernels_nmf_bintile.hip): the column statistics then come from its tile records
+  // (tileStat: generation statGen of [B][48][nRec], nRec > 0) instead of the reduce launch's, and doW == 2 leaves only the
+  // Nyquist bin's numerator partials, one per workgroup, in sideOut [B][workgroups][16]
+  const double* tileStat = nullptr;
+  int nRec = 0;
+  double* sideOut = nullptr;
 };
 bool nmf_strip_supported(int F, int T, int Kp);
 int nmf_strip_workgroups(int T);
@@ -241,6 +247,29 @@ int64_t nmf_strip_part_doubles(int F, int T, int B);
 void launch_nmf_strip(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_reduce(const StripArgs& a, hipStream_t s);
 void launch_nmf_strip_wstats(const StripArgs& a, hipStream_t s);
+// Bin-tiled W update of the same schedule (kernels_nmf_bintile.hip, round 5): a workgroup owns four bins and all frames, no
+// partials of the numerator in memory, no reduce launch.  alg/NMF.hpp:158-161; :162 stays deferred (tile records).
+struct BinTileArgs
+{
+  const double* VT;  // magT [B][Fp][ldT]
+  int64_t strideVT, ldT;
+  double* W;         // [B][Fp][16]
+  int64_t strideW;
+  const double* H;   // [B][Tp][16]
+  int64_t strideH;
+  double* work;      // nmf_bintile_doubles(): two generations of tile records, then the side partials
+  const double* sidePart; // the side partials the strip launch left (nmf_bintile_side_area()), or null: no Nyquist side row
+  int nSideWG;
+  int statGen;       // generation of records that describes the W in memory; the launch writes the other one
+  int F, K, B, wPend;
+};
+bool nmf_bintile_supported(int F, int T, int Kp);
+int nmf_bintile_records(int F);
+int64_t nmf_bintile_doubles(int F, int B, int nSideWG);
+double* nmf_bintile_side_area(const BinTileArgs& s);
+const double* nmf_bintile_records_ptr(const BinTileArgs& s, int gen);
+void launch_nmf_bintile(const BinTileArgs& s, hipStream_t st);
+void launch_nmf_bintile_wstats(const BinTileArgs& s, hipStream_t st);
 // the W update of the frame-strip schedule as its own launch over bin strips (no numerator partials of the whole matrix, no
 // reduce launch); `work`: nmf_binstrip_doubles() doubles, zeroed once
 int64_t nmf_binstrip_doubles(int F, int T, int B);

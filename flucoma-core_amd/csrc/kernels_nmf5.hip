@@ -82,24 +82,27 @@ constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
 #define FLUHIP_SHARED_RECIPROCAL 1
 #endif
 constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
-// FLUHIP_M2_DBG (bisecting builds of the in-place pipeline form only, tools/mode2_bisect.sh): bit 0 = every ds_read drained before
-// a slot's refill is issued, bit 1 = every DMA landed at the head of a step, bit 2 = the in-place operand reads one chunk
-// later than the MFMAs that free their registers, bit 3 = nothing refilled in place in the out-phase (mb read at the head
-// of the next step instead), bit 4 = nothing refilled in place in the Q-phase (ma read after the phase)
-#ifndef FLUHIP_M2_DBG
-#define FLUHIP_M2_DBG 0
-#endif
-constexpr int kM2Dbg = FLUHIP_M2_DBG;
 // The results of a launch leave with write-through (sc1) stores: with plain stores the kernel ends on tens of MB of
 // dirty L2 lines that the end-of-kernel release has to write back before the next launch may start
 // (MI355X_MICROARCH.md "publish-large": 8.2 vs 3.0 us for 64 KB per workgroup).  -DFLUHIP_EPILOGUE_SC1=0: plain stores.
 #ifndef FLUHIP_EPILOGUE_SC1
 #define FLUHIP_EPILOGUE_SC1 1
 #endif
+// THE TWO WAIT STATES BEHIND THE STORE ARE LOAD-BEARING (round 5; DESIGN section 3 "The store hazard behind the inline asm").
+// gfx940-class parts read the data registers of a store of MORE than 64 bits over several cycles after issue, and a VALU
+// instruction that writes one of them within two wait states corrupts what is stored.  The compiler's hazard recognizer
+// (GCNHazardRecognizer, the "VMEM store data" hazard) inserts those wait states behind the stores IT emits, but it does not look
+// inside an inline-asm statement -- so when the register allocator reuses one of the four data registers for whatever comes
+// next (one instantiation did: <8 x 4 components, 8 groups, in-place pipeline> restored a spilled lane index into the second
+// of them with v_accvgpr_read_b32 right behind the asm), lanes of the store leave with the NEW value in that dword: the high
+// halves of four components in the first four columns of every strip, run-to-run different -- the "MODE 2 race" of rounds
+// 3 and 4.  Found and proven at the instruction level (tools/m2_isa_probe.cpp: 45 000 wrong entries per launch without,
+// none with `s_nop 1` patched behind the stores of the unchanged compiler output); tools/isa_store_hazard.py audits the
+// shipped code objects for the pattern.
 __device__ __forceinline__ void store_result16(double* p, double __attribute__((ext_vector_type(2))) t)
 {
 #if FLUHIP_EPILOGUE_SC1
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 #else
   *reinterpret_cast<double __attribute__((ext_vector_type(2)))*>(p) = t;
 #endif
@@ -629,8 +632,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         // stages s+1, s+2 landed.  (Refills past the last step re-read the last step's rows -- L2 hits; skipping
         // them was measured slower both ways: a branch per DMA splits the MFMA stream into basic blocks, and
         // issuing them under EXEC = 0 stalls on every EXEC write.)
-        if constexpr (kM2Dbg & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
         ratio_phase(v, qc, ratio);
 #pragma unroll
         for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
@@ -657,38 +659,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
               if ((m & 1) && g == NG - 1) // chunk m/2 of ma(s+1) is spent: its registers take ma(s+2)
               {
-                constexpr int lag = (kM2Dbg & 4) ? 1 : 0;
-                if constexpr (!(kM2Dbg & 16))
-                  if (m / 2 - lag >= 0)
-                  {
-                    __builtin_amdgcn_sched_barrier(0);
-                    d2 t = *reinterpret_cast<const d2*>(maAddr[m / 2 - lag] + u2 * MSTAGE);
-                    ma[m - 1 - 2 * lag] = t[0];
-                    ma[m - 2 * lag] = t[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                  }
+                __builtin_amdgcn_sched_barrier(0);
+                d2 t = *reinterpret_cast<const d2*>(maAddr[m / 2] + u2 * MSTAGE);
+                ma[m - 1] = t[0];
+                ma[m] = t[1];
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
-          if constexpr ((kM2Dbg & 4) && !(kM2Dbg & 16))
-          {
-            __builtin_amdgcn_sched_barrier(0);
-            d2 t = *reinterpret_cast<const d2*>(maAddr[M / 2 - 1] + u2 * MSTAGE);
-            ma[M - 2] = t[0];
-            ma[M - 1] = t[1];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if constexpr ((kM2Dbg & 16) != 0)
-          {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < M / 2; j++)
-            {
-              d2 t = *reinterpret_cast<const d2*>(maAddr[j] + u2 * MSTAGE);
-              ma[2 * j] = t[0];
-              ma[2 * j + 1] = t[1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
 #pragma unroll
           for (int g = 0; g < NG; g++)
           {
@@ -704,8 +681,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
           const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
           const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
           // every ds_read of slot u was issued in earlier steps; the Q-phase above issued QREADS newer ones
-          if constexpr (kM2Dbg & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
+          asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
 #pragma unroll
           for (int m = 0; m < M; m++)
 #pragma unroll
@@ -722,38 +698,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
               if ((m & 1) && g == NG - 1) // chunk m/2 of mb(s) is spent: its registers take mb(s+1)
               {
-                constexpr int lag = (kM2Dbg & 4) ? 1 : 0;
-                if constexpr (!(kM2Dbg & 8))
-                  if (m / 2 - lag >= 0)
-                  {
-                    __builtin_amdgcn_sched_barrier(0);
-                    d2 t = *reinterpret_cast<const d2*>(mbAddr[m / 2 - lag] + u1 * MSTAGE);
-                    mb[m - 1 - 2 * lag] = t[0];
-                    mb[m - 2 * lag] = t[1];
-                    __builtin_amdgcn_sched_barrier(0);
-                  }
+                __builtin_amdgcn_sched_barrier(0);
+                d2 t = *reinterpret_cast<const d2*>(mbAddr[m / 2] + u1 * MSTAGE);
+                mb[m - 1] = t[0];
+                mb[m] = t[1];
+                __builtin_amdgcn_sched_barrier(0);
               }
             }
-          if constexpr ((kM2Dbg & 4) && !(kM2Dbg & 8))
-          {
-            __builtin_amdgcn_sched_barrier(0);
-            d2 t = *reinterpret_cast<const d2*>(mbAddr[M / 2 - 1] + u1 * MSTAGE);
-            mb[M - 2] = t[0];
-            mb[M - 1] = t[1];
-            __builtin_amdgcn_sched_barrier(0);
-          }
-          if constexpr ((kM2Dbg & 8) != 0)
-          {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < M / 2; j++)
-            {
-              d2 t = *reinterpret_cast<const d2*>(mbAddr[j] + u1 * MSTAGE);
-              mb[2 * j] = t[0];
-              mb[2 * j + 1] = t[1];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          }
         }
         __builtin_amdgcn_sched_barrier(0);
       };
@@ -1155,12 +1106,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             const double r0 = v * dy[m + e];
             const double r = __builtin_fma(__builtin_fma(-dd[m + e], r0, v), dy[m + e], r0);
             r2[e] = r;
-            if constexpr (MODE == 2 && (kM2Dbg & 32) != 0) // (bisecting build: one lane's epilogue operands, 32 words of dpart)
-              if (g == 0 && blockIdx.x == 0 && wave == 0 && lane == 3 && a.dpart)
-              {
-                a.dpart[(m + e) * 4 + 0] = so; a.dpart[(m + e) * 4 + 1] = acc[g][m + e];
-                a.dpart[(m + e) * 4 + 2] = dy[m + e]; a.dpart[(m + e) * 4 + 3] = r;
-              }
             if constexpr (SIDEQ) rr[m + e] = r;
             if (live)
             {
@@ -1437,12 +1382,11 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         // operand set, 2 = overlapped with one set refilled in place (the only overlapped form that fits
         // M = 32); default: 2 for M >= 16, 1 below
         static const int mode = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_MODE"); return e ? std::atoi(e) : -1; }();
-        // (mode 2 is honoured from M = 16 on, where it is the production form.  Forced onto M = 8 it is wrong in the batched
-        //  whole-strip regime -- components 24, 26, 28, 30 of the first four columns of every strip, found by the round-3
-        //  variants test on a 128-buffer corpus; single buffers pass -- and since nothing ever selected it there it was
-        //  switched off rather than debugged.)
-        static const int anyM = [] { const char* e = fluhip::ab_getenv("FLUHIP_K5_MODE_ANY"); return e ? std::atoi(e) : 0; }(); // (debugging)
-        const int eff = (mode >= 0 && !(mode == 2 && M < 16 && !anyM)) ? mode : (M >= 16 ? 2 : 1);
+        // (rounds 3 - 4 honoured mode 2 from M = 16 on only: forced onto M = 8 it came out wrong on a 128-buffer corpus and was
+        //  taken for a race of the in-place refill.  Round 5 found the cause elsewhere -- the store hazard behind the inline asm
+        //  of store_result16, which that one instantiation's register allocation happened to expose -- and with it repaired the
+        //  form is right at every rank; FLUHIP_K5_MODE_ANY is no longer needed and is accepted for old scripts.)
+        const int eff = mode >= 0 ? mode : (M >= 16 ? 2 : 1);
         if constexpr (M == 32)
         {
           // rank 65..128: the in-place overlapped form only fits without the M column-sum accumulators;
