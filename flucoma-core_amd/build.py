@@ -35,7 +35,7 @@ VARIANTS = {
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf_strip.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api_core.hip", "api_corpus.hip", "api_algorithms.hip", "api_features.hip", "api_frames.hip", "api_pool.cpp"]
+SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf_strip.hip", "kernels_nmf_bintile.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api_core.hip", "api_corpus.hip", "api_algorithms.hip", "api_features.hip", "api_frames.hip", "api_pool.cpp"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
 
 
@@ -55,7 +55,8 @@ def _newer(target, sources):
 # per-file extras: the factor-update kernels never see NaNs by construction (every operand is
 # clamped to >= eps or is a finite product of finite inputs), and fmax() without the sNaN
 # canonicalisation saves one op per quotient on the FP64 datapath the MFMAs share.
-EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"], "kernels_nmf.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"], "kernels_nmf.hip": ["-fno-honor-nans"],
+               "kernels_nmf_bintile.hip": ["-fno-honor-nans", "-Wno-inline-asm", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _compile(src, variant="default"):

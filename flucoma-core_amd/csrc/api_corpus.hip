@@ -223,6 +223,23 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       if (c->stripBin)
         HIPCHK(ctx, c->binWork.alloc((size_t) nmf_binstrip_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), true, s));
 #endif
+      // Round 5: the W update as the BIN-TILED launch (kernels_nmf_bintile.hip: four bins and ALL frames per workgroup, no
+      // numerator partials in memory, no reduce launch, no ticket), the strip kernel doing the H update and the Nyquist bin's
+      // partials.  Built to the review's specification, parity-green at full size, and measured at config 2
+      // (profiles/r05/c2_bintile.md): 20.3 us for the launch in three layouts against the review's 13 us kill line --
+      // 4.3 us is what an EMPTY launch of the shape costs, 3.9 prologue + epilogue, 1.4 the ring fill, 10.6 the frame loop
+      // (FP64-datapath-bound: the quotient and the bookkeeping adds cost what the eight MFMAs of a step cost) -- so that
+      // an iteration is 19.0 + 20.3 = 40.9 us against 38.9 for the fused form + reduce launch.  Not adopted: A/B build only,
+      // FLUHIP_STRIP_TILE=1.
+      static const int tileEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_TILE"); return e ? std::atoi(e) : 0; }();
+#ifdef FLUHIP_AB_SWITCHES
+      c->stripTile = !c->stripBin && tileEnv == 1 && nmf_bintile_supported((int) c->F, (int) c->T, (int) c->Kp) &&
+                     nmf_strip_tile_supported((int) c->F, (int) c->T, (int) c->Kp);
+      if (c->stripTile)
+        HIPCHK(ctx, c->tileWork.alloc((size_t) nmf_bintile_doubles((int) c->F, (int) B, nmf_strip_workgroups((int) c->T)) * sizeof(double), true, s));
+#else
+      (void) tileEnv;
+#endif
     }
     // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
     // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
@@ -852,13 +869,56 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
     a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = B;
     a.doH = a.doW = 0; a.wPend = c->wPending ? 1 : 0;
+#ifdef FLUHIP_AB_SWITCHES
+    BinTileArgs bt{};
+    if (c->stripTile)
+    {
+      bt.VT = c->magT.as<double>(); bt.strideVT = c->Fp * c->Tp; bt.ldT = c->Tp;
+      bt.W = a.W; bt.strideW = a.strideW; bt.H = a.H; bt.strideH = a.strideH;
+      bt.work = c->tileWork.as<double>(); bt.nSideWG = nmf_strip_workgroups((int) c->T);
+      bt.F = a.F; bt.K = a.K; bt.B = B;
+      a.nRec = nmf_bintile_records(a.F); a.sideOut = nmf_bintile_side_area(bt);
+    }
+    // (the strip launches of the tiled form read the tile records of the generation current at their launch)
+    auto tile_gen = [&]() { if (c->stripTile) a.tileStat = nmf_bintile_records_ptr(bt, c->stripGen); };
+#else
+    auto tile_gen = [] {};
+#endif
     if (!c->stripStatsValid)
     {
       // W was written by something else (initialisation, the normalisation at the end of the last call)
       a.statGen = c->stripGen;
+#ifdef FLUHIP_AB_SWITCHES
+      if (c->stripTile) { bt.statGen = c->stripGen; bt.wPend = 0; launch_nmf_bintile_wstats(bt, s); }
+      else
+#endif
       launch_nmf_strip_wstats(a, s);
       c->stripStatsValid = true;
     }
+#ifdef FLUHIP_AB_SWITCHES
+    if (updateW && c->stripTile)
+    {
+      // alg/NMF.hpp:158-161 as ONE launch over tiles of four bins; :162 stays deferred (tile records of the other generation)
+      if (!c->stripSideReady)
+      {
+        // the Nyquist bin's numerator partials from the H in memory (first iteration of a call, W-only iterations)
+        a.doH = 0; a.doW = 2; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen; tile_gen();
+        ProfScope p(ctx, 3);
+        launch_nmf_strip(a, s);
+      }
+      bt.sidePart = a.sideOut; bt.statGen = c->stripGen; bt.wPend = c->wPending ? 1 : 0;
+      {
+        ProfScope p(ctx, 1);
+        launch_nmf_bintile(bt, s);
+      }
+      c->stripGen ^= 1;
+      c->wPending = true;
+      c->stripSideReady = false;
+      c->stripReady = false;
+      c->stripNormFresh = false;
+    }
+    else
+#endif
     if (updateW && c->stripBin)
     {
       // alg/NMF.hpp:158-161 as one launch over bin strips: reads W', its records and the H in memory, leaves the new W' and
@@ -897,10 +957,12 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     if (updateH)
     {
       // :165-170, and behind it the numerator of the next iteration's W update while the new H is at hand
-      a.doH = 1; a.doW = (updateW && !last && !c->stripBin) ? 1 : 0; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
+      a.doH = 1; a.doW = (updateW && !last && !c->stripBin) ? (c->stripTile ? 2 : 1) : 0; a.wPend = c->wPending ? 1 : 0; a.statGen = c->stripGen;
+      tile_gen();
       ProfScope p(ctx, 1);
       launch_nmf_strip(a, s);
-      c->stripReady = a.doW != 0;
+      c->stripReady = a.doW == 1;
+      c->stripSideReady = a.doW == 2;
       c->stripNormFresh = true;
     }
     return;
@@ -1219,6 +1281,7 @@ int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
   if (c->strip)
   {
     c->stripReady = false; // H may change before the next call
+    c->stripSideReady = false;
     if (c->wPending && !c->stripNormFresh)
     {
       // the last launch was a reduce: one workgroup per buffer recomputes the column norms of W'
@@ -1229,6 +1292,14 @@ int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
       a.part = c->stripPart.as<double>(); a.nrm = c->wnorm.as<double>();
       a.F = (int) c->F; a.T = (int) c->T; a.K = (int) c->K; a.B = (int) c->B;
       a.doH = a.doW = 0; a.wPend = 1; a.statGen = c->stripGen;
+#ifdef FLUHIP_AB_SWITCHES
+      if (c->stripTile)
+      {
+        BinTileArgs bt{};
+        bt.work = c->tileWork.as<double>(); bt.F = a.F; bt.B = a.B;
+        a.nRec = nmf_bintile_records(a.F); a.tileStat = nmf_bintile_records_ptr(bt, c->stripGen);
+      }
+#endif
       launch_nmf_strip(a, c->ctx->stream);
       c->stripNormFresh = true;
     }
@@ -1732,7 +1803,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
   out8[4] = c->sideW ? 1 : 0;
   out8[5] = c->stripsW;
   out8[6] = c->Kp;
-  out8[7] = c->strip ? (c->stripBin ? 2 : 1) : 0; // 2: the W update as a bin-strip launch
+  out8[7] = c->strip ? (c->stripTile ? 3 : (c->stripBin ? 2 : 1)) : 0; // 2: the W update as a bin-strip launch (A/B); 3: as the bin-tiled launch
   return FLUHIP_OK;
 }
 

@@ -254,6 +254,9 @@ struct fluhip_corpus
   // numerator partials of the whole matrix, no reduce launch, the strip kernel runs its H phase only
   bool stripBin = false;
   DevBuf binWork;
+  bool stripTile = false;      // round 5: the W update as the bin-tiled launch (kernels_nmf_bintile.hip)
+  bool stripSideReady = false; // the Nyquist bin's numerator partials of the next W update are in tileWork
+  DevBuf tileWork;
   bool haveMag = false, haveFactors = false;
   bool touched = false; // work that reads the audio has been enqueued on the compute stream
   // Seed / Fixed factors of the batched form (fluhip_corpus_set_factors): host copies, [B][K][F] and [B][K][T] floats

@@ -242,6 +242,7 @@ struct StripArgs
   double* sideOut = nullptr;
 };
 bool nmf_strip_supported(int F, int T, int Kp);
+bool nmf_strip_tile_supported(int F, int T, int Kp); // ... with the bin-tiled W update (StripArgs::tileStat)
 int nmf_strip_workgroups(int T);
 int64_t nmf_strip_part_doubles(int F, int T, int B);
 void launch_nmf_strip(const StripArgs& a, hipStream_t s);

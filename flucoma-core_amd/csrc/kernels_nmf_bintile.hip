@@ -29,6 +29,8 @@
 #include "fluhip_kernels.h"
 #include "nmf_tile_stats.h"
 
+#ifdef FLUHIP_AB_SWITCHES // (measured slower than the fused form at config 2, profiles/r05/c2_bintile.md: A/B build only)
+
 #include <algorithm>
 
 namespace fluhip {
@@ -49,7 +51,9 @@ struct TileK
   double* statOut;       // ... of the W' this launch leaves
   const double* sidePart; // [B][nSideWG][16] numerator partials of bin F - 1, or null (no side row)
   int nSideWG;
-  int F, K, nRec, nStages, wPend;
+  int F, K, nRec, nSteps, wPend;
+  int dbg; // A/B build, FLUHIP_TILE_DBG (timing experiments, results wrong): 1 = no H refills, 2 = no V refills, 4 = no frame loop,
+           // 8 = no ring fill in the prologue, 16 = one statistics record instead of all
 };
 
 #define MFMA44(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
@@ -69,25 +73,33 @@ __device__ __forceinline__ double dppmov(double v)
   return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
 }
 
-// One stage of a wavefront's rings = 32 frames: V 4 bins x 32 frames (1 KB, one DMA), H 32 frames x 16 (4 KB, four DMAs).
-// LDS images (the DMA writes lane * 16 linearly, so the arrangement is applied to the SOURCE addresses):
+// A wavefront walks its frames in STEPS of 16 (one 4x4x4 four-block tile: 4 bins x 4 quads of 4 frames).  Rings per
+// wavefront: H in stages of one step (16 frames x 16 = 2 KB, two DMAs), V in units of two steps (4 bins x 32 frames = 1 KB,
+// one DMA).  LDS images (the DMA writes lane * 16 linearly, so the arrangement is applied to the SOURCE addresses):
 //   V  row r (bin) at r * 256, its 16-byte chunks rotated by (r & 1) + 8 (r >> 1): the 32 lanes of a ds_read_b64 group
 //      (frames 4 blk + y, y in {0, 1} or {2, 3}, all four bins) hit 32 different 8-byte slots
 //   H  frame t at t * 128, chunk c at position c ^ g(t), g(t) = bit 2 of t | bit 1 of t << 2: both operand read patterns
 //      (frame by x, chunks by y; frame by y, chunks by x) touch 16 different 16-byte slots per ds_read_b128 lane group
-//      (searched exhaustively over the XOR-linear maps: tools/README.md "bintile swizzle")
+//      (searched exhaustively over the XOR-linear maps of t; PMC: SQ_LDS_BANK_CONFLICT ~ 0)
+// Why 16 wavefronts of 9 KB and not fewer with deeper rings (profiles/r05/c2_bintile.md): a step is ONE dependent chain --
+// LDS reads -> first product -> sum, max, rcp, Newton, multiply -> second product -- of ~1 000 cycles for 128 cycles of matrix
+// work; the first form (8 wavefronts, 32-frame stages) ran 19 us with or without its memory traffic.  Four wavefronts per
+// SIMD hide each other's chains.
 __device__ __forceinline__ int hswz(int t) { return ((t >> 2) & 1) | (((t >> 1) & 1) << 2); }
 
 template <int NW, int NSV, int NSH>
 __global__ __launch_bounds__(64 * NW) void nmf_bintile_kernel(TileK a)
 {
-  static_assert(NSV >= NSH && NSH >= 2, "ring depths");
-  constexpr int VSTG = 1024, HSTG = 4096;
+  static_assert(NW == 16, "column statistics: one wavefront per column");
+  static_assert(NSH == 3 && NSV == 3, "the wait counts below are written for rings of three steps / three units");
+  constexpr int VSTG = 1024, HSTG = 2048;
   constexpr int WAVE_LDS = NSV * VSTG + NSH * HSTG;
-  constexpr int UNR = (NSV % NSH == 0) ? NSV : NSV * NSH; // slots repeat together
+  constexpr int UNR = 2 * NSV * NSH / ((2 * NSV) % NSH == 0 ? NSH : 1) / (NSH % (2 * NSV) == 0 ? 2 * NSV : 1); // steps after which slots repeat
+  static_assert(UNR % 2 == 0 && UNR % NSH == 0 && UNR % (2 * NSV) == 0, "unroll");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __shared__ double sc[48], nrmL[16], csL[16], denL[16], sideL[16];
 
+  if (a.dbg & 32) return; // (timing experiment: what an empty launch of this shape costs)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int x = lane & 3, blk = (lane >> 2) & 3, y = lane >> 4;
@@ -97,9 +109,11 @@ __global__ __launch_bounds__(64 * NW) void nmf_bintile_kernel(TileK a)
   const double* Hg = a.H + (int64_t) b * a.strideH;
   double* Wg = a.W + (int64_t) b * a.strideW;
 
-  // this wavefront's stages (32 frames each), dealt evenly
-  const int base = a.nStages / NW, rem = a.nStages % NW;
+  // this wavefront's steps (16 frames each), dealt evenly; a V unit is two of ITS steps (an odd count leaves half of the
+  // last unit unused: 128 bytes of the next wavefront's frames or of the row's padding are read and ignored)
+  const int base = a.nSteps / NW, rem = a.nSteps % NW;
   const int sBeg = wv * base + min(wv, rem), cnt = base + (wv < rem ? 1 : 0);
+  const int lastUnit = (cnt - 1) >> 1;
 
   unsigned char* vring = smem + wv * WAVE_LDS;
   unsigned char* hring = vring + NSV * VSTG;
@@ -113,51 +127,49 @@ __global__ __launch_bounds__(64 * NW) void nmf_bintile_kernel(TileK a)
     const int srcc = (pos - ((r & 1) + 8 * (r >> 1))) & 15;
     voff = (unsigned) ((r * a.ldT + 2 * srcc) * 8);
   }
-  unsigned hoff[4];
+  unsigned hoff[2];
 #pragma unroll
-  for (int j = 0; j < 4; j++)
+  for (int j = 0; j < 2; j++)
   {
     const int t = 8 * j + (lane >> 3), cp = lane & 7;
     hoff[j] = (unsigned) (t * 128 + ((cp ^ hswz(t)) * 16));
   }
-  auto issue_v = [&](int st, int slot) {
-    const int sc_ = sBeg + min(st, cnt - 1); // past the end: a harmless re-read of the last stage
-    glds16(VT + (int64_t) sc_ * 32, voff, vringA + slot * VSTG);
+  auto issue_v = [&](int unit, int slot) {
+    const int u_ = min(unit, lastUnit); // past the end: a harmless re-read of the last unit
+    glds16(VT + (int64_t) (sBeg + 2 * u_) * 16, voff, vringA + slot * VSTG);
   };
   auto issue_h = [&](int st, int slot) {
-    const int sc_ = sBeg + min(st, cnt - 1);
-    const double* src = Hg + (int64_t) sc_ * 32 * 16;
+    const int s_ = sBeg + min(st, cnt - 1);
+    const double* src = Hg + (int64_t) s_ * 16 * 16;
 #pragma unroll
-    for (int j = 0; j < 4; j++) glds16(src, hoff[j], hringA + slot * HSTG + j * 1024);
+    for (int j = 0; j < 2; j++) glds16(src, hoff[j], hringA + slot * HSTG + j * 1024);
   };
-  if (cnt > 0)
+  if (cnt > 0 && !(a.dbg & 8))
   {
-    // issue order of the steady state from the start (V then H per step), the extra depth of the V ring first
-#pragma unroll
-    for (int t = 0; t < NSV - NSH; t++) issue_v(t, t);
-#pragma unroll
-    for (int j = 0; j < NSH; j++)
-    {
-      issue_v(NSV - NSH + j, NSV - NSH + j);
-      issue_h(j, j);
-    }
+    // the issue order of the steady state from the start -- an odd step issues V then H, an even step H: five requests per
+    // two steps -- so that "at most 5 requests outstanding" means "step s has landed" at every wait
+    static_assert(NSV == 3, "prologue order");
+    issue_v(0, 0);
+    issue_v(1, 1); issue_h(0, 0);
+    issue_h(1, 1);
+    issue_v(2, 2); issue_h(2, 2);
   }
 
   // ---- prologue requests: statistics records, this lane's stationary rows, the old values of the final threads ----------
-  const TileStatRaw straw = tile_column_stats_load(a.statIn + (int64_t) b * 48 * a.nRec, a.nRec, tid);
+  const TileStatRaw<4> straw = tile_column_stats_load<4>(a.statIn + (int64_t) b * 48 * a.nRec, (a.dbg & 16) ? 1 : a.nRec, tid);
   d2 wr[2];
   {
     const double* wp = Wg + (int64_t) (f0 + x) * 16 + 4 * y;
     wr[0] = *reinterpret_cast<const d2*>(wp);
     wr[1] = *reinterpret_cast<const d2*>(wp + 2);
   }
-  const int fr = tid >> 4, fk = tid & 15; // final threads (tid < 64): bin f0 + fr, component fk
+  const int fr = (tid >> 4) & 3, fk = tid & 15; // final threads (tid < 64): bin f0 + fr, component fk
   double wold = 0.0;
   if (tid < 64) wold = Wg[(int64_t) (f0 + fr) * 16 + fk];
   // side row (last tile workgroup): the partials of bin F - 1's numerator, thread (group tid >> 4, component tid & 15)
   const bool side = a.sidePart != nullptr && rec == a.nRec - 1;
   constexpr int SG = 4 * NW; // groups of 16 threads
-  constexpr int SU = 8;      // partials per thread and round
+  constexpr int SU = 4;      // partials per thread and round
   double sp[SU];
   double woldN = 0.0;
   if (side)
@@ -169,90 +181,72 @@ __global__ __launch_bounds__(64 * NW) void nmf_bintile_kernel(TileK a)
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  tile_column_stats(straw, a.nRec, a.K, a.wPend, sc, nrmL, csL, tid);
+  tile_column_stats<4>(straw, a.nRec, a.K, a.wPend, sc, nrmL, csL, tid);
   double wB[4]; // Wn[bin x][4 y + c]
 #pragma unroll
   for (int c = 0; c < 4; c++) wB[c] = wr[c >> 1][c & 1] / nrmL[4 * y + c];
 
-  // ---- LDS read addresses (bytes within a stage), [chunk of 16 frames h][16-byte half cc] --------------------------------
-  int offA[2][2], offB[2][2], offV[2];
-#pragma unroll
-  for (int h = 0; h < 2; h++)
+  // ---- LDS read addresses (bytes within a stage / unit) -------------------------------------------------------------------
+  int offA[2], offB[2], offV[2];
   {
-    const int tA = 16 * h + 4 * blk + x, tB = 16 * h + 4 * blk + y;
+    const int tA = 4 * blk + x, tB = 4 * blk + y;
 #pragma unroll
     for (int cc = 0; cc < 2; cc++)
     {
-      offA[h][cc] = tA * 128 + (((2 * y + cc) ^ hswz(tA)) * 16);
-      offB[h][cc] = tB * 128 + (((2 * x + cc) ^ hswz(tB)) * 16);
+      offA[cc] = tA * 128 + (((2 * y + cc) ^ hswz(tA)) * 16);
+      offB[cc] = tB * 128 + (((2 * x + cc) ^ hswz(tB)) * 16);
     }
-    offV[h] = x * 256 + (((16 * h + 4 * blk + y) + 2 * (x & 1) + 16 * (x >> 1)) & 31) * 8;
+#pragma unroll
+    for (int h = 0; h < 2; h++) offV[h] = x * 256 + (((16 * h + 4 * blk + y) + 2 * (x & 1) + 16 * (x >> 1)) & 31) * 8;
   }
 
+  // (every MFMA of a phase has its own accumulator: the first product's four k-chunks are summed by the VALU)
   double num[4] = {0.0, 0.0, 0.0, 0.0}, dacc[4] = {0.0, 0.0, 0.0, 0.0};
-  auto step = [&](int s, int slotV, int slotH) {
-    // stage s has landed: at most the (NSH - 1) younger steps' requests are outstanding
-    asm volatile("s_waitcnt vmcnt(%0)" : : "n"((NSH - 1) * 5) : "memory");
+  auto step = [&](int s, int half, int slotV, int slotH) {
+    // step s has landed: at most 5 younger requests are outstanding
+    asm volatile("s_waitcnt vmcnt(5)" : : : "memory");
     const unsigned char* vp = vring + slotV * VSTG;
     const unsigned char* hp = hring + slotH * HSTG;
-    double vv[2];
-    d2 ha[2][2], hb[2][2];
+    d2 ha[2], hb[2];
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-    {
-      vv[h] = *reinterpret_cast<const double*>(vp + offV[h]);
+    for (int cc = 0; cc < 2; cc++) ha[cc] = *reinterpret_cast<const d2*>(hp + offA[cc]);
+    const double vv = *reinterpret_cast<const double*>(vp + offV[half]);
 #pragma unroll
-      for (int cc = 0; cc < 2; cc++)
-      {
-        ha[h][cc] = *reinterpret_cast<const d2*>(hp + offA[h][cc]);
-        hb[h][cc] = *reinterpret_cast<const d2*>(hp + offB[h][cc]);
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory"); // the slots are read: their refill may be issued
-    issue_v(s + NSV, slotV);
-    issue_h(s + NSH, slotH);
-    double Q[2] = {0.0, 0.0};
+    for (int cc = 0; cc < 2; cc++) hb[cc] = *reinterpret_cast<const d2*>(hp + offB[cc]);
+    double Qp[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) Qp[c] = MFMA44(ha[c >> 1][c & 1], wB[c], 0.0);
+    __builtin_amdgcn_sched_barrier(0);
+    // every read of the slots has returned: the refill goes out under the matrix work (V: behind the unit's second half)
+    asm volatile("s_waitcnt lgkmcnt(0)" : : : "memory");
+    if (!(a.dbg & 2)) { if (half) issue_v((s >> 1) + NSV, slotV); }
+    if (!(a.dbg & 1)) issue_h(s + NSH, slotH);
+    __builtin_amdgcn_sched_barrier(0);
+    const double d_ = fmax((Qp[0] + Qp[1]) + (Qp[2] + Qp[3]), kEpsilon);
+    double y_ = __builtin_amdgcn_rcp(d_);
+    y_ = __builtin_fma(y_, __builtin_fma(-d_, y_, 1.0), y_);
+    const double R = vv * y_;
 #pragma unroll
     for (int c = 0; c < 4; c++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) Q[h] = MFMA44(ha[h][c >> 1][c & 1], wB[c], Q[h]);
-    double R[2];
     {
-      double d_[2], y_[2], e_[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) d_[h] = fmax(Q[h], kEpsilon);
-#pragma unroll
-      for (int h = 0; h < 2; h++) y_[h] = __builtin_amdgcn_rcp(d_[h]);
-#pragma unroll
-      for (int h = 0; h < 2; h++) e_[h] = __builtin_fma(-d_[h], y_[h], 1.0);
-#pragma unroll
-      for (int h = 0; h < 2; h++) y_[h] = __builtin_fma(y_[h], e_[h], y_[h]);
-#pragma unroll
-      for (int h = 0; h < 2; h++) R[h] = vv[h] * y_[h];
+      const double hv = hb[c >> 1][c & 1];
+      num[c] = MFMA44(R, hv, num[c]);
+      dacc[c] += hv;
     }
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-      for (int c = 0; c < 4; c++)
-      {
-        const double hv = hb[h][c >> 1][c & 1];
-        num[c] = MFMA44(R[h], hv, num[c]);
-        dacc[c] += hv;
-      }
   };
-  for (int s = 0; s < cnt; s += UNR)
+  for (int s = 0; s < ((a.dbg & 4) ? 0 : cnt); s += UNR)
   {
 #pragma unroll
     for (int u = 0; u < UNR; u++)
     {
       if (s + u >= cnt) break;
-      step(s + u, u % NSV, u % NSH);
+      step(s + u, u & 1, (u >> 1) % NSV, u % NSH);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); // the run-ahead requests have landed: the rings are free
 
   // ---- the wavefronts' numerators and column sums, in wavefront order ----------------------------------------------------
-  double* red = reinterpret_cast<double*>(smem); // [NW][4][16] numerators, then [NW][16] column sums (ring of wavefront 0)
+  double* red = reinterpret_cast<double*>(smem); // [NW][4][16] numerators, then [NW][16] column sums, then the side groups
   double* dred = red + NW * 64;
   __syncthreads(); // (every wavefront is done with its ring)
 #pragma unroll
@@ -361,7 +355,7 @@ __global__ __launch_bounds__(64) void nmf_bintile_wstats_kernel(TileK a)
 } // namespace bintile
 using namespace bintile;
 
-constexpr int kTileNW = 8, kTileNSV = 6, kTileNSH = 3;
+constexpr int kTileNW = 16, kTileNSV = 3, kTileNSH = 3;
 
 // shapes: rank <= 16 (Kp = 16), F = 4 nRec + 1 with at most 16 * kRecU records, enough tiles to occupy the part
 bool nmf_bintile_supported(int F, int T, int Kp)
@@ -385,7 +379,9 @@ static TileK make_tile(const BinTileArgs& s)
   k.statIn = s.statGen ? stat1 : stat0;
   k.statOut = s.statGen ? stat0 : stat1;
   k.sidePart = s.sidePart; k.nSideWG = s.nSideWG;
-  k.F = s.F; k.K = s.K; k.nStages = (int) (s.ldT / 32); k.wPend = s.wPend;
+  k.F = s.F; k.K = s.K; k.nSteps = (int) (s.ldT / 16); k.wPend = s.wPend;
+  static const int dbg = [] { const char* e = fluhip::ab_getenv("FLUHIP_TILE_DBG"); return e ? std::atoi(e) : 0; }();
+  k.dbg = dbg;
   return k;
 }
 double* nmf_bintile_side_area(const BinTileArgs& s) { return s.work + (int64_t) s.B * 2 * 48 * nmf_bintile_records(s.F); }
@@ -399,7 +395,7 @@ const double* nmf_bintile_records_ptr(const BinTileArgs& s, int gen)
 void launch_nmf_bintile(const BinTileArgs& s, hipStream_t st)
 {
   const TileK k = make_tile(s);
-  constexpr size_t shmem = (size_t) kTileNW * (kTileNSV * 1024 + kTileNSH * 4096);
+  constexpr size_t shmem = (size_t) kTileNW * (kTileNSV * 1024 + kTileNSH * 2048);
   static_assert(shmem + 1024 <= 160 * 1024, "LDS");
   auto kern = nmf_bintile_kernel<kTileNW, kTileNSV, kTileNSH>;
   request_dynamic_lds(kern, shmem);
@@ -415,3 +411,5 @@ void launch_nmf_bintile_wstats(const BinTileArgs& s, hipStream_t st)
 }
 
 } // namespace fluhip
+
+#endif // FLUHIP_AB_SWITCHES

@@ -28,6 +28,7 @@
 //             num[f][k] += sum_t (V/Q)[t][f] H[k][t]
 // so in both phases the first product's result registers are the second product's A operand (no shuffles).
 #include "fluhip_kernels.h"
+#include "nmf_tile_stats.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -69,6 +70,9 @@ struct StripK
   int F, T, K, nPairs, nBlk, nq, nWG, qBase, qRem;
   int doH, doW, wPend;
   long long* dbg; // FLUHIP_STRIP_INSTR: shader-clock stamps of workgroup 0 (tools/strip_timing.py)
+  const double* tileStat; // TILE instantiations: tile records [B][48][nRec] of the W' in memory (kernels_nmf_bintile.hip)
+  int nRec;
+  double* sideOut;        // doW == 2: bin F - 1's numerator partials, [B][nWG][16]
 };
 
 // LDS image of W (each wavefront keeps the bin pairs it works on): byte offset of row f, 16-byte chunk c = columns
@@ -205,7 +209,9 @@ __device__ __forceinline__ void strip_column_stats(const StripStatRaw& w, int nS
 // Q_N = sum_k W'_N[k] H[frame][k] / nrm[k], the quotient V[frame][F - 1] / max(Q_N, eps) times W'_N[k] joins the numerator of
 // the H update (alg/NMF.hpp:165-170), and the same with the NEW H gives the strip's share of bin F - 1's row of the next W
 // update's numerator (:158-160), which leaves in the partial slots that bin has in the layout of the reduce launch.
-template <int NPW, int NQ, bool INSTR, bool SIDE = false>
+// TILE (round 5): the W update is the bin-tiled launch of kernels_nmf_bintile.hip -- the column statistics come from ITS tile
+// records, and a launch with doW == 2 leaves nothing of the next W update but bin F - 1's numerator partials (a.sideOut).
+template <int NPW, int NQ, bool INSTR, bool SIDE = false, bool TILE = false>
 __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -274,7 +280,10 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   d2 wt[2][4];
   d2 Hsv[NQ][2];
   STRIP_STAMP(10)
-  const StripStatRaw straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, tid);
+  [[maybe_unused]] StripStatRaw straw;
+  [[maybe_unused]] bintile::TileStatRaw<1> traw;
+  if constexpr (TILE) traw = bintile::tile_column_stats_load<1>(a.tileStat + (int64_t) b * 48 * a.nRec, a.nRec, tid);
+  else straw = strip_column_stats_load(a.statIn + (int64_t) b * a.nBlk * kStatW, a.nBlk / 4, tid);
   __builtin_amdgcn_sched_barrier(0);
   STRIP_STAMP(11)
   {
@@ -311,7 +320,8 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
   STRIP_STAMP(9)
   *reinterpret_cast<d2*>(zeroPage + tid * 16) = d2{0.0, 0.0};
 
-  strip_column_stats(straw, a.nBlk / 4, a.K, a.wPend, red, nrmL, csL, tid, true);
+  if constexpr (TILE) bintile::tile_column_stats<1>(traw, a.nRec, a.K, a.wPend, red, nrmL, csL, tid);
+  else strip_column_stats(straw, a.nBlk / 4, a.K, a.wPend, red, nrmL, csL, tid, true);
   STRIP_STAMP(15)
   if (g == 0 && tid < 16) a.nrm[(int64_t) b * 16 + tid] = nrmL[tid];
   if (!a.doH && !a.doW) return;
@@ -537,10 +547,12 @@ __global__ __launch_bounds__(256) void nmf_strip_kernel(StripK a)
         const int tidk = lane;
         // bin F - 1's share: its 16 values sit in blocks m = k & 3 of step (last pair, e = 0) at lane x = k >> 2
         double* dst = a.part + ((int64_t) b * a.nBlk * a.nWG + 4 * g) * 64 + ((int64_t) ((a.nPairs - 1) * 2) * a.nWG * 4 + (tidk & 3)) * 64 + (tidk >> 2);
+        if constexpr (TILE) dst = a.sideOut + ((int64_t) b * a.nWG + g) * 16 + tidk; // (one partial per workgroup, strip order)
         if (kWriteThrough) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" : : "v"(dst), "v"(sN) : "memory");
         else *dst = sN;
       }
     }
+    if constexpr (TILE) return; // (the rest of the W update is the bin-tiled launch's)
     // ---- W phase: the strip's share of the next W update's numerator (alg/NMF.hpp:158-160), on the tiles the H phase
     // used (no second read of V).
     double Ha[NQ][4], Hb[NQ][4];
@@ -1065,6 +1077,13 @@ bool nmf_strip_supported(int F, int T, int Kp)
 {
   return Kp == 16 && F >= 1 && T >= 1 && strip_pairs(F) <= 36 && strip_shmem(strip_pairs(F)) <= (size_t) 160 * 1024;
 }
+// the frame-strip H update paired with the bin-tiled W update: the side-column form of the kernel (F = 32 j + 1), 3 .. 8 pair
+// slots per wavefront (fft 1024 / 2048)
+bool nmf_strip_tile_supported(int F, int T, int Kp)
+{
+  const int nPairs = strip_pairs(F);
+  return nmf_strip_supported(F, T, Kp) && nPairs >= 2 && (F - 1) % 32 == 0 && (nPairs - 1 + 3) / 4 >= 3;
+}
 // at most kNQ frame quads per workgroup: 256 workgroups (one per CU) while that holds, more for longer buffers
 int nmf_strip_workgroups(int T)
 {
@@ -1100,26 +1119,27 @@ static StripK make_k(const StripArgs& s)
   k.qRem = k.nq % k.nWG;
   k.doH = s.doH; k.doW = s.doW; k.wPend = s.wPend;
   k.dbg = reinterpret_cast<long long*>(stat1 + (int64_t) s.B * k.nBlk * kStatW);
+  k.tileStat = s.tileStat; k.nRec = s.nRec; k.sideOut = s.sideOut;
   return k;
 }
 
-template <int NPW, int NQ, bool INSTR = false, bool SIDE = false>
+template <int NPW, int NQ, bool INSTR = false, bool SIDE = false, bool TILE = false>
 static void launch_strip_t(const StripK& k, int B, hipStream_t s)
 {
   const size_t shmem = strip_shmem(k.nPairs); // <= 160 KiB: nmf_strip_supported() is what the planner asks
-  auto kern = nmf_strip_kernel<NPW, NQ, INSTR, SIDE>;
+  auto kern = nmf_strip_kernel<NPW, NQ, INSTR, SIDE, TILE>;
   request_dynamic_lds(kern, (size_t) (shmem));
   const unsigned grid = (k.doH || k.doW) ? (unsigned) k.nWG : 1u;
   hipLaunchKernelGGL(kern, dim3(grid, (unsigned) B), dim3(256), shmem, s, k);
 }
 
-template <int NPW, bool SIDE>
+template <int NPW, bool SIDE, bool TILE = false>
 static void launch_strip_q(const StripK& k, int B, hipStream_t s)
 {
   // widest strip of the launch, in frame quads: the tile loops are built for 2, 4 or 6
   const int widest = (k.nq + k.nWG - 1) / k.nWG;
-  if (widest <= 2) launch_strip_t<NPW, 2, false, SIDE>(k, B, s);
-  else if (widest <= 4) launch_strip_t<NPW, 4, false, SIDE>(k, B, s);
+  if (widest <= 2) launch_strip_t<NPW, 2, false, SIDE, TILE>(k, B, s);
+  else if (widest <= 4) launch_strip_t<NPW, 4, false, SIDE, TILE>(k, B, s);
   else
   {
     if constexpr (NPW == 9 && !SIDE)
@@ -1127,7 +1147,7 @@ static void launch_strip_q(const StripK& k, int B, hipStream_t s)
       static const int instr = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_INSTR"); return e ? std::atoi(e) : 0; }();
       if (instr && k.doH && k.doW) { launch_strip_t<9, kNQ, true>(k, B, s); return; }
     }
-    launch_strip_t<NPW, kNQ, false, SIDE>(k, B, s);
+    launch_strip_t<NPW, kNQ, false, SIDE, TILE>(k, B, s);
   }
 }
 
@@ -1141,6 +1161,16 @@ static bool strip_side(const StripK& k)
 void launch_nmf_strip(const StripArgs& a, hipStream_t s)
 {
   const StripK k = make_k(a);
+#ifdef FLUHIP_AB_SWITCHES
+  if (k.nRec > 0)
+  {
+    // the W update is the bin-tiled launch's (nmf_strip_tile_supported() is what the planner asked): tile records, side partials
+    const int npw = (k.nPairs - 1 + 3) / 4;
+    if (npw <= 4) launch_strip_q<4, true, true>(k, a.B, s);
+    else launch_strip_q<8, true, true>(k, a.B, s);
+    return;
+  }
+#endif
   if (strip_side(k))
   {
     const int npw = (k.nPairs - 1 + 3) / 4; // pair slots per wavefront without the Nyquist pair: 8 at fft 2048, 4 at fft 1024

@@ -22,6 +22,7 @@ from helpers import rel_err
 o = oracle_c.get("native")
 ctx = fluhip.Context(0)
 worst = 0.0
+WANT = 3 if os.environ.get("FLUHIP_STRIP_TILE") == "1" else (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1)
 def data(T, F):
     rs = np.random.RandomState(T * 7 + F)
     return np.abs(rs.standard_normal((T, 3)) @ rs.standard_normal((3, F))) + 0.01 * rs.uniform(0, 1, (T, F))
@@ -67,7 +68,7 @@ assert rc == fluhip.CANCELLED and seen == [1, 2, 3, 4, 5], (rc, seen)
 # a corpus of several buffers on the strip schedule
 audio = np.stack([oracle_np.synth_audio(30000, 1000 + b) for b in range(5)])
 c = fluhip.Corpus(ctx, 5, 30000, 1024, 1024, 256, 8)
-assert c.plan()["strip"] == (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1), c.plan()   # 2: bin strips for W
+assert c.plan()["strip"] == WANT, c.plan()   # 1: fused form + reduce launch, 2: bin strips for W (A/B), 3: bin-tiled W update
 c.set_audio(audio); c.stft(); c.nmf(10, seed=42)
 mag, W1, H1 = c.read_f64()
 for b in (0, 4):
@@ -79,7 +80,7 @@ for b in (0, 4):
 # ... and at fft 2048 (nine bin pairs per wavefront), three buffers, seeds per buffer
 audio = np.stack([oracle_np.synth_audio(40000, 2000 + b) for b in range(3)])
 c = fluhip.Corpus(ctx, 3, 40000, 2048, 2048, 512, 16)
-assert c.plan()["strip"] == (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1), c.plan()   # 2: bin strips for W
+assert c.plan()["strip"] == WANT, c.plan()   # 1: fused form + reduce launch, 2: bin strips for W (A/B), 3: bin-tiled W update
 c.set_audio(audio); c.stft(); c.nmf(6, seeds=[5, 6, 5])
 mag, W1, H1 = c.read_f64()
 for b in range(3):
@@ -93,13 +94,18 @@ assert worst < 1e-9, worst
 '''
 
 
-@pytest.mark.parametrize("bin_launch", ["0", "1"])
-def test_strip_schedule_against_the_oracle(ab_lib_paths, bin_launch):
-    """bin_launch 0: the fused form, W partials behind the H phase + the reduce launch (production); 1: the W update as its
-    own launch over bin strips (FLUHIP_STRIP_BIN=1, A/B build: measured slower, kept as a tested alternative)"""
+@pytest.mark.parametrize("form", ["fused", "bin_strips", "bin_tiles"])
+def test_strip_schedule_against_the_oracle(ab_lib_paths, form):
+    """fused: W partials behind the H phase + the reduce launch (what short buffers and fft 1024 get); bin_strips: the W update
+    as its own launch over bin strips with a last-arriver combine (FLUHIP_STRIP_BIN=1, A/B build: measured slower, kept as a
+    tested alternative); bin_tiles: the round-5 W update over tiles of four bins and ALL frames (kernels_nmf_bintile.hip;
+    FLUHIP_STRIP_TILE=1, A/B build: measured slower at config 2, profiles/r05/c2_bintile.md), forced here onto every shape it supports -- one and a few stages per wavefront, wavefronts without any,
+    fft 1024 and 2048, rank 1 .. 16, batches, the update-flag combinations (the Nyquist partials then come from a strip launch
+    of their own), seeded factors; shapes it does not support fall back inside the same run"""
     e = dict(os.environ)
     e["FLUHIP_STRIP"] = "1"
-    e["FLUHIP_STRIP_BIN"] = bin_launch
+    e["FLUHIP_STRIP_BIN"] = "1" if form == "bin_strips" else "0"
+    e["FLUHIP_STRIP_TILE"] = "1" if form == "bin_tiles" else "0"
     e["FLUHIP_LIB"] = ab_lib_paths[0]
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
@@ -110,6 +116,8 @@ def test_strip_schedule_is_what_config_2_gets():
     import fluhip
     ctx = fluhip.Context(0)
     c = fluhip.Corpus(ctx, 1, 60 * 44100, 2048, 2048, 512, 16)
-    assert c.plan()["strip"] == 1, c.plan()
+    assert c.plan()["strip"] == 1, c.plan()     # (the bin-tiled W update of round 5 measured slower: A/B build only)
+    c = fluhip.Corpus(ctx, 1, 453932, 1024, 1024, 512, 3)
+    assert c.plan()["strip"] == 1, c.plan()     # config 1
     c = fluhip.Corpus(ctx, 128, 10 * 44100, 2048, 2048, 512, 32)
     assert c.plan()["strip"] == 0, c.plan()
