@@ -205,6 +205,7 @@ public:
   // cc/MemoryBufferAdaptor.hpp:51-67
   void copyToOrigin(Result& r)
   {
+    mCacheTrusted = r.status() == Result::Status::kOk; // (what this copy holds is what its origin holds only behind a clean job)
     if (!mWrite || !mOrigin) return;
     BufferAdaptor::Access dst(mOrigin.get());
     if (!dst.exists()) return;
@@ -252,8 +253,12 @@ private:
       const float* base = contents ? interleavedBase(src, stride) : nullptr;
       if (!contents) // shape only (a buffer the job writes and never reads): zeros unless the cached copy already has the shape
       {
-        // (a cached copy of the same shape holds what the last job copied back to this very origin: the host's own content)
-        if (!sameShape) mData.assign(static_cast<size_t>(mFrames * mChans), 0.0f);
+        // (a cached copy of the same shape holds what the last job copied back to this very origin -- the host's own content --
+        //  IF that job ended kOk: every client writes every sample of an output it sized on success.  After a warning, an
+        //  error or a cancellation the cache may hold samples nobody wrote this time, and a later job that takes a warning
+        //  path itself would hand them to the host: then it starts from zeros.  ADVICE r04.)
+        if (!sameShape || !mCacheTrusted) mData.assign(static_cast<size_t>(mFrames * mChans), 0.0f);
+        mCacheTrusted = false; // until the job that starts now has copied back with kOk
       }
       else if (base && stride == mChans) // the same layout as this one: one pass, allocation and copy together
         mData.assign(base, base + mFrames * mChans);
@@ -310,6 +315,7 @@ private:
   index                          mFrames{0}, mChans{0};
   double                         mSampleRate{44100};
   bool                           mValid{true}, mExists{true}, mWrite{false};
+  bool                           mCacheTrusted{false}; // the samples are those of the origin (see copyFrom, contents = false)
 };
 
 } // namespace fluhip

@@ -216,7 +216,10 @@ public:
       FluidContext* c;
       int           count;
       double        total;
+      double        floor = 0.0; // least count to report (a job that fell back from the batched block does not report less than it had)
     };
+    // fraction of the whole job the batched block had reported when it handed the job to the channel loop (0: it never ran)
+    double progressFloor = 0.0;
 
     // ---- several devices: the channels run concurrently, one host thread + context per listed device --------------
     // (the reference runs them one after the other on its single thread, :233; they share no state -- a fresh
@@ -417,8 +420,15 @@ public:
                                  perChannelSeeds.empty() ? nullptr : perChannelSeeds.data(), cb, &prog);      // :268-271
         lap("nmf");
         if (rc == FLUHIP_CANCELLED || (c.task() && c.task()->cancelled())) return {S::kCancelled, ""};        // :273-274
-#ifdef FLUHIP_AB_SWITCHES // tests: a failure of the batched block behind the iterations (as an allocation of the resynthesis would be)
-        if (rc == FLUHIP_OK && std::getenv("FLUHIP_CLIENT_FAIL_BATCHED")) rc = FLUHIP_ERROR;
+        bool injectedAllocFailure = false;
+#ifdef FLUHIP_AB_SWITCHES // tests: a failure of the batched block behind the iterations -- "1": as an out-of-memory allocation of
+                          // the resynthesis would be (falls back); "other": any other error (reported at once)
+        if (rc == FLUHIP_OK)
+          if (const char* inj = std::getenv("FLUHIP_CLIENT_FAIL_BATCHED"))
+          {
+            rc = FLUHIP_ERROR;
+            injectedAllocFailure = std::strcmp(inj, "other") != 0;
+          }
 #endif
         std::vector<float> outWAll, outHAll, outRAll;
         if (hasFilters && !fixFilters) outWAll.resize(nc * static_cast<size_t>(rank * nBins));
@@ -486,7 +496,15 @@ public:
         lap("scatter to buffers");
         return {S::kOk, ""};
         }
+        // only an ALLOCATION failure is worth a second attempt with one channel's worth of memory; a device fault or
+        // an argument error would fail again after a whole second job, with the first message lost and the progress restarted
+        {
+          const char* why = fluhip_last_error(mCtx);
+          const bool  alloc = injectedAllocFailure || (why && (std::strstr(why, "out of memory") || std::strstr(why, "OutOfMemory")));
+          if (!alloc) return {S::kError, "BufNMF: ", why ? why : "the batched job failed"};
+        }
         batchedFallbacks() += 1; // (read by tests: the batched block failed and the sequential loop took the job)
+        progressFloor = prog.count / std::max(1.0, prog.total); // (the task's progress does not go backwards: see the loop below)
       }
       // the corpus could not be created, or a later allocation of the batched block failed (device memory): the
       // channel-by-channel loop below needs one channel at a time
@@ -515,10 +533,13 @@ public:
           VectorView<float>(seedH.data() + j * nWindows, nWindows) <<=
               VectorView<const float>(BufferAdaptor::Access(P.activations.get()).samps(i * rank + j));
       }
-      Prog prog{&c, 0, progressTotal};
+      // (channel i covers the fractions [i, i + 1) / nChannels of the job: what the batched block had already reported is the floor)
+      Prog prog{&c, 0, progressTotal,
+                std::min(progressTotal, std::max(0.0, (progressFloor * static_cast<double>(nChannels) - static_cast<double>(i)) * progressTotal))};
       auto cb = [](int64_t, void* u) -> int { // :261-267
         auto* p = static_cast<Prog*>(u);
-        return p->c->task() ? (p->c->task()->processUpdate(static_cast<double>(++p->count), p->total) ? 1 : 0) : 1;
+        ++p->count;
+        return p->c->task() ? (p->c->task()->processUpdate(std::max(static_cast<double>(p->count), p->floor), p->total) ? 1 : 0) : 1;
       };
       const int rc = fluhip_bufnmf_channel_f32(
           mCtx, mono.data(), nFrames, 1, fftParams.winSize(), fftParams.fftSize(), hop, rank,
@@ -547,7 +568,7 @@ public:
         for (index j = 0; j < rank; ++j)
         {
           for (int step = 0; step < 3; ++step)
-            if (c.task() && !c.task()->processUpdate(++prog.count, progressTotal)) return {S::kCancelled, ""};
+            if (c.task() && !c.task()->processUpdate(std::max(static_cast<double>(++prog.count), prog.floor), progressTotal)) return {S::kCancelled, ""};
         }
       }
     }

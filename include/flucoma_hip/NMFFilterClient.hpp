@@ -103,7 +103,9 @@ public:
           VectorView<float>(bases.data() + i * f.frameSize(), f.frameSize()) <<= filterBuffer.samps(i);
       }
     }
-    const index nOut = rank > 0 ? rank : P.maxComponents; // audioChannelsOut(): maxComponents as constructed (:57)
+    // audioChannelsOut() is maxComponents as constructed and never narrows (rt/NMFFilterClient.hpp:57-59; only NMFMatch narrows
+    // its control outputs to the bases' rank): channels past the rank stay silent.  ADVICE r04.
+    const index nOut = P.maxComponents;
 
     BufferAdaptor::ReadAccess source(P.source.get());
     const double              sampleRate = source.sampleRate();
@@ -116,9 +118,17 @@ public:
       for (index i = 0; i < nChans; ++i) // :499-509
         VectorView<float>(audio.data() + i * nFrames, nFrames) <<= source.samps(P.startFrame, nFrames, P.startChan + i);
       if (c.task() && !c.task()->iterationUpdate(0.0, 1.0)) return {S::kCancelled, ""};
+      // the device writes channels x rank rows; the output buffer has maxComponents rows per channel
+      std::vector<float> dense;
+      float*             dst = out.data();
+      if (rank != nOut) { dense.resize(static_cast<size_t>(nChans * rank * nFrames)); dst = dense.data(); }
       const int rc = fluhip_nmffilter_f32(mDevice.get(), audio.data(), nChans, nFrames, f.winSize(), f.fftSize(), f.hopSize(),
-                                          bases.data(), rank, P.iterations, P.seed, out.data());
+                                          bases.data(), rank, P.iterations, P.seed, dst);
       if (rc != FLUHIP_OK) return mDevice.result(rc);
+      if (rank != nOut)
+        for (index i = 0; i < nChans; ++i)
+          for (index j = 0; j < rank; ++j)
+            std::memcpy(out.data() + (i * nOut + j) * nFrames, dense.data() + (i * rank + j) * nFrames, sizeof(float) * static_cast<size_t>(nFrames));
     }
     // :526-530 reports progress per host vector; the batch is one step
     if (FluidTask* task = c.task())

@@ -254,6 +254,10 @@ def test_client_batched_failure_falls_back_to_the_channel_loop(driver, tmp_path,
         outs[tag] = [read_buffer(prefix + s)[0] for s in ("_bases.bin", "_acts.bin", "_resynth.bin")]
     for a, b in zip(outs["batched"], outs["failed"]):
         assert a.shape == b.shape and rel_err(a, b) < 1e-6
+    # ... and only an ALLOCATION failure is worth the second attempt: any other error comes back at once
+    r = run(driver, "run", inp, frames, chans, win, hop, fft, K, iters, seed, 0, 0, 1, 0, -1, 0, -1, str(tmp_path / "other"),
+            env={"FLUHIP_CLIENT_FAIL_BATCHED": "other", "CLIENT_RESYNTH": "1"})
+    assert r["result"][0] == ERROR and r["fallbacks"][0] == 0, r
 
 
 @pytest.mark.gpu
@@ -493,8 +497,8 @@ def test_nmfmatch_client(driver, onp, tmp_path, use_async, ctx):
 @pytest.mark.parametrize("use_async", [0, 1])
 def test_nmffilter_client(driver, onp, tmp_path, use_async, ctx):
     """NRTThreadedNMFFilterClient (include/flucoma_hip/NMFFilterClient.hpp): NMFFilter behind the reference's Streaming
-    wrapper -- two channels, three components, sync and async: resynth buffer of frames x (channels * rank) at the source's
-    sample rate, component j of channel i in buffer channel i * rank + j, against the numpy restatement; the components of
+    wrapper -- two channels, three components, sync and async: resynth buffer of frames x (channels * maxComponents) at the source's
+    sample rate, component j of channel i in buffer channel i * maxComponents + j, against the numpy restatement; the components of
     a channel add back up to it; a bases buffer of the wrong frame count leaves zeros (rt/NMFFilterClient.hpp:93)"""
     frames, chans, win, hop, fft, K, iters, seed = 15000, 2, 1024, 512, 1024, 3, 10, 42
     F = fft // 2 + 1
@@ -507,12 +511,16 @@ def test_nmffilter_client(driver, onp, tmp_path, use_async, ctx):
     r = run(driver, "nmffilter", inp, frames, chans, win, hop, fft, 20, iters, seed, bf, K, use_async, prefix)
     assert r["result"] == (OK, "")
     out, sr = read_buffer(prefix + "_resynth.bin")
-    assert out.shape == (chans * K, frames) and sr == pytest.approx(44100.0)
+    # maxComponents (20) outputs per channel whatever the rank of the bases (rt/NMFFilterClient.hpp:57-59: audioChannelsOut is
+    # fixed at construction): the K live ones first, the rest silent
+    M = 20
+    assert out.shape == (chans * M, frames) and sr == pytest.approx(44100.0)
     for c in range(chans):
         x = np.ascontiguousarray(audio[:, c]).astype(np.float32)
         ref = onp.nmffilter_channel(x, bases, win, fft, hop, iters, seed)
-        assert np.abs(out[c * K:(c + 1) * K] - ref).max() / np.abs(ref).max() < 1e-5, c
-        assert np.abs(out[c * K:(c + 1) * K].sum(axis=0) - x).max() < 1e-4
+        assert np.abs(out[c * M:c * M + K] - ref).max() / np.abs(ref).max() < 1e-5, c
+        assert np.abs(out[c * M:c * M + K].sum(axis=0) - x).max() < 1e-4
+        assert not out[c * M + K:(c + 1) * M].any()
     bases[:, :100].tofile(tmp_path / "short.f32")                 # 100 frames instead of 513
     r = run(driver, "nmffilter", inp, frames, chans, win, hop, fft, 2, iters, seed, tmp_path / "short.f32", K, use_async, prefix + "0")
     assert r["result"] == (OK, "")

@@ -130,6 +130,26 @@ def test_c5_multi_chunk_feature_path(ab_ctx, oracle, onp, fused):
         assert rel_err(out[b], ref) < 1e-5
 
 
+def test_c5_production_library_crosses_its_2_gib_chunk(ctx, oracle, onp):
+    """the PRODUCTION library's own chunk loop (api_features.hip: staging chunks of 2 GiB, which the test above only reaches in
+    the A/B build with shrunken chunks): 6 200 slices of 2 s = 2.19 GB of audio in one fluhip_bufmfcc_f32 call, neighbouring
+    slices different, every slice against the single-slice call of its audio, boundary slices against the oracle"""
+    n, win, fft, hop = 88200, 1024, 1024, 512
+    distinct = np.stack([onp.synth_audio(n, 1000 + b) for b in range(16)])
+    count = 6200
+    per_chunk = (2 << 30) // (n * 4)
+    assert per_chunk < count, "the call must cross the chunk boundary"
+    order = (np.arange(count) * 7) % 16
+    singles = [ctx.bufmfcc(distinct[i][None, :], win, fft, hop)[0] for i in range(16)]
+    out = ctx.bufmfcc(distinct[order], win, fft, hop)
+    assert out.shape == (count, 13, 173)
+    for b in range(count):
+        assert np.array_equal(out[b], singles[order[b]]), b
+    for b in (0, per_chunk - 1, per_chunk, per_chunk + 1, count - 1):
+        ref = oracle.bufmfcc_channel(distinct[order[b]], win, fft, hop)
+        assert rel_err(out[b], ref) < 1e-5, b
+
+
 def test_c5_device_resident_corpus(ctx, onp):
     """audio and features already in HBM (what a device-side pipeline hands over): same floats as the host-buffer call"""
     import ctypes

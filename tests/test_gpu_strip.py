@@ -23,6 +23,8 @@ o = oracle_c.get("native")
 ctx = fluhip.Context(0)
 worst = 0.0
 WANT = 3 if os.environ.get("FLUHIP_STRIP_TILE") == "1" else (2 if os.environ.get("FLUHIP_STRIP_BIN") == "1" else 1)
+if os.environ.get("STRIP_TEST_PRODUCTION") == "1":
+    WANT = 0   # the production library takes the schedule for SINGLE buffers on its own; batches stay with the batched kernels
 def data(T, F):
     rs = np.random.RandomState(T * 7 + F)
     return np.abs(rs.standard_normal((T, 3)) @ rs.standard_normal((3, F))) + 0.01 * rs.uniform(0, 1, (T, F))
@@ -94,19 +96,25 @@ assert worst < 1e-9, worst
 '''
 
 
-@pytest.mark.parametrize("form", ["fused", "bin_strips", "bin_tiles"])
-def test_strip_schedule_against_the_oracle(ab_lib_paths, form):
-    """fused: W partials behind the H phase + the reduce launch (what short buffers and fft 1024 get); bin_strips: the W update
+@pytest.mark.parametrize("form", ["production", "fused", "bin_strips", "bin_tiles"])
+def test_strip_schedule_against_the_oracle(ab_lib_paths, fluhip_lib_path, form):
+    """production: the shipped library, no switches.  fused: W partials behind the H phase + the reduce launch (what short buffers and fft 1024 get); bin_strips: the W update
     as its own launch over bin strips with a last-arriver combine (FLUHIP_STRIP_BIN=1, A/B build: measured slower, kept as a
     tested alternative); bin_tiles: the round-5 W update over tiles of four bins and ALL frames (kernels_nmf_bintile.hip;
     FLUHIP_STRIP_TILE=1, A/B build: measured slower at config 2, profiles/r05/c2_bintile.md), forced here onto every shape it supports -- one and a few stages per wavefront, wavefronts without any,
     fft 1024 and 2048, rank 1 .. 16, batches, the update-flag combinations (the Nyquist partials then come from a strip launch
     of their own), seeded factors; shapes it does not support fall back inside the same run"""
     e = dict(os.environ)
-    e["FLUHIP_STRIP"] = "1"
-    e["FLUHIP_STRIP_BIN"] = "1" if form == "bin_strips" else "0"
-    e["FLUHIP_STRIP_TILE"] = "1" if form == "bin_tiles" else "0"
-    e["FLUHIP_LIB"] = ab_lib_paths[0]
+    if form == "production":
+        # the PRODUCTION library (it reads no switches): every single-buffer shape of the script that the planner gives the
+        # schedule by itself -- rank <= 16, F <= 1120, one round of workgroups -- runs the same kernels the A/B build is forced onto
+        e["FLUHIP_LIB"] = fluhip_lib_path
+        e["STRIP_TEST_PRODUCTION"] = "1"
+    else:
+        e["FLUHIP_STRIP"] = "1"
+        e["FLUHIP_STRIP_BIN"] = "1" if form == "bin_strips" else "0"
+        e["FLUHIP_STRIP_TILE"] = "1" if form == "bin_tiles" else "0"
+        e["FLUHIP_LIB"] = ab_lib_paths[0]
     p = subprocess.run([sys.executable, "-c", SCRIPT, ROOT], capture_output=True, text=True, timeout=900, env=e)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
 

@@ -205,10 +205,22 @@ def run_c5(ctx, with_cpu):
         _, ms_feat = ctx.prof_read(2)
         ctx.prof_enable(False)
         nbytes = (hop * 4.0 + nc * 4.0) * frames
+        # Both roofs.  HBM: the samples in, the coefficients out.  FP64 vector: the arithmetic of a frame --
+        # 2.5 fft log2(fft) for the half-size complex transform + split, fft for the window, 3 F for the magnitudes, the 40
+        # triangular bands as two running sums over the bins (4 F), dB (~20 per band) and the DCT rows (2 bands coefficients)
+        # -- against the FP64 VALU peak (= the FP64 matrix peak on this part).  The binding roof is the one that gives the
+        # LONGER time; the kernel's distance from it is the fraction to read.
+        F = fft // 2 + 1
+        flops = frames * (2.5 * fft * np.log2(fft) + fft + 3.0 * F + 4.0 * F + 20.0 * 40 + 2.0 * 40 * nc)
+        t_hbm, t_valu = nbytes / (PEAK_HBM_GBS * 1e9), flops / (PEAK_FP64_TFLOPS * 1e12)
+        bound = "fp64_valu" if t_valu > t_hbm else "hbm"
+        roofs = {"hbm": {"achieved": nbytes / dd / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": t_hbm / dd, "bytes": nbytes},
+                 "fp64_valu": {"achieved": flops / dd / 1e12, "peak": PEAK_FP64_TFLOPS, "unit": "TFLOP/s", "frac": t_valu / dd, "flop": flops}}
         res.update({"value": frames / dd, "ms": dd * 1e3, "kernel_ms": {"stft": ms_stft, "features": ms_feat},
-                    "roofline": {"bound": "hbm", "achieved": nbytes / dd / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                 "frac": nbytes / dd / 1e9 / PEAK_HBM_GBS, "bytes": nbytes, "traffic": None,
-                                 "per": "whole call, audio and features resident in HBM"}})
+                    "roofline": {"bound": bound, **{k: v for k, v in roofs[bound].items()}, "traffic": None,
+                                 "per": "whole call, audio and features resident in HBM", "roofs": roofs,
+                                 "note": "the binding roof is the one whose floor is the longer time; counters put the kernel "
+                                         "at ~800 VALU instructions per frame, 330 of them not FP64 (profiles/r04/c5_sq_counters.json)"}})
     else:
         res["value"] = frames / dt_host
     if with_cpu:
