@@ -398,6 +398,7 @@ def test_c1_on_the_named_input(ctx, oracle):
     rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, seed)
     assert rel_err(mag[0], rmag) < TOL_STFT
     assert rel_err(W1[0], rW) < TOL_FACTORS_TIGHT and rel_err(H1[0], rH) < TOL_FACTORS_TIGHT
+    assert elementwise_rel_err(W1[0], rW) < TOL_FACTORS and elementwise_rel_err(H1[0], rH) < TOL_FACTORS
 
 
 def test_bufnmf_seeded_and_fixed_bases(ctx, oracle, onp):
