@@ -114,6 +114,11 @@ static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
 }
 
 static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
+static bool offsize_enabled()
+{
+  static const int offEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_OFFSIZE"); return e ? std::atoi(e) : 1; }();
+  return offEnv != 0;
+}
 // where the work-list form beats the uniform split schedule for equal-length corpora (tools/batch_timing.py with
 // FLUHIP_LIST_PLAN=0|1, profiles/r03/small_batches_*.jsonl)
 struct PlanShape { int64_t B, T, F, Kp; }; // what the choice of schedule depends on (also reachable without a corpus: fluhip_debug_plan_kind)
@@ -270,6 +275,13 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
       }
     }
   }
+  // Off-size ranks (round 5): 33 .. 48 and 65 .. 96 keep the ARRAYS of rank 64 / 128 -- every helper kernel runs its rank-64 /
+  // rank-128 form on zero columns -- and the factor updates compute 12 / 24 MFMAs per product instead of 16 / 32
+  // (kernels_nmf5.hip KPM): three quarters of the matrix work of the padded rank.  The plain and the split-contraction
+  // schedules and the work lists; the strip schedule (rank <= 16) has no off-size rank.
+  // FLUHIP_OFFSIZE=0 (A/B build): the padded forms, for the comparison.
+  c->Kc = (offsize_enabled() && c->lazy && !c->strip && update_variant((int) c->Kp) == 5)
+              ? nmf_update5_compute_rank((int) c->K, (int) c->Kp) : (int) c->Kp;
   if (int rc = alloc_update_scratch(ctx, c)) return rc;
   HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
   if (c->lazy)
@@ -592,6 +604,7 @@ static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)
   hipStream_t s = ctx->stream;
   const int B = (int) c->B, Kp = (int) c->Kp;
   c->lazy = true; c->strip = false;
+  c->Kc = offsize_enabled() ? nmf_update5_compute_rank((int) c->K, Kp) : Kp; // (off-size ranks: see plan_updates)
   ListPlanHost plan;
   build_list_plan(c->tOf, (int) c->T, (int) c->F, Kp, plan);
   c->sideW = plan.sideW;
@@ -982,7 +995,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.V = magTW; a.ldv = c->Tp; a.strideV = c->Fp * c->Tp;
     a.Mv = WfW; a.strideM = c->Fp * c->Kp;
     a.S = H1W; a.strideS = c->Tp * c->Kp;
-    a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp;
+    a.R = (int) c->F; a.C = (int) c->T; a.B = Bw; a.Kp = (int) c->Kp; a.Kc = c->Kc;
     if (c->winB) a.stripsOverride = c->winStripsH;
     a.nsplit = c->nsplitH; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Tp; a.colsumScratch = c->csumScratch.as<double>();
@@ -1016,7 +1029,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
     a.V = magW; a.ldv = c->Fp; a.strideV = c->Tp * c->Fp;
     a.Mv = H1W; a.strideM = c->Tp * c->Kp;
     a.S = WfW; a.strideS = c->Fp * c->Kp;
-    a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = Bw; a.Kp = (int) c->Kp;
+    a.R = (int) c->T; a.C = (int) c->F - (c->sideW ? 1 : 0); a.B = Bw; a.Kp = (int) c->Kp; a.Kc = c->Kc;
     if (c->winB) a.stripsOverride = c->winStripsW;
     a.nsplit = c->nsplitW; a.part = c->part.as<double>(); a.dpart = c->dpart.as<double>();
     a.Cp = c->useLists ? std::max(c->Fp, c->Tp) : c->Fp; a.colsumScratch = c->csumScratch.as<double>();
@@ -1802,7 +1815,7 @@ int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
   out8[3] = c->lazy ? 1 : 0;
   out8[4] = c->sideW ? 1 : 0;
   out8[5] = c->stripsW;
-  out8[6] = c->Kp;
+  out8[6] = c->Kp | ((int64_t) (c->Kc > 0 ? c->Kc : c->Kp) << 16); // (the rank the factor updates compute in the high half)
   out8[7] = c->strip ? (c->stripTile ? 3 : (c->stripBin ? 2 : 1)) : 0; // 2: the W update as a bin-strip launch (A/B); 3: as the bin-tiled launch
   return FLUHIP_OK;
 }

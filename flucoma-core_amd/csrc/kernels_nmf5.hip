@@ -171,10 +171,16 @@ __device__ __forceinline__ double quad_dpp(double v)
 // of a launch in between (5.7 us + a kernel boundary per iteration of the bench shard).  The wavefronts of a buffer all store
 // the (identical) side row; strip 0 stores the norms.  Nothing in this launch reads either back from memory except each
 // wavefront's own last DMA stage (row R - 1 of W'), 270 us behind its own store.
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0, int SIDEQ = 0>
+// KPM (round 5): the rank the ARRAYS are laid out for (row stride of S and Mv, of the per-buffer vectors and of the statistics /
+// partial records), KPM >= KP = 4 M the rank the kernel computes.  KPM > KP serves the off-size ranks: 33 .. 48 compute twelve
+// MFMAs per product on the layout of rank 64 (every helper kernel keeps its rank-64 form; components 48 .. 63 are zero
+// and are neither read nor written here), 65 .. 96 twenty-four on the layout of rank 128 -- three quarters of the matrix work
+// the padded form pays (clients/nrt/NMFClient.hpp:68: `components` is any integer >= 1).
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int LIST = 0, int SIDEQ = 0, int KPM = 4 * M>
 __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 {
   constexpr int KP = 4 * M;
+  static_assert(KPM >= KP && KPM % 16 == 0, "array rank");
   constexpr int SPR = KP / 2;                      // 16-byte chunks per Mv row
   constexpr int NJV = (32 * NG + 63) / 64;         // DMA instructions per V stage
   constexpr int NJM = (4 * SPR + 63) / 64;         // DMA instructions per Mv stage
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     if (row > 3) row = 3;
     const int cs = (pos - row + SPR) % SPR;          // undo the per-row rotation ...
     const int c = cs ^ (((cs >> 4) & 3) << 2);         // ... and the XOR of slot bits 2-3 with bits 4-5
-    moffs[j] = (unsigned) ((row * KP + c * 2) * 8);    // slot pos of row `row` holds chunk c
+    moffs[j] = (unsigned) ((row * KPM + c * 2) * 8);    // slot pos of row `row` holds chunk c
   }
 
   int s0, s1;
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     const int sc = min(st, sLast); // past the end: harmless re-read of the last step
     const int slot = st % NS;
     const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16); // uniform
-    const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);                        // uniform
+    const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KPM);                        // uniform
 #pragma unroll
     for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + slot * VSTAGE + j * 1024);
 #pragma unroll
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       {
         const int sc = min(s0 + t, sLast);
         const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
-        const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+        const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KPM);
 #pragma unroll
         for (int j = 0; j < NJV; j++) FLUHIP_GLDS(vsrc + voffs[j], vring + t * VSTAGE + j * 1024);
 #pragma unroll
@@ -358,14 +364,14 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int u = 0; u < 8; u++) { cs[u] = 0.0; cm[u] = -INFINITY; cn[u] = 0.0; cd[u] = 0.0; }
     if (lane < KP)
     {
-      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KP + lane;
-      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KP + lane;
-      cwo = a.cmbWold[(int64_t) buf * KP + lane];
+      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KPM + lane;
+      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KPM + lane;
+      cwo = a.cmbWold[(int64_t) buf * KPM + lane];
 #pragma unroll
       for (int u = 0; u < 8; u++)
       {
-        if (u < a.cmbParts) { cs[u] = sp[(int64_t) u * 2 * KP]; cm[u] = sp[(int64_t) u * 2 * KP + KP]; }
-        if (u < a.cmbSlices) { cn[u] = qp[(int64_t) u * 2 * KP]; cd[u] = qp[(int64_t) u * 2 * KP + KP]; }
+        if (u < a.cmbParts) { cs[u] = sp[(int64_t) u * 2 * KPM]; cm[u] = sp[(int64_t) u * 2 * KPM + KPM]; }
+        if (u < a.cmbSlices) { cn[u] = qp[(int64_t) u * 2 * KPM]; cd[u] = qp[(int64_t) u * 2 * KPM + KPM]; }
       }
     }
   }
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     sideL = lds + WPB * WAVE_REGION + wave * (1 + NJSV) * 1024;
     if constexpr (!NORMQ)
     {
-      const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KP) + min(lane, SPR - 1) * 16;
+      const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KPM) + min(lane, SPR - 1) * 16;
       FLUHIP_GLDS(wsrc, sideL);
     }
 #pragma unroll
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   {
 #pragma unroll
     for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
-    if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KP + M * y);
+    if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KPM + M * y);
   }
   if constexpr (NORMQ)
   {
@@ -405,10 +411,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     for (int u = 0; u < 8; u++) { t += cs[u]; mv = fmax(mv, cm[u]); n += cn[u]; d += cd[u]; }
     if (lane < KP)
     {
-      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KP + lane;
-      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KP + lane;
-      for (int j = 8; j < a.cmbParts; j++) { t += sp[(int64_t) j * 2 * KP]; mv = fmax(mv, sp[(int64_t) j * 2 * KP + KP]); }
-      for (int j = 8; j < a.cmbSlices; j++) { n += qp[(int64_t) j * 2 * KP]; d += qp[(int64_t) j * 2 * KP + KP]; }
+      const double* sp = a.cmbStat + (int64_t) buf * a.cmbParts * 2 * KPM + lane;
+      const double* qp = a.cmbSide + (int64_t) buf * a.cmbSlices * 2 * KPM + lane;
+      for (int j = 8; j < a.cmbParts; j++) { t += sp[(int64_t) j * 2 * KPM]; mv = fmax(mv, sp[(int64_t) j * 2 * KPM + KPM]); }
+      for (int j = 8; j < a.cmbSlices; j++) { n += qp[(int64_t) j * 2 * KPM]; d += qp[(int64_t) j * 2 * KPM + KPM]; }
     }
     // the side row (not normalised, like every other row of W') and alg/NMF.hpp:162 for the whole column
     const bool liveK = lane < a.cmbK;
@@ -423,8 +429,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     {
       ldsW[lane] = wnew;
       ldsW[64 + lane] = nv;
-      a.cmbRowOut[(int64_t) buf * a.strideM + (int64_t) (a.R - 1) * KP + lane] = wnew;
-      if (strip == 0) a.cmbNrmOut[(int64_t) buf * KP + lane] = nv;
+      a.cmbRowOut[(int64_t) buf * a.strideM + (int64_t) (a.R - 1) * KPM + lane] = wnew;
+      if (strip == 0) a.cmbNrmOut[(int64_t) buf * KPM + lane] = nv;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       for (int m = 0; m < M; m++) nr[m] = ldsN[M * y + m];
     }
     else
-    load_vec5<M>(nr, a.nrm + (int64_t) buf * KP + M * y);
+    load_vec5<M>(nr, a.nrm + (int64_t) buf * KPM + M * y);
 #pragma unroll
     for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -500,7 +506,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // Q for one 4-row step.  A dependent v_mfma_f64_4x4x4 cannot issue back to back on its own
   // accumulator, so each group's contraction over m is split into P interleaved partial chains
   // (>= 8 independent accumulators in flight, the count at which the probe reaches 73 TFLOP/s).
-  constexpr int P = (NG >= 5) ? 1 : (NG >= 3 ? 2 : (NG >= 2 ? 4 : 8));
+  constexpr int P0 = (NG >= 5) ? 1 : (NG >= 3 ? 2 : (NG >= 2 ? 4 : 8));
+  constexpr int P = (M % P0 == 0 || M < P0) ? P0 : P0 / 2; // (M = 12: four chains where eight do not divide)
   static_assert(M % P == 0 || M < P, "partial chains");
   auto q_phase = [&](const double (&ma)[M], double (&q)[NG]) {
     constexpr int PP = (P <= M) ? P : M;
@@ -679,7 +686,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         {
           const int sc = min(s + NS, sLast);
           const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
-          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KPM);
           // every ds_read of slot u was issued in earlier steps; the Q-phase above issued QREADS newer ones
           asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(QREADS < 15 ? QREADS : 15) : "memory");
 #pragma unroll
@@ -844,7 +851,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         {
           const int sc = min(s + NS, sLast);
           const char* vsrc = reinterpret_cast<const char*>(V + (int64_t) sc * 4 * a.ldv + (int64_t) g0 * 16);
-          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KP);
+          const char* msrc = reinterpret_cast<const char*>(Mv + (int64_t) sc * 4 * KPM);
 #pragma unroll
           for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -1013,7 +1020,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   {
     // DS == 0: the column sums of Mv were taken by launch_colsum into slot (buf, split 0) of dpart (the wide
     // ranks have no registers to spare for M accumulators every wavefront would hold identically)
-    load_vec5<M>(dsum, a.dpart + (int64_t) buf * KP + M * x);
+    load_vec5<M>(dsum, a.dpart + (int64_t) buf * KPM + M * x);
   }
 
   if (whole())
@@ -1029,8 +1036,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     }
     else
     {
-      if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KP + M * x);
-      if constexpr (SIDEQ) if (strip == 0 && lane < KP) nrL = a.nrm[(int64_t) buf * KP + lane];
+      if (a.nrmMode) load_vec5<M>(nrE, a.nrm + (int64_t) buf * KPM + M * x);
+      if constexpr (SIDEQ) if (strip == 0 && lane < KP) nrL = a.nrm[(int64_t) buf * KPM + lane];
     }
     if (a.nrmMode == 2)
     {
@@ -1144,7 +1151,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             const int r = c / CPR, piece = c % CPR;
             const d2 t = *reinterpret_cast<const d2*>(stg + (g - gb) * GRPB + r * ROWB + piece * 16);
             const int col = (g0 + g) * 16 + r;
-            if (col < a.C) store_result16(S + (int64_t) col * KP + piece * 2, t);
+            if (col < a.C) store_result16(S + (int64_t) col * KPM + piece * 2, t);
           }
         }
       }
@@ -1171,10 +1178,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         double n = 0.0, d = 0.0;
 #pragma unroll
         for (int j = 0; j < 16; j++) { n += pn[j]; d += pd[j]; }
-        double* sp = a.sidePart + ((int64_t) buf * a.wavesPerBuf + strip) * 2 * KP;
+        double* sp = a.sidePart + ((int64_t) buf * a.wavesPerBuf + strip) * 2 * KPM;
         sp[lane] = n;
-        sp[KP + lane] = d;
-        if (strip == 0) a.sideWold[(int64_t) buf * KP + lane] = reinterpret_cast<const double*>(sideL)[lane] / nrL;
+        sp[KPM + lane] = d;
+        if (strip == 0) a.sideWold[(int64_t) buf * KPM + lane] = reinterpret_cast<const double*>(sideL)[lane] / nrL;
       }
     }
     if (a.statPart)
@@ -1196,29 +1203,29 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       }
       if (lane < 4)
       {
-        double* sp = a.statPart + (LIST ? (int64_t) lStat : ((int64_t) buf * a.wavesPerBuf + strip)) * 2 * KP + M * x;
+        double* sp = a.statPart + (LIST ? (int64_t) lStat : ((int64_t) buf * a.wavesPerBuf + strip)) * 2 * KPM + M * x;
 #pragma unroll
-        for (int m = 0; m < M; m++) { sp[m] = ss[m]; sp[KP + m] = mx[m]; }
+        for (int m = 0; m < M; m++) { sp[m] = ss[m]; sp[KPM + m] = mx[m]; }
       }
     }
   }
   else
   {
-    double* part = a.part + (LIST ? (int64_t) lPart : ((int64_t) buf * a.nsplit + split)) * a.Cp * KP;
+    double* part = a.part + (LIST ? (int64_t) lPart : ((int64_t) buf * a.nsplit + split)) * a.Cp * KPM;
 #pragma unroll
     for (int g = 0; g < NG; g++)
     {
       if (g < ng)
       {
         const int col = (g0 + g) * 16 + 4 * blk + y;
-        double* pp = part + (int64_t) col * KP + M * x;
+        double* pp = part + (int64_t) col * KPM + M * x;
 #pragma unroll
         for (int m = 0; m < M; m++) pp[m] = acc[g][m];
       }
     }
     if (DS && (LIST ? lD >= 0 : strip == 0) && blk == 0 && y == 0)
     {
-      double* dp = a.dpart + (LIST ? (int64_t) lD : ((int64_t) buf * a.nsplit + split)) * KP + M * x;
+      double* dp = a.dpart + (LIST ? (int64_t) lD : ((int64_t) buf * a.nsplit + split)) * KPM + M * x;
 #pragma unroll
       for (int m = 0; m < M; m++) dp[m] = dsum[m];
     }
@@ -1241,7 +1248,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 
 
 // work-list mode: the LIST instantiation of the same kernel, one workgroup per four descriptors
-template <int M, int NG, int NS, int MODE>
+template <int M, int NG, int NS, int MODE, int KPM = 4 * M>
 static void launch5_list(const UpdateArgs& a, hipStream_t s)
 {
   Upd5Args k{};
@@ -1259,12 +1266,12 @@ static void launch5_list(const UpdateArgs& a, hipStream_t s)
   constexpr size_t ring = (size_t) NS * (NJV + NJM) * 1024, stg = (size_t) (NG * M + M) * 512;
   constexpr size_t shmem = 4 * ((stg > ring && 4 * stg <= 160 * 1024) ? stg : ring);
   static_assert(shmem <= 160 * 1024, "LDS");
-  auto kern = nmf_update5_kernel<M, NG, NS, 1, 0, MODE, 1, 1>;
+  auto kern = nmf_update5_kernel<M, NG, NS, 1, 0, MODE, 1, 1, 0, KPM>;
   request_dynamic_lds(kern, (size_t) (shmem));
   hipLaunchKernelGGL(kern, dim3((unsigned) a.listWGs), dim3(256), shmem, s, k);
 }
 
-template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int SIDEQ = 0>
+template <int M, int NG, int NS, int WPS, int INSTR = 0, int MODE = 0, int DS = 1, int SIDEQ = 0, int KPM = 4 * M>
 static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 {
   Upd5Args k;
@@ -1295,7 +1302,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
   constexpr size_t shmem = (size_t) 4 * WPS * (NS * (NJV + NJM) + (SIDEQ ? 1 + (NG * 128 + 1023) / 1024 : 0)) * 1024;
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
-  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS, 0, SIDEQ>;
+  auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS, 0, SIDEQ, KPM>;
   request_dynamic_lds(kern, (size_t) (shmem));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * WPS), shmem, s, k);
   if (k.nsplit > 1)
@@ -1306,8 +1313,8 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
 static int max_groups(int M)
 {
   if (M <= 8) return 9;
-  if (M <= 16) return 4;
-  return 2;
+  if (M <= 16) return 4; // (M = 12: five groups are the most without spills; four keep the strips of rank 64 and its whole rounds)
+  return 2;              // (M = 24: two, as at M = 32)
 }
 
 // strips (wavefronts) per buffer: fill the 1024 SIMDs in whole rounds, then as few strips as the
@@ -1432,26 +1439,57 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
   return 0;
 }
 
-// the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
-// sets up to rank 32, refilled in place at rank 64, grouped at rank 128 (the in-place form has no room for the column sums
-// there, and the pre-pass that replaces them deals its slots per equal-length buffer)
-template <int M, int NG>
-static void launch5_list_ng(const UpdateArgs& a, int ng, hipStream_t s)
+// Off-size ranks (round 5): M = 12 / 24 MFMAs per product on the arrays of rank 64 / 128 (KPM).  One pipeline form each -- the
+// two-operand-set form at M = 12 (the side column of the next W update and the norm combine ride in the H launch as at rank 32),
+// the in-place form at M = 24 -- for the plain one-launch and split-contraction schedules; work lists and ragged corpora keep
+// the padded rank.
+template <int M, int NG, int KPM>
+static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 {
-  if constexpr (NG == 1) launch5_list<M, 1, ring_depth<M, 1, 1>(), 0>(a, s);
+  if constexpr (NG == 1) { launch5_t<M, 1, ring_depth<M, 1, 1>(), 1, 0, 0, 1, 0, KPM>(a, w, s); return 0; }
   else
   {
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, 1>();
-      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M == 32 ? 0 : (M == 16 ? 2 : 1)) : 0;
-      launch5_list<M, NG, NS, MODE>(a, s);
+      static_assert(NS >= 4 && NS % 2 == 0, "overlapped pipeline: even ring depth >= 4");
+      if constexpr (M == 12)
+      {
+        const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1 && w <= kSideFromHSlots;
+        const bool normq = sideq && a.cmbStat && a.cmbSide && a.cmbWold && a.cmbNrmOut && a.cmbRowOut && (a.R + 3) / 4 > 12;
+        if (normq) { launch5_t<M, NG, NS, 1, 0, 1, 1, 3, KPM>(a, w, s); return 3; }
+        if (sideq) { launch5_t<M, NG, NS, 1, 0, 1, 1, 1, KPM>(a, w, s); return 1; }
+        launch5_t<M, NG, NS, 1, 0, 1, 1, 0, KPM>(a, w, s);
+      }
+      else launch5_t<M, NG, NS, 1, 0, 2, 1, 0, KPM>(a, w, s);
+      return 0;
     }
-    else launch5_list_ng<M, NG - 1>(a, ng, s);
+    return launch5_off_ng<M, NG - 1, KPM>(a, w, ng, s);
+  }
+}
+
+// the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
+// sets up to rank 32, refilled in place at rank 64, grouped at rank 128 (the in-place form has no room for the column sums
+// there, and the pre-pass that replaces them deals its slots per equal-length buffer)
+template <int M, int NG, int KPM = 4 * M>
+static void launch5_list_ng(const UpdateArgs& a, int ng, hipStream_t s)
+{
+  if constexpr (NG == 1) launch5_list<M, 1, ring_depth<M, 1, 1>(), 0, KPM>(a, s);
+  else
+  {
+    if (ng >= NG)
+    {
+      constexpr int NS = ring_depth<M, NG, 1>();
+      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M == 32 ? 0 : (M >= 16 ? 2 : 1)) : 0;
+      launch5_list<M, NG, NS, MODE, KPM>(a, s);
+    }
+    else launch5_list_ng<M, NG - 1, KPM>(a, ng, s);
   }
 }
 
 bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
+// compute rank of the off-size forms for a (true) rank K on arrays of rank Kp: 48 for 33 .. 48, 96 for 65 .. 96, else Kp
+int nmf_update5_compute_rank(int K, int Kp) { return (Kp == 64 && K <= 48) ? 48 : ((Kp == 128 && K <= 96) ? 96 : Kp); }
 static int k5_wps()
 {
   // two wavefronts per SIMD measured no faster than one (profiles/r01/update_kernel_notes.md)
@@ -1471,11 +1509,14 @@ int nmf_update5_strips(int C, int Kp, int B)
 // keeps at least one group
 int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
-  if (a.dryRun && (a.list || a.Kp > 64)) return 0; // (nothing but the plain un-split forms up to rank 64 take anything over)
+  if (a.dryRun && (a.list || a.Kp > 64 || (a.Kc > 48 && a.Kc != a.Kp))) return 0; // (nothing but the plain un-split forms up to rank 64 take anything over)
   if (a.list)
   {
     // work-list mode: one wavefront per SIMD, the widest strip of the list picks the instantiation; the column sums
     // always ride in the kernel (no pre-pass: its per-buffer slots are dealt differently here)
+    // (off-size ranks: 12 / 24 MFMAs per product on the arrays of rank 64 / 128, as in the uniform forms)
+    if (a.Kc == 48 && a.Kp == 64) { launch5_list_ng<12, 4, 64>(a, a.listNG, s); return 0; }
+    if (a.Kc == 96 && a.Kp == 128) { launch5_list_ng<24, 2, 128>(a, a.listNG, s); return 0; }
     switch (a.Kp / 4)
     {
     case 4: launch5_list_ng<4, 9>(a, a.listNG, s); break;
@@ -1487,9 +1528,15 @@ int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
     return 0;
   }
   const int G = (a.C + 15) / 16;
-  const int w = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips(a.C, a.Kp, a.B);
-  const bool two = a.stripsOverride > 0 ? false : w != nmf_update5_waves_per_buffer(a.C, a.Kp, a.B);
+  const int kc = a.Kc > 0 ? a.Kc : a.Kp; // (compute rank: planning is by the MFMAs per product)
+  const int w = a.stripsOverride > 0 ? std::min(a.stripsOverride, G) : nmf_update5_strips(a.C, kc, a.B);
+  const bool two = a.stripsOverride > 0 ? false : w != nmf_update5_waves_per_buffer(a.C, kc, a.B);
   const int ng = (G + w - 1) / w;
+  if (kc != a.Kp)
+  {
+    if (kc == 48 && a.Kp == 64) return launch5_off_ng<12, 4, 64>(a, w, ng, s);
+    if (kc == 96 && a.Kp == 128) return launch5_off_ng<24, 2, 128>(a, w, ng, s);
+  }
   if (two)
   {
     switch (a.Kp / 4)

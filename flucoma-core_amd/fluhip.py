@@ -548,6 +548,8 @@ class Corpus:
         self.ctx._check(self.ctx.lib.fluhip_corpus_plan(self.h, out))
         keys = ("kernel", "split_w", "split_h", "deferred_norm", "side_column", "strips_w", "padded_rank", "strip")
         d = dict(zip(keys, [int(v) for v in out]))
+        d["compute_rank"] = d["padded_rank"] >> 16   # rank the factor updates compute (48 / 96 for the off-size ranks)
+        d["padded_rank"] &= 0xFFFF
         d["tail_h"] = d["split_h"] >> 16  # pieces of the tail launch of a two-launch H update (0: one launch)
         d["split_h"] &= 0xFFFF
         return d

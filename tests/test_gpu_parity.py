@@ -852,6 +852,32 @@ def test_h_update_of_more_than_64_strips_keeps_the_side_column_launch(ctx, oracl
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, b
 
 
+@pytest.mark.parametrize("K", [33, 40, 48, 65, 96, 100])
+def test_offsize_ranks_compute_three_quarters(ctx, oracle, onp, K):
+    """ranks 33 .. 48 and 65 .. 96 (clients/nrt/NMFClient.hpp:68: `components` is any integer >= 1): the arrays keep rank 64 / 128,
+    the factor updates compute 12 / 24 MFMAs per product (kernels_nmf5.hip KPM; round 5) -- a full chip of 128 buffers on the
+    plain schedule (every replica bit for bit, two against the oracle), a stereo pair and a single buffer on the split
+    schedule; rank 100 stays on the padded form"""
+    import fluhip
+    n, win, fft, hop, iters = 60000, 2048, 2048, 512, 6
+    want = 48 if K <= 48 else (96 if K <= 96 else 128)
+    distinct = [onp.synth_audio(n, 6100 + b) for b in range(4)]
+    for B in (128, 2, 1):
+        audio = np.stack([distinct[b % 4] for b in range(B)])
+        c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+        plan = c.plan()
+        c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+        mag, W1, H1 = c.read_f64()
+        c.close()
+        if B == 128:
+            assert plan["compute_rank"] == want and plan["padded_rank"] == (64 if K <= 64 else 128), plan
+        for b in range(4, B):
+            assert np.array_equal(W1[b], W1[b % 4]) and np.array_equal(H1[b], H1[b % 4]), (B, b)
+        for b in range(min(B, 2)):
+            rW, rH, _, _ = oracle.nmf_process(mag[b], K, iters, True, True, 42)
+            assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (B, b, plan)
+
+
 def test_corpus_buffers_are_independent_and_order_free(ctx, onp):
     """sharding property: a buffer's result does not depend on which batch (or rank) holds it"""
     import fluhip
