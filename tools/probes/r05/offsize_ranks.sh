@@ -1,7 +1,7 @@
 #!/bin/bash
 # off-size ranks: the bench shard's corpus (128 x 10 s, fft 2048 / hop 512, 50 iterations) at ranks 40 and 100 with the
 # 12 / 24-MFMA forms (default) against the padded forms of rank 64 / 128 (FLUHIP_OFFSIZE=0), A/B build, one box, alternating
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../../.." || exit 1
 export FLUHIP_AB=1
 for rep in 1 2; do
   for K in 40 48 64 100 96 128; do

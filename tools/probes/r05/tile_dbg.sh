@@ -1,7 +1,7 @@
 #!/bin/bash
 # timing experiments of the bin-tiled W update (A/B build, FLUHIP_TILE_DBG: results are wrong, durations are what is read):
 # rocprofv3 kernel durations of config 2 with the H refills, the V refills or both switched off
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../../.." || exit 1
 export TMPDIR=/tmp FLUHIP_AB=1
 out=gpurun_out/tile_dbg; mkdir -p $out
 for d in ${*:-0 1 2 3}; do
