@@ -18,7 +18,7 @@ def _cases():
     rs = np.random.RandomState(seed)
     out = []
     ffts = [64, 128, 256, 512, 1024, 2048]
-    ranks = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 64, 65, 100, 128]
+    ranks = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 48, 49, 64, 65, 70, 96, 97, 100, 128]
     for i in range(count):
         fft = ffts[rs.randint(len(ffts))]
         win = fft if rs.rand() < 0.7 else fft // 2
@@ -49,6 +49,12 @@ def test_random_shape(ctx, oracle, onp, case):
     mag, W1, H1 = c.read_f64()
     plan = c.plan()
     c.close()
+    # every replica of an input, wherever it sits in the corpus: the last window of a corpus may run with another
+    # contraction split than the full ones (another summation order, a few 1e-15: tools/probes/r05/replica_diff.py), so
+    # the replicas are held to 1e-12 of the first copy rather than to its bits -- the first copy is held to the oracle below
+    for b in range(len(distinct), B):
+        r = b % len(distinct)
+        assert rel_err(W1[b], W1[r]) < 1e-12 and rel_err(H1[b], H1[r]) < 1e-12 and np.array_equal(mag[b], mag[r]), (b, plan)
     for b in sorted({0, B - 1, min(B - 1, 2)}):
         _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
         assert rel_err(mag[b], rmag) < 1e-12, plan
