@@ -31,11 +31,11 @@ VARIANTS = {
     "default": (OBJ, [], None, None),
     "ab": (os.path.join(HERE, "build_ab"), ["-DFLUHIP_AB_SWITCHES"], None, None),
     "qc": (os.path.join(HERE, "build_qc"), ["-DFLUHIP_AB_SWITCHES", "-DFLUHIP_QUOTIENT_CORRECTION=1"],
-           ["kernels_nmf5.hip", "kernels_nmf_strip.hip"], "ab"),
+           ["kernels_nmf5.hip", "kernels_nmf5_off.hip", "kernels_nmf_strip.hip"], "ab"),
 }
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
-SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf_strip.hip", "kernels_nmf_bintile.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api_core.hip", "api_corpus.hip", "api_algorithms.hip", "api_features.hip", "api_frames.hip", "api_pool.cpp"]
+SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf5_off.hip", "kernels_nmf_strip.hip", "kernels_nmf_bintile.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api_core.hip", "api_corpus.hip", "api_algorithms.hip", "api_features.hip", "api_frames.hip", "api_pool.cpp"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
 
 
@@ -55,8 +55,12 @@ def _newer(target, sources):
 # per-file extras: the factor-update kernels never see NaNs by construction (every operand is
 # clamped to >= eps or is a finite product of finite inputs), and fmax() without the sNaN
 # canonicalisation saves one op per quotient on the FP64 datapath the MFMAs share.
-EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"], "kernels_nmf.hip": ["-fno-honor-nans"],
+EXTRA_FLAGS = {"kernels_nmf_wide.hip": ["-fno-honor-nans"], "kernels_nmf5.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf5_off.hip": ["-fno-honor-nans", "-Wno-inline-asm"], "kernels_nmf_strip.hip": ["-fno-honor-nans", "-mllvm", "-amdgpu-mfma-vgpr-form"], "kernels_nmf.hip": ["-fno-honor-nans"],
                "kernels_nmf_bintile.hip": ["-fno-honor-nans", "-Wno-inline-asm", "-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
+
+# sources a file includes beside the headers (the off-size half of the factor-update kernel's instantiation list)
+INCLUDES = {"kernels_nmf5_off.hip": ["kernels_nmf5.hip"]}
 
 
 def _compile(src, variant="default"):
@@ -66,7 +70,8 @@ def _compile(src, variant="default"):
     os.makedirs(objdir, exist_ok=True)
     obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
     path = os.path.join(CSRC, src)
-    if _newer(obj, [path] + _deps() + [os.path.abspath(__file__)]):
+    extra = [os.path.join(CSRC, f) for f in INCLUDES.get(src, [])]
+    if _newer(obj, [path] + extra + _deps() + [os.path.abspath(__file__)]):
         if src.endswith(".cpp"):   # host-only C++ above the C ABI: no device code, plain g++
             cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", *defines, "-c", path, "-o", obj]
         else:

@@ -301,7 +301,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     int row = p / SPR, pos = p % SPR;
     if (row > 3) row = 3;
     const int cs = (pos - row + SPR) % SPR;          // undo the per-row rotation ...
-    const int c = cs ^ (((cs >> 4) & 3) << 2);         // ... and the XOR of slot bits 2-3 with bits 4-5
+    const int cx = cs ^ (((cs >> 4) & 3) << 2);        // ... and the XOR of slot bits 2-3 with bits 4-5
+    const int c = cx < SPR ? cx : cs;                  // (rows that end inside a block of 16 chunks -- the off-size forms M = 10, 14, 20, 28: a chunk whose partner lies past the row stays where it is)
     moffs[j] = (unsigned) ((row * KPM + c * 2) * 8);    // slot pos of row `row` holds chunk c
   }
 
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // ma: row x, chunks M/2*y .. ; mb: row y, chunks M/2*x ..  Chunk c of row r sits at slot
   // ((c ^ (((c >> 4) & 3) << 2)) + r) % SPR: the rotation separates the 4 rows, the XOR separates
   // chunks 16 apart (rows longer than 256 B), so both distributions are conflict free per lane group.
-  auto slot_of = [](int c, int r) { return ((c ^ (((c >> 4) & 3) << 2)) + r) % SPR; };
+  auto slot_of = [](int c, int r) { const int cx = c ^ (((c >> 4) & 3) << 2); return ((cx < SPR ? cx : c) + r) % SPR; };
   int maOff[M / 2], mbOff[M / 2];
 #pragma unroll
   for (int j = 0; j < M / 2; j++)
@@ -507,8 +508,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // accumulator, so each group's contraction over m is split into P interleaved partial chains
   // (>= 8 independent accumulators in flight, the count at which the probe reaches 73 TFLOP/s).
   constexpr int P0 = (NG >= 5) ? 1 : (NG >= 3 ? 2 : (NG >= 2 ? 4 : 8));
-  constexpr int P = (M % P0 == 0 || M < P0) ? P0 : P0 / 2; // (M = 12: four chains where eight do not divide)
-  static_assert(M % P == 0 || M < P, "partial chains");
+  // (M = 12: four chains where eight do not divide; the other off-size forms -- M = 6, 10, 14, 20, 28 -- take P0 chains of
+  //  unequal length: qp[g][m % P])
+  constexpr int P = (M % P0 == 0 || M < P0) ? P0 : (M == 12 ? P0 / 2 : P0);
   auto q_phase = [&](const double (&ma)[M], double (&q)[NG]) {
     constexpr int PP = (P <= M) ? P : M;
     double qp[NG][PP];
@@ -1310,6 +1312,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
                            a.statPart);
 }
 
+#ifndef FLUHIP_K5_OFFSIZE_TU
 static int max_groups(int M)
 {
   if (M <= 8) return 9;
@@ -1349,6 +1352,8 @@ int nmf_update5_waves_per_buffer(int C, int Kp, int B)
 }
 
 
+#endif // !FLUHIP_K5_OFFSIZE_TU
+
 // ring depth bounded by the 160 KiB of LDS: 4*WPS wavefronts x NS x (V + Mv stage)
 template <int M, int NG, int WPS>
 constexpr int ring_depth()
@@ -1358,6 +1363,7 @@ constexpr int ring_depth()
   return fit >= 6 ? 6 : (fit < 3 ? 3 : fit);
 }
 
+#ifndef FLUHIP_K5_OFFSIZE_TU
 // bit 0: the launch also left the side-column partials UpdateArgs::sideOut asks for; bit 1: it did the norm combine
 // UpdateArgs::cmb* describes (the SIDEQ instantiations: ranks up to 64, the production pipeline form of the rank, strips of
 // two groups or more, deferred normalisation, un-split)
@@ -1439,10 +1445,16 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
   return 0;
 }
 
-// Off-size ranks (round 5): M = 12 / 24 MFMAs per product on the arrays of rank 64 / 128 (KPM).  One pipeline form each -- the
-// two-operand-set form at M = 12 (the side column of the next W update and the norm combine ride in the H launch as at rank 32),
-// the in-place form at M = 24 -- for the plain one-launch and split-contraction schedules; work lists and ragged corpora keep
-// the padded rank.
+#endif // !FLUHIP_K5_OFFSIZE_TU
+
+#ifdef FLUHIP_K5_OFFSIZE_TU
+// Off-size ranks (round 5): fewer MFMAs per product than the rank the arrays are laid out for (KPM) --
+//   arrays of rank 32 : M = 6 (ranks 17 .. 24)                          arrays of rank 64 : M = 10 / 12 / 14 (33 .. 40 / 48 / 56)
+//   arrays of rank 128: M = 20 / 24 / 28 (65 .. 80 / 96 / 112)
+// One pipeline form each: the two-operand-set form up to M = 12 and the in-place form at M = 14, both with the side column of
+// the next W update and the norm combine riding in the H launch as at ranks 32 / 64; the in-place form with its column sums
+// from M = 20 on.  They are compiled as their own translation unit (kernels_nmf5_off.hip includes this file with
+// FLUHIP_K5_OFFSIZE_TU defined) so that the two halves of the instantiation list build side by side.
 template <int M, int NG, int KPM>
 static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 {
@@ -1453,13 +1465,26 @@ static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
     {
       constexpr int NS = ring_depth<M, NG, 1>();
       static_assert(NS >= 4 && NS % 2 == 0, "overlapped pipeline: even ring depth >= 4");
-      if constexpr (M == 12)
+      if constexpr (M <= 14)
       {
+        constexpr int MODE = M <= 12 ? 1 : 2;
         const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1 && w <= kSideFromHSlots;
         const bool normq = sideq && a.cmbStat && a.cmbSide && a.cmbWold && a.cmbNrmOut && a.cmbRowOut && (a.R + 3) / 4 > 12;
-        if (normq) { launch5_t<M, NG, NS, 1, 0, 1, 1, 3, KPM>(a, w, s); return 3; }
-        if (sideq) { launch5_t<M, NG, NS, 1, 0, 1, 1, 1, KPM>(a, w, s); return 1; }
-        launch5_t<M, NG, NS, 1, 0, 1, 1, 0, KPM>(a, w, s);
+        if (normq) { launch5_t<M, NG, NS, 1, 0, MODE, 1, 3, KPM>(a, w, s); return 3; }
+        if (sideq) { launch5_t<M, NG, NS, 1, 0, MODE, 1, 1, KPM>(a, w, s); return 1; }
+        launch5_t<M, NG, NS, 1, 0, MODE, 1, 0, KPM>(a, w, s);
+      }
+      else if constexpr (M >= 28)
+      {
+        // as at M = 32: the in-place form fits without the M column-sum accumulators only; a pre-pass takes them
+        if (a.colsumScratch)
+        {
+          const int ns = a.nsplit < 1 ? 1 : a.nsplit;
+          if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
+          else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
+          launch5_t<M, NG, NS, 1, 0, 2, 0, 0, KPM>(a, w, s);
+        }
+        else launch5_t<M, NG, NS, 1, 0, 0, 1, 0, KPM>(a, w, s);
       }
       else launch5_t<M, NG, NS, 1, 0, 2, 1, 0, KPM>(a, w, s);
       return 0;
@@ -1467,6 +1492,7 @@ static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
     return launch5_off_ng<M, NG - 1, KPM>(a, w, ng, s);
   }
 }
+#endif // FLUHIP_K5_OFFSIZE_TU
 
 // the instantiation whose strip width is the list's widest; one pipeline form per rank class: overlapped with two operand
 // sets up to rank 32, refilled in place at rank 64, grouped at rank 128 (the in-place form has no room for the column sums
@@ -1480,16 +1506,72 @@ static void launch5_list_ng(const UpdateArgs& a, int ng, hipStream_t s)
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, 1>();
-      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M == 32 ? 0 : (M >= 16 ? 2 : 1)) : 0;
+      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M >= 28 ? 0 : (M >= 14 ? 2 : 1)) : 0;
       launch5_list<M, NG, NS, MODE, KPM>(a, s);
     }
     else launch5_list_ng<M, NG - 1, KPM>(a, ng, s);
   }
 }
 
+#ifdef FLUHIP_K5_OFFSIZE_TU
+// the off-size forms' entry points (called from launch_nmf_update5 in the other translation unit); -1 / false: no such form,
+// the caller runs the padded rank
+int launch_nmf_update5_offsize(const UpdateArgs& a, int kc, int w, int ng, hipStream_t s)
+{
+  if (a.Kp == 32 && kc == 24) return launch5_off_ng<6, 9, 32>(a, w, ng, s);
+  if (a.Kp == 64)
+    switch (kc)
+    {
+    case 40: return launch5_off_ng<10, 4, 64>(a, w, ng, s);
+    case 48: return launch5_off_ng<12, 4, 64>(a, w, ng, s);
+    case 56: return launch5_off_ng<14, 4, 64>(a, w, ng, s);
+    default: break;
+    }
+  if (a.Kp == 128)
+    switch (kc)
+    {
+    case 80: return launch5_off_ng<20, 2, 128>(a, w, ng, s);
+    case 96: return launch5_off_ng<24, 2, 128>(a, w, ng, s);
+    case 112: return launch5_off_ng<28, 2, 128>(a, w, ng, s);
+    default: break;
+    }
+  return -1;
+}
+bool launch_nmf_update5_offsize_list(const UpdateArgs& a, hipStream_t s)
+{
+  if (a.Kp == 32 && a.Kc == 24) { launch5_list_ng<6, 9, 32>(a, a.listNG, s); return true; }
+  if (a.Kp == 64)
+    switch (a.Kc)
+    {
+    case 40: launch5_list_ng<10, 4, 64>(a, a.listNG, s); return true;
+    case 48: launch5_list_ng<12, 4, 64>(a, a.listNG, s); return true;
+    case 56: launch5_list_ng<14, 4, 64>(a, a.listNG, s); return true;
+    default: break;
+    }
+  if (a.Kp == 128)
+    switch (a.Kc)
+    {
+    case 80: launch5_list_ng<20, 2, 128>(a, a.listNG, s); return true;
+    case 96: launch5_list_ng<24, 2, 128>(a, a.listNG, s); return true;
+    case 112: launch5_list_ng<28, 2, 128>(a, a.listNG, s); return true;
+    default: break;
+    }
+  return false;
+}
+#else
+int launch_nmf_update5_offsize(const UpdateArgs& a, int kc, int w, int ng, hipStream_t s);
+bool launch_nmf_update5_offsize_list(const UpdateArgs& a, hipStream_t s);
+
 bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
-// compute rank of the off-size forms for a (true) rank K on arrays of rank Kp: 48 for 33 .. 48, 96 for 65 .. 96, else Kp
-int nmf_update5_compute_rank(int K, int Kp) { return (Kp == 64 && K <= 48) ? 48 : ((Kp == 128 && K <= 96) ? 96 : Kp); }
+// compute rank of the off-size forms for a (true) rank K on arrays of rank Kp (the smallest form that holds K): 24 on arrays
+// of rank 32; 40 / 48 / 56 on 64; 80 / 96 / 112 on 128; else Kp
+int nmf_update5_compute_rank(int K, int Kp)
+{
+  if (Kp == 32) return K <= 24 ? 24 : 32;
+  if (Kp == 64) return K <= 40 ? 40 : (K <= 48 ? 48 : (K <= 56 ? 56 : 64));
+  if (Kp == 128) return K <= 80 ? 80 : (K <= 96 ? 96 : (K <= 112 ? 112 : 128));
+  return Kp;
+}
 static int k5_wps()
 {
   // two wavefronts per SIMD measured no faster than one (profiles/r01/update_kernel_notes.md)
@@ -1509,14 +1591,13 @@ int nmf_update5_strips(int C, int Kp, int B)
 // keeps at least one group
 int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
 {
-  if (a.dryRun && (a.list || a.Kp > 64 || (a.Kc > 48 && a.Kc != a.Kp))) return 0; // (nothing but the plain un-split forms up to rank 64 take anything over)
+  if (a.dryRun && (a.list || a.Kp > 64)) return 0; // (nothing but the plain un-split forms on arrays up to rank 64 take anything over)
   if (a.list)
   {
     // work-list mode: one wavefront per SIMD, the widest strip of the list picks the instantiation; the column sums
     // always ride in the kernel (no pre-pass: its per-buffer slots are dealt differently here)
-    // (off-size ranks: 12 / 24 MFMAs per product on the arrays of rank 64 / 128, as in the uniform forms)
-    if (a.Kc == 48 && a.Kp == 64) { launch5_list_ng<12, 4, 64>(a, a.listNG, s); return 0; }
-    if (a.Kc == 96 && a.Kp == 128) { launch5_list_ng<24, 2, 128>(a, a.listNG, s); return 0; }
+    // (off-size ranks: fewer MFMAs per product on the arrays of the padded rank, as in the uniform forms)
+    if (a.Kc > 0 && a.Kc != a.Kp && launch_nmf_update5_offsize_list(a, s)) return 0;
     switch (a.Kp / 4)
     {
     case 4: launch5_list_ng<4, 9>(a, a.listNG, s); break;
@@ -1534,8 +1615,8 @@ int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
   const int ng = (G + w - 1) / w;
   if (kc != a.Kp)
   {
-    if (kc == 48 && a.Kp == 64) return launch5_off_ng<12, 4, 64>(a, w, ng, s);
-    if (kc == 96 && a.Kp == 128) return launch5_off_ng<24, 2, 128>(a, w, ng, s);
+    const int r = launch_nmf_update5_offsize(a, kc, w, ng, s);
+    if (r >= 0) return r;
   }
   if (two)
   {
@@ -1559,5 +1640,7 @@ int launch_nmf_update5(const UpdateArgs& a, hipStream_t s)
   }
   return 0;
 }
+
+#endif // FLUHIP_K5_OFFSIZE_TU
 
 } // namespace fluhip

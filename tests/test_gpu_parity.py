@@ -852,15 +852,22 @@ def test_h_update_of_more_than_64_strips_keeps_the_side_column_launch(ctx, oracl
         assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, b
 
 
-@pytest.mark.parametrize("K", [33, 40, 48, 65, 96, 100])
-def test_offsize_ranks_compute_three_quarters(ctx, oracle, onp, K):
-    """ranks 33 .. 48 and 65 .. 96 (clients/nrt/NMFClient.hpp:68: `components` is any integer >= 1): the arrays keep rank 64 / 128,
-    the factor updates compute 12 / 24 MFMAs per product (kernels_nmf5.hip KPM; round 5) -- a full chip of 128 buffers on the
-    plain schedule (every replica bit for bit, two against the oracle), a stereo pair and a single buffer on the split
-    schedule; rank 100 stays on the padded form"""
+def _offsize_compute_rank(K):
+    """smallest form that holds K (kernels_nmf5.hip nmf_update5_compute_rank)"""
+    for kc in (16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128):
+        if K <= kc:
+            return kc
+
+
+@pytest.mark.parametrize("K", [17, 20, 24, 25, 33, 40, 41, 48, 49, 56, 57, 65, 80, 81, 96, 97, 100, 112, 113])
+def test_offsize_ranks_compute_fewer_products(ctx, oracle, onp, K):
+    """ranks between two array ranks (clients/nrt/NMFClient.hpp:68: `components` is any integer >= 1): the arrays keep rank 32 / 64 /
+    128, the factor updates compute 6 | 10 / 12 / 14 | 20 / 24 / 28 MFMAs per product (kernels_nmf5.hip KPM; round 5) -- a full
+    chip of 128 buffers on the plain schedule (every replica bit for bit, two against the oracle), a stereo pair and a single
+    buffer on the split schedule; ranks 25, 57, 113 stay on the padded forms"""
     import fluhip
     n, win, fft, hop, iters = 60000, 2048, 2048, 512, 6
-    want = 48 if K <= 48 else (96 if K <= 96 else 128)
+    want = _offsize_compute_rank(K)
     distinct = [onp.synth_audio(n, 6100 + b) for b in range(4)]
     for B in (128, 2, 1):
         audio = np.stack([distinct[b % 4] for b in range(B)])
@@ -870,7 +877,7 @@ def test_offsize_ranks_compute_three_quarters(ctx, oracle, onp, K):
         mag, W1, H1 = c.read_f64()
         c.close()
         if B == 128:
-            assert plan["compute_rank"] == want and plan["padded_rank"] == (64 if K <= 64 else 128), plan
+            assert plan["compute_rank"] == want and plan["padded_rank"] == (32 if K <= 32 else (64 if K <= 64 else 128)), plan
         for b in range(4, B):
             assert np.array_equal(W1[b], W1[b % 4]) and np.array_equal(H1[b], H1[b % 4]), (B, b)
         for b in range(min(B, 2)):
