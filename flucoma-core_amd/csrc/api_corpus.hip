@@ -277,8 +277,8 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
   }
   // Off-size ranks (round 5): a rank between two array ranks keeps the ARRAYS of the padded rank (32 / 64 / 128) -- every
   // helper kernel runs its form of that rank on zero columns -- and the factor updates compute fewer MFMAs per product
-  // (kernels_nmf5.hip KPM, nmf_update5_compute_rank): 6 of 8 for ranks 17 .. 24; 10 / 12 / 14 of 16 for 33 .. 40 / 48 / 56; 20 / 24 /
-  // 28 of 32 for 65 .. 80 / 96 / 112.  The plain and the split-contraction schedules and the work lists; the strip schedule
+  // (kernels_nmf5.hip KPM, nmf_update5_compute_rank): 6 of 8 for ranks 17 .. 24; 10 / 12 / 14 of 16 for 33 .. 40 / 48 / 56; 18, 20 .. 28
+  // of 32 for 65 .. 72, .. 80, .. 112.  The plain and the split-contraction schedules and the work lists; the strip schedule
   // (rank <= 16) has no off-size rank.  FLUHIP_OFFSIZE=0 (A/B build): the padded forms, for the comparison.
   c->Kc = (offsize_enabled() && c->lazy && !c->strip && update_variant((int) c->Kp) == 5)
               ? nmf_update5_compute_rank((int) c->K, (int) c->Kp) : (int) c->Kp;

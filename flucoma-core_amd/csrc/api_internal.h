@@ -254,7 +254,7 @@ struct fluhip_corpus
   // numerator partials of the whole matrix, no reduce launch, the strip kernel runs its H phase only
   bool stripBin = false;
   DevBuf binWork;
-  int Kc = 0;                  // compute rank of the factor updates (off-size ranks: 24 on arrays of rank 32; 40 / 48 / 56 on 64; 80 / 96 / 112 on 128), else Kp
+  int Kc = 0;                  // compute rank of the factor updates (off-size ranks: 24 on arrays of rank 32; 40 / 48 / 56 on 64; 72 .. 112 in eights on 128), else Kp
   bool stripTile = false;      // round 5: the W update as the bin-tiled launch (kernels_nmf_bintile.hip)
   bool stripSideReady = false; // the Nyquist bin's numerator partials of the next W update are in tileWork
   DevBuf tileWork;

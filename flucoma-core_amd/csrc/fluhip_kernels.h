@@ -104,7 +104,7 @@ struct UpdateArgs
   int64_t strideS;
   int R, C, B;
   int Kp;
-  int Kc = 0;       // compute rank of the off-size forms (24 on arrays of rank 32; 40 / 48 / 56 on 64; 80 / 96 / 112 on 128: nmf_update5_compute_rank); 0 = Kp
+  int Kc = 0;       // compute rank of the off-size forms (24 on arrays of rank 32; 40 / 48 / 56 on 64; 72 .. 112 in eights on 128: nmf_update5_compute_rank); 0 = Kp
   // split-R mode (single large buffer): partial numerators / denominators
   int nsplit;
   double* part;     // [B][nsplit][Cp][Kp]
@@ -214,7 +214,7 @@ double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen);
 // S = S / nrm in memory, nrm = 1
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);
 void launch_fill_ones(double* p, int64_t n, hipStream_t s);
-int nmf_update5_compute_rank(int K, int Kp);  // the off-size forms' compute rank for rank K on arrays of rank Kp (UpdateArgs::Kc): 24 | 40 / 48 / 56 | 80 / 96 / 112, else Kp
+int nmf_update5_compute_rank(int K, int Kp);  // the off-size forms' compute rank for rank K on arrays of rank Kp (UpdateArgs::Kc): 24 | 40 / 48 / 56 | 72 .. 112 in eights, else Kp
 int nmf_update5_strips(int C, int Kp, int B); // wavefronts per buffer launch_nmf_update5 uses (nsplit == 1)
 int nmf_update5_max_groups(int Kp);           // widest strip (16-column groups) a wavefront can hold at this rank
 

@@ -1450,10 +1450,10 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 #ifdef FLUHIP_K5_OFFSIZE_TU
 // Off-size ranks (round 5): fewer MFMAs per product than the rank the arrays are laid out for (KPM) --
 //   arrays of rank 32 : M = 6 (ranks 17 .. 24)                          arrays of rank 64 : M = 10 / 12 / 14 (33 .. 40 / 48 / 56)
-//   arrays of rank 128: M = 20 / 24 / 28 (65 .. 80 / 96 / 112)
+//   arrays of rank 128: M = 18, 20 .. 28 (65 .. 72, .. 80, .. 112)
 // One pipeline form each: the two-operand-set form up to M = 12 and the in-place form at M = 14, both with the side column of
 // the next W update and the norm combine riding in the H launch as at ranks 32 / 64; the in-place form with its column sums
-// from M = 20 on.  They are compiled as their own translation unit (kernels_nmf5_off.hip includes this file with
+// from M = 18 on (28 with the column sums from the pre-pass, as 32).  They are compiled as their own translation unit (kernels_nmf5_off.hip includes this file with
 // FLUHIP_K5_OFFSIZE_TU defined) so that the two halves of the instantiation list build side by side.
 template <int M, int NG, int KPM>
 static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
@@ -1530,8 +1530,11 @@ int launch_nmf_update5_offsize(const UpdateArgs& a, int kc, int w, int ng, hipSt
   if (a.Kp == 128)
     switch (kc)
     {
+    case 72: return launch5_off_ng<18, 2, 128>(a, w, ng, s);
     case 80: return launch5_off_ng<20, 2, 128>(a, w, ng, s);
+    case 88: return launch5_off_ng<22, 2, 128>(a, w, ng, s);
     case 96: return launch5_off_ng<24, 2, 128>(a, w, ng, s);
+    case 104: return launch5_off_ng<26, 2, 128>(a, w, ng, s);
     case 112: return launch5_off_ng<28, 2, 128>(a, w, ng, s);
     default: break;
     }
@@ -1551,8 +1554,11 @@ bool launch_nmf_update5_offsize_list(const UpdateArgs& a, hipStream_t s)
   if (a.Kp == 128)
     switch (a.Kc)
     {
+    case 72: launch5_list_ng<18, 2, 128>(a, a.listNG, s); return true;
     case 80: launch5_list_ng<20, 2, 128>(a, a.listNG, s); return true;
+    case 88: launch5_list_ng<22, 2, 128>(a, a.listNG, s); return true;
     case 96: launch5_list_ng<24, 2, 128>(a, a.listNG, s); return true;
+    case 104: launch5_list_ng<26, 2, 128>(a, a.listNG, s); return true;
     case 112: launch5_list_ng<28, 2, 128>(a, a.listNG, s); return true;
     default: break;
     }
@@ -1564,12 +1570,12 @@ bool launch_nmf_update5_offsize_list(const UpdateArgs& a, hipStream_t s);
 
 bool nmf_update5_supported(int Kp) { return Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128; }
 // compute rank of the off-size forms for a (true) rank K on arrays of rank Kp (the smallest form that holds K): 24 on arrays
-// of rank 32; 40 / 48 / 56 on 64; 80 / 96 / 112 on 128; else Kp
+// of rank 32; 40 / 48 / 56 on 64; 72 .. 112 in steps of 8 on 128; else Kp
 int nmf_update5_compute_rank(int K, int Kp)
 {
   if (Kp == 32) return K <= 24 ? 24 : 32;
   if (Kp == 64) return K <= 40 ? 40 : (K <= 48 ? 48 : (K <= 56 ? 56 : 64));
-  if (Kp == 128) return K <= 80 ? 80 : (K <= 96 ? 96 : (K <= 112 ? 112 : 128));
+  if (Kp == 128) return K <= 72 ? 72 : (K <= 112 ? ((K + 7) / 8) * 8 : 128); // (30 of 32 products measured no faster than 32)
   return Kp;
 }
 static int k5_wps()

@@ -330,7 +330,7 @@ int fluhip_corpus_read_f64(fluhip_corpus* c, double* mag, double* W1, double* H1
  * bits 16.. = the pieces of the tail launch when the H update goes out as two launches, 0 otherwise),
  * deferred column normalisation of W (alg/NMF.hpp:162 applied on load) 0/1, Nyquist bin as a side column 0/1,
  * wavefronts per buffer of the W update, padded rank (low 16 bits: the rank the arrays are laid out for -- 16, 32, 64, 128;
- * bits 16..: the rank the factor updates COMPUTE -- 24 for ranks 17 .. 24; 40 / 48 / 56 for 33 .. 40 / 48 / 56; 80 / 96 / 112 for 65 .. 80 / 96 / 112; else the padded rank),
+ * bits 16..: the rank the factor updates COMPUTE -- 24 for ranks 17 .. 24; 40 / 48 / 56 for 33 .. 40 / 48 / 56; 72, 80 .. 112 for 65 .. 72, .. 80, .. 112; else the padded rank),
  * frame-strip schedule 0/1 (a single buffer of rank <= 16: the H
  * update local to a strip of frames, the W update's numerator as per-workgroup partials + a reduce launch; the split
  * counts before it then describe the schedule it replaces) }. */

@@ -854,15 +854,15 @@ def test_h_update_of_more_than_64_strips_keeps_the_side_column_launch(ctx, oracl
 
 def _offsize_compute_rank(K):
     """smallest form that holds K (kernels_nmf5.hip nmf_update5_compute_rank)"""
-    for kc in (16, 24, 32, 40, 48, 56, 64, 80, 96, 112, 128):
+    for kc in (16, 24, 32, 40, 48, 56, 64, 72, 80, 88, 96, 104, 112, 128):
         if K <= kc:
             return kc
 
 
-@pytest.mark.parametrize("K", [17, 20, 24, 25, 33, 40, 41, 48, 49, 56, 57, 65, 80, 81, 96, 97, 100, 112, 113])
+@pytest.mark.parametrize("K", [17, 20, 24, 25, 33, 40, 41, 48, 49, 56, 57, 65, 72, 73, 80, 88, 96, 100, 104, 105, 112, 113])
 def test_offsize_ranks_compute_fewer_products(ctx, oracle, onp, K):
     """ranks between two array ranks (clients/nrt/NMFClient.hpp:68: `components` is any integer >= 1): the arrays keep rank 32 / 64 /
-    128, the factor updates compute 6 | 10 / 12 / 14 | 20 / 24 / 28 MFMAs per product (kernels_nmf5.hip KPM; round 5) -- a full
+    128, the factor updates compute 6 | 10 / 12 / 14 | 18 .. 28 MFMAs per product (kernels_nmf5.hip KPM; round 5) -- a full
     chip of 128 buffers on the plain schedule (every replica bit for bit, two against the oracle), a stereo pair and a single
     buffer on the split schedule; ranks 25, 57, 113 stay on the padded forms"""
     import fluhip
