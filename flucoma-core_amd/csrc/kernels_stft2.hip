@@ -69,6 +69,10 @@ struct StftBArgs
 };
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// -DFLUHIP_SPLIT_VIA_LDS=0: the ds_bpermute partner exchange of rounds 1 - 4 (FftCore::split)
+#ifndef FLUHIP_SPLIT_VIA_LDS
+#define FLUHIP_SPLIT_VIA_LDS 1
+#endif
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains the wavefront's global stores
 // (s_waitcnt vmcnt(0)), which here would serialise every frame's stores with the next frame's arithmetic
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -185,7 +189,10 @@ struct FftCore
   static_assert(NB1 >= 1 && NB2 >= 1 && (NB3 == 1 || NB3 == 2), "tiling");
   static constexpr int NS2 = R1, NS3 = R1 * R2;
   static constexpr bool LOCAL = NB3 == 2;        // both bins of a split pair in one lane
-  static constexpr int BUFD = N + N / 16 + 2;    // doubles per wavefront (the + 2 staggers the buffers over the banks)
+  // XL (round 5, the one-butterfly-per-lane transform of fft 1024): the real-FFT split fetches its partner bins through the
+  // staging buffer instead of with ds_bpermute -- a plane of N + 64 slots, see split()
+  static constexpr bool XL = FLUHIP_SPLIT_VIA_LDS != 0 && NB3 == 1;
+  static constexpr int BUFD = N + N / 16 + (XL ? 34 : 2);    // doubles per wavefront (the + 2 staggers the buffers over the banks)
   static constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
   // SWZ (round 4, the 8 x 8 x 8 transform of fft 1024): the exchange buffer is addressed through bit swizzles instead of the
   // one-in-sixteen padding.  The padding serves the first exchange's stores (ds_write_b64: groups of 16 lanes over 32 dword
@@ -450,6 +457,29 @@ struct FftCore
       return cx{l0 ? own.re : re, l0 ? own.im : im};
     }
   };
+  // XL: the partner of bin k = j + r NS3 is bin N - k = (NS3 - j) + (R3 - 1 - r) NS3 in lane NS3 - j -- and for j = 0 the same
+  // expression names bin N - r NS3, which is lane 0's own register R3 - r once bin N is read as bin 0 (the transform is
+  // periodic).  So the lanes lay one plane of Z (real parts, then imaginary parts) into the staging buffer, slot = bin, with
+  // bin 0 once more at slot N, and every lane reads slot (NS3 - lane) + (R3 - 1 - r) NS3: no lane is special, where the
+  // ds_bpermute form needed a select per dword for lane 0 (32 v_cndmask + 32 ds_bpermute per frame; now 18 + 16 LDS accesses of
+  // 8 bytes and no VALU).  One plane at a time, and the magnitudes go to the same slots: the real parts of all R3 partners
+  // are fetched before the imaginary plane overwrites them, and the magnitudes wait in registers for the last partner read
+  // (lane 0's partners lie in its own column of slots).
+  [[maybe_unused]] double pre[R3], mg[R3];
+  [[maybe_unused]] const double* rpx = nullptr;
+  if constexpr (XL)
+  {
+    double* wpx = xb + lq;
+    rpx = xb + (NS3 - lq);
+#pragma unroll
+    for (int r = 0; r < R3; r++) wpx[NS3 * r] = p3[r].re;
+    wpx[N] = p3[0].re;
+#pragma unroll
+    for (int r = 0; r < R3; r++) pre[r] = lds_read1(rpx + NS3 * (R3 - 1 - r));
+#pragma unroll
+    for (int r = 0; r < R3; r++) wpx[NS3 * r] = p3[r].im;
+    wpx[N] = p3[0].im;
+  }
 #pragma unroll
   for (int bb = 0; bb < NB3; bb++)
   {
@@ -461,7 +491,10 @@ struct FftCore
       const int i = bb * R3 + r;
       // X[k] = (Z[k] + conj Z[N-k]) / 2 - i / 2 e^{-2 pi i k / fft} (Z[k] - conj Z[N-k]); the halves ride on the twiddle
       // (wj = e^{...} / 2) and on one multiplier of the sum
-      const cx A = p3[i], Bc = partner(bb, r);
+      cx Bc;
+      if constexpr (XL) Bc = cx{pre[r], lds_read1(rpx + NS3 * (R3 - 1 - r))};
+      else Bc = partner(bb, r);
+      const cx A = p3[i];
       const double er = A.re + Bc.re, ei = A.im - Bc.im;
       const double dr = A.re - Bc.re, di = A.im + Bc.im;
       cx w;
@@ -472,10 +505,16 @@ struct FftCore
       const int k = j + r * NS3;
       if (k == 0) xi = 0.0;                     // DC is purely real (util/FFT.hpp:99-101)
       const double m = mag_sqrt2(xr * xr + xi * xi);
-      xb[k] = m;                                // staged (the exchange buffer is idle now)
+      if constexpr (XL) mg[r] = m;
+      else xb[k] = m;                           // staged (the exchange buffer is idle now)
       if constexpr (SPEC) specRow[k] = d2{xr, xi};
       if (r & 1) SCHED_FENCE();                 // two bins' chains in flight, not sixteen
     }
+  }
+  if constexpr (XL)
+  {
+#pragma unroll
+    for (int r = 0; r < R3; r++) xb[lq + NS3 * r] = mg[r];
   }
   if (lane == 0)
   {
@@ -727,7 +766,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   constexpr int NB1 = N / (64 * R1), NB2 = N / (64 * R2), NB3 = N / (64 * R3);
   static_assert(NB1 >= 1 && NB2 >= 1 && (NB3 == 1 || NB3 == 2), "tiling");
   constexpr int NS2 = R1, NS3 = R1 * R2;
-  constexpr int BUFD = N + N / 16 + 2;        // doubles per wavefront (the + 2 staggers the wavefronts' buffers over the banks)
+  constexpr int BUFD = FftCore<R1, R2, R3>::BUFD; // doubles per wavefront
   constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
   extern __shared__ __attribute__((aligned(16))) double lds[];
   d2* tw2 = reinterpret_cast<d2*>(lds);       // [R2-1][NS2]
@@ -1481,7 +1520,7 @@ template <int R1, int R2, int R3, int NW, int WINLDS, int FPW = 1>
 static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
 {
   constexpr int N = R1 * R2 * R3;
-  constexpr int BUFD = N + N / 16 + 2;
+  constexpr int BUFD = FftCore<R1, R2, R3>::BUFD;
   constexpr int TW = (R2 - 1) * R1 + (R3 - 1) * R1 * R2;
   constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * FPW * BUFD * 8;
   static_assert(shmem <= 160 * 1024, "LDS");
