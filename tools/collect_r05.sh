@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4 records (run on the GPU box, copies go to profiles/r05/): the bench line, the rocprofv3 kernel stats of the same
+# round 5 records (run on the GPU box, copies go to profiles/r05/): the bench line, the rocprofv3 kernel stats of the same
 # command, the PMC passes of the update kernel (tied to the kernel source by its hash), and the per-config sets for c2, c3, c5
 export TMPDIR=/tmp; out=gpurun_out/r05final; tag=${1:-v1}; mkdir -p $out
 python bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
