@@ -1451,8 +1451,8 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
 // Off-size ranks (round 5): fewer MFMAs per product than the rank the arrays are laid out for (KPM) --
 //   arrays of rank 32 : M = 6 (ranks 17 .. 24)                          arrays of rank 64 : M = 10 / 12 / 14 (33 .. 40 / 48 / 56)
 //   arrays of rank 128: M = 18, 20 .. 28 (65 .. 72, .. 80, .. 112)
-// One pipeline form each: the two-operand-set form up to M = 12 and the in-place form at M = 14, both with the side column of
-// the next W update and the norm combine riding in the H launch as at ranks 32 / 64; the in-place form with its column sums
+// One pipeline form each: the two-operand-set form up to M = 14, with the side column of the next W update and the norm
+// combine riding in the H launch as at ranks 32 / 64; the in-place form with its column sums
 // from M = 18 on (28 with the column sums from the pre-pass, as 32).  They are compiled as their own translation unit (kernels_nmf5_off.hip includes this file with
 // FLUHIP_K5_OFFSIZE_TU defined) so that the two halves of the instantiation list build side by side.
 template <int M, int NG, int KPM>
@@ -1467,7 +1467,7 @@ static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
       static_assert(NS >= 4 && NS % 2 == 0, "overlapped pipeline: even ring depth >= 4");
       if constexpr (M <= 14)
       {
-        constexpr int MODE = M <= 12 ? 1 : 2;
+        constexpr int MODE = 1;   // (two operand sets fit up to M = 14 at four groups -- 460 of 512 registers -- and measure 3 % ahead of the in-place form there: rank 56 51.6 -> 50.1 ms per 50 iterations of the bench corpus)
         const bool sideq = a.sideOut && a.sideWold && a.nrmMode == 2 && a.nsplit <= 1 && w <= kSideFromHSlots;
         const bool normq = sideq && a.cmbStat && a.cmbSide && a.cmbWold && a.cmbNrmOut && a.cmbRowOut && (a.R + 3) / 4 > 12;
         if (normq) { launch5_t<M, NG, NS, 1, 0, MODE, 1, 3, KPM>(a, w, s); return 3; }
@@ -1506,7 +1506,7 @@ static void launch5_list_ng(const UpdateArgs& a, int ng, hipStream_t s)
     if (ng >= NG)
     {
       constexpr int NS = ring_depth<M, NG, 1>();
-      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M >= 28 ? 0 : (M >= 14 ? 2 : 1)) : 0;
+      constexpr int MODE = (NS >= 4 && NS % 2 == 0) ? (M >= 28 ? 0 : (M >= 16 ? 2 : 1)) : 0;
       launch5_list<M, NG, NS, MODE, KPM>(a, s);
     }
     else launch5_list_ng<M, NG - 1, KPM>(a, ng, s);
