@@ -10,6 +10,7 @@
 #pragma once
 
 #include "BufferAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 #include "DeviceContext.hpp"
 #include "NRTThreadingAdaptor.hpp"
 
@@ -78,6 +79,8 @@ class BufferSTFTClient
 {
 public:
   using ParamSetViewType = BufSTFTParams;
+  // the parameter table a host enumerates (nrt/BufSTFTClient.hpp; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufSTFT); }
 
   BufferSTFTClient(BufSTFTParams& p, FluidContext&) : mParams(&p) {}
   void setParams(BufSTFTParams& p) { mParams = &p; }

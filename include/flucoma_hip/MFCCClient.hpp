@@ -13,6 +13,7 @@
 
 #include "NRTControlAdaptor.hpp"
 #include "NRTThreadingAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 
 namespace fluhip {
 namespace mfcc {
@@ -45,6 +46,8 @@ class NRTMFCCClient
 {
 public:
   using ParamSetViewType = mfcc::NRTMFCCParams;
+  // the parameter table a host enumerates (rt/MFCCClient.hpp:171-175; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufMFCC); }
 
   NRTMFCCClient(ParamSetViewType& p, FluidContext&) : mParams(&p) {}
   void setParams(ParamSetViewType& p) { mParams = &p; }

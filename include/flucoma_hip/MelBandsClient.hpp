@@ -11,6 +11,7 @@
 
 #include "NRTControlAdaptor.hpp"
 #include "NRTThreadingAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 
 namespace fluhip {
 namespace melbands {
@@ -43,6 +44,8 @@ class NRTMelBandsClient
 {
 public:
   using ParamSetViewType = melbands::NRTMelBandsParams;
+  // the parameter table a host enumerates (rt/MelBandsClient.hpp:151-155; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufMelBands); }
 
   NRTMelBandsClient(ParamSetViewType& p, FluidContext&) : mParams(&p) {}
   void setParams(ParamSetViewType& p) { mParams = &p; }

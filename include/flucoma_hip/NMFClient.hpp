@@ -12,6 +12,7 @@
 
 #include "../flucoma_hip.h"
 #include "BufferAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -94,6 +95,8 @@ class NMFClient
 {
 public:
   using ParamSetViewType = NMFParams;
+  // the parameter table a host enumerates (nrt/NMFClient.hpp:81; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufNMF); }
 
   NMFClient(NMFParams& p, FluidContext&) : mParams(&p) {}
   ~NMFClient()

@@ -21,6 +21,7 @@
 #pragma once
 
 #include "BufferAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 #include "DeviceContext.hpp"
 #include "NRTControlAdaptor.hpp"
 #include "NRTThreadingAdaptor.hpp"
@@ -73,6 +74,8 @@ class NRTNMFFilterClient
 {
 public:
   using ParamSetViewType = nmffilter::NRTNMFFilterParams;
+  // the parameter table a host enumerates (the offline wrapper's parameters in front of rt/NMFFilterClient.hpp:34-38; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufNMFFilter); }
 
   NRTNMFFilterClient(ParamSetViewType& p, FluidContext&) : mParams(&p) {}
   void setParams(ParamSetViewType& p) { mParams = &p; }

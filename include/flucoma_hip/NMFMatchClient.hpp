@@ -15,6 +15,7 @@
 
 #include "NRTControlAdaptor.hpp"
 #include "NRTThreadingAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 
 namespace fluhip {
 namespace nmfmatch {
@@ -55,6 +56,8 @@ class NRTNMFMatchClient
 {
 public:
   using ParamSetViewType = nmfmatch::NRTNMFMatchParams;
+  // the parameter table a host enumerates (the offline wrapper's parameters in front of rt/NMFMatchClient.hpp:32-38; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufNMFMatch); }
 
   NRTNMFMatchClient(ParamSetViewType& p, FluidContext&) : mParams(&p) {}
   void setParams(ParamSetViewType& p) { mParams = &p; }

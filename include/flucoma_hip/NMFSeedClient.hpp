@@ -8,6 +8,7 @@
 #pragma once
 
 #include "BufferAdaptor.hpp"
+#include "ParamDescriptors.hpp"
 #include "DeviceContext.hpp"
 #include "NRTThreadingAdaptor.hpp"
 
@@ -63,6 +64,8 @@ class NMFSeedClient
 {
 public:
   using ParamSetViewType = NMFSeedParams;
+  // the parameter table a host enumerates (nrt/NMFSeedClient.hpp; ParamDescriptors.hpp)
+  static constexpr ParamDescriptorList getParameterDescriptors() { return paramdesc::list(paramdesc::kBufNMFSeed); }
 
   NMFSeedClient(NMFSeedParams& p, FluidContext&) : mParams(&p) {}
   void setParams(NMFSeedParams& p) { mParams = &p; }

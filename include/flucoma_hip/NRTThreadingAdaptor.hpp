@@ -50,6 +50,9 @@ public:
   using Client = NRTClient;
   using ParamSetType = typename NRTClient::ParamSetViewType;
 
+  // cc/FluidNRTClientWrapper.hpp:801-804: the wrapped client's table, for the host wrapper that builds its attributes from it
+  static constexpr auto getParameterDescriptors() { return NRTClient::getParameterDescriptors(); }
+
   // ONE client for the adaptor's lifetime, handed to every task (:831 mClient{new NRTClient{mHostParams, c}}, :883): the
   // client's device context -- and with it the cached device blocks and loaded code objects -- outlives a job
   explicit NRTThreadingAdaptor(ParamSetType& p, FluidContext c = {})

@@ -238,10 +238,52 @@ static int runErrors2()
   return 0;
 }
 
+// the parameter tables as JSON, one object per client, through the adaptor the host would hold
+template <class Adaptor>
+static void printDescriptors(const char* client, bool last)
+{
+  constexpr auto list = Adaptor::getParameterDescriptors();
+  static const char* kinds[] = {"InputBuffer", "Buffer", "Long", "Float", "Enum", "FFT"};
+  std::printf("\"%s\": [", client);
+  for (std::size_t i = 0; i < list.size(); i++)
+  {
+    const fluhip::ParamDescriptor& d = list[i];
+    std::printf("%s{\"name\": \"%s\", \"display\": \"%s\", \"kind\": \"%s\"", i ? ", " : "", d.name, d.displayName,
+                kinds[static_cast<int>(d.kind)]);
+    if (d.kind == fluhip::ParamKind::kLong || d.kind == fluhip::ParamKind::kFloat || d.kind == fluhip::ParamKind::kEnum)
+      std::printf(", \"default\": %.17g", d.defaultValue);
+    if (d.kind == fluhip::ParamKind::kFFT) std::printf(", \"default\": [%ld, %ld, %ld]", (long) d.defaultValue, d.fftHop, d.fftSize);
+    if (d.kind != fluhip::ParamKind::kEnum && d.hasMin) std::printf(", \"min\": %.17g", d.min);
+    if (d.kind != fluhip::ParamKind::kEnum && d.hasMax) std::printf(", \"max\": %.17g", d.max);
+    if (d.kind == fluhip::ParamKind::kEnum)
+    {
+      std::printf(", \"strings\": [");
+      for (int j = 0; j < d.numEnumStrings; j++) std::printf("%s\"%s\"", j ? ", " : "", d.enumStrings[j]);
+      std::printf("]");
+    }
+    if (d.relational) std::printf(", \"relational\": \"%s\"", d.relational);
+    std::printf("}");
+  }
+  std::printf("]%s\n", last ? "" : ",");
+}
+
 int main(int argc, char** argv)
 {
   if (argc < 2) return 2;
   const std::string mode = argv[1];
+  if (mode == "descriptors")
+  {
+    std::printf("{\n");
+    printDescriptors<NRTThreadedNMFClient>("BufNMF", false);
+    printDescriptors<fluhip::NRTThreadedNMFSeedClient>("BufNMFSeed", false);
+    printDescriptors<fluhip::NRTThreadedBufferSTFTClient>("BufSTFT", false);
+    printDescriptors<fluhip::NRTThreadedMFCCClient>("BufMFCC", false);
+    printDescriptors<fluhip::NRTThreadedMelBandsClient>("BufMelBands", false);
+    printDescriptors<fluhip::NRTThreadedNMFFilterClient>("BufNMFFilter", false);
+    printDescriptors<fluhip::NRTThreadedNMFMatchClient>("BufNMFMatch", true);
+    std::printf("}\n");
+    return 0;
+  }
   if (mode == "errors") return runErrors();
   if (mode == "errors2") return runErrors2();
 

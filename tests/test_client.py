@@ -11,6 +11,7 @@ import importlib.util
 import os
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -41,6 +42,30 @@ def read_buffer(path):
 
 
 OK, WARNING, ERROR, CANCELLED = 0, 1, 2, 3
+
+
+def test_parameter_descriptors_are_the_references_tables(driver):
+    """what a host wrapper builds its attributes from (`getParameterDescriptors()`, clients/common/FluidNRTClientWrapper.hpp:801-804;
+    include/flucoma_hip/ParamDescriptors.hpp): every mirrored client's table, through its NRTThreadingAdaptor, against the
+    reference's own -- names, display names, types, defaults, bounds, enum strings, the order.  The fixture was minted from the
+    reference headers (tools/make_param_descriptor_fixture.py); where the reference is present the fixture itself is re-derived
+    and held to it"""
+    import json
+    out = subprocess.run([driver, "descriptors"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    mine = json.loads(out.stdout)
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "param_descriptors.json")))
+    assert list(mine) == list(want) == ["BufNMF", "BufNMFSeed", "BufSTFT", "BufMFCC", "BufMelBands", "BufNMFFilter", "BufNMFMatch"]
+    for client in want:
+        assert mine[client] == want[client], client
+    assert [d["name"] for d in mine["BufNMF"]] == ["source", "startFrame", "numFrames", "startChan", "numChans", "resynth", "resynthMode",
+                                                   "bases", "basesMode", "activations", "actMode", "components", "iterations", "seed",
+                                                   "fftSettings"]          # nrt/NMFClient.hpp:36-52, the index enum's order
+    if os.path.isdir("/root/reference/include/flucoma"):
+        gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_param_descriptor_fixture.py"), "/root/reference"],
+                             capture_output=True, text=True, timeout=60)
+        assert gen.returncode == 0, gen.stderr
+        assert json.loads(gen.stdout) == want
 
 
 def test_validation_messages(driver):
