@@ -14,6 +14,7 @@
 #pragma once
 
 #include "NMFClient.hpp"
+#include "ParamDescriptors.hpp"
 
 #include <deque>
 #include <functional>
@@ -23,6 +24,7 @@
 namespace fluhip {
 
 enum ProcessState { kNoProcess, kProcessing, kDone, kDoneStillProcessing }; // cc/FluidBaseClient.hpp:32
+struct ControlChannel { index count{0}; index size{-1}; index max{-1}; };          // cc/FluidBaseClient.hpp:34-38
 
 namespace impl {
 // parameter sets with write-only buffers offer forEachBuffer(in, out, outOnly); the others forEachBuffer(in, out)
@@ -52,6 +54,16 @@ public:
 
   // cc/FluidNRTClientWrapper.hpp:801-804: the wrapped client's table, for the host wrapper that builds its attributes from it
   static constexpr auto getParameterDescriptors() { return NRTClient::getParameterDescriptors(); }
+  // :806-809 (none of the mirrored clients defines a message: an empty list)
+  static constexpr ParamDescriptorList getMessageDescriptors() { return {nullptr, 0}; }
+
+  // :811-822: an offline object has no audio or control connections; its inputs and outputs are its buffer parameters
+  index          audioChannelsIn() const noexcept { return 0; }
+  index          audioChannelsOut() const noexcept { return 0; }
+  index          controlChannelsIn() const noexcept { return 0; }
+  ControlChannel controlChannelsOut() const noexcept { return {0, 0}; }
+  index          audioBuffersIn() const noexcept { return countKind(ParamKind::kInputBuffer); }
+  index          audioBuffersOut() const noexcept { return countKind(ParamKind::kBuffer); }
 
   // ONE client for the adaptor's lifetime, handed to every task (:831 mClient{new NRTClient{mHostParams, c}}, :883): the
   // client's device context -- and with it the cached device blocks and loaded code objects -- outlives a job
@@ -125,6 +137,12 @@ public:
   ProcessState state() const { return mTask ? mTask->state() : kNoProcess; }
 
 private:
+  static constexpr index countKind(ParamKind k)
+  {
+    index n = 0;
+    for (const ParamDescriptor& d : NRTClient::getParameterDescriptors()) n += d.kind == k ? 1 : 0;
+    return n;
+  }
   struct NRTJob
   {
     ParamSetType          params;

@@ -266,6 +266,17 @@ static void printDescriptors(const char* client, bool last)
   }
   std::printf("]%s\n", last ? "" : ",");
 }
+// the adaptor's connection counts (cc/FluidNRTClientWrapper.hpp:811-822): "client|buffersIn buffersOut audioIn audioOut controlIn controlOut.count|messages"
+template <class Adaptor, class Params>
+static void printConnections(const char* client)
+{
+  Params       p;
+  FluidContext ctx;
+  Adaptor      a(p, ctx);
+  std::printf("%s|%ld %ld %ld %ld %ld %ld|%ld\n", client, (long) a.audioBuffersIn(), (long) a.audioBuffersOut(), (long) a.audioChannelsIn(),
+              (long) a.audioChannelsOut(), (long) a.controlChannelsIn(), (long) a.controlChannelsOut().count,
+              (long) Adaptor::getMessageDescriptors().size());
+}
 
 int main(int argc, char** argv)
 {
@@ -282,6 +293,17 @@ int main(int argc, char** argv)
     printDescriptors<fluhip::NRTThreadedNMFFilterClient>("BufNMFFilter", false);
     printDescriptors<fluhip::NRTThreadedNMFMatchClient>("BufNMFMatch", true);
     std::printf("}\n");
+    return 0;
+  }
+  if (mode == "connections")
+  {
+    printConnections<NRTThreadedNMFClient, bufnmf::NMFParams>("BufNMF");
+    printConnections<fluhip::NRTThreadedNMFSeedClient, fluhip::nndsvd::NMFSeedParams>("BufNMFSeed");
+    printConnections<fluhip::NRTThreadedBufferSTFTClient, fluhip::bufstft::BufSTFTParams>("BufSTFT");
+    printConnections<fluhip::NRTThreadedMFCCClient, fluhip::mfcc::NRTMFCCParams>("BufMFCC");
+    printConnections<fluhip::NRTThreadedMelBandsClient, fluhip::melbands::NRTMelBandsParams>("BufMelBands");
+    printConnections<fluhip::NRTThreadedNMFFilterClient, fluhip::nmffilter::NRTNMFFilterParams>("BufNMFFilter");
+    printConnections<fluhip::NRTThreadedNMFMatchClient, fluhip::nmfmatch::NRTNMFMatchParams>("BufNMFMatch");
     return 0;
   }
   if (mode == "errors") return runErrors();

@@ -61,6 +61,14 @@ def test_parameter_descriptors_are_the_references_tables(driver):
     assert [d["name"] for d in mine["BufNMF"]] == ["source", "startFrame", "numFrames", "startChan", "numChans", "resynth", "resynthMode",
                                                    "bases", "basesMode", "activations", "actMode", "components", "iterations", "seed",
                                                    "fftSettings"]          # nrt/NMFClient.hpp:36-52, the index enum's order
+    # the adaptor's connection counts (:811-822): no audio or control connections, buffers in / out = its buffer parameters; no messages
+    con = subprocess.run([driver, "connections"], capture_output=True, text=True, timeout=60)
+    assert con.returncode == 0, con.stderr
+    got = {l.split("|")[0]: l.split("|")[1:] for l in con.stdout.splitlines()}
+    for client, table in want.items():
+        n_in = sum(d["kind"] == "InputBuffer" for d in table)
+        n_out = sum(d["kind"] == "Buffer" for d in table)
+        assert got[client] == ["%d %d 0 0 0 0" % (n_in, n_out), "0"], (client, got[client])
     if os.path.isdir("/root/reference/include/flucoma"):
         gen = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_param_descriptor_fixture.py"), "/root/reference"],
                              capture_output=True, text=True, timeout=60)
