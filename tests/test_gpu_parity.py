@@ -1427,3 +1427,55 @@ def test_nmffilter_vs_oracle(ctx, onp, n, win, fft, hop, K, iters):
             assert np.abs(got[c].sum(axis=0) - audio[c]).max() < 1e-4
     with pytest.raises(Exception):
         ctx.nmffilter(audio, bases, 256, 256, 300)
+
+
+def test_no_device_memory_is_left_behind(ctx, onp):
+    """a host keeps ONE context for its lifetime and runs thousands of jobs through it (clients/common/FluidNRTClientWrapper.hpp:831:
+    one client per adaptor): corpora of every schedule family created, run and destroyed in a loop -- plain, split, work lists,
+    ragged, off-size rank, the any-rank path, the single-call client entry with resynthesis -- must hand all their device memory
+    back (hipMemGetInfo before and after, behind one warm-up pass that fills the context's own caches)"""
+    import ctypes
+    import fluhip
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipDeviceSynchronize() == 0
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    n = 44100
+    audio = {B: np.stack([onp.synth_audio(n, 9100 + b) for b in range(min(B, 3))] * ((B + 2) // 3))[:B] for B in (1, 2, 16, 130)}
+
+    def one_pass():
+        for B, K in ((130, 32), (16, 40), (2, 100), (1, 16), (1, 150)):
+            c = fluhip.Corpus(ctx, B, n, 1024, 1024, 256, K)
+            c.set_audio(audio[B]); c.stft(); c.nmf(2, seed=42)
+            c.read_f64()
+            c.close()
+        lens = [n, n // 2, n // 3, 5000, 300]
+        r = fluhip.RaggedCorpus(ctx, lens, 1024, 1024, 256, 24)
+        r.set_audio([audio[16][i % 16][:m] for i, m in enumerate(lens)]); r.stft(); r.nmf(2, seed=42)
+        r.read_f64()
+        r.close()
+        _, _, res, rc = ctx.bufnmf_channel(audio[1][0], 1024, 1024, 256, 5, 3, 42, resynth=True)
+        assert rc == 0 and np.isfinite(res).all()
+
+    one_pass()
+    before = free_bytes()
+    for _ in range(12):
+        one_pass()
+    after = free_bytes()
+    assert before - after < (8 << 20), (before, after, before - after)
+    # and whole contexts (a client that is destroyed takes its context along: NMFClient.hpp ~NMFClient)
+    def ctx_pass():
+        c2 = fluhip.Context(0, ctx.lib)
+        _, _, rc = c2.bufnmf_channel(audio[1][0], 1024, 1024, 256, 3, 2, 42)
+        assert rc == 0
+        c2.close()
+    ctx_pass()
+    before = free_bytes()
+    for _ in range(6):
+        ctx_pass()
+    after = free_bytes()
+    assert before - after < (8 << 20), (before, after, before - after)
