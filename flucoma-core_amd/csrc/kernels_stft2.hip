@@ -758,7 +758,10 @@ __device__ __forceinline__ void window_samples(const float2 (&raw)[N / 64], int 
 // FPW frames per wavefront and round: a block stages NW * FPW consecutive frames before the bin-major flush, so a bin's
 // piece of the transposed copy is NW * FPW * 8 bytes -- a full 128-byte line at fft 2048 with 8 wavefronts x 2 frames
 // (64-byte pieces measured 3.3 TB/s against 4.4 - 5.9 for full lines, tools/hbm_write_probe.hip).
-template <int R1, int R2, int R3, int NW, int WINLDS, bool SPEC, int FPW = 1>
+// DB (round 5): TWO sets of staging buffers, used in turn -- the flush of round r reads set r & 1 while the transforms of
+// round r + 1 fill the other, so the barrier behind the flush goes (a wavefront reaches the next round's barrier only after its
+// own flush reads, and nobody writes a set before everybody has passed that barrier).
+template <int R1, int R2, int R3, int NW, int WINLDS, bool SPEC, int FPW = 1, bool DB = false>
 __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
 {
   constexpr int N = R1 * R2 * R3;  // complex points per frame = fft / 2
@@ -834,6 +837,8 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
     int b, t0;
     if ((L >> 3) >= chunk) break;
     if (!decode(L, b, t0)) continue;
+    [[maybe_unused]] double* const xcur = DB ? core.xb - wave * FPW * BUFD : xall;   // this round's set of staging buffers
+    [[maybe_unused]] double* const xbw = DB ? core.xb : xb;
     // ragged corpora: the buffer's own length decides its frame count (alg/STFT.hpp:98-99); frames past it are padding
     const int64_t nSamples = a.nTab ? a.nTab[b] : a.n;
     const int Tb = a.nTab ? (int) ((nSamples + a.hop) / a.hop) : a.T;
@@ -872,7 +877,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
         if (t >= Tb) break;
         // frame-major row from the wavefront's own staging buffer, 16 bytes per lane
         double* magRow = a.mag + (int64_t) b * a.magStride + (int64_t) t * a.ldMag;
-        const double* xs = xb + fj * BUFD;
+        const double* xs = xbw + fj * BUFD;
 #pragma unroll
         for (int q = 0; q < N / 128; q++)
         {
@@ -897,11 +902,17 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
         const int tc = t0 + 2 * p;
         if (i < ITEMS && tc < a.ldMagT)
         {
-          const double v0 = xall[(2 * p) * BUFD + f], v1 = xall[(2 * p + 1) * BUFD + f];
+          const double v0 = xcur[(2 * p) * BUFD + f], v1 = xcur[(2 * p + 1) * BUFD + f];
           *reinterpret_cast<d2*>(outT + (int64_t) f * a.ldMagT + tc) = d2{v0, v1};
         }
       }
-      LDS_BARRIER();
+      if constexpr (!DB) LDS_BARRIER();
+    }
+    if constexpr (DB)
+    {
+      // the other set of staging buffers for the next round
+      const int set = (int) ((core.xb - xall) >= NW * FPW * BUFD);
+      core.shift(set ? -NW * FPW * BUFD : NW * FPW * BUFD);
     }
   }
 }
@@ -1516,13 +1527,13 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
 }
 int stft_features_bins_per_lane(int fft) { return (fft / 2 + 1 + 63) / 64; }
 
-template <int R1, int R2, int R3, int NW, int WINLDS, int FPW = 1>
+template <int R1, int R2, int R3, int NW, int WINLDS, int FPW = 1, bool DB = false>
 static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
 {
   constexpr int N = R1 * R2 * R3;
   constexpr int BUFD = FftCore<R1, R2, R3>::BUFD;
   constexpr int TW = (R2 - 1) * R1 + (R3 - 1) * R1 * R2;
-  constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) NW * FPW * BUFD * 8;
+  constexpr size_t shmem = ((size_t) TW + (WINLDS ? N : 0)) * 16 + (size_t) (DB ? 2 : 1) * NW * FPW * BUFD * 8;
   static_assert(shmem <= 160 * 1024, "LDS");
   StftBArgs k = k0;
   static const int pf = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_PREFETCH"); return e ? std::atoi(e) : 1; }();
@@ -1530,7 +1541,7 @@ static bool launch_block_t(const StftBArgs& k0, hipStream_t s)
   k.blocksPerBuf = (k.T + NW * FPW - 1) / (NW * FPW);
   k.totalBlocks = (int64_t) k.B * k.blocksPerBuf;
   if (k.totalBlocks < 1) return true;
-  auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true, FPW> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false, FPW>;   // the complex spectrum is kept for resynthesis / BufSTFT only
+  auto kern = k.spec ? stft_block_kernel<R1, R2, R3, NW, WINLDS, true, FPW, DB> : stft_block_kernel<R1, R2, R3, NW, WINLDS, false, FPW, DB>;   // the complex spectrum is kept for resynthesis / BufSTFT only
   request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
   int64_t grid = 8 * chunk;
@@ -1569,6 +1580,12 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
     // phase waits for (fft 1024 already writes 128-byte pieces and runs at the same bytes per second), so it stays off.
     static const int fpw = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_FPW"); return e ? std::atoi(e) : 1; }();
     if (fpw == 2) return launch_block_t<16, 8, 8, 8, 0, 2>(k, s);
+    // Two sets of staging buffers used in turn (round 5): the bin-major flush of round r runs under the transforms of round
+    // r + 1 and the barrier behind the flush goes -- 565 - 580 -> 513 - 542 us per launch of the bench corpus's STFT, same box,
+    // alternating (profiles/r05/stft_double_buffer.txt).  The second set takes the room of the window table: the window is
+    // read through the L1.  Without a bin-major copy there is no barrier to save; FLUHIP_STFT_DB=0 (A/B build): one set.
+    static const int db = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_DB"); return e ? std::atoi(e) : 1; }();
+    if (db == 1 && magT) return launch_block_t<16, 8, 8, 8, 0, 1, true>(k, s);
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
   }
   if (a.fft == 4096)
@@ -1579,6 +1596,8 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
   if (a.fft == 1024)
   {
     // 16 frames per block (128 registers, four wavefronts per SIMD): 128-byte pieces of the bin-major rows
+    // (two sets of staging buffers, as at fft 2048, measured slower here -- 681 - 690 against 659 - 663 us for 128 x 10 s at hop
+    //  256: four wavefronts per SIMD already overlap the flush, and the window through the L1 costs more than the barrier)
     return launch_block_t<8, 8, 8, 16, 1>(k, s);
   }
   return false;
