@@ -82,16 +82,23 @@ namespace {
 __device__ __forceinline__ cx cmul2(cx a, cx b) { return cx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
 __device__ __forceinline__ cx mul_mi2(cx a) { return cx{a.im, -a.re}; } // a * (-i)
 
-// sqrt(x), x >= 0: v_rsq_f64 seed y = (1 + e) / sqrt(x), |e| ~ 2^-23; one coupled Goldschmidt step leaves g = sqrt(x) (1 - 1.5 e^2)
+// sqrt(x), x >= DBL_MIN: v_rsq_f64 seed y = (1 + e) / sqrt(x), |e| ~ 2^-23; one coupled Goldschmidt step leaves g = sqrt(x) (1 - 1.5 e^2)
 // (~2e-14) and h = 1 / (2 g) to the same order; the exact residual d = x - g^2 times h then squares that again: rounding
-// error only, in 9 FP64 operations (the wave kernel of round 1 ran a second Goldschmidt step first: 12).
+// error only, in 8 FP64 operations behind the seed (the wave kernel of round 1 ran a second Goldschmidt step first: 12).
+// FAST (the fused feature kernel, whose bands leave as float32 behind a single-precision logarithm): the Goldschmidt step
+// alone, 2e-14 relative -- nine orders below the float output's resolution -- in 5 operations.
+// The callers keep x >= DBL_MIN by starting the sum of squares from DBL_MIN (mag_sumsq: adding it is exact-no-op for any
+// power above 1e-290 and costs nothing, where fmax(x, DBL_MIN) was an instruction per bin).
+constexpr double kDblMin = 2.2250738585072014e-308;
+__device__ __forceinline__ double mag_sumsq(double re, double im) { return __builtin_fma(re, re, __builtin_fma(im, im, kDblMin)); }
+template <bool FAST = false>
 __device__ __forceinline__ double mag_sqrt2(double x)
 {
-  x = fmax(x, 2.2250738585072014e-308);
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
   const double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
+  if constexpr (FAST) return g;
   h = __builtin_fma(h, r, h);
   const double d = __builtin_fma(-g, g, x);
   return __builtin_fma(d, h, g);
@@ -295,12 +302,12 @@ struct FftCore
   // TAB: the split's twiddles e^{-2 pi i k / fft} / 2 come from a table in the LDS (splitTab[k], k < N) instead of being
   // formed per frame as products of the lane's factor with compile-time constants (28 FP64 instructions at R3 = 8)
   const d2* splitTab = nullptr;
-  template <bool SPEC, bool TAB = false>
+  template <bool SPEC, bool TAB = false, bool FASTMAG = false>
   __device__ __forceinline__ void run(cx (&pts)[PPL], d2* specRow)
   {
     cx p3[PPL];
     passes(pts, p3);
-    split<SPEC, TAB>(p3, specRow);
+    split<SPEC, TAB, FASTMAG>(p3, specRow);
   }
 
   // the three passes of the complex transform: points m = lane + 64 bb + r N/R1 in, bins j + r NS3 out (j = lane, and for
@@ -418,7 +425,7 @@ struct FftCore
   SCHED_FENCE();
   }
 
-  template <bool SPEC, bool TAB = false>
+  template <bool SPEC, bool TAB = false, bool FASTMAG = false>
   __device__ __forceinline__ void split(cx (&p3)[PPL], d2* specRow)
   {
   // ---- real-FFT split (util/FFT.hpp:99-106) + magnitude (alg/STFT.hpp:61-66) ------------------------------
@@ -504,7 +511,7 @@ struct FftCore
       double xi = __builtin_fma(0.5, ei, __builtin_fma(w.im, di, -(w.re * dr)));
       const int k = j + r * NS3;
       if (k == 0) xi = 0.0;                     // DC is purely real (util/FFT.hpp:99-101)
-      const double m = mag_sqrt2(xr * xr + xi * xi);
+      const double m = mag_sqrt2<FASTMAG>(mag_sumsq(xr, xi));
       if constexpr (XL) mg[r] = m;
       else xb[k] = m;                           // staged (the exchange buffer is idle now)
       if constexpr (SPEC) specRow[k] = d2{xr, xi};
@@ -922,6 +929,14 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64(double x)
 {
   const long long b = __double_as_longlong(x);
+  if constexpr (ROWMASK == 0xf)
+  {
+    // every row enabled: bound_ctrl supplies the zeros of the lanes a shift does not reach, and the move has no `old`
+    // operand to initialise (update_dpp(0, ...) cost a v_mov_b32 per half: 20 per frame of the feature kernel)
+    const int lo = __builtin_amdgcn_mov_dpp((int) (b & 0xffffffff), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int) (b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
+  }
   const int lo = __builtin_amdgcn_update_dpp(0, (int) (b & 0xffffffff), CTRL, ROWMASK, 0xf, false);
   const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), CTRL, ROWMASK, 0xf, false);
   return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
@@ -975,7 +990,9 @@ struct FeatFusedArgs
 // SMALL (round 4): the layout for TWO workgroups per CU (20 wavefronts, five per SIMD, where one workgroup of 1024 threads stops
 // at four): the window pairs come through the L1 instead of the LDS and the per-wavefront scratch of the band stage lies in
 // the wavefront's staging buffer, which is idle by then -- 67 KB per workgroup of ten wavefronts at fft 1024.
-template <int R1, int R2, int R3, int NW, bool DYN = true, bool SMALL = false>
+// FASTMAG (round 5): the magnitudes behind one Goldschmidt step (mag_sqrt2<true>: 2e-14 relative, 24 VALU instructions per frame
+// fewer at fft 1024) -- they feed band sums that leave as float32.  FLUHIP_FEAT_FASTMAG=0 (A/B build): the full square root.
+template <int R1, int R2, int R3, int NW, bool DYN = true, bool SMALL = false, bool FASTMAG = true>
 __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftBArgs a, FeatFusedArgs fa)
 {
   using Core = FftCore<R1, R2, R3>;
@@ -1112,7 +1129,7 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       gather_points<R1, N>(a, b, t, lane, SMALL ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #endif
       SCHED_FENCE();
-      core.template run<false, TAB>(pts, nullptr);
+      core.template run<false, TAB, FASTMAG>(pts, nullptr);
     }
     SCHED_FENCE();
     // ---- band sums ------------------------------------------------------------------------------------------
@@ -1191,11 +1208,21 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       const double* drow = dctl + (live ? fa.startCoeff + j : 0) * dld + part * dq;
       const double* bq = bands + part * dq;
       double sacc = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; i++)                            // (nBands <= 64: dq <= 16)
+      if (dq == 10)
       {
-        if (i >= dq) break;
-        sacc = __builtin_fma(lds_read1(drow + i), lds_read1(bq + i), sacc);
+        // 37 .. 40 bands (the MFCC default): the quarter row unrolled, every position an immediate offset -- as a loop with a
+        // trip count from a register the compiler kept an address add per read (18 v_add_u32 per eight products)
+#pragma unroll
+        for (int i = 0; i < 10; i++) sacc = __builtin_fma(lds_read1(drow + i), lds_read1(bq + i), sacc);
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < 16; i++)                            // (nBands <= 64: dq <= 16)
+        {
+          if (i >= dq) break;
+          sacc = __builtin_fma(lds_read1(drow + i), lds_read1(bq + i), sacc);
+        }
       }
       sacc += __shfl_xor(sacc, 1);
       sacc += __shfl_xor(sacc, 2);
@@ -1440,6 +1467,8 @@ static bool launch_feat_t(const StftBArgs& k0, const FeatFusedArgs& fa, hipStrea
 #ifdef FLUHIP_AB_SWITCHES // FLUHIP_FEAT_DYN=0: a fixed share of the frames per wavefront (rounds 2 - 3)
   static const int dynOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_DYN"); return e && std::atoi(e) == 0 ? 1 : 0; }();
   if (dynOff && !SMALL) kern = stft_feat_kernel<R1, R2, R3, NW, false>;
+  static const int slowMag = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_FASTMAG"); return e && std::atoi(e) == 0 ? 1 : 0; }();
+  if (slowMag && !dynOff && !SMALL) kern = stft_feat_kernel<R1, R2, R3, NW, true, false, false>;
 #endif
   request_dynamic_lds(kern, (size_t) (shmem));
   const int64_t chunk = (k.totalBlocks + 7) / 8;
