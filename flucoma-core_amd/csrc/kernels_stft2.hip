@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
   // -> 697 / 691 us for the bench workload's STFT phase (profiles/r03/stft_prefetch.txt; FLUHIP_STFT_PREFETCH=0 is the
   // round-2 order).  Requesting them before the transform instead (35 more registers) measured the same, and two
   // 4-wavefront blocks per CU instead of one of 8 measured slower (754 / 763 us): neither is kept.
-  constexpr bool PREFETCH = FPW == 1 && PPL == 16;         // fft 2048 only: fft 1024 (4 wavefronts per SIMD) measures the same either way, fft 4096 has no registers to spare
+  constexpr bool PREFETCH = FPW == 1 && PPL == 16 && NW <= 12; // fft 2048 at two or three wavefronts per SIMD only: fft 1024 (4 wavefronts per SIMD) measures the same either way, fft 4096 has no registers to spare, and 16 wavefronts of fft 2048 need the 32 registers
   float2 raw[PPL];
   int rawB = -1, rawT = -1;
   auto prefetch = [&](int64_t Ln) {
@@ -1614,6 +1614,17 @@ bool launch_stft_block(const StftArgs& a, double* magT, int64_t magTStride, int6
     // alternating (profiles/r05/stft_double_buffer.txt).  The second set takes the room of the window table: the window is
     // read through the L1.  Without a bin-major copy there is no barrier to save; FLUHIP_STFT_DB=0 (A/B build): one set.
     static const int db = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_DB"); return e ? std::atoi(e) : 1; }();
+#ifdef FLUHIP_AB_SWITCHES
+    // FLUHIP_STFT_NW=16 (A/B build, round 5): sixteen frames per block, four wavefronts per SIMD, one set of staging buffers, no
+    // sample prefetch -- the form fft 1024 runs in; a bin's piece of the bin-major copy is a full 128-byte line.  At 128
+    // registers the 16-point-per-lane transform spills 41 of them: 878 - 887 us per STFT phase of the bench corpus against
+    // 651 - 652 for the production form (tools/stft_timing.py, profiles/r05/stft_nw16.txt; twelve wavefronts at 168 registers
+    // spill 59: 1 240 us).  Not adopted.
+    {
+      static const int nw = [] { const char* e = fluhip::ab_getenv("FLUHIP_STFT_NW"); return e ? std::atoi(e) : 8; }();
+      if (nw == 16) return launch_block_t<16, 8, 8, 16, 0>(k, s);
+    }
+#endif
     if (db == 1 && magT) return launch_block_t<16, 8, 8, 8, 0, 1, true>(k, s);
     return launch_block_t<16, 8, 8, 8, 1>(k, s);
   }
