@@ -511,3 +511,38 @@ def test_nmfmatch_and_nmffilter_closed_forms_against_the_literal_clients(onp, n,
     # a maxComponents below the buffer's channel count takes the first components only (:93)
     a2 = onp.nmfmatch_streaming_control(x, bases, win, fft, hop, 42, mode, max_rank=1)
     assert a2.shape[0] == 1 and np.array_equal(a2, onp.nmfmatch_channel(x, bases[:1], win, fft, hop, 42, mode))
+
+
+@pytest.mark.parametrize("faithful", [False, True])
+def test_update_arithmetic_against_scikit_learns_multiplicative_updates(oracle, onp, faithful):
+    """The NMF arithmetic has no reference-held answer (tests/algorithms/public/TestNMF.cpp:11-46 asserts determinism only,
+    and alg/NMF.hpp needs Eigen to compile).  A third implementation by an unrelated party stands in as a cross-check of
+    the two update formulas: scikit-learn's `_multiplicative_update_w / _h` with beta_loss = 1 are the KL multiplicative
+    updates of alg/NMF.hpp:158-161 and :165-170 (numerator (V / WH) H^T over the row sums of H; W^T (V / WH) over the
+    column sums of W).  Driven from the oracle's own start (libstdc++ RNG, clamp, normalise: :149-153) in the reference's
+    order -- W update, column-normalise W (:162), H update with the new W -- they must land where both oracles land.
+    scikit-learn clamps WH at float32 epsilon where the reference clamps at double epsilon, so the input is strictly
+    positive and no clamp is active; what is left is summation order."""
+    nmf = pytest.importorskip("sklearn.decomposition._nmf")
+    rs = np.random.RandomState(11)
+    T, F, K, iters = 60, 33, 5, 40
+    X = np.abs(rs.standard_normal((T, F))) + 0.05                # [T, F] as the oracles take it
+    W1, H1, V1, rc = oracle.nmf_process(X, K, iters, True, True, 42, faithful=faithful)
+    assert rc == 0
+    Wn, Hn, Vn = onp.nmf_process(X, K, iters, seed=42)
+    # the same start as oracle_np.nmf_process (alg/NMF.hpp:118-153)
+    W = onp.rng_uniform01(42, F * K).reshape(K, F).T.copy()
+    H = onp.rng_uniform01(42, K * T).reshape(T, K).T.copy()
+    W = np.maximum(W, onp.EPS); H = np.maximum(H, onp.EPS)
+    W = W / np.sqrt((W * W).sum(axis=0, keepdims=True))
+    H = H / np.sqrt((H * H).sum(axis=1, keepdims=True))
+    V = X.T.copy()                                                # F x T = W (F x K) H (K x T)
+    for _ in range(iters):
+        W = nmf._multiplicative_update_w(V, W, H, beta_loss=1, l1_reg_W=0, l2_reg_W=0, gamma=1.0)[0]
+        W = W / np.sqrt((W * W).sum(axis=0, keepdims=True))
+        H = nmf._multiplicative_update_h(V, W, H, beta_loss=1, l1_reg_H=0, l2_reg_H=0, gamma=1.0)
+    assert (W @ H).min() > 1e-4                                   # no clamp of either implementation was ever near
+    for got_w, got_h in ((W1, H1), (Wn, Hn)):
+        assert rel_err(got_w, W.T) < 1e-11
+        assert rel_err(got_h, H.T) < 1e-11
+    assert rel_err(V1, (W @ H).T) < 1e-11
