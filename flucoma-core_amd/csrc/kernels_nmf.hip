@@ -30,20 +30,36 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // partials -- and only then starts adding; the first form walked its 16 rows in four dependent batches behind a
 // denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
 constexpr int kFinSG = 4;      // thread groups sharing the split partials of an element
-constexpr int kFinBatch = 4;   // rows per row group, all in flight together
+constexpr int kFinBatch = 4;   // rows per row group in flight together (a workgroup takes BATCH = 4, 8 or 16 of them, four at a time)
 // (split partials per thread group: nsplit <= 64, the kernel is built for 1, 2, 4, 8 and 16)
 
 static int fin_row_groups(int Kp) { int nrg = 256 / (Kp * kFinSG); return nrg < 1 ? 1 : nrg; }
-int update_finalize_rows(int Kp) { return kFinBatch * fin_row_groups(Kp); }
-int update_finalize_parts(int C, int Kp) { const int rows = update_finalize_rows(Kp); return (C + rows - 1) / rows; }
+// Rows per row group and workgroup.  Four in production.  Round 5 looked at config 3 (2 048 bins at rank 128) launch by launch:
+// 512 workgroups of four rows per channel leave 512 statistics records of 2 KB for ONE workgroup per channel to add up
+// (wnorm_combine_kernel<1024>: 25.8 us), so 8 / 16 rows per row group were built (FLUHIP_FIN_BATCH=8|16, A/B build) and measured:
+// 128 records bring the combine to 15.1 us, but the finalize launches themselves get slower by more than that (23.7 -> 34.8
+// and 11.2 -> 16.2 us: they live on their workgroup count) -- profiles/r05/c3_fin_batch.txt.  What was adopted instead is a
+// pre-reduction of the records by sixteen workgroups per buffer (wnorm_prereduce_kernel below).
+// A function of (C, Kp) alone: the planner sizes the statistics area with it before any launch.
+static int fin_batch(int C, int Kp)
+{
+  (void) C; (void) Kp;
+#ifdef FLUHIP_AB_SWITCHES
+  static const int forced = [] { const char* e = fluhip::ab_getenv("FLUHIP_FIN_BATCH"); return e ? std::atoi(e) : 0; }();
+  if (forced == 8 || forced == 16) return forced;
+#endif
+  return kFinBatch;
+}
+int update_finalize_rows(int C, int Kp) { return fin_batch(C, Kp) * fin_row_groups(Kp); }
+int update_finalize_parts(int C, int Kp) { const int rows = update_finalize_rows(C, Kp); return (C + rows - 1) / rows; }
 
-template <int PER>
+template <int PER, int BATCH = kFinBatch>
 __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int64_t strideS, const double* part,
                                            const double* dpart, int C, int Kp, int64_t Cp,
                                            int nsplit, const double* nrm, int nrmMode, double* statPart, int nch,
                                            const int* splitTab)
 {
-  extern __shared__ double sh[]; // [kFinSG][nrg][kFinBatch][Kp] partial numerators, then [kFinSG][Kp] denominators; reused for the statistics
+  extern __shared__ double sh[]; // [kFinSG][nrg][BATCH][Kp] partial numerators, then [kFinSG][Kp] denominators; reused for the statistics
   const int chunk = blockIdx.x, buf = blockIdx.y;
   // work-list mode (ragged corpora): buffer b owns the partials [splitTab[2 b], splitTab[2 b] + splitTab[2 b + 1])
   int64_t pbase = (int64_t) buf * nsplit;
@@ -56,40 +72,44 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
   const int k = threadIdx.x % Kp, rg = (threadIdx.x / Kp) % nrg, sg = threadIdx.x / (Kp * nrg);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const int sb = sg * per, se = min(nsplit, sb + per);
-  const int rows = kFinBatch * nrg;
+  const int rows = BATCH * nrg;
   const int rbeg = chunk * rows, rend = min(rbeg + rows, C);
   const double* p0 = part + pbase * Cp * Kp;
   const int64_t sstride = Cp * Kp;
-  // ---- every load of this thread, issued before anything is consumed ---------------------------------------------
-  double pv[kFinBatch][PER];
-  double sold[kFinBatch];
+  double* shn = sh;                                   // [kFinSG][nrg][BATCH][Kp]
+  double* shd = sh + kFinSG * nrg * BATCH * Kp;       // [kFinSG][Kp]
+  // ---- the loads of this thread, issued before anything is consumed: kFinBatch rows at a time ------------------------
+  double sold[BATCH];
   double dv[PER];
-#pragma unroll
-  for (int i = 0; i < kFinBatch; i++)
-  {
-    const int r = rbeg + i * nrg + rg;
-    const int64_t idx = (int64_t) min(r, C - 1) * Kp + k;
-#pragma unroll
-    for (int u = 0; u < PER; u++) pv[i][u] = (u < per) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
-    sold[i] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
-  }
   {
     const double* dp = dpart + pbase * Kp + k;
 #pragma unroll
     for (int u = 0; u < PER; u++) dv[u] = (rg == 0 && u < per) ? dp[(int64_t) min(sb + u, nsplit - 1) * Kp] : 0.0;
   }
   const double nk = (nrmMode && sg == 0) ? nrm[(int64_t) buf * Kp + k] : 1.0;
-  // ---- quarter sums in split order, combined in group order through LDS ----------------------------------------------------
-  double* shn = sh;                                   // [kFinSG][nrg][kFinBatch][Kp]
-  double* shd = sh + kFinSG * nrg * kFinBatch * Kp;   // [kFinSG][Kp]
 #pragma unroll
-  for (int i = 0; i < kFinBatch; i++)
+  for (int i0 = 0; i0 < BATCH; i0 += kFinBatch)
   {
-    double num = 0.0;
+    double pv[kFinBatch][PER];
 #pragma unroll
-    for (int u = 0; u < PER; u++)
-      if (sb + u < se) num += pv[i][u];
-    shn[((sg * nrg + rg) * kFinBatch + i) * Kp + k] = num;
+    for (int j = 0; j < kFinBatch; j++)
+    {
+      const int r = rbeg + (i0 + j) * nrg + rg;
+      const int64_t idx = (int64_t) min(r, C - 1) * Kp + k;
+#pragma unroll
+      for (int u = 0; u < PER; u++) pv[j][u] = (u < per) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
+      sold[i0 + j] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
+    }
+    // ---- quarter sums in split order, combined in group order through LDS (below) ---------------------------------------
+#pragma unroll
+    for (int j = 0; j < kFinBatch; j++)
+    {
+      double num = 0.0;
+#pragma unroll
+      for (int u = 0; u < PER; u++)
+        if (sb + u < se) num += pv[j][u];
+      shn[((sg * nrg + rg) * BATCH + i0 + j) * Kp + k] = num;
+    }
   }
   if (rg == 0)
   {
@@ -109,14 +129,14 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
     if (nrmMode == 2) den = den / nk;
     den = fmax(den, kEpsilon);
 #pragma unroll
-    for (int i = 0; i < kFinBatch; i++)
+    for (int i = 0; i < BATCH; i++)
     {
       const int r = rbeg + i * nrg + rg;
       if (r < rend)
       {
-        double t = shn[(rg * kFinBatch + i) * Kp + k];
+        double t = shn[(rg * BATCH + i) * Kp + k];
 #pragma unroll
-        for (int g = 1; g < kFinSG; g++) t += shn[((g * nrg + rg) * kFinBatch + i) * Kp + k];
+        for (int g = 1; g < kFinSG; g++) t += shn[((g * nrg + rg) * BATCH + i) * Kp + k];
         double so = sold[i];
         if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
         const double x = (so * t) / den;
@@ -154,16 +174,33 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
 {
   const int nrg = fin_row_groups(Kp);
   const int nch = update_finalize_parts(C, Kp);
-  const size_t shmem = ((size_t) kFinSG * nrg * kFinBatch * Kp + (size_t) kFinSG * Kp) * sizeof(double);
+  const int batch = fin_batch(C, Kp);
+  const size_t shmem = ((size_t) kFinSG * nrg * batch * Kp + (size_t) kFinSG * Kp) * sizeof(double);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const dim3 grid((unsigned) nch, (unsigned) B), block((unsigned) (kFinSG * nrg * Kp));
-#define FLUHIP_FIN(P) hipLaunchKernelGGL(nmf_update_finalize_kernel<P>, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, \
-                                         nsplit, nrm, nrmMode, statPart, nch, splitTab)
-  if (per <= 1) FLUHIP_FIN(1);
-  else if (per <= 2) FLUHIP_FIN(2);
-  else if (per <= 4) FLUHIP_FIN(4);
-  else if (per <= 8) FLUHIP_FIN(8);
-  else FLUHIP_FIN(16);
+#define FLUHIP_FIN_B(P, BT)                                                                                                   \
+  {                                                                                                                           \
+    auto kern = nmf_update_finalize_kernel<P, BT>;                                                                            \
+    if (shmem > 48 * 1024) request_dynamic_lds(kern, shmem);                                                                  \
+    hipLaunchKernelGGL(kern, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, nsplit, nrm, nrmMode, statPart, nch,  \
+                       splitTab);                                                                                             \
+  }
+#ifdef FLUHIP_AB_SWITCHES
+#define FLUHIP_FIN(P)                                                                                                         \
+  {                                                                                                                           \
+    if (batch == 16) FLUHIP_FIN_B(P, 16)                                                                                      \
+    else if (batch == 8) FLUHIP_FIN_B(P, 8)                                                                                   \
+    else FLUHIP_FIN_B(P, 4)                                                                                                   \
+  }
+#else
+#define FLUHIP_FIN(P) FLUHIP_FIN_B(P, 4)
+#endif
+  if (per <= 1) FLUHIP_FIN(1)
+  else if (per <= 2) FLUHIP_FIN(2)
+  else if (per <= 4) FLUHIP_FIN(4)
+  else if (per <= 8) FLUHIP_FIN(8)
+  else FLUHIP_FIN(16)
+#undef FLUHIP_FIN_B
 #undef FLUHIP_FIN
 }
 
@@ -601,6 +638,70 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
   }
 }
 
+// Long factors (config 3: 512 statistics records + 256 side-column slices of 2 KB per channel, two channels): ONE workgroup
+// per buffer pulling 1.5 MB through its CU took 25.8 us per iteration.  kPreGroups workgroups per buffer add up a sixteenth of
+// the records each -- thread (sub, k) a contiguous run in index order, the runs in fixed order through the LDS -- and leave
+// kPreGroups records per buffer in the SAME two layouts, which the 256-thread combine then reads.  No atomics, no tickets.
+constexpr int kPreGroups = 16;
+__global__ __launch_bounds__(512) void wnorm_prereduce_kernel(int Kp, const double* statPart, int nParts, const double* sidePart,
+                                                              int nsl, double* statOut, double* sideOut)
+{
+  __shared__ double sa[512], sb[512];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int nsub = blockDim.x / Kp, k = threadIdx.x % Kp, sub = threadIdx.x / Kp;
+  auto run = [&](int n, int& j0, int& j1) {
+    const int perG = (n + kPreGroups - 1) / kPreGroups;
+    const int g0 = min(n, g * perG), g1 = min(n, g0 + perG);
+    const int perS = (g1 - g0 + nsub - 1) / nsub;
+    j0 = min(g1, g0 + sub * perS);
+    j1 = min(g1, j0 + perS);
+  };
+  // pass 0: the statistics (sum x^2, max); pass 1: the side-column slices (numerator, denominator)
+  for (int pass = 0; pass < 2; pass++)
+  {
+    const double* src = pass == 0 ? statPart : sidePart;
+    const int n = pass == 0 ? nParts : nsl;
+    if (!src) continue;
+    const double* p = src + (int64_t) b * n * 2 * Kp;
+    int j0, j1;
+    run(n, j0, j1);
+    double t = 0.0, m = pass == 0 ? -INFINITY : 0.0;
+    for (int j = j0; j < j1; j += 8)
+    {
+      double va[8], vb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+      {
+        const int jj = min(j + u, j1 - 1);
+        va[u] = p[(int64_t) jj * 2 * Kp + k];
+        vb[u] = p[(int64_t) jj * 2 * Kp + Kp + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j + u < j1)
+        {
+          t += va[u];
+          m = pass == 0 ? fmax(m, vb[u]) : m + vb[u];
+        }
+    }
+    __syncthreads();
+    sa[threadIdx.x] = t;
+    sb[threadIdx.x] = m;
+    __syncthreads();
+    if (sub == 0)
+    {
+      for (int q = 1; q < nsub; q++)
+      {
+        t += sa[q * Kp + k];
+        m = pass == 0 ? fmax(m, sb[q * Kp + k]) : m + sb[q * Kp + k];
+      }
+      double* o = (pass == 0 ? statOut : sideOut) + ((int64_t) b * kPreGroups + g) * 2 * Kp;
+      o[k] = t;
+      o[Kp + k] = m;
+    }
+  }
+}
+
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
                                                                 const double* statPart, int nParts, const double* sidePart,
@@ -815,7 +916,9 @@ bool nmf_side_column_supported(int R, int C, int Kp)
   (void) R; // any length: slices beyond a block's capacity are taken in chunks
   return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128);
 }
-int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
+static int64_t wnorm_scratch_base_doubles(int Kp, int B, int nStrips) { return (int64_t) B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
+// ... and behind them the pre-reduced records of long factors: [B][kPreGroups][2][Kp] statistics, then as many of the side column
+int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return (int) (wnorm_scratch_base_doubles(Kp, B, nStrips) + (int64_t) B * kPreGroups * 4 * Kp); }
 
 static_assert(kSideSlices == 4 * kSideFromHSlots, "two generations of 128 slices: 64 of partials, then the old side row");
 double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen)
@@ -879,7 +982,18 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   if (sidePhase == 1) return;
   // one block per buffer sums nStrips statistics parts and nsl side slices per component: 1024 threads where that is long
   // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
-  if (nStrips > 128 || nsl > 64)
+  // FLUHIP_WNORM_PRE=0 (A/B build): the one-workgroup combine of rounds 3 - 4 for long factors
+  static const bool pre = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) != 0 : true; }();
+  if ((nStrips > 128 || nsl > 64) && pre && Kp <= 512)
+  {
+    double* statOut = scratch + wnorm_scratch_base_doubles(Kp, B, nStrips);
+    double* sideOut = statOut + (int64_t) B * kPreGroups * 2 * Kp;
+    hipLaunchKernelGGL(wnorm_prereduce_kernel, dim3(kPreGroups, (unsigned) B), dim3(512), 0, s, Kp, statPart, nStrips,
+                       side ? sidePart : nullptr, nsl, statOut, sideOut);
+    hipLaunchKernelGGL(wnorm_combine_kernel<256>, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statOut,
+                       kPreGroups, side ? sideOut : nullptr, side ? kPreGroups : 0, wold, nrm);
+  }
+  else if (nStrips > 128 || nsl > 64)
     hipLaunchKernelGGL(wnorm_combine_kernel<1024>, dim3((unsigned) B), dim3(1024), 0, s, S, strideS, C, K, Kp, statPart,
                        nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
   else
