@@ -1059,6 +1059,25 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
         ctx->sideTurn++;
         if (hipEventRecord(fork, s) != hipSuccess || hipStreamWaitEvent(ctx->sideStream, fork, 0) != hipSuccess) join = nullptr;
       }
+      // Arrays of rank 128 at compute ranks above 104 take the update's column sums of H from a pre-pass -- and the side
+      // column's denominator is that same sum.  There the side-column launch goes IN FRONT of the update (it reads H, V, the old
+      // side row and the old norms: nothing the update writes) and its slices' denominators are added into the update's
+      // denominator slots: one sweep over H instead of two (config 3: colsum_part_kernel's 11 - 16 us per iteration gone).
+      // FLUHIP_COLSUM_FROM_SIDE=0 (A/B build): the pre-pass as before.
+      static const bool csFromSide = [] { const char* e = fluhip::ab_getenv("FLUHIP_COLSUM_FROM_SIDE"); return e ? std::atoi(e) != 0 : true; }();
+      static const bool sideFused = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();   // (A/B: the combine rides in the side-column launch, which must then follow the update)
+      const bool sideFirst = csFromSide && !sideFused && c->sideW && !sideReady && !join && !c->useLists && c->Kp == 128 &&
+                             (c->Kc <= 0 || c->Kc > 104) && a.colsumScratch && update_variant(a.Kp) == 5;
+      if (sideFirst)
+      {
+        ProfScope p(ctx, 3);
+        launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                             c->wscratch.as<double>(), wnormW, &sc, s, 1);
+        const int ns = a.nsplit < 1 ? 1 : a.nsplit;
+        launch_colsum_from_side(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW, wnorm_side_slices(sc.R, (int) c->Kp),
+                                a.dpart, (int64_t) ns * c->Kp, ns - 1, s);
+        a.colsumInPlace = true;
+      }
       {
         ProfScope p(ctx, 1);
         launch_nmf_update5(a, s);
@@ -1090,8 +1109,28 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
           launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
                                c->wscratch.as<double>(), wnormW, &sc, s, 2, c->sideFromHSlices, c->sideGen);
         else
-          launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
-                               c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s, join ? 2 : 0);
+        {
+          // ... and where the H update behind takes ITS column sums (of the new W') from a pre-pass, the combine launch leaves
+          // them in that update's denominator slots (long factors: launch_wnorm_combine says whether it did)
+          WnormColsum wc;
+          if (csFromSide && updateH && !c->useLists && uvH == 5 && c->Kp == 128 && (c->Kc <= 0 || c->Kc > 104) && c->csumScratch.p)
+          {
+            double* dp = c->dpart.as<double>();
+            if (c->tailSplitH > 1 && !c->winB)
+            {
+              wc.out1 = dp; wc.stride1 = c->Kp; wc.zero1 = 0;
+              wc.out2 = dp + (int64_t) Bw * c->Kp; wc.stride2 = (int64_t) c->tailSplitH * c->Kp; wc.zero2 = c->tailSplitH - 1;
+            }
+            else
+            {
+              const int nsH = c->nsplitH < 1 ? 1 : c->nsplitH;
+              wc.out1 = dp; wc.stride1 = (int64_t) nsH * c->Kp; wc.zero1 = nsH - 1;
+            }
+          }
+          c->colsumWInPlace = launch_wnorm_combine(WfW, c->Fp * c->Kp, (int) c->F, (int) c->K, (int) c->Kp, Bw, c->stripsW,
+                                                   c->wscratch.as<double>(), wnormW, c->sideW ? &sc : nullptr, s,
+                                                   (join || sideFirst) ? 2 : 0, 0, -1, wc.out1 ? &wc : nullptr);
+        }
       }
       c->wPending = true;
     }
@@ -1111,6 +1150,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
   {
     UpdateArgs a = h_args();
     if (c->wPending) { a.nrm = wnormW; a.nrmMode = 2; }
+    const bool csIn = c->colsumWInPlace;   // (the column sums of W' are in this update's denominator slots already)
+    c->colsumWInPlace = false;
     ProfScope p(ctx, 1);
     const int uv = uvH;
     if (c->useLists)
@@ -1126,12 +1167,14 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // two launches (plan_tail): whole contractions for the frames that fill whole rounds, split ones for the rest
       UpdateArgs a1 = a;
       a1.C = c->tailColsH; a1.stripsOverride = c->tailStripsH; a1.nsplit = 1;
+      a1.colsumInPlace = csIn;
       launch_nmf_update5(a1, s);
       UpdateArgs a2 = a;
       a2.V = a.V + c->tailColsH; a2.S = a.S + (int64_t) c->tailColsH * c->Kp; a2.C = a.C - c->tailColsH;
       a2.stripsOverride = c->tailRestH; a2.nsplit = c->tailSplitH; a2.Cp = round_up(a2.C, 32);
       a2.dpart = a.dpart + (int64_t) Bw * c->Kp;
-      if (c->Kp > 64) a2.colsumGiven = a.dpart; // (the first launch's pre-pass left the column sums of W there)
+      if (csIn) a2.colsumInPlace = true;
+      else if (c->Kp > 64) a2.colsumGiven = a.dpart; // (the first launch's pre-pass left the column sums of W there)
       a2.clk = nullptr;                         // the clock stamps stay those of the whole-contraction wavefront
       launch_nmf_update5(a2, s);
     }
@@ -1143,6 +1186,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // FLUHIP_SIDE_FROM_H=0 (A/B build): the side-column launch as before.
       // (the norm combine of the W update in front, if that was left to this launch: c->normDue)
       const bool wantNorm = c->normDue;
+      a.colsumInPlace = csIn;
       if (wantNorm || (fromH && updateW && !last && c->lazy && c->sideW && c->wPending && c->nsplitH == 1)) side_io(a, wantNorm);
       const int did = launch_nmf_update5(a, s);
       if (wantNorm && !(did & 2)) c->planError = true; // (cannot happen: the dry run in the W update's step took the same arguments)
@@ -1167,6 +1211,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
 {
   fluhip_ctx* ctx = c->ctx;
   c->sideFromH = false; // (side-column partials an H update leaves are only ever used by the W update enqueued right behind it)
+  c->colsumWInPlace = false;
   c->normDue = false;
   if (!progress)
   {

@@ -236,6 +236,7 @@ struct fluhip_corpus
   bool sideW = false;    // ... with the Nyquist bin of the W update as a side column
   bool wPending = false; // W in memory is W' = W diag(wnorm)
   bool sideFromH = false; // the H update enqueued last left the next W update's side-column partials (sideFromHSlices per buffer)
+  bool colsumWInPlace = false; // the W update enqueued last left the column sums of the new W' in the H update's denominator slots (launch_wnorm_combine)
   int sideFromHSlices = 0;
   int sideGen = 0;        // which of the two side-partial areas of wscratch holds them (an H update reads one and fills the other)
   bool normDue = false;   // the W update enqueued last left its norm combine to the H update behind it

@@ -124,6 +124,10 @@ struct UpdateArgs
   // rank 65..128, optional: the column sums of Mv already taken by an earlier launch of the same update ([B][Kp], dense) --
   // copied into the denominator slots instead of a second pre-pass (the tail launch of a two-launch update)
   const double* colsumGiven = nullptr;
+  // rank 65..128, optional: slot (buffer, split 0) of dpart holds the column sums of Mv already and the other splits' slots
+  // are zero (launch_colsum_from_side, or a combine launch that left them there): the forms that take their column sums from
+  // a pre-pass skip it; the forms that accumulate their own overwrite the slots as always
+  bool colsumInPlace = false;
   // kernels_nmf5.hip: {launches, shader cycles, 100 MHz ticks} of one wavefront per launch, accumulated (or null)
   long long* clk = nullptr;
   // kernels_nmf5.hip work-list mode: listWGs workgroups of 4 wavefronts, list[4 * listWGs]; listNG = the widest strip;
@@ -203,8 +207,26 @@ bool nmf_side_column_supported(int R, int C, int Kp);
 // after a W update launched with UpdateArgs::statPart = scratch and nStrips wavefronts per buffer:
 // [side column ->] new nrm [B][Kp] (1 where alg/NMF.hpp:162 would skip the normalisation)
 int wnorm_scratch_doubles(int Kp, int B, int nStrips);
-void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase = 0, int sideSlices = 0, int sideGen = -1);
+// the side-column launch's slices per buffer (sidePhase 0 / 1 of launch_wnorm_combine), and the column sums of the moving
+// factor from those slices' denominators into the update launch's denominator slots (see kernels_nmf.hip)
+int wnorm_side_slices(int R, int Kp);
+void launch_colsum_from_side(const double* scratch, int Kp, int B, int nStrips, int nsl, double* out, int64_t outStride,
+                             int zeroSlots, hipStream_t s);
+// colsum (long factors only: the pre-reduced combine): the column sums of the new W' -- what the H update behind divides by --
+// written by the combine launch into that update's denominator slots (slot 0 the sums, `zero` further rows of Kp cleared: the
+// layout of launch_colsum), for one or two launches of it; launch_wnorm_combine returns true when it did
+struct WnormColsum
+{
+  double* out1 = nullptr;
+  int64_t stride1 = 0;
+  int zero1 = 0;
+  double* out2 = nullptr;
+  int64_t stride2 = 0;
+  int zero2 = 0;
+};
+bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase = 0, int sideSlices = 0, int sideGen = -1,
+                          const WnormColsum* colsum = nullptr);
 // Where the side-column partials / the old side row of an H update with UpdateArgs::sideOut live inside `scratch`: two
 // areas (gen 0 / 1) inside the slice region, up to 64 slices per buffer each -- an H update that does the norm combine reads
 // one generation in its prologue while its own epilogues fill the other.

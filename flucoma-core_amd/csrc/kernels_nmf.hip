@@ -349,21 +349,23 @@ __global__ void colsum_part_kernel(const double* Mvbase, int64_t strideM, int R,
 
 // zeroSlots: that many further rows of Kp behind the sums are cleared (the other splits' denominator slots); nch == 0 with
 // part = [B][Kp] sums already taken: copy them
-__global__ void colsum_combine_kernel(const double* part, int nch, int Kp, double* out, int64_t outStride, int zeroSlots)
+// (recStride: doubles from one partial record to the next -- Kp for the pre-pass's own records)
+__global__ void colsum_combine_kernel(const double* part, int nch, int Kp, double* out, int64_t outStride, int zeroSlots,
+                                      int recStride)
 {
   const int b = blockIdx.x, k = threadIdx.x;
-  const double* p = part + (int64_t) b * nch * Kp + k;
+  const double* p = part + (int64_t) b * nch * recStride + k;
   double t = 0.0;
   int j = 0;
   for (; j + 8 <= nch; j += 8) // eight independent loads in flight, summed in index order
   {
     double v[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = p[(int64_t) (j + u) * Kp];
+    for (int u = 0; u < 8; u++) v[u] = p[(int64_t) (j + u) * recStride];
 #pragma unroll
     for (int u = 0; u < 8; u++) t += v[u];
   }
-  for (; j < nch; j++) t += p[(int64_t) j * Kp];
+  for (; j < nch; j++) t += p[(int64_t) j * recStride];
   if (nch == 0) t = part[(int64_t) b * Kp + k];
   out[(int64_t) b * outStride + k] = t;
   for (int z = 1; z <= zeroSlots; z++) out[(int64_t) b * outStride + (int64_t) z * Kp + k] = 0.0;
@@ -380,13 +382,13 @@ void launch_colsum(const double* Mv, int64_t strideM, int R, int Kp, int B, doub
   hipLaunchKernelGGL(colsum_part_kernel, dim3((unsigned) nch, (unsigned) B), dim3((unsigned) (nrg * Kp)),
                      (size_t) nrg * Kp * sizeof(double), s, Mv, strideM, R, Kp, scratch, nch);
   hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, scratch, nch, Kp, out,
-                     outStride, zeroSlots);
+                     outStride, zeroSlots, Kp);
 }
 
 void launch_colsum_spread(const double* sums, int Kp, int B, double* out, int64_t outStride, int zeroSlots, hipStream_t s)
 {
   hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, sums, 0, Kp, out, outStride,
-                     zeroSlots);
+                     zeroSlots, Kp);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -643,8 +645,11 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
 // the records each -- thread (sub, k) a contiguous run in index order, the runs in fixed order through the LDS -- and leave
 // kPreGroups records per buffer in the SAME two layouts, which the 256-thread combine then reads.  No atomics, no tickets.
 constexpr int kPreGroups = 16;
+// colOut != nullptr: the groups also add up the rows [0, C - 1) of the new W' they are dealt (what the H update behind divides
+// by: alg/NMF.hpp:169), one record of Kp sums per group; the combine adds the records and the side row.
 __global__ __launch_bounds__(512) void wnorm_prereduce_kernel(int Kp, const double* statPart, int nParts, const double* sidePart,
-                                                              int nsl, double* statOut, double* sideOut)
+                                                              int nsl, double* statOut, double* sideOut, const double* Sbase,
+                                                              int64_t strideS, int C, double* colOut)
 {
   __shared__ double sa[512], sb[512];
   const int g = blockIdx.x, b = blockIdx.y;
@@ -700,17 +705,73 @@ __global__ __launch_bounds__(512) void wnorm_prereduce_kernel(int Kp, const doub
       o[Kp + k] = m;
     }
   }
+  if (colOut)
+  {
+    const double* S = Sbase + (int64_t) b * strideS;
+    int j0, j1;
+    run(C - 1, j0, j1);
+    double t = 0.0;
+    for (int j = j0; j < j1; j += 8)
+    {
+      double va[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) va[u] = S[(int64_t) min(j + u, j1 - 1) * Kp + k];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j + u < j1) t += va[u];
+    }
+    __syncthreads();
+    sa[threadIdx.x] = t;
+    __syncthreads();
+    if (sub == 0)
+    {
+      for (int q = 1; q < nsub; q++) t += sa[q * Kp + k];
+      colOut[((int64_t) b * kPreGroups + g) * Kp + k] = t;
+    }
+  }
 }
 
+// cs.part != nullptr: the column sums of the new W' -- the pre-reduction's kPreGroups records per buffer plus the side row this
+// workgroup has just written -- go straight into the denominator slots of the H update behind (one or two launches of it:
+// slot 0 the sums, `zero` further rows of Kp cleared: the layout of launch_colsum)
+struct ColsumOut
+{
+  const double* part = nullptr;   // [B][kPreGroups][Kp]
+  double* out1 = nullptr;
+  int64_t stride1 = 0;
+  int zero1 = 0;
+  double* out2 = nullptr;
+  int64_t stride2 = 0;
+  int zero2 = 0;
+};
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void wnorm_combine_kernel(double* Sbase, int64_t strideS, int C, int K, int Kp,
                                                                 const double* statPart, int nParts, const double* sidePart,
-                                                                int nsl, const double* wold, double* nrm)
+                                                                int nsl, const double* wold, double* nrm, ColsumOut cs)
 {
   __shared__ double shs[THREADS], shm[THREADS], smax[128];
   __shared__ double shn[THREADS > 256 ? THREADS : 1], shd[THREADS > 256 ? THREADS : 1];
   wnorm_combine_body(Sbase, strideS, C, K, Kp, statPart, nParts, sidePart, nsl, wold, nrm, (int) blockIdx.x, shs, shm, smax, shn,
                      shd);
+  if (cs.part && (int) threadIdx.x < Kp)
+  {
+    const int b = blockIdx.x, k = threadIdx.x;
+    const double* p = cs.part + (int64_t) b * kPreGroups * Kp + k;
+    double v[kPreGroups];
+#pragma unroll
+    for (int g = 0; g < kPreGroups; g++) v[g] = p[(int64_t) g * Kp];
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < kPreGroups; g++) t += v[g];
+    t += Sbase[(int64_t) b * strideS + (int64_t) (C - 1) * Kp + k];   // (the side row: this thread wrote it in the body)
+    cs.out1[(int64_t) b * cs.stride1 + k] = t;
+    for (int z = 1; z <= cs.zero1; z++) cs.out1[(int64_t) b * cs.stride1 + (int64_t) z * Kp + k] = 0.0;
+    if (cs.out2)
+    {
+      cs.out2[(int64_t) b * cs.stride2 + k] = t;
+      for (int z = 1; z <= cs.zero2; z++) cs.out2[(int64_t) b * cs.stride2 + (int64_t) z * Kp + k] = 0.0;
+    }
+  }
 }
 
 // ---- side column and norm combine in ONE launch, one workgroup of 1024 threads per buffer (round 4) -----------------------
@@ -917,8 +978,8 @@ bool nmf_side_column_supported(int R, int C, int Kp)
   return C % 16 == 1 && C > 16 && (Kp == 16 || Kp == 32 || Kp == 64 || Kp == 128);
 }
 static int64_t wnorm_scratch_base_doubles(int Kp, int B, int nStrips) { return (int64_t) B * (nStrips * 2 * Kp + kSideSlices * 2 * Kp + Kp) + B; } // + arrival tickets
-// ... and behind them the pre-reduced records of long factors: [B][kPreGroups][2][Kp] statistics, then as many of the side column
-int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return (int) (wnorm_scratch_base_doubles(Kp, B, nStrips) + (int64_t) B * kPreGroups * 4 * Kp); }
+// ... and behind them the pre-reduced records of long factors: [B][kPreGroups][2][Kp] statistics, as many of the side column, [B][kPreGroups][Kp] column sums
+int wnorm_scratch_doubles(int Kp, int B, int nStrips) { return (int) (wnorm_scratch_base_doubles(Kp, B, nStrips) + (int64_t) B * kPreGroups * 5 * Kp); }
 
 static_assert(kSideSlices == 4 * kSideFromHSlots, "two generations of 128 slices: 64 of partials, then the old side row");
 double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen)
@@ -930,8 +991,9 @@ double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen)
   return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * kSideFromHSlots * 2 * Kp;
 }
 
-void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
-                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices, int sideGen)
+bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
+                          double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices, int sideGen,
+                          const WnormColsum* colsum)
 {
   // sideSlices > 0 (with sidePhase 2): the side column's partials are there already, sideSlices per buffer, dense -- left by
   // the H update in front (UpdateArgs::sideOut)
@@ -956,7 +1018,7 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     else if (Kp == 32) hipLaunchKernelGGL(side_norm_kernel<32>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
     else if (Kp == 64) hipLaunchKernelGGL(side_norm_kernel<64>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
     else hipLaunchKernelGGL(side_norm_kernel<128>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
-    return;
+    return false;
   }
   if (side && sidePhase != 2)
   {
@@ -977,9 +1039,9 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     else if (Kp == 64) hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     else hipLaunchKernelGGL(side_slices_kernel<128>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
-    if (fused) return;
+    if (fused) return false;
   }
-  if (sidePhase == 1) return;
+  if (sidePhase == 1) return false;
   // one block per buffer sums nStrips statistics parts and nsl side slices per component: 1024 threads where that is long
   // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
   // FLUHIP_WNORM_PRE=0 (A/B build): the one-workgroup combine of rounds 3 - 4 for long factors
@@ -988,17 +1050,41 @@ void launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   {
     double* statOut = scratch + wnorm_scratch_base_doubles(Kp, B, nStrips);
     double* sideOut = statOut + (int64_t) B * kPreGroups * 2 * Kp;
+    double* colPart = sideOut + (int64_t) B * kPreGroups * 2 * Kp;
+    ColsumOut cs;
+    if (colsum && colsum->out1)
+    {
+      cs.part = colPart;
+      cs.out1 = colsum->out1; cs.stride1 = colsum->stride1; cs.zero1 = colsum->zero1;
+      cs.out2 = colsum->out2; cs.stride2 = colsum->stride2; cs.zero2 = colsum->zero2;
+    }
     hipLaunchKernelGGL(wnorm_prereduce_kernel, dim3(kPreGroups, (unsigned) B), dim3(512), 0, s, Kp, statPart, nStrips,
-                       side ? sidePart : nullptr, nsl, statOut, sideOut);
+                       side ? sidePart : nullptr, nsl, statOut, sideOut, S, strideS, C, cs.part ? colPart : nullptr);
     hipLaunchKernelGGL(wnorm_combine_kernel<256>, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statOut,
-                       kPreGroups, side ? sideOut : nullptr, side ? kPreGroups : 0, wold, nrm);
+                       kPreGroups, side ? sideOut : nullptr, side ? kPreGroups : 0, wold, nrm, cs);
+    return cs.part != nullptr;
   }
   else if (nStrips > 128 || nsl > 64)
     hipLaunchKernelGGL(wnorm_combine_kernel<1024>, dim3((unsigned) B), dim3(1024), 0, s, S, strideS, C, K, Kp, statPart,
-                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
+                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm, ColsumOut{});
   else
     hipLaunchKernelGGL(wnorm_combine_kernel<256>, dim3((unsigned) B), dim3(256), 0, s, S, strideS, C, K, Kp, statPart,
-                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm);
+                       nStrips, side ? sidePart : nullptr, nsl, wold, nrm, ColsumOut{});
+  return false;
+}
+
+// The side column's slices carry (numerator, denominator) per component, and the denominator of bin C - 1 of the W update IS
+// the column sum of the moving factor H that every other bin divides by (alg/NMF.hpp:160): where the update launch takes its
+// column sums from a pre-pass (arrays of rank 128), the side-column launch (sidePhase 1) goes IN FRONT of it and this adds
+// its slices' denominators into the update's denominator slots -- the pre-pass's own sweep over H (config 3: 11 - 16 us per
+// iteration) is not needed.  Same slots as launch_colsum: (buffer, split 0) the sums, zeroSlots further rows cleared.
+int wnorm_side_slices(int R, int Kp) { return side_slices_for(R, Kp); }
+void launch_colsum_from_side(const double* scratch, int Kp, int B, int nStrips, int nsl, double* out, int64_t outStride,
+                             int zeroSlots, hipStream_t s)
+{
+  const double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;   // (the layout of launch_wnorm_combine, no generation)
+  hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, sidePart + Kp, nsl, Kp, out, outStride,
+                     zeroSlots, 2 * Kp);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)

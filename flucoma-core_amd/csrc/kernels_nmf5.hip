@@ -1408,7 +1408,8 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
           {
             const int ns = a.nsplit < 1 ? 1 : a.nsplit;
             // slot (buffer, split 0) of dpart takes the sums, the other splits' slots zero (the finalize adds them up)
-            if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
+            if (a.colsumInPlace) { /* the sums are in their slots already */ }
+            else if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
             else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
             launch5_t<M, NG, NS, WPS, 0, 2, 0>(a, w, s);
             return 0;
@@ -1480,7 +1481,8 @@ static int launch5_off_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
         if (a.colsumScratch)
         {
           const int ns = a.nsplit < 1 ? 1 : a.nsplit;
-          if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
+          if (a.colsumInPlace) { /* the sums are in their slots already */ }
+          else if (a.colsumGiven) launch_colsum_spread(a.colsumGiven, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, ns - 1, s);
           else launch_colsum(a.Mv, a.strideM, a.R, a.Kp, a.B, a.dpart, (int64_t) ns * a.Kp, a.colsumScratch, s, ns - 1);
           launch5_t<M, NG, NS, 1, 0, 2, 0, 0, KPM>(a, w, s);
         }
