@@ -1067,7 +1067,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       static const bool csFromSide = [] { const char* e = fluhip::ab_getenv("FLUHIP_COLSUM_FROM_SIDE"); return e ? std::atoi(e) != 0 : true; }();
       static const bool sideFused = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();   // (A/B: the combine rides in the side-column launch, which must then follow the update)
       const bool sideFirst = csFromSide && !sideFused && c->sideW && !sideReady && !join && !c->useLists && c->Kp == 128 &&
-                             (c->Kc <= 0 || c->Kc > 104) && a.colsumScratch && update_variant(a.Kp) == 5;
+                             (c->Kc <= 0 || c->Kc > 104) && a.colsumScratch && update_variant(a.Kp) == 5 &&
+                             !wnorm_side_norm_shape(Bw, c->stripsW, sc.R, (int) c->Kp);
       if (sideFirst)
       {
         ProfScope p(ctx, 3);

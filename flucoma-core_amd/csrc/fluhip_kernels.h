@@ -210,6 +210,8 @@ int wnorm_scratch_doubles(int Kp, int B, int nStrips);
 // the side-column launch's slices per buffer (sidePhase 0 / 1 of launch_wnorm_combine), and the column sums of the moving
 // factor from those slices' denominators into the update launch's denominator slots (see kernels_nmf.hip)
 int wnorm_side_slices(int R, int Kp);
+// the shapes whose side column and norm combine are ONE launch (side_norm_kernel, sidePhase 0): they keep that launch
+bool wnorm_side_norm_shape(int B, int nStrips, int R, int Kp);
 void launch_colsum_from_side(const double* scratch, int Kp, int B, int nStrips, int nsl, double* out, int64_t outStride,
                              int zeroSlots, hipStream_t s);
 // colsum (long factors only: the pre-reduced combine): the column sums of the new W' -- what the H update behind divides by --

@@ -991,6 +991,8 @@ double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen)
   return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * kSideFromHSlots * 2 * Kp;
 }
 
+// corpora: enough buffers to occupy the part, few enough rows that one workgroup walks them in a few passes, few statistics parts
+bool wnorm_side_norm_shape(int B, int nStrips, int R, int Kp) { return B >= 64 && nStrips <= 64 && (int64_t) R * Kp <= (int64_t) 64 * 2048; }
 bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
                           double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices, int sideGen,
                           const WnormColsum* colsum)
@@ -1011,7 +1013,7 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   // corpora: one launch, one workgroup per buffer (side_norm_kernel) -- enough buffers to occupy the part, few enough rows
   // that a workgroup walks them in a few passes, few statistics parts.  FLUHIP_SIDE_NORM=0 (A/B build): the two launches.
   static const bool oneLaunch = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_NORM"); return e ? std::atoi(e) != 0 : true; }();
-  if (side && sidePhase == 0 && oneLaunch && B >= 64 && nStrips <= 64 && (int64_t) side->R * Kp <= (int64_t) 64 * 2048)
+  if (side && sidePhase == 0 && oneLaunch && wnorm_side_norm_shape(B, nStrips, side->R, Kp))
   {
     const dim3 grid((unsigned) B), block(1024);
     if (Kp == 16) hipLaunchKernelGGL(side_norm_kernel<16>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
@@ -1079,12 +1081,41 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
 // its slices' denominators into the update's denominator slots -- the pre-pass's own sweep over H (config 3: 11 - 16 us per
 // iteration) is not needed.  Same slots as launch_colsum: (buffer, split 0) the sums, zeroSlots further rows cleared.
 int wnorm_side_slices(int R, int Kp) { return side_slices_for(R, Kp); }
+// (one workgroup of 1024 threads per buffer, thread = (run of slices, k): 128 threads walking 256 records of 2 KB one after the
+//  other -- colsum_combine_kernel with a record stride -- took 10.6 us on config 3)
+__global__ __launch_bounds__(1024) void colsum_side_kernel(const double* den, int nsl, int Kp, double* out, int64_t outStride,
+                                                           int zeroSlots)
+{
+  __shared__ double sh[1024];
+  const int b = blockIdx.x, k = threadIdx.x % Kp, pg = threadIdx.x / Kp, npg = blockDim.x / Kp;
+  const int per = (nsl + npg - 1) / npg, j0 = min(nsl, pg * per), j1 = min(nsl, j0 + per);
+  const double* p = den + (int64_t) b * nsl * 2 * Kp + k;
+  double t = 0.0;
+  for (int j = j0; j < j1; j += 8)
+  {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = p[(int64_t) min(j + u, j1 - 1) * 2 * Kp];
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (j + u < j1) t += v[u];
+  }
+  sh[threadIdx.x] = t;
+  __syncthreads();
+  if (pg == 0)
+  {
+    for (int g = 1; g < npg; g++) t += sh[g * Kp + k];
+    out[(int64_t) b * outStride + k] = t;
+    for (int z = 1; z <= zeroSlots; z++) out[(int64_t) b * outStride + (int64_t) z * Kp + k] = 0.0;
+  }
+}
 void launch_colsum_from_side(const double* scratch, int Kp, int B, int nStrips, int nsl, double* out, int64_t outStride,
                              int zeroSlots, hipStream_t s)
 {
   const double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;   // (the layout of launch_wnorm_combine, no generation)
-  hipLaunchKernelGGL(colsum_combine_kernel, dim3((unsigned) B), dim3((unsigned) Kp), 0, s, sidePart + Kp, nsl, Kp, out, outStride,
-                     zeroSlots, 2 * Kp);
+  const int threads = std::max(Kp, std::min(1024, Kp * std::max(1, nsl / 16)));   // sixteen slices or more per run
+  hipLaunchKernelGGL(colsum_side_kernel, dim3((unsigned) B), dim3((unsigned) threads), 0, s, sidePart + Kp, nsl, Kp, out, outStride,
+                     zeroSlots);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)
