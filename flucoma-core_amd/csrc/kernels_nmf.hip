@@ -81,12 +81,7 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
   // ---- the loads of this thread, issued before anything is consumed: kFinBatch rows at a time ------------------------
   double sold[BATCH];
   double dv[PER];
-  {
-    const double* dp = dpart + pbase * Kp + k;
-#pragma unroll
-    for (int u = 0; u < PER; u++) dv[u] = (rg == 0 && u < per) ? dp[(int64_t) min(sb + u, nsplit - 1) * Kp] : 0.0;
-  }
-  const double nk = (nrmMode && sg == 0) ? nrm[(int64_t) buf * Kp + k] : 1.0;
+  double nk = 1.0;
 #pragma unroll
   for (int i0 = 0; i0 < BATCH; i0 += kFinBatch)
   {
@@ -99,6 +94,13 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
 #pragma unroll
       for (int u = 0; u < PER; u++) pv[j][u] = (u < per) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
       sold[i0 + j] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
+    }
+    if (i0 == 0)   // (behind the first rows' requests, as the four-row form always had them)
+    {
+      const double* dp = dpart + pbase * Kp + k;
+#pragma unroll
+      for (int u = 0; u < PER; u++) dv[u] = (rg == 0 && u < per) ? dp[(int64_t) min(sb + u, nsplit - 1) * Kp] : 0.0;
+      nk = (nrmMode && sg == 0) ? nrm[(int64_t) buf * Kp + k] : 1.0;
     }
     // ---- quarter sums in split order, combined in group order through LDS (below) ---------------------------------------
 #pragma unroll
@@ -1048,7 +1050,11 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
   // FLUHIP_WNORM_PRE=0 (A/B build): the one-workgroup combine of rounds 3 - 4 for long factors
   static const bool pre = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) != 0 : true; }();
-  if ((nStrips > 128 || nsl > 64) && pre && Kp <= 512)
+  // (where the records are few kilobytes each -- one 10 s buffer at rank 32: 129 records of 512 B -- the one-workgroup combine is
+  //  the shorter chain: 9.0 us for the two launches against ~6 measured on BASELINE config 4's single buffer; the pre-reduction
+  //  pays from a few hundred kilobytes of records per buffer, or where it also takes the column sums of W' for the H update)
+  const bool bigRecords = (int64_t) (nStrips + nsl) * Kp > 40000;
+  if ((nStrips > 128 || nsl > 64) && pre && Kp <= 512 && (bigRecords || (colsum && colsum->out1)))
   {
     double* statOut = scratch + wnorm_scratch_base_doubles(Kp, B, nStrips);
     double* sideOut = statOut + (int64_t) B * kPreGroups * 2 * Kp;
