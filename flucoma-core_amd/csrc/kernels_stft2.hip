@@ -1070,6 +1070,25 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
 #endif
   const double scale1 = 1.0 / ((double) a.win / 4.0);                          // alg/MelBands.hpp:49
   const double scale2 = 1.0 / (2.0 * (double) (2 * N) / (double) a.win);       // :52
+  // Lane constants of the band stage kept in registers across the frame loop (round 5: the kernel sits at 101 of its 128
+  // registers, and the LDS pipe co-limits it): the boundary slot of each of the lane's CH bins (was a ds_read_i16 and a shift
+  // per bin and frame) and, for the MFCC default's ten products per lane, the lane's quarter row of the DCT table.
+  constexpr bool HOIST = !SMALL;
+  [[maybe_unused]] int slotReg[CH];
+  if constexpr (HOIST)
+  {
+#pragma unroll
+    for (int i = 0; i < CH; i++) slotReg[i] = slotl[i * 64 + lane];
+  }
+  const bool dct10 = HOIST && fa.dct && 4 * fa.nOut <= 64 && dq == 10;
+  [[maybe_unused]] double drowReg[10];
+  {
+    const int j = lane >> 2, part = lane & 3;
+    const bool live = j < fa.nOut && fa.startCoeff + j < fa.nDct;
+    const double* drow = dctl + (live ? fa.startCoeff + j : 0) * dld + part * dq;
+#pragma unroll
+    for (int i = 0; i < 10; i++) drowReg[i] = dct10 ? drow[i] : 0.0;
+  }
 
   const int64_t chunk = (a.totalBlocks + 7) / 8;
   // (Round 4: what these measurements were really showing is in the DYN comment at the head of the kernel.)
@@ -1174,7 +1193,9 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
 #pragma unroll
     for (int i = 0; i < CH; i++)
     {
-      const int sl = slotl[i * 64 + ln];
+      int sl;
+      if constexpr (HOIST) sl = slotReg[i];
+      else sl = slotl[i * 64 + ln];
       bu[sl] = eu + pu[i];
       bd[sl] = ed + pd[i];
     }
@@ -1208,10 +1229,16 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
       const double* drow = dctl + (live ? fa.startCoeff + j : 0) * dld + part * dq;
       const double* bq = bands + part * dq;
       double sacc = 0.0;
-      if (dq == 10)
+      if (dct10)
       {
-        // 37 .. 40 bands (the MFCC default): the quarter row unrolled, every position an immediate offset -- as a loop with a
-        // trip count from a register the compiler kept an address add per read (18 v_add_u32 per eight products)
+        // 37 .. 40 bands (the MFCC default): the lane's quarter row of the table from registers, the bands at immediate offsets
+#pragma unroll
+        for (int i = 0; i < 10; i++) sacc = __builtin_fma(drowReg[i], lds_read1(bq + i), sacc);
+      }
+      else if (dq == 10)
+      {
+        // (the same unrolled: as a loop with a trip count from a register the compiler kept an address add per read -- 18
+        //  v_add_u32 per eight products)
 #pragma unroll
         for (int i = 0; i < 10; i++) sacc = __builtin_fma(lds_read1(drow + i), lds_read1(bq + i), sacc);
       }
