@@ -1080,7 +1080,9 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
 #pragma unroll
     for (int i = 0; i < CH; i++) slotReg[i] = slotl[i * 64 + lane];
   }
-  const bool dct10 = HOIST && fa.dct && 4 * fa.nOut <= 64 && dq == 10;
+  // (the A/B build's kernel carries the experiment switches of rounds 3 - 4 and has no room for the ten coefficients: with them it
+  //  spills 16 registers to scratch -- 3.4 ms on config 5)
+  const bool dct10 = HOIST && !kAbSwitches && fa.dct && 4 * fa.nOut <= 64 && dq == 10;
   [[maybe_unused]] double drowReg[10];
   {
     const int j = lane >> 2, part = lane & 3;
