@@ -859,6 +859,7 @@ int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds,
 
 // the second stream and the fork / join events of the W update's side column (created on first use; false: stay on one stream)
 constexpr bool kSideBesideDefault = false;
+constexpr bool kSideFirstCorpora = false;
 static bool side_stream_ready(fluhip_ctx* ctx)
 {
   if (ctx->sideStream) return ctx->sideEv[7] != nullptr;
@@ -1066,9 +1067,12 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // FLUHIP_COLSUM_FROM_SIDE=0 (A/B build): the pre-pass as before.
       static const bool csFromSide = [] { const char* e = fluhip::ab_getenv("FLUHIP_COLSUM_FROM_SIDE"); return e ? std::atoi(e) != 0 : true; }();
       static const bool sideFused = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FUSED"); return e && std::atoi(e) == 1; }();   // (A/B: the combine rides in the side-column launch, which must then follow the update)
+      // FLUHIP_SIDE_FIRST_CORPORA=0|1 (A/B build): whether corpora whose side column and norm combine are ONE launch behind the
+      // update (side_norm_kernel) give that up for the side-first order
+      static const bool sideFirstCorpora = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_FIRST_CORPORA"); return e ? std::atoi(e) != 0 : kSideFirstCorpora; }();
       const bool sideFirst = csFromSide && !sideFused && c->sideW && !sideReady && !join && !c->useLists && c->Kp == 128 &&
                              (c->Kc <= 0 || c->Kc > 104) && a.colsumScratch && update_variant(a.Kp) == 5 &&
-                             !wnorm_side_norm_shape(Bw, c->stripsW, sc.R, (int) c->Kp);
+                             (sideFirstCorpora || !wnorm_side_norm_shape(Bw, c->stripsW, sc.R, (int) c->Kp));
       if (sideFirst)
       {
         ProfScope p(ctx, 3);
