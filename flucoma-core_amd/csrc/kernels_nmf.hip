@@ -68,6 +68,12 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
     pbase = splitTab[2 * buf];
     nsplit = splitTab[2 * buf + 1];
   }
+#ifdef FLUHIP_AB_SWITCHES
+  const int dbgBits = nrmMode >> 8;
+  nrmMode &= 255;
+#else
+  constexpr int dbgBits = 0;
+#endif
   const int nrg = blockDim.x / (Kp * kFinSG);
   const int k = threadIdx.x % Kp, rg = (threadIdx.x / Kp) % nrg, sg = threadIdx.x / (Kp * nrg);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
@@ -92,8 +98,8 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
       const int r = rbeg + (i0 + j) * nrg + rg;
       const int64_t idx = (int64_t) min(r, C - 1) * Kp + k;
 #pragma unroll
-      for (int u = 0; u < PER; u++) pv[j][u] = (u < per) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
-      sold[i0 + j] = (sg == 0) ? S[(int64_t) buf * strideS + idx] : 0.0;
+      for (int u = 0; u < PER; u++) pv[j][u] = (u < per && !(dbgBits & 2)) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
+      sold[i0 + j] = (sg == 0 && !(dbgBits & 8)) ? S[(int64_t) buf * strideS + idx] : 0.0;
     }
     if (i0 == 0)   // (behind the first rows' requests, as the four-row form always had them)
     {
@@ -142,12 +148,15 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
         double so = sold[i];
         if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
         const double x = (so * t) / den;
-        S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
+        if (!(dbgBits & 4)) S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
         ss += x * x;
         mx = fmax(mx, x);
       }
     }
   }
+#ifdef FLUHIP_AB_SWITCHES
+  if (nch < 0) return;   // (FLUHIP_FIN_DBG=1: timing experiment, no statistics -- wrong norms)
+#endif
   if (!statPart) return;
   __syncthreads();
   if (sg == 0)
@@ -180,11 +189,18 @@ void launch_update_finalize(double* S, int64_t strideS, const double* part, cons
   const size_t shmem = ((size_t) kFinSG * nrg * batch * Kp + (size_t) kFinSG * Kp) * sizeof(double);
   const int per = (nsplit + kFinSG - 1) / kFinSG;
   const dim3 grid((unsigned) nch, (unsigned) B), block((unsigned) (kFinSG * nrg * Kp));
+  int nchArg = nch;
+#ifdef FLUHIP_AB_SWITCHES
+  // FLUHIP_FIN_DBG (timing experiments, wrong results): 1 no statistics, 2 no partial loads, 4 no result store, 8 no old-value load
+  static const int dbg = [] { const char* e = fluhip::ab_getenv("FLUHIP_FIN_DBG"); return e ? std::atoi(e) : 0; }();
+  if (dbg & 1) nchArg = -nch;
+  nrmMode |= (dbg & 14) << 8;
+#endif
 #define FLUHIP_FIN_B(P, BT)                                                                                                   \
   {                                                                                                                           \
     auto kern = nmf_update_finalize_kernel<P, BT>;                                                                            \
     if (shmem > 48 * 1024) request_dynamic_lds(kern, shmem);                                                                  \
-    hipLaunchKernelGGL(kern, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, nsplit, nrm, nrmMode, statPart, nch,  \
+    hipLaunchKernelGGL(kern, grid, block, shmem, s, S, strideS, part, dpart, C, Kp, Cp, nsplit, nrm, nrmMode, statPart, nchArg, \
                        splitTab);                                                                                             \
   }
 #ifdef FLUHIP_AB_SWITCHES
