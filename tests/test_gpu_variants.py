@@ -54,6 +54,19 @@ for K in (12, 32, 64, 128):
         rW, rH, _, _ = o.nmf_process(rmag, K, 4, True, True, 42)
         assert max(rel_err(W1[b], rW), rel_err(H1[b], rH)) < 1e-9, (K, b)
     c.close()
+# one long-ish buffer at ranks 112 / 128 (the forms that take their column sums from a pre-pass, the contraction split, 256
+# statistics records): the side column in front of the W update with its denominators as the column sums of H, the
+# pre-reduced norm combine that also leaves the column sums of W' for the H update (round 5) -- and, with
+# FLUHIP_COLSUM_FROM_SIDE=0 / FLUHIP_WNORM_PRE=0 / FLUHIP_FIN_BATCH, the forms they replaced
+xl = oracle_np.synth_audio(200000, 4321)
+_, magl = o.stft_f32(xl, 2048, 2048, 512)
+for K in (112, 128):
+    c = fluhip.Corpus(ctx, 1, 200000, 2048, 2048, 512, K)
+    c.set_audio(xl[None, :]); c.stft(); c.nmf(6, seed=42)
+    _, W1, H1 = c.read_f64()
+    rW, rH, _, _ = o.nmf_process(magl, K, 6, True, True, 42)
+    assert max(rel_err(W1[0], rW), rel_err(H1[0], rH)) < 1e-9, (K, rel_err(W1[0], rW), rel_err(H1[0], rH))
+    c.close()
 # resynthesis at fft 2048 against the oracle (FLUHIP_RESYNTH_BATCH=0: the per-buffer frame + overlap-add kernels there;
 # FLUHIP_STFT_PREFETCH=0: the STFT's round-2 load order)
 x = oracle_np.synth_audio(30000, 77)
@@ -76,7 +89,9 @@ for k in range(9):
                                  {"FLUHIP_NO_LAZY": "1"}, {"FLUHIP_NO_SIDE": "1"}, {"FLUHIP_SIDE_FUSED": "1"}, {"FLUHIP_LIST_PLAN": "0"}, {"FLUHIP_LIST_PLAN": "1"}, {"FLUHIP_STFT_BLOCK": "0"},
                                  {"FLUHIP_STFT_GENERIC": "1"}, {"FLUHIP_K5_MODE": "0"}, {"FLUHIP_K5_MODE": "1"}, {"FLUHIP_TAIL_SPLIT": "0"}, {"FLUHIP_GRAPH_ITERS": "4"}, {"FLUHIP_K5_MODE": "2"}, {"FLUHIP_K5_MODE": "2", "FLUHIP_K5_MODE_ANY": "1"}, {"FLUHIP_STRIP": "0"}, {"FLUHIP_STRIP_BIN": "1"}, {"FLUHIP_STRIP_SIDE": "0"},
                                  {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
-                                 {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}, {"FLUHIP_NORM_IN_H": "0"}],
+                                 {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}, {"FLUHIP_NORM_IN_H": "0"},
+                                 {"FLUHIP_COLSUM_FROM_SIDE": "0"}, {"FLUHIP_WNORM_PRE": "0"}, {"FLUHIP_FIN_BATCH": "8"}, {"FLUHIP_FIN_BATCH": "16"},
+                                 {"FLUHIP_SIDE_FIRST_CORPORA": "1"}, {"FLUHIP_STFT_NW": "16"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env, ab_lib_paths):
     e = dict(os.environ)
