@@ -1479,3 +1479,23 @@ def test_no_device_memory_is_left_behind(ctx, onp):
         ctx_pass()
     after = free_bytes()
     assert before - after < (8 << 20), (before, after, before - after)
+
+
+@pytest.mark.parametrize("K", [105, 120, 128])
+def test_long_factors_at_rank_128_in_every_update_mode(ctx, oracle, K):
+    """Round 5's shortcuts of long single buffers on the arrays of rank 128 (the forms that take their column sums from a
+    pre-pass): the side column in front of the W update with its denominators as the column sums of H, the pre-reduced norm
+    combine leaving the column sums of the new W' in the H update's denominator slots.  Every pairing of the two updates must
+    leave the right sums where the next launch reads them: both factors (alg/NMF.hpp:154-181), W alone against a fixed H, H
+    alone against a fixed W, and both from seeded factors -- K = 105 (28 of 32 MFMAs), 120 (zero columns), 128."""
+    rs = np.random.RandomState(K)
+    T, F, iters = 420, 1025, 7
+    X = np.abs(rs.standard_normal((T, 6)) @ rs.standard_normal((6, F))) + 0.01 * rs.uniform(0, 1, (T, F))
+    W0 = rs.uniform(0.1, 1.0, (K, F))
+    H0 = rs.uniform(0.1, 1.0, (T, K))
+    for uw, uh, w0, h0 in ((True, True, None, None), (True, False, None, H0), (False, True, W0, None), (True, True, W0, H0)):
+        W1, H1, V1, rc = ctx.nmf_process(X, K, iters, uw, uh, 42, w0, h0)
+        rW, rH, rV, _ = oracle.nmf_process(X, K, iters, uw, uh, 42, w0, h0)
+        assert rc == 0
+        assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT and rel_err(V1, rV) < TOL_FACTORS_TIGHT, \
+            (K, uw, uh, rel_err(W1, rW), rel_err(H1, rH))
