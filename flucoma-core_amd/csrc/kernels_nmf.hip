@@ -954,6 +954,100 @@ __global__ __launch_bounds__(1024) void side_norm_kernel(double* Sbase, int64_t 
   }
 }
 
+// ---- the side column's slices with a row per lane group (round 5) ------------------------------------------------------------
+// side_slices_kernel's first pass takes a row per THREAD (two at rank 128): neighbouring lanes read 512 bytes apart, and the
+// rows are read a second time for the sums -- 19.5 us per iteration for config 3's 53 MB of H (2.7 TB/s).  This is
+// side_norm_kernel's lane layout on a slice of the rows: the Kp / 2 16-byte pieces of a row on adjacent lanes (one coalesced
+// kilobyte per wavefront load at rank 128), the row's quotient by the DPP butterfly, its contribution to (num, den) kept in
+// the lane's registers, every row read once, eight rows per lane in flight; the 1024 / (Kp / 2) row groups are added in fixed
+// order through the LDS and the slice's record goes where side_slices_kernel leaves it.  Ranks 64 and 128.
+template <int Kp>
+__global__ __launch_bounds__(1024) void side_rows_kernel(const double* Sbase, int64_t strideS, int C, SideColumn side,
+                                                        const double* nrm, double* sidePart, double* wold)
+{
+  // (1024 threads: 16 rows per pass at rank 128, eight passes in flight -- a slice of config 3's 101 rows is ONE round trip; with
+  //  256 threads it was four dependent batches and 27.8 us)
+  constexpr int PPR = Kp / 2, FPB = 1024 / PPR;
+  __shared__ double wsh[Kp];
+  __shared__ double shN[FPB * Kp], shD[FPB * Kp];
+  const int slice = blockIdx.x, nsl = gridDim.x, b = blockIdx.y, tid = threadIdx.x;
+  const double* S = Sbase + (int64_t) b * strideS;
+  const double* Mv = side.Mv + (int64_t) b * side.strideM;
+  const double* vcol = side.vcol + (int64_t) b * side.strideV;
+  const int RS = (side.R + nsl - 1) / nsl;
+  const int r0s = slice * RS, r1s = min(r0s + RS, side.R);
+  const int p = tid % PPR, g = tid / PPR;
+  auto request = [&](int r0, d2 (&h)[kSideNormUnr], double (&v)[kSideNormUnr]) {
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++)
+    {
+      const int r = r0 + u * FPB + g;
+      h[u] = d2{0.0, 0.0};
+      v[u] = 0.0;
+      if (r < r1s)
+      {
+        h[u] = *reinterpret_cast<const d2*>(Mv + (int64_t) r * Kp + 2 * p);
+        v[u] = vcol[r];
+      }
+    }
+  };
+  double sraw = 0.0, nr = 1.0;
+  if (tid < Kp)
+  {
+    sraw = S[(int64_t) (C - 1) * Kp + tid];
+    if (nrm) nr = nrm[(int64_t) b * Kp + tid];
+  }
+  d2 h[kSideNormUnr];
+  double v[kSideNormUnr];
+  request(r0s, h, v);
+  // the stationary row, normalised the way the update kernel normalises its rows (S = W' / nrm)
+  if (tid < Kp)
+  {
+    const double w = sraw / nr;
+    wsh[tid] = w;
+    if (slice == 0) wold[(int64_t) b * Kp + tid] = w;
+  }
+  __syncthreads();
+  const double w0 = wsh[2 * p], w1 = wsh[2 * p + 1];
+  double n0 = 0.0, n1 = 0.0, d0 = 0.0, d1 = 0.0;
+  auto work = [&](const d2 (&h)[kSideNormUnr], const double (&v)[kSideNormUnr]) {
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++)
+    {
+      // (rows past the end: h = 0, v = 0 -> 0 / eps = 0, nothing added)
+      const double q = side_group_sum<PPR>(__builtin_fma(h[u][0], w0, h[u][1] * w1));
+      const double ratio = side_div(v[u], fmax(q, kEpsilon));
+      n0 = __builtin_fma(ratio, h[u][0], n0);
+      n1 = __builtin_fma(ratio, h[u][1], n1);
+      d0 += h[u][0];
+      d1 += h[u][1];
+    }
+  };
+#pragma unroll 1
+  for (int r0 = r0s + FPB * kSideNormUnr; r0 < r1s; r0 += FPB * kSideNormUnr)
+  {
+    d2 hn[kSideNormUnr];
+    double vn[kSideNormUnr];
+    request(r0, hn, vn);
+    work(h, v);
+#pragma unroll
+    for (int u = 0; u < kSideNormUnr; u++) { h[u] = hn[u]; v[u] = vn[u]; }
+  }
+  work(h, v);
+  shN[g * Kp + 2 * p] = n0; shN[g * Kp + 2 * p + 1] = n1;
+  shD[g * Kp + 2 * p] = d0; shD[g * Kp + 2 * p + 1] = d1;
+  __syncthreads();
+  if (tid < Kp)
+  {
+    double n = 0.0, d = 0.0;
+#pragma unroll
+    for (int j = 0; j < FPB; j++) { n += shN[j * Kp + tid]; d += shD[j * Kp + tid]; }
+    double* o = sidePart + ((int64_t) b * nsl + slice) * 2 * Kp;
+    o[tid] = n;
+    o[Kp + tid] = d;
+  }
+}
+
 // W = W' / nrm in memory, nrm = 1: leaves the deferred form (after the last iteration, before anything
 // outside the two update kernels reads W)
 __global__ void wnorm_apply_kernel(double* Sbase, int64_t strideS, int C, int Kp, double* nrm)
@@ -1055,6 +1149,13 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     SideFuse fz{nullptr, nullptr, nullptr, 0, 0, nullptr};
     if (fused)
       fz = SideFuse{reinterpret_cast<int*>(wold + (int64_t) B * Kp), S, statPart, nStrips, K, nrm};
+    // FLUHIP_SIDE_ROWS=0 (A/B build): the row-per-thread slices kernel at ranks 64 / 128 too
+    static const bool rowsForm = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_ROWS"); return e ? std::atoi(e) != 0 : true; }();
+    if (rowsForm && !fused && Kp == 128)
+      hipLaunchKernelGGL(side_rows_kernel<128>, grid, dim3(1024), 0, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else if (rowsForm && !fused && Kp == 64)
+      hipLaunchKernelGGL(side_rows_kernel<64>, grid, dim3(1024), 0, s, S, strideS, C, *side, nrm, sidePart, wold);
+    else
     if (Kp == 16) hipLaunchKernelGGL(side_slices_kernel<16>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     else if (Kp == 32) hipLaunchKernelGGL(side_slices_kernel<32>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
     else if (Kp == 64) hipLaunchKernelGGL(side_slices_kernel<64>, grid, block, sh, s, S, strideS, C, *side, nrm, sidePart, wold, fz);
