@@ -91,7 +91,7 @@ for k in range(9):
                                  {"FLUHIP_RESYNTH_BATCH": "0"}, {"FLUHIP_RESYNTH_SHARED": "0"}, {"FLUHIP_STFT_PREFETCH": "0"},
                                  {"FLUHIP_SIDE_SLICES": "2"}, {"FLUHIP_SIDE_STREAM": "1"}, {"FLUHIP_SIDE_NORM": "0"}, {"FLUHIP_SIDE_FROM_H": "0"}, {"FLUHIP_NORM_IN_H": "0"},
                                  {"FLUHIP_COLSUM_FROM_SIDE": "0"}, {"FLUHIP_WNORM_PRE": "0"}, {"FLUHIP_FIN_BATCH": "8"}, {"FLUHIP_FIN_BATCH": "16"},
-                                 {"FLUHIP_SIDE_FIRST_CORPORA": "1"}, {"FLUHIP_STFT_NW": "16"}],
+                                 {"FLUHIP_SIDE_FIRST_CORPORA": "1"}, {"FLUHIP_STFT_NW": "16"}, {"FLUHIP_SIDE_ROWS": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_alternative_kernel_forms_against_the_oracle(env, ab_lib_paths):
     e = dict(os.environ)
