@@ -220,7 +220,7 @@ def run_c5(ctx, with_cpu):
                     "roofline": {"bound": bound, **{k: v for k, v in roofs[bound].items()}, "traffic": None,
                                  "per": "whole call, audio and features resident in HBM", "roofs": roofs,
                                  "note": "the binding roof is the one whose floor is the longer time; counters put the kernel "
-                                         "at 479 VALU and 149 LDS instructions per frame and wavefront (profiles/r05/cfg_v4/c5_pmc.json; 542 / 149 "
+                                         "at 467 VALU and 134 LDS instructions per frame and wavefront (profiles/r05/cfg_v5/c5_pmc.json; 542 / 149 "
                                          "before the trims of round 5): the LDS pipe co-limits"}})
     else:
         res["value"] = frames / dt_host
