@@ -1171,7 +1171,12 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
   //  the shorter chain: 9.0 us for the two launches against ~6 measured on BASELINE config 4's single buffer; the pre-reduction
   //  pays from a few hundred kilobytes of records per buffer, or where it also takes the column sums of W' for the H update)
   const bool bigRecords = (int64_t) (nStrips + nsl) * Kp > 40000;
-  if ((nStrips > 128 || nsl > 64) && pre && Kp <= 512 && (bigRecords || (colsum && colsum->out1)))
+  // (the column sums of W' alone are worth the extra launch where the H update would otherwise run its pre-pass: windows of a
+  //  rank-128 corpus, 16 buffers each -- colsum_part + colsum_combine 14 us against ~6 for the pre-reduction; FLUHIP_WNORM_PRE=2
+  //  (A/B build): only where the records are long, as in the first form)
+  static const bool preAlways = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) != 2 : true; }();
+  const bool wantCol = colsum && colsum->out1;
+  if (pre && Kp <= 512 && (((nStrips > 128 || nsl > 64) && (bigRecords || wantCol)) || (wantCol && preAlways)))
   {
     double* statOut = scratch + wnorm_scratch_base_doubles(Kp, B, nStrips);
     double* sideOut = statOut + (int64_t) B * kPreGroups * 2 * Kp;
