@@ -18,7 +18,7 @@ def _cases():
     rs = np.random.RandomState(seed)
     out = []
     ffts = [64, 128, 256, 512, 1024, 2048]
-    ranks = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 48, 49, 64, 65, 70, 96, 97, 100, 128]
+    ranks = [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 40, 48, 49, 64, 65, 70, 96, 97, 100, 105, 112, 128]   # (105 / 112: 28 of 32 MFMAs, column sums from a pre-pass like 128)
     for i in range(count):
         fft = ffts[rs.randint(len(ffts))]
         win = fft if rs.rand() < 0.7 else fft // 2
