@@ -662,7 +662,7 @@ __device__ __forceinline__ void wnorm_combine_body(double* Sbase, int64_t stride
 // per buffer pulling 1.5 MB through its CU took 25.8 us per iteration.  kPreGroups workgroups per buffer add up a sixteenth of
 // the records each -- thread (sub, k) a contiguous run in index order, the runs in fixed order through the LDS -- and leave
 // kPreGroups records per buffer in the SAME two layouts, which the 256-thread combine then reads.  No atomics, no tickets.
-constexpr int kPreGroups = 16;
+constexpr int kPreGroups = 16;   // (32 measured: the pre-reduction 8.9 -> 7.6 us on config 3, the combine behind it 7.1 -> 9.0: profiles/r05/c3_pre32.txt)
 // colOut != nullptr: the groups also add up the rows [0, C - 1) of the new W' they are dealt (what the H update behind divides
 // by: alg/NMF.hpp:169), one record of Kp sums per group; the combine adds the records and the side row.
 __global__ __launch_bounds__(512) void wnorm_prereduce_kernel(int Kp, const double* statPart, int nParts, const double* sidePart,
@@ -1214,8 +1214,11 @@ int wnorm_side_slices(int R, int Kp) { return side_slices_for(R, Kp); }
 __global__ __launch_bounds__(1024) void colsum_side_kernel(const double* den, int nsl, int Kp, double* out, int64_t outStride,
                                                            int zeroSlots)
 {
+  // (blockIdx.y: a block of KB = Kp / gridDim.y columns per workgroup -- four workgroups per buffer at rank 128)
   __shared__ double sh[1024];
-  const int b = blockIdx.x, k = threadIdx.x % Kp, pg = threadIdx.x / Kp, npg = blockDim.x / Kp;
+  const int KB = Kp / (int) gridDim.y;
+  const int b = blockIdx.x, kl = threadIdx.x % KB, pg = threadIdx.x / KB, npg = blockDim.x / KB;
+  const int k = (int) blockIdx.y * KB + kl;
   const int per = (nsl + npg - 1) / npg, j0 = min(nsl, pg * per), j1 = min(nsl, j0 + per);
   const double* p = den + (int64_t) b * nsl * 2 * Kp + k;
   double t = 0.0;
@@ -1232,7 +1235,7 @@ __global__ __launch_bounds__(1024) void colsum_side_kernel(const double* den, in
   __syncthreads();
   if (pg == 0)
   {
-    for (int g = 1; g < npg; g++) t += sh[g * Kp + k];
+    for (int g = 1; g < npg; g++) t += sh[g * KB + kl];
     out[(int64_t) b * outStride + k] = t;
     for (int z = 1; z <= zeroSlots; z++) out[(int64_t) b * outStride + (int64_t) z * Kp + k] = 0.0;
   }
@@ -1241,9 +1244,11 @@ void launch_colsum_from_side(const double* scratch, int Kp, int B, int nStrips, 
                              int zeroSlots, hipStream_t s)
 {
   const double* sidePart = scratch + (int64_t) B * nStrips * 2 * Kp;   // (the layout of launch_wnorm_combine, no generation)
-  const int threads = std::max(Kp, std::min(1024, Kp * std::max(1, nsl / 16)));   // sixteen slices or more per run
-  hipLaunchKernelGGL(colsum_side_kernel, dim3((unsigned) B), dim3((unsigned) threads), 0, s, sidePart + Kp, nsl, Kp, out, outStride,
-                     zeroSlots);
+  const int kblocks = (Kp >= 128 && nsl >= 64) ? 4 : 1;                            // column blocks (workgroups) per buffer
+  const int KB = Kp / kblocks;
+  const int threads = std::max(KB, std::min(1024, KB * std::max(1, nsl / 8)));     // eight slices or more per run
+  hipLaunchKernelGGL(colsum_side_kernel, dim3((unsigned) B, (unsigned) kblocks), dim3((unsigned) threads), 0, s, sidePart + Kp, nsl, Kp,
+                     out, outStride, zeroSlots);
 }
 
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s)
