@@ -248,11 +248,14 @@ def main():
         gathered["bases"] = sharding.gather_buffer(bases if backend == "nccl" else host_b, world)
         gathered["acts"] = sharding.gather_buffer(acts if backend == "nccl" else host_a, world)
 
+    loop_ms = []   # device time of every step's iteration loop (two HIP events per step, recorded by the library on its stream)
+
     def step():
         corpus.stft()
         corpus.nmf(iters, seed=wl["seed"])
         corpus.writeback_dev(bases.data_ptr(), acts.data_ptr())
         ctx.synchronize()
+        loop_ms.append(corpus.last_loop_ms())
         if use_dist:  # the one collective of the path: final dictionary/activation gather (RCCL)
             if backend == "nccl":
                 src_b, src_a = bases, acts
@@ -279,11 +282,13 @@ def main():
         ctx.prof_enable(True)
         ctx.prof_reset()
     corpus.update_clocks(reset=True)
+    del loop_ms[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    timed_loop_ms = list(loop_ms)
     if not args.prof_in_timed_region:
         ctx.prof_enable(True)
         ctx.prof_reset()
@@ -341,7 +346,18 @@ def main():
         buffers_per_launch = B * (2.0 * iters * prof_steps) / max(n_upd, 1)
         flop_per_launch = 4.0 * F * T * K * buffers_per_launch
         bytes_per_launch = (F * T * 8.0 + 2.0 * (F * K + K * T) * 8.0) * buffers_per_launch
-        avg_ms = ms_upd / max(n_upd, 1)
+        stft_ms = ms_stft / max(n_stft, 1)
+        stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
+        # The dominant kernel's average launch duration, over the TIMED steps: the iteration loop of a
+        # step is 2 x iters launches of nmf_update5_kernel back to back and nothing else in the stream (the side column and
+        # the norm combine ride inside them; the helper launches of a call's first iteration are in the figure too), and the
+        # library brackets that loop with two HIP events on the stream it launches on -- behind the host-side initialisation,
+        # behind the last launch.  loop time / launches is the launch duration with its boundary to the next launch, and by
+        # construction launches x avg_launch_ms + STFT <= ms_per_step.  The per-launch event pairs of one extra step (which
+        # perturb the stream they measure: a pair per launch) are kept beside it as `avg_launch_ms_event_pairs`.
+        avg_ms_pairs = ms_upd / max(n_upd, 1)
+        launches_per_step = n_upd / prof_steps
+        avg_ms = (sum(timed_loop_ms) / len(timed_loop_ms)) / max(launches_per_step, 1) if timed_loop_ms else avg_ms_pairs
         ach_tflops = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         ach_gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the
@@ -377,8 +393,6 @@ def main():
         mhz = [c["sustained_mhz"] for c in clocks.values() if c["sustained_mhz"]]
         cycles_per_launch = sum(cyc) / len(cyc) if cyc else None
         sustained_mhz = sum(mhz) / len(mhz) if mhz else None
-        stft_ms = ms_stft / max(n_stft, 1)
-        stft_bytes = (wl["hop"] * 4.0 + F * 8.0) * T * B
         out = {
             "metric": f"NMF iterations/sec (buffer-iterations over the whole BufNMF job: STFT + {iters}-iter "
                       f"KL-NMF + write-back), rank-{K} fft{wl['fft']}",
@@ -395,8 +409,17 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "nmf_update5_kernel (v_mfma_f64_4x4x4_4b + LDS-DMA)", "achieved": ach_tflops,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach_tflops / PEAK_FP64_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_from_profile": traffic_src,
-                         "launches": int(n_upd), "avg_launch_ms": avg_ms, "buffers_per_launch": buffers_per_launch,
-                         "events": "in the timed steps" if args.prof_in_timed_region else "one extra step right behind the timed ones",
+                         "launches": int(launches_per_step), "launches_per": "step", "avg_launch_ms": avg_ms,
+                         "buffers_per_launch": buffers_per_launch,
+                         "events": "two HIP events per TIMED step around its iteration loop, on the library's stream "
+                                   "(fluhip_corpus_last_loop_ms): loop time / launches",
+                         "timed_loop_ms_per_step": {"mean": sum(timed_loop_ms) / max(len(timed_loop_ms), 1),
+                                                    "min": min(timed_loop_ms) if timed_loop_ms else None,
+                                                    "max": max(timed_loop_ms) if timed_loop_ms else None},
+                         "closes": {"launches_x_avg_launch_ms_plus_stft": launches_per_step * avg_ms + stft_ms,
+                                    "ms_per_step": ms_per_step},
+                         "avg_launch_ms_event_pairs": avg_ms_pairs,
+                         "event_pairs": "in the timed steps" if args.prof_in_timed_region else "one extra step right behind the timed ones",
                          "profiled_step_ms": profiled_step_ms,
                          "shader_cycles_per_launch": cycles_per_launch, "sustained_mhz": sustained_mhz,
                          "datasheet_mhz": PEAK_MHZ,
@@ -455,6 +478,9 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
             out["configs"] = bench_configs.bench_line_configs(ctx, names)
+        cl = out["roofline"]["closes"]
+        assert cl["launches_x_avg_launch_ms_plus_stft"] <= cl["ms_per_step"] * 1.0005, \
+            f"the roofline's launch time does not fit into the step it was taken from: {cl}"
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()

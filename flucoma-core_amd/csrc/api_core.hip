@@ -16,7 +16,7 @@ double* big_fft_scratch(fluhip_ctx* ctx, int64_t win, int64_t fft, int64_t frame
     if (ctx->bigFft) (void) hipFree(ctx->bigFft);
     ctx->bigFft = nullptr;
     ctx->bigFftBytes = 0;
-    if (hipMalloc(&ctx->bigFft, need) != hipSuccess) { fail(ctx, "out of device memory for the FFT workspace"); return nullptr; }
+    if (hipMalloc(&ctx->bigFft, need) != hipSuccess) { (void) hipGetLastError(); fail_oom(ctx, "out of device memory for the FFT workspace"); return nullptr; }
     ctx->bigFftBytes = need;
   }
   return static_cast<double*>(ctx->bigFft);
@@ -24,8 +24,21 @@ double* big_fft_scratch(fluhip_ctx* ctx, int64_t win, int64_t fft, int64_t frame
 
 int fail(fluhip_ctx* ctx, const std::string& msg, int status)
 {
-  if (ctx) ctx->err = msg;
+  if (ctx) { ctx->err = msg; ctx->errOom = false; }
   return status;
+}
+
+int fail_oom(fluhip_ctx* ctx, const std::string& msg)
+{
+  if (ctx) { ctx->err = msg; ctx->errOom = true; }
+  return FLUHIP_ERROR;
+}
+
+int fail_hip(fluhip_ctx* ctx, hipError_t e, const char* what)
+{
+  const std::string msg = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+  if (e == hipErrorOutOfMemory) { (void) hipGetLastError(); return fail_oom(ctx, msg); } // (the sticky-less error is consumed: a retry with less memory starts clean)
+  return fail(ctx, msg);
 }
 
 // Large results to pageable host memory: a plain hipMemcpy stages them through the runtime's small pinned buffers (measured
@@ -256,6 +269,8 @@ void fluhip_ctx_destroy(fluhip_ctx* ctx)
 }
 
 const char* fluhip_last_error(const fluhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+int fluhip_last_error_is_out_of_memory(const fluhip_ctx* ctx) { return ctx && ctx->errOom ? 1 : 0; }
+void fluhip_clear_error(fluhip_ctx* ctx) { if (ctx) { ctx->err.clear(); ctx->errOom = false; } }
 
 int fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char* arch,
                            int arch_len, int* compute_units)

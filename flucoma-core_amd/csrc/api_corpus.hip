@@ -1340,7 +1340,11 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
 int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
                           fluhip_progress_fn progress, void* user)
 {
+  c->loopTimed = false;
+  if (!c->loopEv0) { c->loopEv0 = take_event(c->ctx); c->loopEv1 = take_event(c->ctx); }
+  const bool ev0 = c->loopEv0 && c->loopEv1 && hipEventRecord(c->loopEv0, c->ctx->stream) == hipSuccess;
   const int rc = corpus_iterate_loop(c, iters, updateW, updateH, progress, user);
+  c->loopTimed = ev0 && hipEventRecord(c->loopEv1, c->ctx->stream) == hipSuccess;
   if (c->strip)
   {
     c->stripReady = false; // H may change before the next call
@@ -1380,9 +1384,18 @@ int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH,
 
 // ---------------------------------------------------------------------------------------
 // C ABI
+// Host allocations inside the library (std::vector images of seeds, plans, staging) can throw: nothing may cross the C ABI.
+// std::bad_alloc is classified like a device out-of-memory (fluhip_last_error_is_out_of_memory), anything else is an error.
+template <typename Fn> static int guarded(fluhip_ctx* ctx, Fn&& fn)
+{
+  try { return fn(); }
+  catch (const std::bad_alloc&) { return fail_oom(ctx, "out of host memory inside libflucoma_hip"); }
+  catch (const std::exception& e) { return fail(ctx, std::string("internal error: ") + e.what()); }
+}
+
 extern "C" {
 
-int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
+static int fluhip_corpus_create_impl(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
                          int64_t hop, int64_t K, fluhip_corpus** out)
 {
   if (!ctx || !out) return FLUHIP_ERROR;
@@ -1490,6 +1503,8 @@ void fluhip_corpus_destroy(fluhip_corpus* c)
   if (!c) return;
   (void) hipSetDevice(c->ctx->device);
   (void) hipStreamSynchronize(c->ctx->stream);
+  if (c->loopEv0) c->ctx->eventPool.push_back(c->loopEv0);
+  if (c->loopEv1) c->ctx->eventPool.push_back(c->loopEv1);
   delete c;
 }
 
@@ -1497,7 +1512,7 @@ int64_t fluhip_corpus_frames(const fluhip_corpus* c) { return c ? c->T : 0; }
 int64_t fluhip_corpus_bins(const fluhip_corpus* c) { return c ? c->F : 0; }
 int64_t fluhip_corpus_device_bytes(const fluhip_corpus* c) { return c ? c->device_bytes() : 0; }
 
-int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio)
+static int fluhip_corpus_set_audio_host_impl(fluhip_corpus* c, const float* audio)
 {
   if (!c || !audio) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
@@ -1522,7 +1537,7 @@ int fluhip_corpus_set_audio_dev(fluhip_corpus* c, const float* audio_dev)
   return FLUHIP_OK;
 }
 
-int fluhip_corpus_stft(fluhip_corpus* c)
+static int fluhip_corpus_stft_impl(fluhip_corpus* c)
 {
   if (!c) return FLUHIP_ERROR;
   if (!c->audioDev) return fail(c->ctx, "corpus has no audio");
@@ -1530,7 +1545,7 @@ int fluhip_corpus_stft(fluhip_corpus* c)
   return corpus_stft(c, c->audioDev, nullptr, c->n);
 }
 
-int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
+static int fluhip_corpus_nmf_impl(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
                       const int64_t* seeds, fluhip_progress_fn progress, void* user)
 {
   if (!c) return FLUHIP_ERROR;
@@ -1546,7 +1561,7 @@ int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_
   return corpus_iterate(c, iters, update_w != 0, update_h != 0, progress, user);
 }
 
-int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
+static int fluhip_corpus_set_factors_impl(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
 {
   if (!c) return FLUHIP_ERROR;
   const size_t nw = (size_t) c->B * c->K * c->F, nh = (size_t) c->B * c->K * c->T;
@@ -1575,7 +1590,7 @@ int fluhip_corpus_writeback_dev(fluhip_corpus* c, float* bases_dev, float* acts_
 }
 
 // clients/nrt/NMFClient.hpp:302-334 for every buffer of the corpus: estimate -> ratio mask -> ISTFT per component
-int fluhip_corpus_keep_spectrum(fluhip_corpus* c, int on)
+static int fluhip_corpus_keep_spectrum_impl(fluhip_corpus* c, int on)
 {
   if (!c) return FLUHIP_ERROR;
   c->keepSpec = on != 0;
@@ -1668,7 +1683,7 @@ int fluhip_corpus_resynth_dev(fluhip_corpus* c, float* out_dev)
   return FLUHIP_OK;
 }
 
-int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out)
+static int fluhip_corpus_resynth_host_impl(fluhip_corpus* c, float* out)
 {
   if (!c || !out) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
@@ -1685,7 +1700,7 @@ int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out)
 // frames x channels): out[t * frame_stride + b * K + k] = component k of buffer b at sample t -- the layout of
 // resynth.samps(i * rank + j) in clients/nrt/NMFClient.hpp:321-326 when the buffer's channels are interleaved.  The
 // transposition happens on the device; the host sees one streaming copy instead of count x K strided passes over its buffer.
-int fluhip_corpus_resynth_interleaved_host(fluhip_corpus* c, float* out, int64_t frame_stride)
+static int fluhip_corpus_resynth_interleaved_host_impl(fluhip_corpus* c, float* out, int64_t frame_stride)
 {
   if (!c || !out) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
@@ -1728,7 +1743,7 @@ int fluhip_corpus_resynth_ragged_host(fluhip_corpus* c, float* const* out)
   return FLUHIP_OK;
 }
 
-int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts)
+static int fluhip_corpus_writeback_host_impl(fluhip_corpus* c, float* bases, float* acts)
 {
   if (!c) return FLUHIP_ERROR;
   fluhip_ctx* ctx = c->ctx;
@@ -1888,6 +1903,17 @@ int fluhip_corpus_debug_words(fluhip_corpus* c, int64_t* out32)
   return FLUHIP_OK;
 }
 
+int fluhip_corpus_last_loop_ms(fluhip_corpus* c, double* ms)
+{
+  if (!c || !ms) return FLUHIP_ERROR;
+  if (!c->loopTimed) return fail(c->ctx, "no iteration loop has been timed on this corpus");
+  float t = 0.f;
+  HIPCHK(c->ctx, hipEventSynchronize(c->loopEv1));
+  HIPCHK(c->ctx, hipEventElapsedTime(&t, c->loopEv0, c->loopEv1));
+  *ms = (double) t;
+  return FLUHIP_OK;
+}
+
 int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset)
 {
   if (!c || !c->clk.p) return FLUHIP_ERROR;
@@ -1897,6 +1923,55 @@ int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset)
   if (out8) HIPCHK(ctx, hipMemcpy(out8, c->clk.p, 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
   if (reset) HIPCHK(ctx, hipMemset(c->clk.p, 0, 8 * sizeof(int64_t)));
   return FLUHIP_OK;
+}
+
+
+// the entry points of the clients' batched block (NMFClient.hpp), exception-tight
+int fluhip_corpus_create(fluhip_ctx* ctx, int64_t count, int64_t n, int64_t win, int64_t fft,
+                         int64_t hop, int64_t K, fluhip_corpus** out)
+{
+  return guarded(ctx, [&] { return fluhip_corpus_create_impl(ctx, count, n, win, fft, hop, K, out); });
+}
+
+int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_set_audio_host_impl(c, audio); });
+}
+
+int fluhip_corpus_stft(fluhip_corpus* c)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_stft_impl(c); });
+}
+
+int fluhip_corpus_set_factors(fluhip_corpus* c, const float* bases_seed, const float* acts_seed)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_set_factors_impl(c, bases_seed, acts_seed); });
+}
+
+int fluhip_corpus_nmf(fluhip_corpus* c, int64_t iters, int update_w, int update_h, int64_t seed,
+                      const int64_t* seeds, fluhip_progress_fn progress, void* user)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_nmf_impl(c, iters, update_w, update_h, seed, seeds, progress, user); });
+}
+
+int fluhip_corpus_writeback_host(fluhip_corpus* c, float* bases, float* acts)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_writeback_host_impl(c, bases, acts); });
+}
+
+int fluhip_corpus_resynth_host(fluhip_corpus* c, float* out)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_resynth_host_impl(c, out); });
+}
+
+int fluhip_corpus_resynth_interleaved_host(fluhip_corpus* c, float* out, int64_t frame_stride)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_resynth_interleaved_host_impl(c, out, frame_stride); });
+}
+
+int fluhip_corpus_keep_spectrum(fluhip_corpus* c, int on)
+{
+  return guarded((c ? c->ctx : nullptr), [&] { return fluhip_corpus_keep_spectrum_impl(c, on); });
 }
 
 } // extern "C"

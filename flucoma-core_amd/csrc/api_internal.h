@@ -44,6 +44,7 @@ struct fluhip_ctx
   hipEvent_t sideEv[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // fork / join pairs, in rotation
   unsigned sideTurn = 0;
   std::string err;
+  bool errOom = false; // the last failure was an allocation the device (or the host) could not serve (fluhip_last_error_is_out_of_memory)
   std::map<std::tuple<int64_t, int64_t, int>, double*> windows; // (win, fft, type) -> device table
   std::map<int, double*> twiddles;                // fft -> device table
   bool prof = false;
@@ -58,13 +59,14 @@ struct fluhip_ctx
 };
 
 int fail(fluhip_ctx* ctx, const std::string& msg, int status = FLUHIP_ERROR);
+int fail_oom(fluhip_ctx* ctx, const std::string& msg); // fail() + the out-of-memory classification (by code, not by text)
+int fail_hip(fluhip_ctx* ctx, hipError_t e, const char* what);
 
 #define HIPCHK(ctx, expr)                                                                        \
   do                                                                                             \
   {                                                                                              \
     hipError_t e__ = (expr);                                                                     \
-    if (e__ != hipSuccess)                                                                       \
-      return fail(ctx, std::string("HIP error: ") + hipGetErrorString(e__) + " in " #expr);      \
+    if (e__ != hipSuccess) return fail_hip(ctx, e__, #expr);                                     \
   } while (0)
 
 // api_core.hip
@@ -244,6 +246,10 @@ struct fluhip_corpus
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
   DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's
+  // events on the context stream around the last iteration loop (behind the host-side initialisation, in front of
+  // nothing but the loop's own launches): fluhip_corpus_last_loop_ms -- device time of the loop for tools/perf_matrix.py
+  hipEvent_t loopEv0 = nullptr, loopEv1 = nullptr;
+  bool loopTimed = false;
   // frame-strip schedule of a single large buffer at rank <= 16 (kernels_nmf_strip.hip)
   bool strip = false;
   bool stripReady = false;     // the numerator partials of the next W update are in stripPart

@@ -65,6 +65,13 @@ int         fluhip_ctx_create(int device, fluhip_ctx** out);
  * stream until fluhip_corpus_destroy returns). */
 void        fluhip_ctx_destroy(fluhip_ctx* ctx);
 const char* fluhip_last_error(const fluhip_ctx* ctx);     /* never NULL */
+/* 1 when the last non-OK result of this context was an allocation the device (hipErrorOutOfMemory, the FFT workspace) or
+ * the host (std::bad_alloc inside the library) could not serve -- the one failure a caller may answer by retrying with a
+ * smaller job (the clients' batched -> channel-by-channel fallback, NMFClient.hpp).  Classified by error CODE at the point
+ * of failure, never by message text.  fluhip_clear_error empties message and flag (call it in front of a block of calls
+ * whose failure you are going to classify, so that nothing stale is read). */
+int         fluhip_last_error_is_out_of_memory(const fluhip_ctx* ctx);
+void        fluhip_clear_error(fluhip_ctx* ctx);
 /* device name / gcnArchName into caller buffers (for bench reports) */
 int         fluhip_ctx_device_info(const fluhip_ctx* ctx, char* name, int name_len, char* arch,
                                    int arch_len, int* compute_units);
@@ -441,6 +448,11 @@ int fluhip_prof_read(fluhip_ctx* ctx, int kernel_class, int64_t* launches, doubl
  * kernel change moves whatever clock the box sustains; cycles / ticks * 100 MHz is that sustained clock.  Zero counts when
  * the corpus runs a schedule without the stamps (frame-strip schedule, A/B kernel forms).  reset != 0 clears the record. */
 int fluhip_corpus_update_clocks(fluhip_corpus* c, int64_t* out8, int reset);
+/* Device time of the last fluhip_corpus_nmf iteration loop of this corpus: two HIP events on the context stream, the first
+ * recorded BEHIND the host-side initialisation (random draws, uploads), the second behind the loop's last launch (the
+ * deferred-normalisation apply excluded).  Synchronises on the second event.  What tools/perf_matrix.py divides by the
+ * iteration count: no host scheduling, no initialisation inside the figure. */
+int fluhip_corpus_last_loop_ms(fluhip_corpus* c, double* ms);
 /* Kernel-developer diagnostic: with FLUHIP_K5_INSTR=1 in the environment the factor-update kernel of the
  * c4-shaped schedules runs an instrumented build that leaves cycle counters and a timeline of one wavefront in the
  * corpus' scratch; this copies the first 32 words out (tools/phase_breakdown.py decodes them).  Without the

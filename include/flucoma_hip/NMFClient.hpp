@@ -388,6 +388,7 @@ public:
       }
       lap("gather channels");
       fluhip_corpus* cor = nullptr;
+      fluhip_clear_error(mCtx);
       if (fluhip_corpus_create(mCtx, nChannels, nFrames, fftParams.winSize(), fftParams.fftSize(), hop, rank, &cor) == FLUHIP_OK)
       {
         struct Guard
@@ -502,8 +503,10 @@ public:
         // only an ALLOCATION failure is worth a second attempt with one channel's worth of memory; a device fault or
         // an argument error would fail again after a whole second job, with the first message lost and the progress restarted
         {
+          // (classified by the library at the point of failure -- hipErrorOutOfMemory, the FFT workspace, a host
+          //  bad_alloc -- not by message text; the flag was cleared in front of the block, so nothing stale is read)
           const char* why = fluhip_last_error(mCtx);
-          const bool  alloc = injectedAllocFailure || (why && (std::strstr(why, "out of memory") || std::strstr(why, "OutOfMemory")));
+          const bool  alloc = injectedAllocFailure || fluhip_last_error_is_out_of_memory(mCtx) != 0;
           if (!alloc) return {S::kError, "BufNMF: ", why ? why : "the batched job failed"};
         }
         batchedFallbacks() += 1; // (read by tests: the batched block failed and the sequential loop took the job)

@@ -21,6 +21,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Run order of the GPU suite.  The driver runs `pytest -m gpu -x`: whatever fails first hides
+# everything behind it, so the cheapest and most fundamental parity evidence goes first -- golden fixtures, config 1,
+# the headline (config 4) workload -- then the large configs, the host clients, the random / variant sweeps, and the
+# tests that spawn `bench.py` as sub-processes (rendezvous, several ranks on one GPU) last.  CPU tests keep file order.
+_GPU_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_configs.py", "test_client.py", "test_gpu_strip.py",
+                   "test_gpu_random_shapes.py", "test_gpu_variants.py"]
+_FIRST = ("golden", "test_c1_", "_c1_", "test_bench_workload_matches_oracle", "test_corpus_c4_", "test_reference_testnmf")
+_LAST = ("test_bench_two_ranks", "test_bench_eight_ranks", "test_bench_one_rank_rccl")
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(pair):
+        idx, item = pair
+        fname = os.path.basename(str(item.fspath))
+        rank = _GPU_FILE_ORDER.index(fname) if fname in _GPU_FILE_ORDER else -1      # CPU-only files first, as collected
+        if item.get_closest_marker("gpu") is None:
+            rank = -1
+        elif item.name.startswith(_LAST):
+            rank = len(_GPU_FILE_ORDER)
+        elif fname == "test_gpu_parity.py" and any(k in item.name for k in _FIRST):
+            return (0, -1, idx)
+        return (rank, 0, idx)
+    items[:] = [it for _, it in sorted(enumerate(items), key=key)]
+
+
 @pytest.fixture(scope="session")
 def golden():
     return np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))

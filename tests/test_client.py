@@ -260,9 +260,8 @@ def test_client_eight_channels_run_as_one_corpus(driver, oracle, onp, tmp_path, 
         else:
             assert np.array_equal(bases[c * K:(c + 1) * K], seedW[c * K:(c + 1) * K])   # fixed bases are not written back
         assert rel_err(acts[c * K:(c + 1) * K], ra) < 1e-6, c
-    if ms:
+    if ms:      # printed, never asserted: wall-clock ratios live in tools/perf_matrix.py (profiles/rNN/perf_matrix.json)
         print(f"8-channel job: batched {ms['batched']:.1f} ms, channel by channel {ms['sequential']:.1f} ms")
-        assert ms["batched"] <= 0.35 * ms["sequential"], ms
 
 
 @pytest.mark.gpu
