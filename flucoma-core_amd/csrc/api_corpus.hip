@@ -289,6 +289,9 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
     HIPCHK(ctx, c->wnorm.alloc(B * c->Kp * sizeof(double), false, s));
     launch_fill_ones(c->wnorm.as<double>(), (int64_t) (B * c->Kp), s);
     HIPCHK(ctx, c->wscratch.alloc((size_t) wnorm_scratch_doubles((int) c->Kp, (int) B, c->stripsW) * sizeof(double), true, s));
+    // column sums of the rows of W' every wavefront of a W update writes (UpdateArgs::colOut; rank 32, the two-launch iteration)
+    if (c->Kp == 32 && !c->strip && c->stripsW > 0)
+      HIPCHK(ctx, c->colPart.alloc((size_t) B * c->stripsW * c->Kp * sizeof(double), true, s));
   }
   return FLUHIP_OK;
 }
@@ -1083,9 +1086,18 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
                                 a.dpart, (int64_t) ns * c->Kp, ns - 1, s);
         a.colsumInPlace = true;
       }
+      // rank 32, steady state of the two-launch iteration: the H update in front left the side column's partials, whose
+      // denominators are the column sums of H this update divides by -- no accumulators in its loop; it leaves the column sums
+      // of its rows for the H update behind (the launcher decides whether the form exists for these arguments: bit 2)
+      if (sideReady && c->sideW && !c->useLists && c->colPart.p && c->sideFromHSlices > 0 && update_variant(a.Kp) == 5)
+      {
+        a.colIn = wnorm_side_part(c->wscratch.as<double>(), (int) c->Kp, Bw, c->stripsW, c->sideGen);
+        a.colInN = c->sideFromHSlices;
+        a.colOut = c->colPart.as<double>();
+      }
       {
         ProfScope p(ctx, 1);
-        launch_nmf_update5(a, s);
+        c->colPartValid = (launch_nmf_update5(a, s) & 4) != 0;
         if (c->useLists && c->listW.partial)
           launch_update_finalize(a.S, a.strideS, a.part, a.dpart, a.C, a.Kp, a.Cp, c->listW.maxSplit, a.B, s, a.nrm, a.nrmMode,
                                  a.statPart, c->listW.splitTab.as<int>());
@@ -1154,6 +1166,8 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
   if (updateH)
   {
     UpdateArgs a = h_args();
+    const bool colValid = c->colPartValid;
+    c->colPartValid = false;
     if (c->wPending) { a.nrm = wnormW; a.nrmMode = 2; }
     const bool csIn = c->colsumWInPlace;   // (the column sums of W' are in this update's denominator slots already)
     c->colsumWInPlace = false;
@@ -1192,6 +1206,7 @@ static void enqueue_iteration(fluhip_corpus* c, bool updateW, bool updateH, bool
       // (the norm combine of the W update in front, if that was left to this launch: c->normDue)
       const bool wantNorm = c->normDue;
       a.colsumInPlace = csIn;
+      if (wantNorm && updateW && colValid) { a.colIn = c->colPart.as<double>(); a.colInN = c->stripsW; }
       if (wantNorm || (fromH && updateW && !last && c->lazy && c->sideW && c->wPending && c->nsplitH == 1)) side_io(a, wantNorm);
       const int did = launch_nmf_update5(a, s);
       if (wantNorm && !(did & 2)) c->planError = true; // (cannot happen: the dry run in the W update's step took the same arguments)
@@ -1216,6 +1231,7 @@ static int corpus_iterate_loop(fluhip_corpus* c, int64_t iters, bool updateW, bo
 {
   fluhip_ctx* ctx = c->ctx;
   c->sideFromH = false; // (side-column partials an H update leaves are only ever used by the W update enqueued right behind it)
+  c->colPartValid = false;
   c->colsumWInPlace = false;
   c->normDue = false;
   if (!progress)

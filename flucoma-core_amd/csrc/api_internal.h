@@ -245,6 +245,8 @@ struct fluhip_corpus
   bool planError = false; // a launch did not take the form its dry run announced (reported by corpus_iterate)
   int stripsW = 0;       // wavefronts per buffer of the W update (statistics partials)
   DevBuf wnorm, wscratch, csumScratch, wideScratch;
+  DevBuf colPart;            // [B][stripsW][Kp]: column sums of the rows of W' each wavefront of the last W update wrote (UpdateArgs::colOut)
+  bool colPartValid = false; // ... and whether that launch filled it (the H update behind then takes its column sums from there)
   DevBuf clk; // UpdateArgs::clk: 4 words for the W update's launches, 4 for the H update's
   // events on the context stream around the last iteration loop (behind the host-side initialisation, in front of
   // nothing but the loop's own launches): fluhip_corpus_last_loop_ms -- device time of the loop for tools/perf_matrix.py

@@ -153,6 +153,15 @@ struct UpdateArgs
   double* cmbNrmOut = nullptr;
   double* cmbRowOut = nullptr;
   int cmbParts = 0, cmbSlices = 0, cmbK = 0;
+  // Column sums of the moving factor from the neighbouring launches instead of accumulators in the loop (round 6; rank 32,
+  // the two-launch iteration of a corpus).  W update: colIn = the side-column partials the H update in front left
+  // ([B][colInN][2][Kp], = cmbSide of the H update behind: their denominators are the column sums of H over each wavefront's
+  // frames), colOut [B][strips][Kp] takes the column sums of the rows of W' this launch writes.  H update (norm form):
+  // colIn = that colOut, colInN = the W update's strips.  Return value of launch_nmf_update5: bit 2 = the launch took its
+  // column sums from colIn (and, W update, filled colOut).
+  const double* colIn = nullptr;
+  double* colOut = nullptr;
+  int colInN = 0;
   bool dryRun = false; // nothing is launched: the return value says what a launch with these arguments would do
 };
 

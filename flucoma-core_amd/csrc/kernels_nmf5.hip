@@ -67,6 +67,14 @@ struct Upd5Args
   double* cmbNrmOut;
   double* cmbRowOut;
   int cmbParts, cmbSlices, cmbK;
+  // DS == 2 (round 6): the column sums of Mv come from what the launch IN FRONT left, and this launch leaves the column sums
+  // of the rows it writes for the launch BEHIND -- no accumulators in the loop (UpdateArgs::colIn / colOut).
+  //   W update: colIn = the side-column partials of the H update in front, [B][colInN][2][KPM] (their denominators ARE the
+  //             column sums of the new H over each wavefront's frames); colOut [B][wavesPerBuf][KPM]
+  //   H update (NORMQ): colIn = the colOut of the W update in front, [B][colInN][KPM]; the side row its prologue forms is added
+  const double* colIn;
+  double* colOut;
+  int colInN;
 };
 
 // The quotients V / max(Q, eps) of the hot loop: v_rcp_f64 (2^29 ulp, i.e. ~23 bits) -> one Newton step (2^-46) -> product.
@@ -189,6 +197,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   constexpr int WAVE_LDS = NS * (VSTAGE + MSTAGE);
   constexpr int IPS = NJV + NJM;                   // vmcnt events per stage
   // work-list mode: a wavefront's LDS region also stages its accumulators for the intra-workgroup reduction
+  // DS == 2: no column-sum accumulators and the first product's results in VGPRs (QV below) -- the two go together: the
+  // sixteen registers of the accumulators are what the VGPR form of the first product needs
+  constexpr bool QV = DS == 2 && MODE == 1;
   constexpr int STG_BYTES = (NG * M + M) * 512;
   constexpr int WAVE_REGION = (LIST != 0 && STG_BYTES > WAVE_LDS && 4 * STG_BYTES <= 160 * 1024) ? STG_BYTES : WAVE_LDS;
 
@@ -358,7 +369,22 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   constexpr bool NORMQ = (SIDEQ & 2) != 0;
   [[maybe_unused]] char* sideL = nullptr;
   // NORMQ: the requests of the norm combine leave first (lane k < KP holds component k)
-  [[maybe_unused]] double cs[8], cm[8], cn[8], cd[8], cwo = 0.0;
+  [[maybe_unused]] double cs[8], cm[8], cn[8], cd[8], cwo = 0.0, cc[8];
+  static_assert(DS != 2 || NORMQ || SIDEQ == 0, "DS == 2: the W update's plain form or the H update's norm form");
+  if constexpr (DS == 2)
+  {
+    // the column sums of Mv from the partials of the launch in front: lane k < KP takes component k (requests first, sums below)
+#pragma unroll
+    for (int u = 0; u < 8; u++) cc[u] = 0.0;
+    if (lane < KP)
+    {
+      // (W update: the denominators of the side-column partials, [n][2][KPM] -- H update: the W update's column partials, [n][KPM])
+      const int64_t rec = NORMQ ? KPM : 2 * KPM;
+      const double* cp = a.colIn + (int64_t) buf * a.colInN * rec + (NORMQ ? 0 : KPM) + lane;
+#pragma unroll
+      for (int u = 0; u < 8; u++) if (u < a.colInN) cc[u] = cp[(int64_t) u * rec];
+    }
+  }
   if constexpr (NORMQ)
   {
 #pragma unroll
@@ -376,9 +402,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       }
     }
   }
+  constexpr int SIDE_BYTES = SIDEQ ? (1 + NJSV) * 1024 : 0;
+  constexpr int EXTRA_BYTES = SIDE_BYTES + (DS == 2 ? 512 : 0);      // per wavefront, behind the rings
+  [[maybe_unused]] double* colL = reinterpret_cast<double*>(lds + WPB * WAVE_REGION + wave * EXTRA_BYTES + SIDE_BYTES);
   if constexpr (SIDEQ)
   {
-    sideL = lds + WPB * WAVE_REGION + wave * (1 + NJSV) * 1024;
+    sideL = lds + WPB * WAVE_REGION + wave * EXTRA_BYTES;
     if constexpr (!NORMQ)
     {
       const char* wsrc = reinterpret_cast<const char*>(Mv + (int64_t) (a.R - 1) * KPM) + min(lane, SPR - 1) * 16;
@@ -403,6 +432,24 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
     for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
     if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KPM + M * y);
+  }
+  [[maybe_unused]] double colSum = 0.0;
+  if constexpr (DS == 2)
+  {
+    // in index order, like every other combine of per-wavefront records (the same sum in every wavefront of the buffer)
+#pragma unroll
+    for (int u = 0; u < 8; u++) colSum += cc[u];
+    if (lane < KP)
+    {
+      const int64_t rec = NORMQ ? KPM : 2 * KPM;
+      const double* cp = a.colIn + (int64_t) buf * a.colInN * rec + (NORMQ ? 0 : KPM) + lane;
+      for (int j = 8; j < a.colInN; j++) colSum += cp[(int64_t) j * rec];
+    }
+    if constexpr (!NORMQ)
+    {
+      if (lane < KP) colL[lane] = colSum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
   }
   if constexpr (NORMQ)
   {
@@ -430,6 +477,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     {
       ldsW[lane] = wnew;
       ldsW[64 + lane] = nv;
+      if constexpr (DS == 2) colL[lane] = colSum + wnew;   // sum_f W'[f][k]: the rows the W update wrote + the side row formed here
       a.cmbRowOut[(int64_t) buf * a.strideM + (int64_t) (a.R - 1) * KPM + lane] = wnew;
       if (strip == 0) a.cmbNrmOut[(int64_t) buf * KPM + lane] = nv;
     }
@@ -587,7 +635,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
       for (int m = 0; m < M; m++) acc[g][m] = __builtin_amdgcn_mfma_f64_4x4x4f64(ratio[g], mb[m], acc[g][m], 0, 0, 0);
 #pragma unroll
-    for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
+    for (int m = 0; m < M; m++) if constexpr (DS == 1) dsum[m] += mb[m];
   };
 
   // ---- pipeline -------------------------------------------------------------------------------
@@ -644,7 +692,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * IPS) : "memory");
         ratio_phase(v, qc, ratio);
 #pragma unroll
-        for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
+        for (int m = 0; m < M; m++) if constexpr (DS == 1) dsum[m] += mb[m];
         __builtin_amdgcn_sched_barrier(0);
         {
           constexpr int PP = (P <= M) ? P : M;
@@ -818,6 +866,19 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
 #pragma unroll
             for (int g = 0; g < NG; g++)
             {
+              if constexpr (QV)
+              {
+                // The first product with VGPR results (round 6).  Every MFMA the compiler selects in a function that needs
+                // AGPRs at all gets an AGPR destination, and the quotient block then opens with 2 NG v_accvgpr_read_b32 to
+                // fetch Q -- which only the VALU ever reads.  Spelled in asm the accumulate chain stays in VGPRs (ACC_CD = 0:
+                // srcC and vdst are one register class per instruction).  Hazards the compiler cannot see inside the asm, by
+                // construction: a chain's links are NG >= 2 MFMAs apart (DMFMA 4x4 -> overlapped SrcC: 4 wait states), the
+                // VALU reads Q a whole second product (NG M MFMAs) later, the operands come from ds_reads behind an
+                // s_waitcnt and from registers last written in the prologue.
+                if (m < PP) asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, 0" : "=&v"(qp[g][m % PP]) : "v"(ma[m]), "v"(sb[g][m]));
+                else asm volatile("v_mfma_f64_4x4x4_4b_f64 %0, %1, %2, %0" : "+v"(qp[g][m % PP]) : "v"(ma[m]), "v"(sb[g][m]));
+              }
+              else
               qp[g][m % PP] = __builtin_amdgcn_mfma_f64_4x4x4f64(ma[m], sb[g][m], qp[g][m % PP], 0, 0, 0);
               const int i = m * NG + g;
               if (i % RDSTEP == RDSTEP - 1 && i / RDSTEP < NRD)
@@ -870,7 +931,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               }
             }
 #pragma unroll
-          for (int m = 0; m < M; m++) if constexpr (DS) dsum[m] += mb[m];
+          for (int m = 0; m < M; m++) if constexpr (DS == 1) dsum[m] += mb[m];
         }
         __builtin_amdgcn_sched_barrier(0);
         const long long c4 = tick();
@@ -1007,7 +1068,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
     lD = __builtin_amdgcn_readfirstlane(wd->dIdx);
   }
   auto whole = [&]() -> bool { if constexpr (LIST != 0) return lPart < 0; else return a.nsplit == 1; };
-  if constexpr (DS)
+  if constexpr (DS == 1)
   {
 #pragma unroll
     for (int m = 0; m < M; m++)
@@ -1017,6 +1078,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       d += __shfl_xor(d, 32);
       dsum[m] = d;
     }
+  }
+  else if constexpr (DS == 2)
+  {
+    // the prologue's sum of the partials the launch in front left (un-split launches only: the launcher sees to it)
+#pragma unroll
+    for (int m = 0; m < M; m++) dsum[m] = colL[M * x + m];
   }
   else if (whole())
   {
@@ -1028,6 +1095,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   if (whole())
   {
     double nrE[M], ss[M], mx[M];
+    [[maybe_unused]] double csum[M];     // DS == 2, W update: column sums of the rows this wavefront writes (colOut)
+    constexpr bool COLOUT = DS == 2 && !NORMQ;
     [[maybe_unused]] double nrL = 1.0;   // SIDEQ: the norm of component `lane` (the old side row leaves normalised)
     if constexpr (NORMQ)
     {
@@ -1057,6 +1126,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       dy[m] = __builtin_fma(y0, __builtin_fma(-dd[m], y0, 1.0), y0);
       ss[m] = 0.0;
       mx[m] = -INFINITY;
+      if constexpr (COLOUT) csum[m] = 0.0;
     }
     // S_old comes from the stationary registers, not from memory: sb holds S (already divided by nrm when the
     // normalisation is deferred) as (col 4 blk + x, k = M y + m); the result layout is (col 4 blk + y,
@@ -1120,6 +1190,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
             {
               ss[m + e] = __builtin_fma(r, r, ss[m + e]);
               mx[m + e] = fmax(mx[m + e], r);
+              if constexpr (COLOUT) csum[m + e] += r;
             }
           }
           *reinterpret_cast<d2*>(row + m * 8) = d2{r2[0], r2[1]};
@@ -1210,6 +1281,24 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         for (int m = 0; m < M; m++) { sp[m] = ss[m]; sp[KPM + m] = mx[m]; }
       }
     }
+    if constexpr (COLOUT)
+    {
+      // the same fixed butterfly over (blk, y); lanes 0 .. 3 store their M components
+#pragma unroll
+      for (int m = 0; m < M; m++)
+      {
+        double t = csum[m];
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) t += __shfl_xor(t, off);
+        csum[m] = t;
+      }
+      if (lane < 4)
+      {
+        double* cp = a.colOut + ((int64_t) buf * a.wavesPerBuf + strip) * KPM + M * x;
+#pragma unroll
+        for (int m = 0; m < M; m++) cp[m] = csum[m];
+      }
+    }
   }
   else
   {
@@ -1281,6 +1370,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   k.sidePart = SIDEQ ? a.sideOut : nullptr; k.sideWold = SIDEQ ? a.sideWold : nullptr;
   k.cmbStat = a.cmbStat; k.cmbSide = a.cmbSide; k.cmbWold = a.cmbWold; k.cmbNrmOut = a.cmbNrmOut; k.cmbRowOut = a.cmbRowOut;
   k.cmbParts = a.cmbParts; k.cmbSlices = a.cmbSlices; k.cmbK = a.cmbK;
+  k.colIn = a.colIn; k.colOut = a.colOut; k.colInN = a.colInN;
   k.V = a.V; k.ldv = a.ldv; k.strideV = a.strideV;
   k.Mv = a.Mv; k.strideM = a.strideM;
   k.S = a.S; k.strideS = a.strideS;
@@ -1302,7 +1392,7 @@ static void launch5_t(const UpdateArgs& a, int wavesPerBuf, hipStream_t s)
   const unsigned grid = (unsigned) (bufs * k.wgPerBuf * k.nsplit);
   constexpr int KP = 4 * M, SPR = KP / 2;
   constexpr int NJV = (32 * NG + 63) / 64, NJM = (4 * SPR + 63) / 64;
-  constexpr size_t shmem = (size_t) 4 * WPS * (NS * (NJV + NJM) + (SIDEQ ? 1 + (NG * 128 + 1023) / 1024 : 0)) * 1024;
+  constexpr size_t shmem = (size_t) 4 * WPS * ((NS * (NJV + NJM) + (SIDEQ ? 1 + (NG * 128 + 1023) / 1024 : 0)) * 1024 + (DS == 2 ? 512 : 0));
   static_assert(shmem <= 160 * 1024, "LDS ring does not fit");
   auto kern = nmf_update5_kernel<M, NG, NS, WPS, INSTR, MODE, DS, 0, SIDEQ, KPM>;
   request_dynamic_lds(kern, (size_t) (shmem));
@@ -1432,8 +1522,23 @@ static int launch5_ng(const UpdateArgs& a, int w, int ng, hipStream_t s)
             {
               // (M = 8 at nine groups per strip sits at 512 registers: the prologue of the norm form would spill 14 of them)
               if constexpr (!(M == 8 && NG == 9))
+              {
+                // round 6, rank 32: no column-sum accumulators in the loop and the first product's results in VGPRs when the
+                // W update in front left the column sums of its rows (UpdateArgs::colIn; return bit 2)
+                // (eight groups per strip: the norm form's prologue and the VGPR first product together spill 66 registers)
+                if constexpr (M == 8 && NG <= 7)
+                  if (normq && a.colIn && a.colInN > 0) { launch5_t<M, NG, NS, WPS, 0, 1, 2, 3>(a, w, s); return 7; }
                 if (normq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 3>(a, w, s); return 3; }
+              }
               if (sideq) { launch5_t<M, NG, NS, WPS, 0, 1, 1, 1>(a, w, s); return 1; }
+              // ... and the W update between two such H updates: its column sums are the denominators of the side-column
+              // partials the H update in front left; it leaves the column sums of the rows it writes (colOut)
+              if constexpr (M == 8 && NG <= 8)
+                if (a.colIn && a.colInN > 0 && a.colOut && a.nsplit <= 1 && a.nrmMode == 1 && a.statPart)
+                {
+                  launch5_t<M, NG, NS, WPS, 0, 1, 2, 0>(a, w, s);
+                  return 4;
+                }
             }
             launch5_t<M, NG, NS, WPS, 0, 1>(a, w, s);
             return 0;
