@@ -829,7 +829,8 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       q_phase(maX, qA);
       read_set(0, 1, vX, maX, mbX, true);
 
-      constexpr int NRD = NG + M;                   // ds_read instructions per operand set
+      constexpr int NVR = QV ? (NG + 1) / 2 : NG;   // read slots of the V slab (QV forms: two groups to an instruction)
+      constexpr int NRD = NVR + M;                  // ds_read instructions per operand set
       constexpr int NMF = M * NG;                   // MFMAs per phase
       constexpr int RDSTEP = (NMF / NRD) >= 2 ? 2 : 1;
       constexpr int DMASTEP = NMF / IPS > 0 ? NMF / IPS : 1;
@@ -884,18 +885,27 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               if (i % RDSTEP == RDSTEP - 1 && i / RDSTEP < NRD)
               {
                 const int r = i / RDSTEP;
-                if (r < NG) vn[r] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + r * 128);
-                else if (r < NG + M / 2)
+                if (r < NVR)
                 {
-                  d2 t = *reinterpret_cast<const d2*>(mbAddr[r - NG] + u1 * MSTAGE);
-                  mbn[2 * (r - NG)] = t[0];
-                  mbn[2 * (r - NG) + 1] = t[1];
+                  if constexpr (QV)
+                  {
+                    // two groups' magnitudes per instruction (ds_read2_b64: the slab's columns of a lane lie 128 bytes apart)
+                    vn[2 * r] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + (2 * r) * 128);
+                    if (2 * r + 1 < NG) vn[2 * r + 1] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + (2 * r + 1) * 128);
+                  }
+                  else vn[r] = *reinterpret_cast<const double*>(vAddr + u1 * VSTAGE + r * 128);
+                }
+                else if (r < NVR + M / 2)
+                {
+                  d2 t = *reinterpret_cast<const d2*>(mbAddr[r - NVR] + u1 * MSTAGE);
+                  mbn[2 * (r - NVR)] = t[0];
+                  mbn[2 * (r - NVR) + 1] = t[1];
                 }
                 else
                 {
-                  d2 t = *reinterpret_cast<const d2*>(maAddr[r - NG - M / 2] + u2 * MSTAGE);
-                  man[2 * (r - NG - M / 2)] = t[0];
-                  man[2 * (r - NG - M / 2) + 1] = t[1];
+                  d2 t = *reinterpret_cast<const d2*>(maAddr[r - NVR - M / 2] + u2 * MSTAGE);
+                  man[2 * (r - NVR - M / 2)] = t[0];
+                  man[2 * (r - NVR - M / 2) + 1] = t[1];
                 }
                 __builtin_amdgcn_sched_barrier(0);
               }
