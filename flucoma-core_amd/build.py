@@ -115,6 +115,13 @@ def build_ab(force: bool = False):
     return _build_variant("ab", LIB_AB, force), _build_variant("qc", LIB_QC, force)
 
 
+def build_exp(name: str, defines, files, base: str = "default") -> str:
+    """an experiment build for one-session A/B runs: `files` recompiled with `defines` into build_<name>/, every other object
+    taken from `base`; the library goes to lib_ab/libflucoma_hip_<name>.so (FLUHIP_LIB=<path> loads it)"""
+    VARIANTS[name] = (os.path.join(HERE, "build_" + name), list(defines), list(files), base)
+    return _build_variant(name, os.path.join(ABDIR, f"libflucoma_hip_{name}.so"))
+
+
 def build_host_tests() -> str:
     """g++ build of the C++ host-client test driver (plain C++17 above the C ABI)."""
     root = os.path.dirname(HERE)
@@ -136,6 +143,11 @@ def build_host_tests() -> str:
 
 
 if __name__ == "__main__":
+    if "--exp" in sys.argv:   # python build.py --exp NAME -DX=1 [-DY] file.hip [file.hip ...]
+        i = sys.argv.index("--exp")
+        rest = sys.argv[i + 2:]
+        print(build_exp(sys.argv[i + 1], [a for a in rest if a.startswith("-D")], [a for a in rest if not a.startswith("-")]))
+        sys.exit(0)
     print(build(force="--force" in sys.argv))
     print(build_host_tests())
     if "--ab" in sys.argv:

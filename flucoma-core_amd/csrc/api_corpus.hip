@@ -43,29 +43,6 @@ static int choose_split4(int64_t B, int C, int R, int Kp)
   return (int) std::max<int64_t>(1, std::min(s, smax));
 }
 
-// workspaces of the factor updates: split-contraction partials, denominators, column-sum pre-pass
-static int alloc_update_scratch(fluhip_ctx* ctx, fluhip_corpus* c)
-{
-  hipStream_t s = ctx->stream;
-  const size_t B = (size_t) c->B;
-  const int ns = std::max(std::max(c->nsplitW, c->nsplitH), c->tailSplitH);
-  if (ns > 1 && !c->strip)
-  {
-    // partial numerators [B][pieces][rows][Kp]: the W update's rows are the bins, the H update's the frames (of the tail launch:
-    // the frames behind the whole-contraction ones); the launches set UpdateArgs::Cp to their own row count
-    const size_t rowsW = c->nsplitW > 1 ? (size_t) c->nsplitW * c->Fp : 0;
-    const size_t rowsH = c->nsplitH > 1 ? (size_t) c->nsplitH * c->Tp : 0;
-    const size_t rowsT = c->tailSplitH > 1 ? (size_t) c->tailSplitH * round_up(c->T - c->tailColsH, 32) : 0;
-    HIPCHK(ctx, c->part.alloc(B * std::max(std::max(rowsW, rowsH), rowsT) * c->Kp * sizeof(double), true, s));
-  }
-  // (the tail launch keeps its denominator slots behind the first launch's B x Kp)
-  HIPCHK(ctx, c->dpart.alloc(std::max<size_t>(256, B * std::max(ns, 1 + c->tailSplitH) * c->Kp * sizeof(double)), true, s));
-  if (c->Kp > 64)
-    HIPCHK(ctx, c->csumScratch.alloc((size_t) colsum_scratch_doubles((int) std::max(c->T, c->F), (int) c->Kp, (int) B) *
-                                         sizeof(double), false, s));
-  return FLUHIP_OK;
-}
-
 // A whole-contraction update whose wavefronts need a last, poorly filled round of the 1024 SIMDs (config 3's H update: 2 x 808
 // strips = 1.58 rounds, paid as 2) goes out as TWO launches: the strips that fill whole rounds as before, then the remaining
 // strips with their contraction cut into `split` pieces (uniform split schedule: partials + finalize), which deals the tail
@@ -113,7 +90,6 @@ static int plan_tail(int64_t B, int C, int R, int Kp, int* stripsA)
   return best;
 }
 
-static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
 static bool offsize_enabled()
 {
   static const int offEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_OFFSIZE"); return e ? std::atoi(e) : 1; }();
@@ -152,148 +128,6 @@ static bool list_plan_pays(const PlanShape* c)
   // lists beyond (1 x 60 s 80.5 -> 72.8, 1 x 300 s 253 -> 163, 2 x 30 s 79.3 -> 71.3, 2 x 300 s 454 -> 340).
   if (c->B <= 2) return c->B * c->T * c->F >= 4200000;
   return w0 != 1024;
-}
-
-// how the factor updates of this shape are scheduled (splits, deferred normalisation, side column) and their
-// workspaces; needs B, T, F, Tp, Fp, Kp
-int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
-{
-  hipStream_t s = ctx->stream;
-  const size_t B = (size_t) c->B;
-  c->tailSplitH = 0;
-  if (update_variant((int) c->Kp) == 0)
-  {
-    c->nsplitW = c->nsplitH = 1;
-    c->lazy = c->sideW = false;
-    const int64_t nd = std::max(nmf_update_wide_scratch_doubles((int) c->T, (int) c->F, (int) c->Kp, (int) B),
-                                nmf_update_wide_scratch_doubles((int) c->F, (int) c->T, (int) c->Kp, (int) B));
-    HIPCHK(ctx, c->wideScratch.alloc((size_t) nd * sizeof(double), false, s));
-  }
-  else
-  {
-    c->nsplitW = choose_split4(c->B, (int) c->F, (int) c->T, (int) c->Kp);
-    c->nsplitH = choose_split4(c->B, (int) c->T, (int) c->F, (int) c->Kp);
-    // Fast path: W stays un-normalised in memory during the loop (UpdateArgs::nrm), the column statistics
-    // come out of the update kernel's epilogue and the Nyquist bin is a side column when that shortens the
-    // widest strip of the MFMA kernel (fluhip_kernels.h SideColumn).
-    static const int lazyOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
-    static const int sideOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
-    c->lazy = !lazyOff && update_variant((int) c->Kp) == 5;
-    c->sideW = false;
-    if (c->lazy && !sideOff && c->nsplitW == 1 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp) &&
-        choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp) == 1)
-    {
-      const int G = ((int) c->F + 15) / 16, G1 = G - 1;
-      const int w = nmf_update5_strips((int) c->F, (int) c->Kp, (int) c->B);
-      const int w1 = nmf_update5_strips((int) c->F - 1, (int) c->Kp, (int) c->B);
-      // worth it when the widest strip gets shorter, or when the launch needs fewer passes over the 1024 SIMDs
-      const int64_t passes = (c->B * w + 1023) / 1024, passes1 = (c->B * w1 + 1023) / 1024;
-      c->sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
-    }
-    else if (c->lazy && !sideOff && c->nsplitW > 1 && nmf_side_column_supported((int) c->T, (int) c->F, (int) c->Kp))
-    {
-      // Split contraction (few buffers): without the 16 m + 1-th bin the strips deal evenly and the pieces get shorter --
-      // config 3 (2 x 2049 bins, rank 128): 130 strips x 7 pieces of 923 steps (910 wavefronts) -> 128 strips x 8 pieces
-      // of 808 steps (1024 wavefronts).  Taken when the longest piece shrinks.
-      const int s1 = choose_split4(c->B, (int) c->F - 1, (int) c->T, (int) c->Kp);
-      const int64_t nSteps = (c->T + 3) / 4;
-      const int64_t w = c->B * nmf_update5_waves_per_buffer((int) c->F, (int) c->Kp, (int) c->B);
-      const int64_t w1 = c->B * nmf_update5_waves_per_buffer((int) c->F - 1, (int) c->Kp, (int) c->B);
-      if (s1 > 1 && w1 * s1 <= 1024 && w * c->nsplitW <= 1024 && (nSteps + s1 - 1) / s1 < (nSteps + c->nsplitW - 1) / c->nsplitW)
-      {
-        c->sideW = true;
-        c->nsplitW = s1;
-      }
-    }
-    // A single buffer of rank <= 16 runs the frame-strip schedule while one round of workgroups covers it (at most 6 frame
-    // quads per CU: 71 s at hop 512): two launches per iteration instead of five and V read once.  Longer buffers and
-    // batches stay with the split / batched kernels, which win there (tools/strip_vs_split.py).  FLUHIP_STRIP=0 off,
-    // =1 wherever the kernel supports the shape.
-    static const int stripEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
-    c->strip = c->lazy && stripEnv != 0 && nmf_strip_supported((int) c->F, (int) c->T, (int) c->Kp) &&
-               (stripEnv == 1 || (c->B == 1 && nmf_strip_workgroups((int) c->T) <= 512));
-    if (c->strip)
-    {
-      c->sideW = false;
-      // (zeroed once: with the Nyquist bin as a side column only 16 values of its partial blocks are ever written, and the
-      //  reduce launch adds the whole blocks before it masks the bins that do not exist)
-      HIPCHK(ctx, c->stripPart.alloc((size_t) nmf_strip_part_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), true, s));
-      // FLUHIP_STRIP_BIN=1 (A/B build only): the W update as its own launch over bin strips instead of the fused form (W
-      // partials behind the H phase + the reduce launch).  Built and measured in round 4 (profiles/r04/c2_forms.md): 45.1 us
-      // per iteration against 40.3 at config 2 -- a tenth of the partial bytes, but the last arriver's chain of cross-XCD
-      // round trips (ticket, partials in two rounds, update) costs what the reduce launch cost.  Not adopted.
-      static const int binEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_BIN"); return e ? std::atoi(e) : 0; }();
-      c->stripBin = kAbSwitches && binEnv != 0;
-#ifdef FLUHIP_AB_SWITCHES
-      if (c->stripBin)
-        HIPCHK(ctx, c->binWork.alloc((size_t) nmf_binstrip_doubles((int) c->F, (int) c->T, (int) B) * sizeof(double), true, s));
-#endif
-      // Round 5: the W update as the BIN-TILED launch (kernels_nmf_bintile.hip: four bins and ALL frames per workgroup, no
-      // numerator partials in memory, no reduce launch, no ticket), the strip kernel doing the H update and the Nyquist bin's
-      // partials.  Built to the review's specification, parity-green at full size, and measured at config 2
-      // (profiles/r05/c2_bintile.md): 20.3 us for the launch in three layouts against the review's 13 us kill line --
-      // 4.3 us is what an EMPTY launch of the shape costs, 3.9 prologue + epilogue, 1.4 the ring fill, 10.6 the frame loop
-      // (FP64-datapath-bound: the quotient and the bookkeeping adds cost what the eight MFMAs of a step cost) -- so that
-      // an iteration is 19.0 + 20.3 = 40.9 us against 38.9 for the fused form + reduce launch.  Not adopted: A/B build only,
-      // FLUHIP_STRIP_TILE=1.
-      static const int tileEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_TILE"); return e ? std::atoi(e) : 0; }();
-#ifdef FLUHIP_AB_SWITCHES
-      c->stripTile = !c->stripBin && tileEnv == 1 && nmf_bintile_supported((int) c->F, (int) c->T, (int) c->Kp) &&
-                     nmf_strip_tile_supported((int) c->F, (int) c->T, (int) c->Kp);
-      if (c->stripTile)
-        HIPCHK(ctx, c->tileWork.alloc((size_t) nmf_bintile_doubles((int) c->F, (int) B, nmf_strip_workgroups((int) c->T)) * sizeof(double), true, s));
-#else
-      (void) tileEnv;
-#endif
-    }
-    // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
-    // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
-    // partials in memory.  FLUHIP_LIST_PLAN=0 keeps the uniform split schedule, =1 takes the lists whenever something is split.
-    static const int listEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
-    if (!c->strip && c->lazy && listEnv != 0 && (listEnv == 1 || [&] { const PlanShape ps{c->B, c->T, c->F, c->Kp}; return list_plan_pays(&ps); }()))
-    {
-      c->tOf.assign(B, (int) c->T);
-      c->useLists = true;
-      return plan_lists(ctx, c);
-    }
-    // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
-    // finalize kernel when the contraction is split
-    c->stripsW = c->nsplitW > 1 ? update_finalize_parts((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp)
-                                : nmf_update5_strips((int) c->F - (c->sideW ? 1 : 0), (int) c->Kp, (int) c->B);
-    c->tailSplitH = 0;
-    if (!c->strip && c->lazy && c->nsplitH == 1)
-    {
-      int wA = 0;
-      const int sp = plan_tail(c->B, (int) c->T, (int) c->F, (int) c->Kp, &wA);
-      if (sp > 1)
-      {
-        const int G = ((int) c->T + 15) / 16, w = nmf_update5_strips((int) c->T, (int) c->Kp, (int) c->B);
-        c->tailSplitH = sp;
-        c->tailStripsH = wA;
-        c->tailRestH = w - wA;
-        c->tailColsH = wA * ((G + w - 1) / w) * 16;
-      }
-    }
-  }
-  // Off-size ranks (round 5): a rank between two array ranks keeps the ARRAYS of the padded rank (32 / 64 / 128) -- every
-  // helper kernel runs its form of that rank on zero columns -- and the factor updates compute fewer MFMAs per product
-  // (kernels_nmf5.hip KPM, nmf_update5_compute_rank): 6 of 8 for ranks 17 .. 24; 10 / 12 / 14 of 16 for 33 .. 40 / 48 / 56; 18, 20 .. 28
-  // of 32 for 65 .. 72, .. 80, .. 112.  The plain and the split-contraction schedules and the work lists; the strip schedule
-  // (rank <= 16) has no off-size rank.  FLUHIP_OFFSIZE=0 (A/B build): the padded forms, for the comparison.
-  c->Kc = (offsize_enabled() && c->lazy && !c->strip && update_variant((int) c->Kp) == 5)
-              ? nmf_update5_compute_rank((int) c->K, (int) c->Kp) : (int) c->Kp;
-  if (int rc = alloc_update_scratch(ctx, c)) return rc;
-  HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
-  if (c->lazy)
-  {
-    HIPCHK(ctx, c->wnorm.alloc(B * c->Kp * sizeof(double), false, s));
-    launch_fill_ones(c->wnorm.as<double>(), (int64_t) (B * c->Kp), s);
-    HIPCHK(ctx, c->wscratch.alloc((size_t) wnorm_scratch_doubles((int) c->Kp, (int) B, c->stripsW) * sizeof(double), true, s));
-    // column sums of the rows of W' every wavefront of a W update writes (UpdateArgs::colOut; rank 32, the two-launch iteration)
-    if (c->Kp == 32 && !c->strip && c->stripsW > 0)
-      HIPCHK(ctx, c->colPart.alloc((size_t) B * c->stripsW * c->Kp * sizeof(double), true, s));
-  }
-  return FLUHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -600,6 +434,206 @@ static void build_list_plan(const std::vector<int>& tOf, int Tmax, int F, int Kp
     out.H.pieces = pieces;
     out.H.splitTab = std::move(splitTab);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// The schedule of the factor updates of a shape as DATA (round 6).  decide_update_plan() is a pure function
+// of (B, T, F, K): no device, no allocation, nothing read from a corpus -- every choice between the uniform / split / work-list /
+// frame-strip / two-launch / any-rank forms, the side column, the off-size compute rank, and the size in doubles of every
+// workspace the launches of that plan index.  plan_updates() copies it onto the corpus and allocates exactly those sizes;
+// fluhip_debug_plan_shape() reports it without a device; tests/test_plan_table.py holds it to its invariants over a grid of
+// shapes and to the pinned plans of the BASELINE and perf-matrix shapes.
+void decide_update_plan(int64_t B, int64_t T, int64_t F, int64_t K, UpdatePlan& p)
+{
+  p = UpdatePlan{};
+  const int64_t Tp = round_up(T, 32), Fp = round_up(F, 32);
+  p.Kp = padded_rank(K);
+  p.variant = update_variant((int) p.Kp);
+  p.Kc = (int) p.Kp;
+  p.nsplitW = p.nsplitH = 1;
+  if (p.variant == 0)
+  {
+    p.wideDoubles = std::max(nmf_update_wide_scratch_doubles((int) T, (int) F, (int) p.Kp, (int) B),
+                             nmf_update_wide_scratch_doubles((int) F, (int) T, (int) p.Kp, (int) B));
+  }
+  else
+  {
+    const int Kp = (int) p.Kp;
+    p.nsplitW = choose_split4(B, (int) F, (int) T, Kp);
+    p.nsplitH = choose_split4(B, (int) T, (int) F, Kp);
+    // Fast path: W stays un-normalised in memory during the loop (UpdateArgs::nrm), the column statistics
+    // come out of the update kernel's epilogue and the Nyquist bin is a side column when that shortens the
+    // widest strip of the MFMA kernel (fluhip_kernels.h SideColumn).
+    static const int lazyOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_LAZY"); return e ? std::atoi(e) : 0; }();
+    static const int sideOff = [] { const char* e = fluhip::ab_getenv("FLUHIP_NO_SIDE"); return e ? std::atoi(e) : 0; }();
+    p.lazy = !lazyOff;
+    if (p.lazy && !sideOff && p.nsplitW == 1 && nmf_side_column_supported((int) T, (int) F, Kp) &&
+        choose_split4(B, (int) F - 1, (int) T, Kp) == 1)
+    {
+      const int G = ((int) F + 15) / 16, G1 = G - 1;
+      const int w = nmf_update5_strips((int) F, Kp, (int) B);
+      const int w1 = nmf_update5_strips((int) F - 1, Kp, (int) B);
+      // worth it when the widest strip gets shorter, or when the launch needs fewer passes over the 1024 SIMDs
+      const int64_t passes = (B * w + 1023) / 1024, passes1 = (B * w1 + 1023) / 1024;
+      p.sideW = w1 <= w && ((G1 + w1 - 1) / w1 < (G + w - 1) / w || passes1 < passes);
+    }
+    else if (p.lazy && !sideOff && p.nsplitW > 1 && nmf_side_column_supported((int) T, (int) F, Kp))
+    {
+      // Split contraction (few buffers): without the 16 m + 1-th bin the strips deal evenly and the pieces get shorter --
+      // config 3 (2 x 2049 bins, rank 128): 130 strips x 7 pieces of 923 steps (910 wavefronts) -> 128 strips x 8 pieces
+      // of 808 steps (1024 wavefronts).  Taken when the longest piece shrinks.
+      const int s1 = choose_split4(B, (int) F - 1, (int) T, Kp);
+      const int64_t nSteps = (T + 3) / 4;
+      const int64_t w = B * nmf_update5_waves_per_buffer((int) F, Kp, (int) B);
+      const int64_t w1 = B * nmf_update5_waves_per_buffer((int) F - 1, Kp, (int) B);
+      if (s1 > 1 && w1 * s1 <= 1024 && w * p.nsplitW <= 1024 && (nSteps + s1 - 1) / s1 < (nSteps + p.nsplitW - 1) / p.nsplitW)
+      {
+        p.sideW = true;
+        p.nsplitW = s1;
+      }
+    }
+    // A single buffer of rank <= 16 runs the frame-strip schedule while one round of workgroups covers it (at most 6 frame
+    // quads per CU: 71 s at hop 512): two launches per iteration instead of five and V read once.  Longer buffers and
+    // batches stay with the split / batched kernels, which win there (tools/strip_vs_split.py).  FLUHIP_STRIP=0 off,
+    // =1 wherever the kernel supports the shape.
+    static const int stripEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP"); return e ? std::atoi(e) : -1; }();
+    p.strip = p.lazy && stripEnv != 0 && nmf_strip_supported((int) F, (int) T, Kp) &&
+              (stripEnv == 1 || (B == 1 && nmf_strip_workgroups((int) T) <= 512));
+    if (p.strip)
+    {
+      p.sideW = false;
+      p.stripPartDoubles = nmf_strip_part_doubles((int) F, (int) T, (int) B);
+      // FLUHIP_STRIP_BIN=1 (A/B build only): the W update as its own launch over bin strips instead of the fused form (W
+      // partials behind the H phase + the reduce launch).  Built and measured in round 4 (profiles/r04/c2_forms.md): 45.1 us
+      // per iteration against 40.3 at config 2 -- a tenth of the partial bytes, but the last arriver's chain of cross-XCD
+      // round trips (ticket, partials in two rounds, update) costs what the reduce launch cost.  Not adopted.
+      static const int binEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_BIN"); return e ? std::atoi(e) : 0; }();
+      p.stripBin = kAbSwitches && binEnv != 0;
+      // Round 5: the W update as the BIN-TILED launch (kernels_nmf_bintile.hip: four bins and ALL frames per workgroup, no
+      // numerator partials in memory, no reduce launch, no ticket), the strip kernel doing the H update and the Nyquist bin's
+      // partials.  Built to the review's specification, parity-green at full size, and measured at config 2
+      // (profiles/r05/c2_bintile.md): 20.3 us for the launch in three layouts against the review's 13 us kill line.  Not
+      // adopted: A/B build only (the kernel is not part of the production library), FLUHIP_STRIP_TILE=1.
+#ifdef FLUHIP_AB_SWITCHES
+      static const int tileEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_STRIP_TILE"); return e ? std::atoi(e) : 0; }();
+      p.stripTile = !p.stripBin && tileEnv == 1 && nmf_bintile_supported((int) F, (int) T, Kp) &&
+                    nmf_strip_tile_supported((int) F, (int) T, Kp);
+#endif
+    }
+    // Equal-length corpora too small to fill the chip with whole contractions: the work-list form (plan_lists) instead of
+    // the uniform split schedule -- narrow strips, the pieces of a contraction added up inside a workgroup, few or no
+    // partials in memory.  FLUHIP_LIST_PLAN=0 keeps the uniform split schedule, =1 takes the lists whenever something is split.
+    static const int listEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_LIST_PLAN"); return e ? std::atoi(e) : -1; }();
+    const PlanShape ps{B, T, F, Kp};
+    p.useLists = !p.strip && p.lazy && listEnv != 0 && (listEnv == 1 || list_plan_pays(&ps));
+    // Off-size ranks (round 5): a rank between two array ranks keeps the ARRAYS of the padded rank (32 / 64 / 128) -- every
+    // helper kernel runs its form of that rank on zero columns -- and the factor updates compute fewer MFMAs per product
+    // (kernels_nmf5.hip KPM, nmf_update5_compute_rank): 6 of 8 for ranks 17 .. 24; 10 / 12 / 14 of 16 for 33 .. 40 / 48 / 56; 18, 20 .. 28
+    // of 32 for 65 .. 72, .. 80, .. 112.  The plain and the split-contraction schedules and the work lists; the strip schedule
+    // (rank <= 16) has no off-size rank.  FLUHIP_OFFSIZE=0 (A/B build): the padded forms, for the comparison.
+    p.Kc = (offsize_enabled() && p.lazy && !p.strip) ? nmf_update5_compute_rank((int) K, Kp) : Kp;
+    if (p.useLists)
+    {
+      // the lists themselves are built (and checked descriptor by descriptor: tests/test_list_plan.py) by build_list_plan
+      ListPlanHost lp;
+      build_list_plan(std::vector<int>((size_t) B, (int) T), (int) T, (int) F, Kp, lp);
+      p.sideW = lp.sideW;
+      p.stripsW = lp.W.statParts;
+      p.nsplitW = lp.W.pieces;
+      p.nsplitH = lp.H.pieces;
+      const int64_t nPart = std::max(lp.W.nPartials, lp.H.nPartials);
+      p.partDoubles = nPart * std::max(Fp, Tp) * Kp;
+      p.dpartDoubles = std::max<int64_t>(32, std::max<int64_t>(nPart, B) * Kp);
+      p.wscratchDoubles = wnorm_scratch_doubles(Kp, (int) B, p.stripsW);
+      return;
+    }
+    // statistics partials of the W update: one per wavefront of a buffer, or one per 64-row chunk from the
+    // finalize kernel when the contraction is split
+    p.stripsW = p.nsplitW > 1 ? update_finalize_parts((int) F - (p.sideW ? 1 : 0), Kp)
+                              : nmf_update5_strips((int) F - (p.sideW ? 1 : 0), Kp, (int) B);
+    if (!p.strip && p.lazy && p.nsplitH == 1)
+    {
+      int wA = 0;
+      const int sp = plan_tail(B, (int) T, (int) F, Kp, &wA);
+      if (sp > 1)
+      {
+        const int G = ((int) T + 15) / 16, w = nmf_update5_strips((int) T, Kp, (int) B);
+        p.tailSplitH = sp;
+        p.tailStripsH = wA;
+        p.tailRestH = w - wA;
+        p.tailColsH = wA * ((G + w - 1) / w) * 16;
+      }
+    }
+    if (!p.strip) p.stripsH = nmf_update5_strips((int) T, p.Kc, (int) B);
+    // workspaces of the factor updates: split-contraction partials, denominators, column-sum pre-pass
+    const int ns = std::max(std::max(p.nsplitW, p.nsplitH), p.tailSplitH);
+    if (ns > 1 && !p.strip)
+    {
+      // partial numerators [B][pieces][rows][Kp]: the W update's rows are the bins, the H update's the frames (of the tail launch:
+      // the frames behind the whole-contraction ones); the launches set UpdateArgs::Cp to their own row count
+      const int64_t rowsW = p.nsplitW > 1 ? (int64_t) p.nsplitW * Fp : 0;
+      const int64_t rowsH = p.nsplitH > 1 ? (int64_t) p.nsplitH * Tp : 0;
+      const int64_t rowsT = p.tailSplitH > 1 ? (int64_t) p.tailSplitH * round_up(T - p.tailColsH, 32) : 0;
+      p.partDoubles = B * std::max(std::max(rowsW, rowsH), rowsT) * Kp;
+    }
+    // (the tail launch keeps its denominator slots behind the first launch's B x Kp)
+    p.dpartDoubles = std::max<int64_t>(32, B * std::max(ns, 1 + p.tailSplitH) * Kp);
+    if (Kp > 64) p.csumDoubles = colsum_scratch_doubles((int) std::max(T, F), Kp, (int) B);
+    if (p.lazy)
+    {
+      p.wscratchDoubles = wnorm_scratch_doubles(Kp, (int) B, p.stripsW);
+      // column sums of the rows of W' every wavefront of a W update writes (UpdateArgs::colOut; rank 32, the two-launch iteration)
+      if (Kp == 32 && !p.strip && p.stripsW > 0) p.colPartDoubles = B * p.stripsW * Kp;
+    }
+  }
+}
+
+static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c);
+// the plan of the corpus's shape onto the corpus + its workspaces; needs B, T, F, Tp, Fp, K, Kp
+int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c)
+{
+  hipStream_t s = ctx->stream;
+  UpdatePlan p;
+  decide_update_plan(c->B, c->T, c->F, c->K, p);
+  if (p.Kp != c->Kp) return fail(ctx, "internal error: the plan's padded rank is not the corpus's");
+  c->nsplitW = p.nsplitW; c->nsplitH = p.nsplitH;
+  c->lazy = p.lazy; c->sideW = p.sideW;
+  c->strip = p.strip; c->stripBin = p.stripBin; c->stripTile = p.stripTile;
+  c->stripsW = p.stripsW;
+  c->tailSplitH = p.tailSplitH; c->tailStripsH = p.tailStripsH; c->tailRestH = p.tailRestH; c->tailColsH = p.tailColsH;
+  c->Kc = p.Kc;
+  if (p.useLists)
+  {
+    c->tOf.assign((size_t) c->B, (int) c->T);
+    c->useLists = true;
+    return plan_lists(ctx, c);
+  }
+  auto bytes = [](int64_t doubles) { return (size_t) doubles * sizeof(double); };
+  if (p.wideDoubles) HIPCHK(ctx, c->wideScratch.alloc(bytes(p.wideDoubles), false, s));
+  // (stripPart zeroed once: with the Nyquist bin as a side column only 16 values of its partial blocks are ever written, and the
+  //  reduce launch adds the whole blocks before it masks the bins that do not exist)
+  if (p.stripPartDoubles) HIPCHK(ctx, c->stripPart.alloc(bytes(p.stripPartDoubles), true, s));
+#ifdef FLUHIP_AB_SWITCHES
+  if (c->stripBin)
+    HIPCHK(ctx, c->binWork.alloc((size_t) nmf_binstrip_doubles((int) c->F, (int) c->T, (int) c->B) * sizeof(double), true, s));
+  if (c->stripTile)
+    HIPCHK(ctx, c->tileWork.alloc((size_t) nmf_bintile_doubles((int) c->F, (int) c->B, nmf_strip_workgroups((int) c->T)) * sizeof(double), true, s));
+#endif
+  if (p.variant != 0)
+  {
+    if (p.partDoubles) HIPCHK(ctx, c->part.alloc(bytes(p.partDoubles), true, s));
+    HIPCHK(ctx, c->dpart.alloc(bytes(p.dpartDoubles), true, s));
+    if (p.csumDoubles) HIPCHK(ctx, c->csumScratch.alloc(bytes(p.csumDoubles), false, s));
+  }
+  HIPCHK(ctx, c->clk.alloc(8 * sizeof(long long), true, s));
+  if (c->lazy && p.variant != 0)
+  {
+    HIPCHK(ctx, c->wnorm.alloc((size_t) c->B * c->Kp * sizeof(double), false, s));
+    launch_fill_ones(c->wnorm.as<double>(), (int64_t) (c->B * c->Kp), s);
+    HIPCHK(ctx, c->wscratch.alloc(bytes(p.wscratchDoubles), true, s));
+    if (p.colPartDoubles) HIPCHK(ctx, c->colPart.alloc(bytes(p.colPartDoubles), true, s));
+  }
+  return FLUHIP_OK;
 }
 
 static int plan_lists(fluhip_ctx* ctx, fluhip_corpus* c)

@@ -220,6 +220,23 @@ struct ProfScope
 // ---------------------------------------------------------------------------------------
 // corpus
 // ---------------------------------------------------------------------------------------
+// the schedule of the factor updates of a shape as data: api_corpus.hip decide_update_plan (round 6)
+struct UpdatePlan
+{
+  int variant = 5;      // 5: kernels_nmf5.hip (ranks up to 128), 0: the any-rank path
+  int64_t Kp = 0;       // rank the arrays are laid out for
+  int Kc = 0;           // rank the factor updates compute (off-size ranks)
+  int nsplitW = 1, nsplitH = 1;
+  bool lazy = false, sideW = false, strip = false, stripBin = false, stripTile = false, useLists = false;
+  int stripsW = 0;      // statistics records per buffer of a W update (its wavefronts, or the finalize's chunks when split)
+  int stripsH = 0;      // wavefronts per buffer of a uniform H update (0: lists / frame strips / any-rank)
+  int tailSplitH = 0, tailStripsH = 0, tailRestH = 0, tailColsH = 0;
+  // workspaces in doubles: what the launches of this plan index (plan_updates allocates exactly these)
+  int64_t partDoubles = 0, dpartDoubles = 0, csumDoubles = 0, wscratchDoubles = 0, colPartDoubles = 0, stripPartDoubles = 0,
+          wideDoubles = 0;
+};
+void decide_update_plan(int64_t B, int64_t T, int64_t F, int64_t K, UpdatePlan& p);
+
 struct fluhip_corpus
 {
   fluhip_ctx* ctx = nullptr;

@@ -142,6 +142,25 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
                : "s"(ldsAddr), "v"(voff), "s"(sbase)
                : "memory", "m0");
 }
+// The V slab's copies are NON-TEMPORAL (round 6): a launch reads its layout of V once -- 905 MB on the bench shard, 3.5 x the
+// 256 MB Infinity Cache -- and with the default policy that stream displaces the factor matrices (61 MB) every launch re-reads
+// from the launch before: the stationary rows of the prologue, the moving factor's slabs.  `nt` on the slab copies of the loop:
+// bench shard 546.6 -> 534.9 us per iteration alternating on one box, and the part clocks 1.2 % HIGHER (profiles/r06/v_nt.txt).
+// -DFLUHIP_V_NT=0: the default policy.
+#ifndef FLUHIP_V_NT
+#define FLUHIP_V_NT 1
+#endif
+__device__ __forceinline__ void glds16_v(const void* sbase, unsigned voff, unsigned ldsAddr)
+{
+#if FLUHIP_V_NT
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt"
+               :
+               : "s"(ldsAddr), "v"(voff), "s"(sbase)
+               : "memory", "m0");
+#else
+  glds16(sbase, voff, ldsAddr);
+#endif
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p)
 {
   return (unsigned) (size_t) (__attribute__((address_space(3))) const void*) p;
@@ -749,7 +768,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               if (i % DMASTEP == DMASTEP / 2 && i / DMASTEP < IPS)
               {
                 const int j = i / DMASTEP;
-                if (j < NJV) glds16(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
+                if (j < NJV) glds16_v(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
                 else glds16(msrc, moffs[j - NJV], mringA + u * MSTAGE + (j - NJV) * 1024);
                 __builtin_amdgcn_sched_barrier(0);
               }
@@ -935,7 +954,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
               if (i % DMASTEP == DMASTEP / 2 && i / DMASTEP < IPS)
               {
                 const int j = i / DMASTEP;
-                if (j < NJV) glds16(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
+                if (j < NJV) glds16_v(vsrc, voffs[j], vringA + u * VSTAGE + j * 1024);
                 else glds16(msrc, moffs[j - NJV], mringA + u * MSTAGE + (j - NJV) * 1024);
                 __builtin_amdgcn_sched_barrier(0);
               }
