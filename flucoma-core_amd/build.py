@@ -36,6 +36,9 @@ VARIANTS = {
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 SOURCES = ["kernels_stft.hip", "kernels_stft2.hip", "kernels_nmf.hip", "kernels_nmf5.hip", "kernels_nmf5_off.hip", "kernels_nmf_strip.hip", "kernels_nmf_bintile.hip", "kernels_nmf_wide.hip", "kernels_istft.hip", "kernels_feat.hip", "kernels_svd.hip", "api_core.hip", "api_corpus.hip", "api_algorithms.hip", "api_features.hip", "api_frames.hip", "api_pool.cpp"]
+# kernel forms no production shape reaches are not part of the production library (kernels_nmf_bintile.hip was 415
+# lines of dead weight in lib/libflucoma_hip.so): compiled into the measurement builds only
+AB_ONLY = {"kernels_nmf_bintile.hip"}
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-result"]
 
 
@@ -88,7 +91,10 @@ def _build_variant(variant: str, lib: str, force: bool = False) -> str:
     objdir = VARIANTS[variant][0]
     os.makedirs(objdir, exist_ok=True)
     os.makedirs(os.path.dirname(lib), exist_ok=True)
-    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    root = variant
+    while VARIANTS[root][3] is not None:
+        root = VARIANTS[root][3]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s)) and not (root == "default" and s in AB_ONLY)]
     if force:
         for s in srcs:
             o = os.path.join(objdir, os.path.splitext(s)[0] + ".o")

@@ -1921,6 +1921,63 @@ int fluhip_debug_plan_tail(int64_t count, int64_t frames, int64_t bins, int64_t 
   return FLUHIP_OK;
 }
 
+// The whole plan of a shape without a device (decide_update_plan), for tests/test_plan_table.py and tools: out32 =
+//  0 variant   1 nsplitW   2 nsplitH   3 lazy   4 sideW   5 stripsW   6 Kp   7 Kc   8 strip (0 no, 1 fused, 2 bin strips, 3 bin tiles)
+//  9 work lists   10 tailSplitH   11 tailStripsH   12 tailRestH   13 tailColsH   14 stripsH
+//  15 .. 21 workspaces in doubles: part, dpart, csum, wscratch, colPart, stripPart, wide
+//  22 what the plain H update takes over (bit 0 side partials, bit 1 norm combine, bit 2 column sums from the W update; 0 when
+//     the schedule has no such launch)   23 form of the norm-combine launch between the updates in the steady state (WnormForm;
+//     -1: none, the H update does it)   24 slices of the side-column launch (0: no side column)
+//  25 kSideFromHSlots   26 the first word of wscratch behind the statistics records (B stripsW 2 Kp)
+int fluhip_debug_plan_shape(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out32)
+{
+  if (count < 1 || frames < 1 || bins < 1 || K < 1 || !out32) return FLUHIP_ERROR;
+  UpdatePlan p;
+  decide_update_plan(count, frames, bins, K, p);
+  std::memset(out32, 0, 32 * sizeof(int64_t));
+  out32[0] = p.variant; out32[1] = p.nsplitW; out32[2] = p.nsplitH; out32[3] = p.lazy; out32[4] = p.sideW; out32[5] = p.stripsW;
+  out32[6] = p.Kp; out32[7] = p.Kc; out32[8] = p.strip ? (p.stripTile ? 3 : (p.stripBin ? 2 : 1)) : 0; out32[9] = p.useLists;
+  out32[10] = p.tailSplitH; out32[11] = p.tailStripsH; out32[12] = p.tailRestH; out32[13] = p.tailColsH; out32[14] = p.stripsH;
+  out32[15] = p.partDoubles; out32[16] = p.dpartDoubles; out32[17] = p.csumDoubles; out32[18] = p.wscratchDoubles;
+  out32[19] = p.colPartDoubles; out32[20] = p.stripPartDoubles; out32[21] = p.wideDoubles;
+  out32[23] = -1;
+  out32[25] = kSideFromHSlots;
+  out32[26] = count * p.stripsW * 2 * p.Kp;
+  if (p.variant == 5 && p.lazy && !p.strip)
+  {
+    const int Kp = (int) p.Kp;
+    int takes = 0;
+    if (!p.useLists && p.sideW && p.nsplitH == 1 && p.tailSplitH <= 1)
+    {
+      // the launcher's own answer (nothing is launched, no device is touched: UpdateArgs::dryRun), asked as the iteration loop asks
+      double dummy = 0.0;
+      UpdateArgs a;
+      a.R = (int) bins; a.C = (int) frames; a.B = (int) count; a.Kp = Kp; a.Kc = p.Kc;
+      a.nsplit = 1;
+      a.nrm = &dummy; a.nrmMode = 2;
+      a.sideOut = &dummy; a.sideWold = &dummy;
+      if (p.stripsW <= 16 && p.stripsH <= 16)
+      {
+        a.cmbStat = &dummy; a.cmbSide = &dummy; a.cmbWold = &dummy; a.cmbNrmOut = &dummy; a.cmbRowOut = &dummy;
+        if (p.colPartDoubles) { a.colIn = &dummy; a.colInN = p.stripsW; }
+      }
+      a.dryRun = true;
+      takes = launch_nmf_update5(a, nullptr);
+    }
+    out32[22] = takes;
+    const int nsl = p.sideW ? wnorm_side_slices((int) frames, Kp) : 0;
+    out32[24] = (takes & 1) ? 0 : nsl;
+    if (!(takes & 2))
+      out32[23] = (int) wnorm_combine_form(Kp, (int) count, p.stripsW, (takes & 1) ? p.stripsH : nsl, (int) frames, (takes & 1) ? 2 : 0, false);
+  }
+  return FLUHIP_OK;
+}
+
+int fluhip_debug_wnorm_form(int Kp, int count, int parts, int slices, int side_rows, int side_phase, int want_colsum)
+{
+  return (int) wnorm_combine_form(Kp, count, parts, slices, side_rows, side_phase, want_colsum != 0);
+}
+
 int fluhip_corpus_plan(const fluhip_corpus* c, int64_t* out8)
 {
   if (!c || !out8) return FLUHIP_ERROR;

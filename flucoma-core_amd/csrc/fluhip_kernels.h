@@ -243,6 +243,9 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
 // one generation in its prologue while its own epilogues fill the other.
 constexpr int kSideFromHSlots = 64; // slices of side-column partials per buffer and generation (H update's SIDEQ epilogue: one per strip)
 double* wnorm_side_part(double* scratch, int Kp, int B, int nStrips, int gen);
+// the form the norm combine takes for a shape (kernels_nmf.hip kWnormForms: the one table of its thresholds)
+enum class WnormForm : int { SideNormOneLaunch = 0, SideOnly = 1, PreReduce = 2, Combine1024 = 3, Combine256 = 4 };
+WnormForm wnorm_combine_form(int Kp, int B, int nStrips, int nsl, int sideR, int sidePhase, bool wantCol);
 double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen);
 // S = S / nrm in memory, nrm = 1
 void launch_wnorm_apply(double* S, int64_t strideS, int C, int Kp, int B, double* nrm, hipStream_t s);

@@ -1103,8 +1103,52 @@ double* wnorm_side_wold(double* scratch, int Kp, int B, int nStrips, int gen)
   return wnorm_side_part(scratch, Kp, B, nStrips, gen) + (int64_t) B * kSideFromHSlots * 2 * Kp;
 }
 
-// corpora: enough buffers to occupy the part, few enough rows that one workgroup walks them in a few passes, few statistics parts
-bool wnorm_side_norm_shape(int B, int nStrips, int R, int Kp) { return B >= 64 && nStrips <= 64 && (int64_t) R * Kp <= (int64_t) 64 * 2048; }
+// ---- which form the norm combine of a W update takes: ONE table (round 6) -------------------------------
+// Every number the choice depends on, with where it was measured.  wnorm_combine_form() is the only reader; the launcher below
+// and the planner's report (fluhip_debug_wnorm_form, tests/test_plan_table.py) both go through it.
+struct WnormFormTable
+{
+  // side column + combine as ONE launch, one workgroup per buffer (side_norm_kernel): enough buffers to occupy the part, few
+  // enough rows that a workgroup walks them in a few passes, few statistics parts (round 2: the bench shard's form before the H
+  // update took both over)
+  int sideNormMinBuffers = 64, sideNormMaxParts = 64;
+  int64_t sideNormMaxRowDoubles = (int64_t) 64 * 2048;
+  // one workgroup per buffer walks the records with 1024 threads instead of 256 from here on (config 3: 512 parts + 256
+  // slices at rank 128 took 38 us with two part groups)
+  int manyParts = 128, manySlices = 64;
+  // sixteen workgroups per buffer pre-reduce the records (wnorm_prereduce_kernel) where they are long AND many: from ~320 KB of
+  // records per buffer (round 5, config 3: 25.8 -> 6 + 9 us); where they are few kilobytes -- one 10 s buffer at rank 32: 129
+  // records of 512 B -- the one-workgroup combine is the shorter chain (9.0 us for the two launches against ~6)
+  int64_t bigRecordDoubles = 40000;
+  // ... or wherever the H update behind would otherwise run its column-sum pre-pass (windows of a rank-128 corpus: colsum_part +
+  // colsum_combine 14 us against ~6 for the pre-reduction)
+  bool preForColumnSums = true;
+  int maxPreRank = 512;
+};
+constexpr WnormFormTable kWnormForms{};
+
+bool wnorm_side_norm_shape(int B, int nStrips, int R, int Kp)
+{
+  return B >= kWnormForms.sideNormMinBuffers && nStrips <= kWnormForms.sideNormMaxParts &&
+         (int64_t) R * Kp <= kWnormForms.sideNormMaxRowDoubles;
+}
+// sidePhase as in launch_wnorm_combine; nsl = the side column's slices (0: none); wantCol = the caller gave column-sum slots
+WnormForm wnorm_combine_form(int Kp, int B, int nStrips, int nsl, int sideR, int sidePhase, bool wantCol)
+{
+  static const bool oneLaunch = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_NORM"); return e ? std::atoi(e) != 0 : true; }();
+  // FLUHIP_WNORM_PRE=0 (A/B build): the one-workgroup combine of rounds 3 - 4 for long factors; =2: the pre-reduction only where
+  // the records are long, as in its first form
+  static const int preEnv = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) : 1; }();
+  if (nsl > 0 && sidePhase == 0 && oneLaunch && wnorm_side_norm_shape(B, nStrips, sideR, Kp)) return WnormForm::SideNormOneLaunch;
+  if (sidePhase == 1) return WnormForm::SideOnly;
+  const bool many = nStrips > kWnormForms.manyParts || nsl > kWnormForms.manySlices;
+  const bool bigRecords = (int64_t) (nStrips + nsl) * Kp > kWnormForms.bigRecordDoubles;
+  const bool preAlways = kWnormForms.preForColumnSums && preEnv != 2;
+  if (preEnv != 0 && Kp <= kWnormForms.maxPreRank && ((many && (bigRecords || wantCol)) || (wantCol && preAlways)))
+    return WnormForm::PreReduce;
+  return many ? WnormForm::Combine1024 : WnormForm::Combine256;
+}
+
 bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int B, int nStrips, double* scratch,
                           double* nrm, const SideColumn* side, hipStream_t s, int sidePhase, int sideSlices, int sideGen,
                           const WnormColsum* colsum)
@@ -1122,10 +1166,10 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     wold = wnorm_side_wold(scratch, Kp, B, nStrips, sideGen);
   }
   int nsl = side ? (sideSlices > 0 ? sideSlices : side_slices_for(side->R, Kp)) : 0;
-  // corpora: one launch, one workgroup per buffer (side_norm_kernel) -- enough buffers to occupy the part, few enough rows
-  // that a workgroup walks them in a few passes, few statistics parts.  FLUHIP_SIDE_NORM=0 (A/B build): the two launches.
-  static const bool oneLaunch = [] { const char* e = fluhip::ab_getenv("FLUHIP_SIDE_NORM"); return e ? std::atoi(e) != 0 : true; }();
-  if (side && sidePhase == 0 && oneLaunch && wnorm_side_norm_shape(B, nStrips, side->R, Kp))
+  const bool wantCol = colsum && colsum->out1;
+  const WnormForm form = wnorm_combine_form(Kp, B, nStrips, nsl, side ? side->R : 0, sidePhase, wantCol);
+  // corpora: one launch, one workgroup per buffer (side_norm_kernel).  FLUHIP_SIDE_NORM=0 (A/B build): the two launches.
+  if (form == WnormForm::SideNormOneLaunch)
   {
     const dim3 grid((unsigned) B), block(1024);
     if (Kp == 16) hipLaunchKernelGGL(side_norm_kernel<16>, grid, block, 0, s, S, strideS, C, K, *side, statPart, nStrips, nrm);
@@ -1163,20 +1207,9 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
     if (fused) return false;
   }
   if (sidePhase == 1) return false;
-  // one block per buffer sums nStrips statistics parts and nsl side slices per component: 1024 threads where that is long
-  // (config 3: 512 parts + 256 slices at rank 128 took 38 us with two part groups)
-  // FLUHIP_WNORM_PRE=0 (A/B build): the one-workgroup combine of rounds 3 - 4 for long factors
-  static const bool pre = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) != 0 : true; }();
-  // (where the records are few kilobytes each -- one 10 s buffer at rank 32: 129 records of 512 B -- the one-workgroup combine is
-  //  the shorter chain: 9.0 us for the two launches against ~6 measured on BASELINE config 4's single buffer; the pre-reduction
-  //  pays from a few hundred kilobytes of records per buffer, or where it also takes the column sums of W' for the H update)
-  const bool bigRecords = (int64_t) (nStrips + nsl) * Kp > 40000;
-  // (the column sums of W' alone are worth the extra launch where the H update would otherwise run its pre-pass: windows of a
-  //  rank-128 corpus, 16 buffers each -- colsum_part + colsum_combine 14 us against ~6 for the pre-reduction; FLUHIP_WNORM_PRE=2
-  //  (A/B build): only where the records are long, as in the first form)
-  static const bool preAlways = [] { const char* e = fluhip::ab_getenv("FLUHIP_WNORM_PRE"); return e ? std::atoi(e) != 2 : true; }();
-  const bool wantCol = colsum && colsum->out1;
-  if (pre && Kp <= 512 && (((nStrips > 128 || nsl > 64) && (bigRecords || wantCol)) || (wantCol && preAlways)))
+  // one block per buffer sums nStrips statistics parts and nsl side slices per component (1024 threads where that is long), or
+  // sixteen workgroups per buffer pre-reduce them first: kWnormForms
+  if (form == WnormForm::PreReduce)
   {
     double* statOut = scratch + wnorm_scratch_base_doubles(Kp, B, nStrips);
     double* sideOut = statOut + (int64_t) B * kPreGroups * 2 * Kp;
@@ -1194,7 +1227,7 @@ bool launch_wnorm_combine(double* S, int64_t strideS, int C, int K, int Kp, int 
                        kPreGroups, side ? sideOut : nullptr, side ? kPreGroups : 0, wold, nrm, cs);
     return cs.part != nullptr;
   }
-  else if (nStrips > 128 || nsl > 64)
+  else if (form == WnormForm::Combine1024)
     hipLaunchKernelGGL(wnorm_combine_kernel<1024>, dim3((unsigned) B), dim3(1024), 0, s, S, strideS, C, K, Kp, statPart,
                        nStrips, side ? sidePart : nullptr, nsl, wold, nrm, ColsumOut{});
   else

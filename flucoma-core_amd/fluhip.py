@@ -63,7 +63,7 @@ EXPORTS = [
     "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
     "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
     "fluhip_corpus_resynth_host", "fluhip_corpus_resynth_interleaved_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
-    "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_corpus_last_loop_ms", "fluhip_last_error_is_out_of_memory", "fluhip_clear_error", "fluhip_debug_plan_lists", "fluhip_debug_plan_tail", "fluhip_debug_plan_kind", "fluhip_debug_plan_h_update",
+    "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_corpus_last_loop_ms", "fluhip_last_error_is_out_of_memory", "fluhip_clear_error", "fluhip_debug_plan_lists", "fluhip_debug_plan_tail", "fluhip_debug_plan_kind", "fluhip_debug_plan_h_update", "fluhip_debug_plan_shape", "fluhip_debug_wnorm_form",
     "fluhip_pool_create", "fluhip_pool_destroy", "fluhip_pool_size", "fluhip_pool_device", "fluhip_pool_last_error",
     "fluhip_pool_bufnmf_f32", "fluhip_pool_bufnmf_job_f32", "fluhip_pool_bufnmf_ragged_f32", "fluhip_pool_bufmfcc_f32",
     "fluhip_pool_bufmelbands_f32", "fluhip_shard_range", "fluhip_balanced_assignment", "fluhip_nmfmatch_f32", "fluhip_nmffilter_f32",
@@ -155,6 +155,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
     L.fluhip_corpus_debug_words.argtypes = [_vp, _ip]
     L.fluhip_corpus_update_clocks.argtypes = [_vp, _ip, ctypes.c_int]
+    L.fluhip_debug_plan_shape.argtypes = [_i64, _i64, _i64, _i64, _ip]
+    L.fluhip_debug_wnorm_form.argtypes = [ctypes.c_int] * 7
     L.fluhip_corpus_last_loop_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]
     L.fluhip_debug_plan_lists.argtypes = [_i64, _ip, _i64, _i64, ctypes.c_int, ctypes.POINTER(ctypes.c_int32), _i64,
                                           ctypes.POINTER(ctypes.c_int32)]

@@ -365,6 +365,24 @@ int fluhip_debug_plan_kind(int64_t count, int64_t frames, int64_t bins, int64_t 
  * comes out of this launch's epilogue, bit 1 = the norm combine of the W update in front is done in its prologue; 0 = neither
  * (rank above 64, work lists, two-launch H update, no side column at this bin count); -1: bad arguments. */
 int fluhip_debug_plan_h_update(int64_t count, int64_t frames, int64_t bins, int64_t K);
+/* The WHOLE schedule of an equal-length corpus of that shape as data, without a device (api_corpus.hip decide_update_plan: the
+ * one function fluhip_corpus_create plans from).  out32 =
+ *   0 kernel family (5 / 0)   1 pieces of the W update's contraction   2 of the H update's   3 deferred normalisation
+ *   4 Nyquist bin as a side column   5 statistics records per buffer of a W update   6 padded rank   7 computed rank
+ *   8 frame-strip schedule (0 no, 1 fused, 2 / 3 the A/B forms)   9 work lists   10 pieces of the tail launch of a two-launch H
+ *   update (0: one launch)   11 strips of its first launch   12 of its tail launch   13 frames in the first launch
+ *   14 wavefronts per buffer of a uniform H update
+ *   15 .. 21 workspaces in doubles, as allocated: split partials, denominators, column-sum pre-pass, norm / side-column scratch,
+ *            column partials of the W update, frame-strip partials, any-rank scratch
+ *   22 what the H update takes over in the steady state (bit 0 side column, bit 1 norm combine, bit 2 column sums from the W update)
+ *   23 form of the norm-combine launch between the updates (fluhip_debug_wnorm_form's codes; -1: no such launch)
+ *   24 slices of the side-column launch (0: none)   25 side-partial slots per buffer and generation   26 doubles of wscratch the
+ *      statistics records occupy.
+ * tests/test_plan_table.py holds this to its invariants over a grid of shapes and to the pinned plans of the BASELINE shapes. */
+int fluhip_debug_plan_shape(int64_t count, int64_t frames, int64_t bins, int64_t K, int64_t* out32);
+/* the form the norm combine of a W update takes (kernels_nmf.hip kWnormForms, the one table of its thresholds): 0 side column +
+ * combine in one launch, 1 side-column launch only, 2 pre-reduction + combine, 3 one workgroup of 1024 threads, 4 of 256 */
+int fluhip_debug_wnorm_form(int Kp, int count, int parts, int slices, int side_rows, int side_phase, int want_colsum);
 
 /* ---- device pool: one host process, several GPUs ------------------------------------------------------------ */
 /* The reference runs one std::thread per job (clients/common/FluidNRTClientWrapper.hpp:1042-1048) and the buffers of
