@@ -22,6 +22,7 @@ static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int
   c.ctx = ctx; c.B = 1; c.n = n; c.win = win; c.fft = fft; c.hop = hop; c.K = 1;
   c.windowType = window_type;
   c.keepSpec = spec != nullptr;
+  c.stftOnly = true;   // STFT::process + magnitude: the frame-major magnitudes (and the spectrum), nothing for factor updates
   rc = corpus_alloc(ctx, &c);
   if (rc) return rc;
   // strided host view -> contiguous device copy (clients/nrt/NMFClient.hpp:240 `tmp <<= samps(...)`)
@@ -30,7 +31,7 @@ static int stft_common(fluhip_ctx* ctx, const float* a32, const double* a64, int
   HIPCHK(ctx, in.alloc((size_t) n * esz, false, ctx->stream));
   HIPCHK(ctx, upload_strided(in.p, a32 ? (const void*) a32 : (const void*) a64, (size_t) n, (size_t) stride, esz,
                              ctx->stream));
-  rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n);
+  rc = corpus_stft(&c, a32 ? in.as<float>() : nullptr, a32 ? nullptr : in.as<double>(), n, true);
   if (rc) return rc;
   if (frames_out) *frames_out = c.T;
   // (long buffers: through the pinned staging blocks -- a minute of audio at fft 2048 is 42 + 85 MB)

@@ -679,6 +679,9 @@ int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c)
   c->Kp = padded_rank(c->K);
   const size_t B = (size_t) c->B;
   HIPCHK(ctx, c->mag.alloc(B * c->Tp * c->Fp * sizeof(double), true, s));
+  // (a corpus that only ever transforms -- algorithm::STFT::process / magnitude at the algorithm level, fluhip_stft_* -- has one
+  //  layout of the magnitudes and no factor workspaces: the bin-major copy exists for the H update alone)
+  if (c->stftOnly) return FLUHIP_OK;
   HIPCHK(ctx, c->magT.alloc(B * c->Fp * c->Tp * sizeof(double), true, s));
   HIPCHK(ctx, c->Wf.alloc(B * c->Fp * c->Kp * sizeof(double), true, s));
   HIPCHK(ctx, c->H1.alloc(B * c->Tp * c->Kp * sizeof(double), true, s));
@@ -720,8 +723,10 @@ int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t ho
   return check_rank(ctx, (n + hop) / hop, fft / 2 + 1, K);
 }
 
-int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride)
+int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride, bool magOnly)
 {
+  // magOnly: the frame-major magnitudes alone (what STFT::process + STFT::magnitude compute, alg/STFT.hpp:90-108, 61-66);
+  // the bin-major copy is written for the factor updates only -- half the kernel's store traffic
   fluhip_ctx* ctx = c->ctx;
   const double *wtab = nullptr, *ttab = nullptr;
   int rc = get_window(ctx, c->win, c->fft, c->windowType, &wtab);
@@ -747,18 +752,18 @@ int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t a
   {
     ProfScope p(ctx, 0);
     if (!stft_needs_scratch(c->win, c->fft))
-      both = launch_stft_block(a, c->magT.as<double>(), c->Fp * c->Tp, c->Tp, ctx->stream);
+      both = launch_stft_block(a, magOnly ? nullptr : c->magT.as<double>(), c->Fp * c->Tp, c->Tp, ctx->stream);
     if (!both && c->ragged) return fail(ctx, "ragged corpora need an STFT shape with a block form (fft 1024 / 2048 / 4096, even window)");
     if (!both) launch_stft(a, ctx->stream);
   }
-  if (!both)
+  if (!both && !magOnly)
   {
     ProfScope p(ctx, 4);
     launch_transpose(c->mag.as<double>(), c->Fp, c->Tp * c->Fp, c->magT.as<double>(), c->Tp,
                      c->Fp * c->Tp, (int) c->T, (int) c->F, (int) c->B, ctx->stream);
   }
   HIPCHK(ctx, hipGetLastError());
-  c->haveMag = true;
+  c->haveMag = !magOnly;   // (the factor updates need both layouts)
   c->touched = true;
   return FLUHIP_OK;
 }
@@ -1585,6 +1590,18 @@ int fluhip_corpus_set_audio_dev(fluhip_corpus* c, const float* audio_dev)
   if (!c || !audio_dev) return FLUHIP_ERROR;
   c->audioDev = audio_dev;
   return FLUHIP_OK;
+}
+
+// the STFT phase with the frame-major magnitudes alone (every buffer's STFT::process + magnitude, nothing for the factor
+// updates): what a spectrogram-only caller -- BufSTFT, the algorithm-level fluhip_stft_* -- pays per frame.  The corpus has no
+// spectrogram for fluhip_corpus_nmf afterwards until fluhip_corpus_stft runs again.
+int fluhip_corpus_stft_mag_only(fluhip_corpus* c)
+{
+  if (!c) return FLUHIP_ERROR;
+  fluhip_ctx* ctx = c->ctx;
+  if (!c->audioDev) return fail(ctx, "corpus has no audio: call fluhip_corpus_set_audio_* first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return corpus_stft(c, c->audioDev, nullptr, c->n, true);
 }
 
 static int fluhip_corpus_stft_impl(fluhip_corpus* c)

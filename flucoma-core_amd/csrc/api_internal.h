@@ -244,6 +244,7 @@ struct fluhip_corpus
   int64_t T = 0, F = 0, Tp = 0, Fp = 0, Kp = 0;
   int windowType = FLUHIP_WINDOW_HANN;
   bool keepSpec = false;
+  bool stftOnly = false; // spectrogram-only use (fluhip_stft_*): one layout of the magnitudes, no factor workspaces
   const float* audioDev = nullptr; // borrowed or owned (audioOwn)
   DevBuf audioOwn, mag, magT, Wf, H1, spec, part, dpart, stage, hmax, normScratch;
   int nsplitW = 1, nsplitH = 1;
@@ -331,7 +332,7 @@ int plan_updates(fluhip_ctx* ctx, fluhip_corpus* c);
 int corpus_alloc(fluhip_ctx* ctx, fluhip_corpus* c);
 int check_rank(fluhip_ctx* ctx, int64_t T, int64_t F, int64_t K);
 int check_shape(fluhip_ctx* ctx, int64_t n, int64_t win, int64_t fft, int64_t hop, int64_t K);
-int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride);
+int corpus_stft(fluhip_corpus* c, const float* a32, const double* a64, int64_t audioStride, bool magOnly = false);
 void draw_uniform(int64_t seed, size_t count, std::vector<double>& out);
 int corpus_init_factors(fluhip_corpus* c, int64_t seed, const int64_t* seeds, const FactorInit& fi);
 int corpus_iterate(fluhip_corpus* c, int64_t iters, bool updateW, bool updateH, fluhip_progress_fn progress, void* user);

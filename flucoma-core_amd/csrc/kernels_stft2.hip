@@ -69,6 +69,21 @@ struct StftBArgs
 };
 
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// The magnitudes leave once and are not read again before the whole corpus's transform is done (the factor updates stream them
+// back much later, 1.9 GB on the bench shard): the two layouts' stores are NON-TEMPORAL (round 6) -- bench shard's STFT phase
+// 0.560 - 0.586 -> 0.487 - 0.499 ms per launch with both layouts, 0.475 - 0.484 -> 0.444 - 0.451 with the frame-major one alone,
+// alternating on one box (profiles/r06/stft_nt.txt).  -DFLUHIP_STFT_NT=0: plain stores.
+#ifndef FLUHIP_STFT_NT
+#define FLUHIP_STFT_NT 1
+#endif
+__device__ __forceinline__ void store_mag16(double* p, double __attribute__((ext_vector_type(2))) v)
+{
+#if FLUHIP_STFT_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<double __attribute__((ext_vector_type(2)))*>(p));
+#else
+  *reinterpret_cast<double __attribute__((ext_vector_type(2)))*>(p) = v;
+#endif
+}
 // -DFLUHIP_SPLIT_VIA_LDS=0: the ds_bpermute partner exchange of rounds 1 - 4 (FftCore::split)
 #ifndef FLUHIP_SPLIT_VIA_LDS
 #define FLUHIP_SPLIT_VIA_LDS 1
@@ -889,7 +904,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
         for (int q = 0; q < N / 128; q++)
         {
           const int k = 2 * (lane + 64 * q);
-          *reinterpret_cast<d2*>(magRow + k) = *reinterpret_cast<const d2*>(xs + k);
+          store_mag16(magRow + k, *reinterpret_cast<const d2*>(xs + k));
         }
         if (lane == 0) magRow[N] = xs[N];
       }
@@ -910,7 +925,7 @@ __global__ __launch_bounds__(64 * NW) void stft_block_kernel(StftBArgs a)
         if (i < ITEMS && tc < a.ldMagT)
         {
           const double v0 = xcur[(2 * p) * BUFD + f], v1 = xcur[(2 * p + 1) * BUFD + f];
-          *reinterpret_cast<d2*>(outT + (int64_t) f * a.ldMagT + tc) = d2{v0, v1};
+          store_mag16(outT + (int64_t) f * a.ldMagT + tc, d2{v0, v1});
         }
       }
       if constexpr (!DB) LDS_BARRIER();

@@ -60,7 +60,7 @@ EXPORTS = [
     "fluhip_corpus_writeback_ragged_host", "fluhip_corpus_resynth_ragged_host",
     "fluhip_corpus_destroy", "fluhip_corpus_frames", "fluhip_corpus_bins",
     "fluhip_corpus_device_bytes", "fluhip_corpus_set_audio_host", "fluhip_corpus_set_audio_dev",
-    "fluhip_corpus_stft", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
+    "fluhip_corpus_stft", "fluhip_corpus_stft_mag_only", "fluhip_corpus_nmf", "fluhip_corpus_set_factors", "fluhip_corpus_writeback_dev",
     "fluhip_corpus_writeback_host", "fluhip_corpus_keep_spectrum", "fluhip_corpus_resynth_dev",
     "fluhip_corpus_resynth_host", "fluhip_corpus_resynth_interleaved_host", "fluhip_corpus_read_f64", "fluhip_corpus_plan", "fluhip_prof_enable",
     "fluhip_prof_reset", "fluhip_prof_read", "fluhip_corpus_debug_words", "fluhip_corpus_update_clocks", "fluhip_corpus_last_loop_ms", "fluhip_last_error_is_out_of_memory", "fluhip_clear_error", "fluhip_debug_plan_lists", "fluhip_debug_plan_tail", "fluhip_debug_plan_kind", "fluhip_debug_plan_h_update", "fluhip_debug_plan_shape", "fluhip_debug_wnorm_form",
@@ -140,6 +140,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_corpus_set_audio_host.argtypes = [_vp, _fp]
     L.fluhip_corpus_set_audio_dev.argtypes = [_vp, _vp]
     L.fluhip_corpus_stft.argtypes = [_vp]
+    L.fluhip_corpus_stft_mag_only.argtypes = [_vp]
     L.fluhip_corpus_nmf.argtypes = [_vp, _i64, ctypes.c_int, ctypes.c_int, _i64, _ip, PROGRESS_FN, _vp]
     L.fluhip_corpus_set_factors.argtypes = [_vp, _fp, _fp]
     L.fluhip_corpus_writeback_dev.argtypes = [_vp, _vp, _vp]
@@ -503,6 +504,10 @@ class Corpus:
 
     def stft(self):
         self.ctx._check(self.ctx.lib.fluhip_corpus_stft(self.h))
+
+    def stft_mag_only(self):
+        """the frame-major magnitudes alone (what a spectrogram-only caller runs); nmf() then needs stft() again"""
+        self.ctx._check(self.ctx.lib.fluhip_corpus_stft_mag_only(self.h))
 
     def nmf(self, iters, seed=42, updateW=True, updateH=True, seeds=None, progress=None):
         sarr = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.int64)

@@ -282,6 +282,10 @@ int fluhip_corpus_set_audio_host(fluhip_corpus* c, const float* audio);
 int fluhip_corpus_set_audio_dev(fluhip_corpus* c, const float* audio_dev);
 /* K1: batched window + real FFT + magnitude for every frame of every buffer */
 int fluhip_corpus_stft(fluhip_corpus* c);
+/* The same transform with the frame-major magnitudes ALONE -- STFT::process + STFT::magnitude of every buffer (alg/STFT.hpp:
+ * 90-108, 61-66), no bin-major copy for the H update: what the spectrogram-only callers (fluhip_stft_*, BufSTFT) run, as a
+ * corpus-sized batch.  fluhip_corpus_nmf then needs fluhip_corpus_stft again. */
+int fluhip_corpus_stft_mag_only(fluhip_corpus* c);
 /* NMF on every buffer; seeds: `count` seeds or NULL (then `seed` for all, like one ParameterSet
  * shared by all jobs).  Asynchronous on the context stream unless a progress callback is
  * given (progress is then reported per iteration across the whole batch). */

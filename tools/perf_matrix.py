@@ -163,9 +163,12 @@ def stft_row(ctx, tm, reps):
     ms = stats([tm.time(cor.stft) for _ in range(reps)])
     T, F = cor.T, cor.F
     nbytes = (hop * 4.0 + F * 8.0) * T * B
+    cor.stft_mag_only(); ctx.synchronize()
+    ms1 = stats([tm.time(cor.stft_mag_only) for _ in range(reps)])
     cor.close()
     return {"unit": "ms per STFT phase of the bench shard, device-timed", "ms": ms, "frames_per_s": B * T / (ms["min"] * 1e-3),
-            "frac_hbm_algorithmic": nbytes / (ms["min"] * 1e-3) / 8e12}
+            "frac_hbm_algorithmic": nbytes / (ms["min"] * 1e-3) / 8e12,
+            "single_layout": {"ms": ms1, "frames_per_s": B * T / (ms1["min"] * 1e-3), "frac_hbm": nbytes / (ms1["min"] * 1e-3) / 8e12}}
 
 
 def client_row(driver, reps, tmp):
@@ -243,7 +246,7 @@ def main():
         r["wall_s"] = time.perf_counter() - t0
         r["prev"] = PREV.get(n)
         rows[n] = r
-        print(n, json.dumps({k: v for k, v in r.items() if k in ("us", "ms", "error", "ratio_to_equal_length_twin", "sustained_mhz")}),
+        print(n, json.dumps({k: v for k, v in r.items() if k in ("us", "ms", "error", "ratio_to_equal_length_twin", "sustained_mhz", "single_layout", "batched", "sequential")}),
               file=sys.stderr, flush=True)
 
     put("bench_shard_128x10s_k32", lambda: corpus_row(ctx, 128, 10, 32, 200 // q, R))
