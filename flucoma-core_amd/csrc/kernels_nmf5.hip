@@ -1339,6 +1339,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       {
         const int col = (g0 + g) * 16 + 4 * blk + y;
         double* pp = part + (int64_t) col * KPM + M * x;
+        // (plain stores: the finalize launch behind reads the partials back from the L2.  Round 6 tried them write-through like
+        //  the results, on the theory that the finalize's 14.6 us "floor" at config 3 was the end-of-kernel write-back of 34 MB of
+        //  dirty lines -- measured the other way: a 10 s buffer at rank 128 100.8 -> 113.0 us per iteration, config 3 1 844 ->
+        //  1 860, profiles/r06/partials_write_through.txt)
 #pragma unroll
         for (int m = 0; m < M; m++) pp[m] = acc[g][m];
       }
