@@ -532,6 +532,13 @@ void decide_update_plan(int64_t B, int64_t T, int64_t F, int64_t K, UpdatePlan& 
     // of 32 for 65 .. 72, .. 80, .. 112.  The plain and the split-contraction schedules and the work lists; the strip schedule
     // (rank <= 16) has no off-size rank.  FLUHIP_OFFSIZE=0 (A/B build): the padded forms, for the comparison.
     p.Kc = (offsize_enabled() && p.lazy && !p.strip) ? nmf_update5_compute_rank((int) K, Kp) : Kp;
+    // (the launcher deals its strips by the COMPUTE rank, everything planned here -- statistics records, side
+    //  slices, the tail launch, the scratch sizes -- by the padded rank.  The two agree because the group limits are the same
+    //  within an off-size class; should a future form break that, the shape keeps the padded rank rather than a layout mismatch)
+    if (p.Kc != Kp && (nmf_update5_strips((int) F, p.Kc, (int) B) != nmf_update5_strips((int) F, Kp, (int) B) ||
+                       nmf_update5_strips((int) F - 1, p.Kc, (int) B) != nmf_update5_strips((int) F - 1, Kp, (int) B) ||
+                       nmf_update5_strips((int) T, p.Kc, (int) B) != nmf_update5_strips((int) T, Kp, (int) B)))
+      p.Kc = Kp;
     if (p.useLists)
     {
       // the lists themselves are built (and checked descriptor by descriptor: tests/test_list_plan.py) by build_list_plan

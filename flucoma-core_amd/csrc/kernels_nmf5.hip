@@ -109,7 +109,13 @@ constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
 // shipped code objects for the pattern.
 __device__ __forceinline__ void store_result16(double* p, double __attribute__((ext_vector_type(2))) t)
 {
-#if FLUHIP_EPILOGUE_SC1
+#if FLUHIP_EPILOGUE_SC1 == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif FLUHIP_EPILOGUE_SC1 == 3
+  asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif FLUHIP_EPILOGUE_SC1 == 4
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+#elif FLUHIP_EPILOGUE_SC1
   asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 #else
   *reinterpret_cast<double __attribute__((ext_vector_type(2)))*>(p) = t;
@@ -218,7 +224,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // work-list mode: a wavefront's LDS region also stages its accumulators for the intra-workgroup reduction
   // DS == 2: no column-sum accumulators and the first product's results in VGPRs (QV below) -- the two go together: the
   // sixteen registers of the accumulators are what the VGPR form of the first product needs
-  constexpr bool QV = DS == 2 && MODE == 1;
+  // (... and every form of the two-operand-set pipeline that has the registers for it WITH its accumulators: rank 16 at any
+  //  strip width, the off-size form of ranks 17 .. 24 up to eight groups, rank 32 up to six -- none of them spills, probed
+  //  instantiation by instantiation; the same MFMAs in the same order, bit for bit the same results)
+  constexpr bool QV = MODE == 1 && (DS == 2 || (DS == 1 && INSTR == 0 && (M == 4 || (M == 6 && NG <= 8) || (M == 8 && NG <= 6))));
   constexpr int STG_BYTES = (NG * M + M) * 512;
   constexpr int WAVE_REGION = (LIST != 0 && STG_BYTES > WAVE_LDS && 4 * STG_BYTES <= 160 * 1024) ? STG_BYTES : WAVE_LDS;
 

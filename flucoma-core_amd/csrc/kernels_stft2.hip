@@ -215,6 +215,9 @@ struct FftCore
   // staging buffer instead of with ds_bpermute -- a plane of N + 64 slots, see split()
   static constexpr bool XL = FLUHIP_SPLIT_VIA_LDS != 0 && NB3 == 1;
   static constexpr int BUFD = N + N / 16 + (XL ? 34 : 2);    // doubles per wavefront (the + 2 staggers the buffers over the banks)
+  // (the XL split writes slot N from every lane -- slots up to N + 63 -- so the padding must cover 64 slots; today's one
+  //  XL form, N = 512, leaves 2 to spare, a smaller one would overrun into the next wavefront's buffer without this)
+  static_assert(!XL || BUFD >= N + 64, "XL split: the staging buffer must hold slots N .. N + 63");
   static constexpr int T2 = (R2 - 1) * NS2, T3 = (R3 - 1) * NS3;
   // SWZ (round 4, the 8 x 8 x 8 transform of fft 1024): the exchange buffer is addressed through bit swizzles instead of the
   // one-in-sixteen padding.  The padding serves the first exchange's stores (ds_write_b64: groups of 16 lanes over 32 dword

@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define FLUHIP_ABI_VERSION 4
+/* 5 (round 6) = 4 + fluhip_last_error_is_out_of_memory, fluhip_clear_error (the host clients' batched -> channel-by-channel
+ * fallback classifies by code: include/flucoma_hip/NMFClient.hpp needs them), fluhip_corpus_stft_mag_only,
+ * fluhip_corpus_last_loop_ms, fluhip_debug_plan_shape, fluhip_debug_wnorm_form.  Nothing of version 4 changed meaning. */
+#define FLUHIP_ABI_VERSION 5
 
 /* clients/common/Result.hpp:24  enum class Status { kOk, kWarning, kError, kCancelled } */
 enum fluhip_status

@@ -39,7 +39,7 @@ def test_python_binding_lists_every_symbol():
 def test_abi_version_and_param_arithmetic(fluhip_lib_path):
     import fluhip
     lib = fluhip.load_library(fluhip_lib_path)
-    assert lib.fluhip_abi_version() == 4
+    assert lib.fluhip_abi_version() == 5
     i64 = ctypes.c_int64
     w, h, f, b = i64(), i64(), i64(), i64()
     # clients/common/ParameterTypes.hpp:295-312 (1024, -1, -1) -> hop 512, fft 1024, 513 bins
