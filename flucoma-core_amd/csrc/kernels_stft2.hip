@@ -76,6 +76,9 @@ struct StftBArgs
 #ifndef FLUHIP_STFT_NT
 #define FLUHIP_STFT_NT 1
 #endif
+#ifndef FLUHIP_RESYNTH_NT
+#define FLUHIP_RESYNTH_NT 0
+#endif
 __device__ __forceinline__ void store_mag16(double* p, double __attribute__((ext_vector_type(2))) v)
 {
 #if FLUHIP_STFT_NT
@@ -1912,7 +1915,16 @@ __global__ __launch_bounds__(64 * NW) void resynth_seq_kernel(ResynthBatchArgs a
           }
           const double y0 = acc[i].re / fmax(n0, kEpsilon), y1 = acc[i].im / fmax(n1, kEpsilon);
           const int64_t i0 = p0 + q - a.trim;
-          if (pairStores && i0 >= 0 && i0 + 1 < nSamples) *reinterpret_cast<float2*>(out + i0) = float2{(float) y0, (float) y1};
+          if (pairStores && i0 >= 0 && i0 + 1 < nSamples)
+          {
+            // (K x the input's samples leave here and nobody on the device reads them again: non-temporal, FLUHIP_RESYNTH_NT)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+#if FLUHIP_RESYNTH_NT
+            __builtin_nontemporal_store(f2v{(float) y0, (float) y1}, reinterpret_cast<f2v*>(out + i0));
+#else
+            *reinterpret_cast<f2v*>(out + i0) = f2v{(float) y0, (float) y1};
+#endif
+          }
           else
           {
             if (i0 >= 0 && i0 < nSamples) out[i0] = (float) y0;

@@ -827,6 +827,47 @@ def test_corpus_side_column_wide_ranks(ctx, oracle, onp, K, iters):
         assert elementwise_rel_err(W1[b], rW) < TOL_FACTORS and elementwise_rel_err(H1[b], rH) < TOL_FACTORS
 
 
+@pytest.mark.parametrize("B,fft,T,takes", [
+    (128, 2048, 730, 7), (128, 2048, 862, 7), (128, 2048, 1000, 3), (128, 2048, 1100, 1),
+    (256, 1024, 200, 7), (256, 1024, 330, 7), (256, 1024, 440, 7), (256, 1024, 500, 3), (512, 512, 130, 7), (512, 512, 60, 7)])
+def test_two_launch_iteration_at_every_strip_width(ctx, oracle, onp, B, fft, T, takes):
+    """Round 6: at rank 32 the two-launch iteration keeps no column-sum accumulators in its loops -- the W update sums the
+    denominators of the side-column partials the H update in front left, the H update sums the column partials the W update
+    left (kernels_nmf5.hip DS = 2) -- and forms its first product with VGPR results (QV).  The forms exist per strip width:
+    W update 8 groups per strip at every one-round shape (128 x 1025 bins, 256 x 513, 512 x 257), H update 2 .. 7 groups with
+    the new form, 8 with the norm form that keeps its accumulators (the W update still takes the new one), 9 with the
+    side-column form only.  `takes` = what the planner says the H update takes over (bit 2: column sums from the W update).
+    Seven iterations (the first has no side partials to start from, the last H update leaves none): EVERY buffer bit for bit
+    against the first replica of its input, three buffers against the oracle."""
+    import ctypes
+    import fluhip
+    win, hop, K, iters = fft, fft // 4, 32, 7
+    F = fft // 2 + 1
+    n = (T - 1) * hop + 3
+    out = (ctypes.c_int64 * 32)()
+    assert ctx.lib.fluhip_debug_plan_shape(B, T, F, K, out) == 0
+    assert (out[0], out[1], out[2], out[4], out[9], out[22]) == (5, 1, 1, 1, 0, takes), list(out)[:27]
+    distinct = [onp.synth_audio(n, 7300 + b) for b in range(3)]
+    audio = np.stack([distinct[b % 3] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    assert c.T == T and c.F == F
+    c.set_audio(audio); c.stft(); c.nmf(iters, seed=42)
+    mag0 = c.read_f64(factors=False)[0][:3].copy()
+    _, W1, H1 = c.read_f64(mag=False)
+    # W-only and H-only calls behind it cross the forms' entry and exit conditions (no side partials / no column partials)
+    c.nmf(2, seed=42, updateH=False)
+    _, W2, _ = c.read_f64(mag=False)
+    c.close()
+    for b in range(3, B):
+        assert np.array_equal(W1[b], W1[b % 3]) and np.array_equal(H1[b], H1[b % 3]), b
+    for b in range(3):
+        rW, rH, _, _ = oracle.nmf_process(mag0[b], K, iters, True, True, 42)
+        assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, b
+        assert elementwise_rel_err(W1[b], rW) < TOL_FACTORS and elementwise_rel_err(H1[b], rH) < TOL_FACTORS
+    rW, _, _, _ = oracle.nmf_process(mag0[0], K, 2, True, False, 42)
+    assert rel_err(W2[0], rW) < TOL_FACTORS_TIGHT
+
+
 def test_h_update_of_more_than_64_strips_keeps_the_side_column_launch(ctx, oracle, onp):
     """long buffers at rank 64: the H update takes 80 strips per buffer, more than the 64 slices per buffer the side-column
     partials of its epilogue have room for (kernels_nmf.hip wnorm_side_part) -- the launcher must leave such shapes on the
