@@ -377,7 +377,7 @@ def main():
             ksha = hashlib.sha256(open(os.path.join(ROOT, "flucoma-core_amd", "csrc", "kernels_nmf5.hip"), "rb").read()).hexdigest()
         except OSError:
             ksha = None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             try:
                 path = os.path.join("profiles", rnd, "pmc_update_kernel.json")
                 pmc = json.load(open(os.path.join(ROOT, path)))
