@@ -29,6 +29,9 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // the split partials for kFinBatch rows at once, the old value of S, and (the first row group) the denominator
 // partials -- and only then starts adding; the first form walked its 16 rows in four dependent batches behind a
 // denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
+#ifndef FLUHIP_FIN_SC1
+#define FLUHIP_FIN_SC1 0
+#endif
 constexpr int kFinSG = 4;      // thread groups sharing the split partials of an element
 constexpr int kFinBatch = 4;   // rows per row group in flight together (a workgroup takes BATCH = 4, 8 or 16 of them, four at a time)
 // (split partials per thread group: nsplit <= 64, the kernel is built for 1, 2, 4, 8 and 16)
@@ -148,7 +151,15 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
         double so = sold[i];
         if (nrmMode) so = so / nk; // W update: W = W'/nrm; H update: (H/nrm) acc == H (acc/nrm)
         const double x = (so * t) / den;
-        if (!(dbgBits & 4)) S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
+        if (!(dbgBits & 4))
+        {
+#if FLUHIP_FIN_SC1
+          // (write-through, like the update kernel's own results: nothing dirty left for the end-of-kernel release -- experiment)
+          asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(S + (int64_t) buf * strideS + (int64_t) r * Kp + k), "v"(x) : "memory");
+#else
+          S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
+#endif
+        }
         ss += x * x;
         mx = fmax(mx, x);
       }

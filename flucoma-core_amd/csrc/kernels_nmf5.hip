@@ -153,6 +153,12 @@ __device__ __forceinline__ void glds16(const void* sbase, unsigned voff, unsigne
 // from the launch before: the stationary rows of the prologue, the moving factor's slabs.  `nt` on the slab copies of the loop:
 // bench shard 546.6 -> 534.9 us per iteration alternating on one box, and the part clocks 1.2 % HIGHER (profiles/r06/v_nt.txt).
 // -DFLUHIP_V_NT=0: the default policy.
+// Split-contraction partials are staged through the LDS and stored write-through in whole lines, like the results (round 6):
+// c4 x 1 47.6 -> 44.6 us per iteration, a 10 s buffer at rank 128 101.1 -> 93.5, config 3 1 831 -> 1 807, alternating on one box
+// (profiles/r06/partials_staged.txt).  -DFLUHIP_PARTIAL_STAGED=0: plain 16-byte stores from the MFMA layout.
+#ifndef FLUHIP_PARTIAL_STAGED
+#define FLUHIP_PARTIAL_STAGED 1
+#endif
 #ifndef FLUHIP_V_NT
 #define FLUHIP_V_NT 1
 #endif
@@ -1341,6 +1347,45 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   else
   {
     double* part = a.part + (LIST ? (int64_t) lPart : ((int64_t) buf * a.nsplit + split)) * a.Cp * KPM;
+#if FLUHIP_PARTIAL_STAGED
+    // The partials leave like the results (round 6): laid out in the wavefront's idle ring, read back linearly and stored a
+    // kilobyte per instruction, write-through -- whole lines per request instead of 64 sixteen-byte pieces 256 bytes apart,
+    // and nothing left dirty in the L2 for the end-of-kernel release to write back in front of the finalize launch.
+    {
+      constexpr int ROWB = KP * 8 + 16;
+      constexpr int GRPB = 16 * ROWB;
+      constexpr int GB = (WAVE_LDS / GRPB) >= NG ? NG : (WAVE_LDS / GRPB);
+      static_assert(GB >= 1, "partial staging does not fit the ring");
+      constexpr int CPR = KP / 2, NST = 16 * CPR / 64;
+      char* stg = lds + wave * WAVE_REGION;
+#pragma unroll
+      for (int gb = 0; gb < NG; gb += GB)
+      {
+#pragma unroll
+        for (int g = gb; g < gb + GB && g < NG; g++)
+        {
+          char* row = stg + (g - gb) * GRPB + (4 * blk + y) * ROWB + (M * x) * 8;
+#pragma unroll
+          for (int m = 0; m < M; m += 2) *reinterpret_cast<d2*>(row + m * 8) = d2{acc[g][m], acc[g][m + 1]};
+        }
+#pragma unroll
+        for (int g = gb; g < gb + GB && g < NG; g++)
+        {
+          if (g < ng)
+          {
+#pragma unroll
+            for (int j = 0; j < NST; j++)
+            {
+              const int c = 64 * j + lane;
+              const int r = c / CPR, piece = c % CPR;
+              const d2 t = *reinterpret_cast<const d2*>(stg + (g - gb) * GRPB + r * ROWB + piece * 16);
+              store_result16(part + (int64_t) ((g0 + g) * 16 + r) * KPM + piece * 2, t);
+            }
+          }
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int g = 0; g < NG; g++)
     {
@@ -1348,14 +1393,13 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       {
         const int col = (g0 + g) * 16 + 4 * blk + y;
         double* pp = part + (int64_t) col * KPM + M * x;
-        // (plain stores: the finalize launch behind reads the partials back from the L2.  Round 6 tried them write-through like
-        //  the results, on the theory that the finalize's 14.6 us "floor" at config 3 was the end-of-kernel write-back of 34 MB of
-        //  dirty lines -- measured the other way: a 10 s buffer at rank 128 100.8 -> 113.0 us per iteration, config 3 1 844 ->
-        //  1 860, profiles/r06/partials_write_through.txt)
+        // (the form of rounds 1 - 5.  Written through piece by piece -- 16 bytes per lane 256 bytes apart -- it measured slower
+        //  still: profiles/r06/partials_write_through.txt)
 #pragma unroll
         for (int m = 0; m < M; m++) pp[m] = acc[g][m];
       }
     }
+#endif
     if (DS && (LIST ? lD >= 0 : strip == 0) && blk == 0 && y == 0)
     {
       double* dp = a.dpart + (LIST ? (int64_t) lD : ((int64_t) buf * a.nsplit + split)) * KPM + M * x;
