@@ -29,8 +29,10 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // the split partials for kFinBatch rows at once, the old value of S, and (the first row group) the denominator
 // partials -- and only then starts adding; the first form walked its 16 rows in four dependent batches behind a
 // denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
+// the finalize launch's results leave write-through like the update kernel's own (round 6: c4 x 1 44.58 -> 44.24 us per iteration,
+// a 10 s buffer at rank 128 93.55 -> 92.5, alternating on one box; config 3 within noise).  -DFLUHIP_FIN_SC1=0: plain stores.
 #ifndef FLUHIP_FIN_SC1
-#define FLUHIP_FIN_SC1 0
+#define FLUHIP_FIN_SC1 1
 #endif
 constexpr int kFinSG = 4;      // thread groups sharing the split partials of an element
 constexpr int kFinBatch = 4;   // rows per row group in flight together (a workgroup takes BATCH = 4, 8 or 16 of them, four at a time)
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
         if (!(dbgBits & 4))
         {
 #if FLUHIP_FIN_SC1
-          // (write-through, like the update kernel's own results: nothing dirty left for the end-of-kernel release -- experiment)
+          // (write-through, like the update kernel's own results: nothing dirty left for the end-of-kernel release)
           asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(S + (int64_t) buf * strideS + (int64_t) r * Kp + k), "v"(x) : "memory");
 #else
           S[(int64_t) buf * strideS + (int64_t) r * Kp + k] = x;
