@@ -29,6 +29,11 @@ constexpr int kNormRows = 64; // rows per chunk of the column-wise passes
 // the split partials for kFinBatch rows at once, the old value of S, and (the first row group) the denominator
 // partials -- and only then starts adding; the first form walked its 16 rows in four dependent batches behind a
 // denominator pass of its own (6.5 us per launch for 6 MB; this form: one round trip).
+// ... and its partial loads are non-temporal (read once): a 10 s buffer at rank 128 93.4 -> 89.9 us per iteration, c4 x 1 the same
+// (round 6; the frame-strip reduce launch measured 0.5 - 1 % SLOWER with the same change and keeps plain loads).
+#ifndef FLUHIP_FIN_NT
+#define FLUHIP_FIN_NT 1
+#endif
 // the finalize launch's results leave write-through like the update kernel's own (round 6: c4 x 1 44.58 -> 44.24 us per iteration,
 // a 10 s buffer at rank 128 93.55 -> 92.5, alternating on one box; config 3 within noise).  -DFLUHIP_FIN_SC1=0: plain stores.
 #ifndef FLUHIP_FIN_SC1
@@ -103,7 +108,14 @@ __global__ __launch_bounds__(512) void nmf_update_finalize_kernel(double* S, int
       const int r = rbeg + (i0 + j) * nrg + rg;
       const int64_t idx = (int64_t) min(r, C - 1) * Kp + k;
 #pragma unroll
-      for (int u = 0; u < PER; u++) pv[j][u] = (u < per && !(dbgBits & 2)) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
+      for (int u = 0; u < PER; u++)
+      {
+#if FLUHIP_FIN_NT
+        pv[j][u] = (u < per && !(dbgBits & 2)) ? __builtin_nontemporal_load(p0 + (int64_t) min(sb + u, nsplit - 1) * sstride + idx) : 0.0;   // (read once)
+#else
+        pv[j][u] = (u < per && !(dbgBits & 2)) ? p0[(int64_t) min(sb + u, nsplit - 1) * sstride + idx] : 0.0;
+#endif
+      }
       sold[i0 + j] = (sg == 0 && !(dbgBits & 8)) ? S[(int64_t) buf * strideS + idx] : 0.0;
     }
     if (i0 == 0)   // (behind the first rows' requests, as the four-row form always had them)

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void nmf_strip_reduce_kernel(StripK
   const double wold = *wp;
   double v[kRedU];
 #pragma unroll
-  for (int u = 0; u < kRedU; u++) v[u] = P[(int64_t) min(wv + kRedWaves * u, a.nWG - 1) * 256];
+  for (int u = 0; u < kRedU; u++) v[u] = P[(int64_t) min(wv + kRedWaves * u, a.nWG - 1) * 256];   // (non-temporal loads measured 0.5 - 1 % slower here, round 6)
   __builtin_amdgcn_sched_barrier(0);
   double dsum = 0.0;
 #pragma unroll
