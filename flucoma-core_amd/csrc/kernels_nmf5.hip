@@ -189,6 +189,27 @@ __device__ __forceinline__ void load_vec5(double (&dst)[N], const double* p)
     dst[j + 1] = t[1];
   }
 }
+// the stationary rows.  Non-temporal loads (-DFLUHIP_STATIONARY_NT=1) were tried in round 6: the bench shard the same (534.6 /
+// 539.3 against 534.5 / 535.6 us per iteration), a 10 s buffer at rank 128 90.1 -> 96.3 (the pieces of a split contraction read
+// the same rows).  Not adopted.
+#ifndef FLUHIP_STATIONARY_NT
+#define FLUHIP_STATIONARY_NT 0
+#endif
+template <int N>
+__device__ __forceinline__ void load_stationary5(double (&dst)[N], const double* p)
+{
+#if FLUHIP_STATIONARY_NT
+#pragma unroll
+  for (int j = 0; j < N; j += 2)
+  {
+    d2 t = __builtin_nontemporal_load(reinterpret_cast<const d2*>(p + j));
+    dst[j] = t[0];
+    dst[j + 1] = t[1];
+  }
+#else
+  load_vec5<N>(dst, p);
+#endif
+}
 
 // quad_perm exchange of a double (the four lanes x = 0 .. 3 of a result row)
 template <int CTRL>
@@ -465,7 +486,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   {
 #pragma unroll
     for (int m = 0; m < M; m++) { acc[g][m] = 0.0; sb[g][m] = 0.0; }
-    if (g < ng) load_vec5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KPM + M * y);
+    if (g < ng) load_stationary5<M>(sb[g], S + (int64_t) ((g0 + g) * 16 + 4 * blk + x) * KPM + M * y);
   }
   [[maybe_unused]] double colSum = 0.0;
   if constexpr (DS == 2)
