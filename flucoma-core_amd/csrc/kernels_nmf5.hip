@@ -252,9 +252,9 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // DS == 2: no column-sum accumulators and the first product's results in VGPRs (QV below) -- the two go together: the
   // sixteen registers of the accumulators are what the VGPR form of the first product needs
   // (... and every form of the two-operand-set pipeline that has the registers for it WITH its accumulators: rank 16 at any
-  //  strip width, the off-size form of ranks 17 .. 24 up to eight groups, rank 32 up to six -- none of them spills, probed
+  //  strip width, the off-size forms of ranks 17 .. 24 (up to eight groups) and 33 .. 40, rank 32 up to six -- none of them spills, probed
   //  instantiation by instantiation; the same MFMAs in the same order, bit for bit the same results)
-  constexpr bool QV = MODE == 1 && (DS == 2 || (DS == 1 && INSTR == 0 && (M == 4 || (M == 6 && NG <= 8) || (M == 8 && NG <= 6))));
+  constexpr bool QV = MODE == 1 && (DS == 2 || (DS == 1 && INSTR == 0 && (M == 4 || (M == 6 && NG <= 8) || (M == 8 && NG <= 6) || (M == 10 && NG <= 4))));
   constexpr int STG_BYTES = (NG * M + M) * 512;
   constexpr int WAVE_REGION = (LIST != 0 && STG_BYTES > WAVE_LDS && 4 * STG_BYTES <= 160 * 1024) ? STG_BYTES : WAVE_LDS;
 
