@@ -156,6 +156,10 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     L.fluhip_prof_read.argtypes = [_vp, ctypes.c_int, _ip, _dp]
     L.fluhip_corpus_debug_words.argtypes = [_vp, _ip]
     L.fluhip_corpus_update_clocks.argtypes = [_vp, _ip, ctypes.c_int]
+    L.fluhip_last_error_is_out_of_memory.argtypes = [_vp]
+    L.fluhip_last_error_is_out_of_memory.restype = ctypes.c_int
+    L.fluhip_clear_error.argtypes = [_vp]
+    L.fluhip_clear_error.restype = None
     L.fluhip_debug_plan_shape.argtypes = [_i64, _i64, _i64, _i64, _ip]
     L.fluhip_debug_wnorm_form.argtypes = [ctypes.c_int] * 7
     L.fluhip_corpus_last_loop_ms.argtypes = [_vp, ctypes.POINTER(ctypes.c_double)]

@@ -1470,6 +1470,32 @@ def test_nmffilter_vs_oracle(ctx, onp, n, win, fft, hop, K, iters):
         ctx.nmffilter(audio, bases, 256, 256, 300)
 
 
+def test_allocation_failures_are_classified_by_code(ctx, onp):
+    """the host client retries a batched job channel by channel only after an ALLOCATION failure, and learns that
+    from `fluhip_last_error_is_out_of_memory` -- set where the failure happens (hipErrorOutOfMemory here: 0.44 TB of magnitudes
+    asked of a 288 GB part, refused by the allocator without touching anything), not from the message text -- cleared by
+    `fluhip_clear_error` and by the next failure of another kind; the context stays usable."""
+    import fluhip
+    lib = ctx.lib
+    lib.fluhip_clear_error(ctx.h)
+    assert lib.fluhip_last_error_is_out_of_memory(ctx.h) == 0 and lib.fluhip_last_error(ctx.h) == b""
+    with pytest.raises(fluhip.FluhipError):
+        fluhip.Corpus(ctx, 60000, 441000, 2048, 2048, 512, 32)
+    assert lib.fluhip_last_error_is_out_of_memory(ctx.h) == 1
+    assert b"out of memory" in lib.fluhip_last_error(ctx.h).lower() or b"hip error" in lib.fluhip_last_error(ctx.h).lower()
+    with pytest.raises(fluhip.FluhipError):            # an argument error: not an allocation failure
+        fluhip.Corpus(ctx, 4, 441000, 2048, 1000, 512, 32)
+    assert lib.fluhip_last_error_is_out_of_memory(ctx.h) == 0
+    with pytest.raises(fluhip.FluhipError):
+        fluhip.Corpus(ctx, 60000, 441000, 2048, 2048, 512, 32)
+    assert lib.fluhip_last_error_is_out_of_memory(ctx.h) == 1
+    lib.fluhip_clear_error(ctx.h)
+    assert lib.fluhip_last_error_is_out_of_memory(ctx.h) == 0
+    x = onp.synth_audio(22050, 1000)
+    bases, acts, rc = ctx.bufnmf_channel(x, 1024, 1024, 512, 3, 5, 42)      # the context is as good as before
+    assert rc == 0 and np.isfinite(bases).all() and np.isfinite(acts).all()
+
+
 def test_no_device_memory_is_left_behind(ctx, onp):
     """a host keeps ONE context for its lifetime and runs thousands of jobs through it (clients/common/FluidNRTClientWrapper.hpp:831:
     one client per adaptor): corpora of every schedule family created, run and destroyed in a loop -- plain, split, work lists,
