@@ -28,6 +28,7 @@
 // LDS-staged result stores and the split-contraction partial stores live in the common prologue / epilogue.
 // DESIGN.md section 3 and profiles/r01/update_kernel_notes.md carry the measurements behind each of these.
 #include "fluhip_kernels.h"
+#include "recip_tree.h"
 
 #include <cstdlib>
 
@@ -90,6 +91,12 @@ constexpr bool kQuotientCorrection = FLUHIP_QUOTIENT_CORRECTION != 0;
 #define FLUHIP_SHARED_RECIPROCAL 1
 #endif
 constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
+// quotients per reciprocal of the hot loop: 2 = pairs (rounds 2 - 5), 4 / 8 = a product tree (ratio_phase)
+#ifndef FLUHIP_RCP_GROUP
+#define FLUHIP_RCP_GROUP 4
+#endif
+constexpr int kRcpGroup = FLUHIP_RCP_GROUP;
+static_assert(kRcpGroup == 2 || kRcpGroup == 4 || kRcpGroup == 8, "quotients per reciprocal");
 // The results of a launch leave with write-through (sc1) stores: with plain stores the kernel ends on tens of MB of
 // dirty L2 lines that the end-of-kernel release has to write back before the next launch may start
 // (MI355X_MICROARCH.md "publish-large": 8.2 vs 3.0 us for 64 KB per workgroup).  -DFLUHIP_EPILOGUE_SC1=0: plain stores.
@@ -649,6 +656,12 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
       for (int g = 0; g < NG; g++) ratio[g] = __builtin_fma(-d[g], yv[g], 1.0);
 #pragma unroll
       for (int g = 0; g < NG; g++) yv[g] = __builtin_fma(yv[g], ratio[g], yv[g]);
+    }
+    else if constexpr (kRcpGroup > 2)
+    {
+      // one reciprocal per group of up to kRcpGroup quotients (round 6, recip_tree.h): NG = 7 / 8 cost 27 / 30 operation slots
+      // where the pairs below cost 33 / 36
+      recip_tree<NG, kRcpGroup>(d, yv);
     }
     else
     {

@@ -29,6 +29,7 @@
 // so in both phases the first product's result registers are the second product's A operand (no shuffles).
 #include "fluhip_kernels.h"
 #include "nmf_tile_stats.h"
+#include "recip_tree.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -94,6 +95,12 @@ __device__ __forceinline__ double dppmov(double v)
   return __longlong_as_double(((long long) hi << 32) | (unsigned) lo);
 }
 
+// quotients per reciprocal (recip_tree.h; round 6): 1 = a v_rcp_f64 per quotient (rounds 2 - 5), 3 / 4 / 6 = product trees
+#ifndef FLUHIP_STRIP_RCP_GROUP
+#define FLUHIP_STRIP_RCP_GROUP 6
+#endif
+constexpr int kStripRcpGroup = FLUHIP_STRIP_RCP_GROUP;
+
 // R[q] = V[q] / max(Q[q], eps) for the kNQ tiles of one step, stage by stage: left to the scheduler the seven dependent
 // operations of one quotient run back to back (register pressure), each waiting for the one before it
 #define STRIP_QUOT(R, V, Q)                                                                                   \
@@ -101,11 +108,18 @@ __device__ __forceinline__ double dppmov(double v)
     double d_[NQ], y_[NQ], e_[NQ];                                                                         \
     _Pragma("unroll") for (int q = 0; q < NQ; q++) d_[q] = fmax(Q[q], kEpsilon);                             \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
+    if constexpr (kStripRcpGroup > 1 && !kQuotientCorrection)                                                 \
+    {                                                                                                         \
+      recip_tree<NQ, kStripRcpGroup>(d_, y_);                                                                 \
+    }                                                                                                         \
+    else                                                                                                      \
+    {                                                                                                         \
     _Pragma("unroll") for (int q = 0; q < NQ; q++) y_[q] = __builtin_amdgcn_rcp(d_[q]);                      \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     _Pragma("unroll") for (int q = 0; q < NQ; q++) e_[q] = __builtin_fma(-d_[q], y_[q], 1.0);                \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     _Pragma("unroll") for (int q = 0; q < NQ; q++) y_[q] = __builtin_fma(y_[q], e_[q], y_[q]);               \
+    }                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                        \
     if constexpr (kQuotientCorrection)                                                                        \
     {                                                                                                         \

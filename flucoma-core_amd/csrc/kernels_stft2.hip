@@ -190,6 +190,57 @@ __device__ __forceinline__ cx split_const(int r)
   return cx{c32[q], -s32[q]};
 }
 
+// ---- register <-> lane transposes without the LDS (round 6, gfx950) --------------------------------------------------
+// One step swaps a bit of the register index with a bit of the lane index: for the register pair (A, B) that differs in the
+// register bit, A keeps its lanes with the lane bit clear and takes B's partner lanes, B the reverse.  Lane bits 5 and 4 are
+// ONE instruction per pair and dword (v_permlane32_swap / v_permlane16_swap: the upper half of A against the lower half of B;
+// the odd rows of A against the even rows of B), lane bit 3 two DPP moves with a bank mask (row_ror:8 = lane ^ 8 inside a
+// row of 16) and the copy that keeps A alive.
+#ifndef FLUHIP_FFT_PERMLANE
+#define FLUHIP_FFT_PERMLANE 0
+#endif
+template <int LANEBIT>
+__device__ __forceinline__ void xpose_dword(int& a, int& b)
+{
+  static_assert(LANEBIT == 5 || LANEBIT == 4 || LANEBIT == 3, "lane bit of the transpose step");
+  if constexpr (LANEBIT == 5)
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+  }
+  else if constexpr (LANEBIT == 4)
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+  }
+  else
+  {
+    const int na = __builtin_amdgcn_update_dpp(a, b, 0x128, 0xf, 0xc, false);   // lanes 8 .. 15 of a row <- b[lane - 8]
+    const int nb = __builtin_amdgcn_update_dpp(b, a, 0x128, 0xf, 0x3, false);   // lanes 0 .. 7           <- a[lane + 8]
+    a = na; b = nb;
+  }
+}
+template <int LANEBIT>
+__device__ __forceinline__ void xpose_f64(double& a, double& b)
+{
+  const long long la = __double_as_longlong(a), lb = __double_as_longlong(b);
+  int a0 = (int) (la & 0xffffffff), a1 = (int) (la >> 32), b0 = (int) (lb & 0xffffffff), b1 = (int) (lb >> 32);
+  xpose_dword<LANEBIT>(a0, b0);
+  xpose_dword<LANEBIT>(a1, b1);
+  a = __longlong_as_double(((long long) a1 << 32) | (unsigned) a0);
+  b = __longlong_as_double(((long long) b1 << 32) | (unsigned) b0);
+}
+// eight values per lane: register bits (2, 1, 0) <-> lane bits (5, 4, 3)
+__device__ __forceinline__ void xpose8_hi(double (&v)[8])
+{
+#pragma unroll
+  for (int r = 0; r < 4; r++) xpose_f64<5>(v[r], v[r + 4]);
+#pragma unroll
+  for (int r = 0; r < 8; r++) if (!(r & 2)) xpose_f64<4>(v[r], v[r + 2]);
+#pragma unroll
+  for (int r = 0; r < 8; r += 2) xpose_f64<3>(v[r], v[r + 1]);
+}
+
 } // namespace
 
 // One frame's transform from the windowed points to the staged magnitudes, shared by the kernel forms below: pass 1,
@@ -232,6 +283,16 @@ struct FftCore
   // instruction meets every bank once.  Per lane that is four store bases + two load bases for the first exchange and two +
   // two for the second, all loop invariant; the offsets stay compile-time immediates.
   static constexpr bool SWZ = R1 == 8 && R2 == 8 && R3 == 8;
+  // PLX (round 6): the first exchange of the 8 x 8 x 8 transform does not touch the LDS.  Pass 1 leaves point
+  // i = 64 a + 8 b + r in register r of lane (a, b) (a = lane >> 3, b = lane & 7); pass 2 wants register a to hold it.  Swapping
+  // the register index with the UPPER lane bits (xpose8_hi: 32 permlane swaps + 48 DPP moves per frame against 16
+  // ds_write_b64 + 16 ds_read_b64, 128 cycles of the CU's one LDS pipe) puts it into lane (r, b): that lane runs butterfly
+  // j = 8 b + r = 8 (lane & 7) + (lane >> 3) of pass 2 -- twiddle row k = j mod 8 = lane >> 3 -- and its outputs go to
+  // i' = 64 (lane & 7) + (lane >> 3) + 8 r of the second exchange, whose slots are i' + 2 (i' >> 6): both the stores (16
+  // consecutive lanes: 2 b + k over 16 bank pairs) and the loads (lane + 66 r) meet every bank once, one base each.
+  // The data movement is exact: the results are the LDS form's bit for bit.
+  static constexpr bool PLX = SWZ && FLUHIP_FFT_PERMLANE != 0;
+  static_assert(!PLX || BUFD >= 7 * 66 + 64, "PLX: slots of the second exchange");
   static_assert(R1 == 16 || R1 == 8, "pass-1 radix");
   static_assert(NS2 % 8 == 0 && NS3 % 16 == 0 && (N / R2) % 16 == 0, "index arithmetic of the exchanges");
   int lane, jA, jB;
@@ -279,7 +340,7 @@ struct FftCore
     //   pass-2 outputs  (j - k) R2 + k + r NS2   pass-3 inputs   j + r NS3
     w1p = xb + (R1 == 16 ? 17 * lane : 8 * lane + (lane >> 1));
     r2p = xb + lane + (lane >> 4);
-    const int k2 = lane & (NS2 - 1);
+    const int k2 = PLX ? (lane >> 3) : (lane & (NS2 - 1));
     const int hi2 = lane - k2;                                  // multiple of NS2
     w2p = xb + hi2 * R2 + ((hi2 * R2) >> 4) + k2;
     r3pA = xb + jA + (jA >> 4);
@@ -305,6 +366,11 @@ struct FftCore
       // second exchange, loads: i = l + 64 r -> i ^ ((r & 1) << 3)
       r3q[0] = xb + l;
       r3q[1] = xb + (l ^ 8);
+      if constexpr (PLX)
+      {
+        w2q[0] = xb + 66 * (l & 7) + (l >> 3);
+        r3q[0] = xb + l;
+      }
     }
   }
 
@@ -350,7 +416,17 @@ struct FftCore
   SCHED_FENCE();
   cx p2[PPL];
   // exchange 1 -> distribution of pass 2 (butterfly j = lane + 64 bb reads j + r N/R2): real plane, then imaginary
-  if constexpr (SWZ)
+  if constexpr (PLX)
+  {
+    double re[8], im[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { re[r] = pts[r].re; im[r] = pts[r].im; }
+    xpose8_hi(re);
+    xpose8_hi(im);
+#pragma unroll
+    for (int r = 0; r < 8; r++) p2[r] = cx{re[r], im[r]};
+  }
+  else if constexpr (SWZ)
   {
 #pragma unroll
     for (int r = 0; r < R1; r++) w1q[r & 3][16 * (r >> 2)] = pts[r].re;
@@ -398,7 +474,18 @@ struct FftCore
   auto in3 = [&](int bb, int r) -> const double* {
     return (LOCAL && bb == 1 ? r3pB : r3pA) + (NS3 + NS3 / 16) * r;
   };
-  if constexpr (SWZ)
+  if constexpr (PLX)
+  {
+#pragma unroll
+    for (int r = 0; r < R2; r++) w2q[0][8 * r] = p2[r].re;
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[r].re = lds_read1(r3q[0] + 66 * r);
+#pragma unroll
+    for (int r = 0; r < R2; r++) w2q[0][8 * r] = p2[r].im;
+#pragma unroll
+    for (int r = 0; r < R3; r++) p3[r].im = lds_read1(r3q[0] + 66 * r);
+  }
+  else if constexpr (SWZ)
   {
 #pragma unroll
     for (int r = 0; r < R2; r++) w2q[r & 1][8 * r] = p2[r].re;
