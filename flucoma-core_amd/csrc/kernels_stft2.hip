@@ -231,7 +231,7 @@ __device__ __forceinline__ void xpose_f64(double& a, double& b)
   b = __longlong_as_double(((long long) b1 << 32) | (unsigned) b0);
 }
 // eight values per lane: register bits (2, 1, 0) <-> lane bits (5, 4, 3)
-__device__ __forceinline__ void xpose8_hi(double (&v)[8])
+[[maybe_unused]] __device__ __forceinline__ void xpose8_hi(double (&v)[8])
 {
 #pragma unroll
   for (int r = 0; r < 4; r++) xpose_f64<5>(v[r], v[r + 4]);

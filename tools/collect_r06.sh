@@ -2,7 +2,7 @@
 # round 6 records (run on the GPU box; copies go to profiles/r06/): the bench line, the rocprofv3 kernel stats of the same command,
 # the PMC passes of the update kernel (tied to the kernel source by its hash), the perf matrix, the rocprofv3 kernel stats of the
 # ragged 64 x 40 corpus, and the per-config sets for c2, c3, c5
-export TMPDIR=/tmp; out=gpurun_out/r06final; tag=${1:-final}; mkdir -p $out
+export TMPDIR=/tmp; tag=${1:-final}; out=${2:-gpurun_out/r06final}; mkdir -p $out
 python bench.py > $out/bench_$tag.json 2> $out/bench_$tag.err
 d=$out/ks; rm -rf $d
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o b -- python bench.py --no-cpu-baseline --configs none > $out/ks.log 2>&1
