@@ -96,6 +96,9 @@ constexpr bool kSharedReciprocal = FLUHIP_SHARED_RECIPROCAL != 0;
 #define FLUHIP_RCP_GROUP 4
 #endif
 constexpr int kRcpGroup = FLUHIP_RCP_GROUP;
+#ifndef FLUHIP_QV_M10
+#define FLUHIP_QV_M10 1
+#endif
 static_assert(kRcpGroup == 2 || kRcpGroup == 4 || kRcpGroup == 8, "quotients per reciprocal");
 // The results of a launch leave with write-through (sc1) stores: with plain stores the kernel ends on tens of MB of
 // dirty L2 lines that the end-of-kernel release has to write back before the next launch may start
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
   // (... and every form of the two-operand-set pipeline that has the registers for it WITH its accumulators: rank 16 at any
   //  strip width, the off-size forms of ranks 17 .. 24 (up to eight groups) and 33 .. 40, rank 32 up to six -- none of them spills, probed
   //  instantiation by instantiation; the same MFMAs in the same order, bit for bit the same results)
-  constexpr bool QV = MODE == 1 && (DS == 2 || (DS == 1 && INSTR == 0 && (M == 4 || (M == 6 && NG <= 8) || (M == 8 && NG <= 6) || (M == 10 && NG <= 4))));
+  constexpr bool QV = MODE == 1 && (DS == 2 || (DS == 1 && INSTR == 0 && (M == 4 || (M == 6 && NG <= 8) || (M == 8 && NG <= 6) || (FLUHIP_QV_M10 && M == 10 && NG <= 4))));
   constexpr int STG_BYTES = (NG * M + M) * 512;
   constexpr int WAVE_REGION = (LIST != 0 && STG_BYTES > WAVE_LDS && 4 * STG_BYTES <= 160 * 1024) ? STG_BYTES : WAVE_LDS;
 
@@ -978,6 +981,23 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
+          if constexpr (QV && PP > 1)
+          {
+            // THE WAIT STATES BEHIND THE ASM CHAIN ARE LOAD-BEARING (round 6, session 2).  With more than one partial chain per
+            // group (NG <= 4) the VALU adds the chains up right here -- and a v_add_f64 that reads the destination of a
+            // double-precision MFMA still in flight reads the OLD register: the hazard recognizer pads the MFMAs it selects itself
+            // (DMFMA 4x4 write -> VALU read), not the inside of an asm statement, and it is free to hoist the adds above the last
+            // asm MFMA as well.  <10, 2> did both (`v_mfma v[126:127] ... ; s_nop 0 ; v_add_f64 .., v[126:127]`): every W update
+            // of a rank 33 .. 40 corpus with two column groups per strip came out 1e-2 wrong (tests/test_gpu_random_shapes.py
+            // r1_B20_K40).  The volatile statements keep their order: the MFMAs, the wait states (twice what the
+            // compiler pads its own double-precision 4x4 MFMAs with), then one empty statement per chain register that the adds
+            // depend on.  tools/isa_mfma_valu_hazard.py audits the shipped code objects for the pattern (CPU test).
+            asm volatile("s_nop 11" ::: "memory");   // 12 wait states (LLVM pads a DMFMA 4x4 write -> VALU read with 6)
+#pragma unroll
+            for (int g = 0; g < NG; g++)
+#pragma unroll
+              for (int p = 0; p < PP; p++) asm volatile("" : "+v"(qp[g][p]));
+          }
 #pragma unroll
           for (int g = 0; g < NG; g++)
           {

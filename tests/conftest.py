@@ -69,6 +69,11 @@ def fluhip_lib_path():
     spec = importlib.util.spec_from_file_location("fluhip_build", os.path.join(ROOT, "flucoma-core_amd", "build.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    if os.environ.get("FLUHIP_LIB"):
+        # an experiment build for a one-session A/B validation (build.py build_exp): the whole suite runs on THAT library --
+        # fluhip.py honours the variable, and a fixture that silently loaded the production library instead made three
+        # "validations" of round 6 validate nothing
+        return os.path.abspath(os.environ["FLUHIP_LIB"])
     if not os.path.exists(mod.LIB):
         mod.build()
     return mod.LIB

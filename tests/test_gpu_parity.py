@@ -1566,3 +1566,29 @@ def test_long_factors_at_rank_128_in_every_update_mode(ctx, oracle, K):
         assert rc == 0
         assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT and rel_err(V1, rV) < TOL_FACTORS_TIGHT, \
             (K, uw, uh, rel_err(W1, rW), rel_err(H1, rH))
+
+
+@pytest.mark.parametrize("K", [4, 16, 20, 24, 32, 33, 40, 48, 56, 64])
+@pytest.mark.parametrize("frames", [9, 20])
+def test_small_corpora_with_narrow_strips_at_every_compute_rank(ctx, oracle, onp, K, frames):
+    """Twenty short buffers: the planner deals each buffer's bins into strips of one to four column groups, the forms whose
+    first product sums several partial accumulate chains per group right behind the MFMAs.  Round 6 spelled those chains in
+    asm (VGPR results) and the compiler neither padded nor ordered the VALU adds behind them: the W update of ranks 33 .. 40
+    at two groups per strip read a chain register two cycles after its MFMA (6e-2 wrong from three steps of four frames on;
+    two steps were right -- `tools/isa_mfma_valu_hazard.py`).  Every rank class of the two-operand-set
+    pipeline, both updates, three steps and five."""
+    import fluhip
+    B, win, fft, hop, iters = 20, 2048, 2048, 1024, 3
+    n = frames * hop - 5
+    src = [onp.synth_audio(n, 8100 + b) for b in range(3)]
+    audio = np.stack([src[b % 3] for b in range(B)])
+    c = fluhip.Corpus(ctx, B, n, win, fft, hop, K)
+    c.set_audio(audio); c.stft()
+    for uw, uh in ((True, False), (True, True)):
+        c.nmf(iters, seed=42, updateW=uw, updateH=uh)
+        mag, W1, H1 = c.read_f64()
+        for b in (0, 1, B - 1):
+            _, rmag = oracle.stft_f32(audio[b], win, fft, hop)
+            rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
+            assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (K, frames, uw, uh, b, c.plan())
+    c.close()
