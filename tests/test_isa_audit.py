@@ -56,11 +56,14 @@ def test_the_mfma_audit_sees_the_pattern_that_bit():
            "\tv_add_f64 v[106:107], v[150:151], v[126:127]\n\ts_endpgm\n")
     good = ("k:\n\tv_mfma_f64_4x4x4_4b_f64 v[126:127], v[108:109], v[20:21], v[126:127]\n\ts_nop 11\n"
             "\tv_add_f64 v[106:107], v[150:151], v[126:127]\n\ts_endpgm\n")
-    chain = ("k:\n\tv_mfma_f64_4x4x4_4b_f64 v[126:127], v[108:109], v[20:21], v[126:127]\n"
-             "\tv_mfma_f64_4x4x4_4b_f64 v[126:127], v[110:111], v[22:23], v[126:127]\n\ts_nop 7\n\tv_add_f64 v[2:3], v[126:127], v[4:5]\n\ts_endpgm\n")
+    link = "\tv_mfma_f64_4x4x4_4b_f64 v[%d:%d], v[108:109], v[20:21], v[%d:%d]\n"
+    chain = ("k:\n" + link % (126, 127, 126, 127) + "".join(link % (r, r + 1, r, r + 1) for r in (128, 130, 132, 134)) + link % (126, 127, 126, 127)
+             + "\ts_nop 7\n\tv_add_f64 v[2:3], v[126:127], v[4:5]\n\ts_endpgm\n")      # links five instructions apart, the sum behind wait states
+    tight = "k:\n" + link % (126, 127, 126, 127) + link % (128, 129, 128, 129) + link % (126, 127, 126, 127) + "\ts_endpgm\n"
     other = ("k:\n\tv_mfma_f64_4x4x4_4b_f64 v[126:127], v[108:109], v[20:21], v[126:127]\n\tv_add_f64 v[106:107], v[150:151], v[128:129]\n"
              "\tds_read_b128 v[124:127], v89\n\ts_endpgm\n")
     store = "k:\n\tv_mfma_f64_4x4x4_4b_f64 v[126:127], v[108:109], v[20:21], 0\n\ts_nop 6\n\tds_write_b64 v1, v[126:127]\n\ts_endpgm\n"
     agpr = "k:\n\tv_mfma_f64_4x4x4_4b_f64 a[0:1], v[108:109], v[20:21], a[0:1]\n\tv_add_f64 v[0:1], v[0:1], v[2:3]\n\ts_endpgm\n"
     assert len(t.audit_text(bad, "x")) == 1 and len(t.audit_text(store, "x")) == 1      # (a memory-class read needs 9)
+    assert len(t.audit_text(tight, "x")) == 1                                            # (a chain's next link two instructions on)
     assert not t.audit_text(good, "x") and not t.audit_text(chain, "x") and not t.audit_text(other, "x") and not t.audit_text(agpr, "x")

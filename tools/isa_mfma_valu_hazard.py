@@ -13,7 +13,7 @@ the MFMA that writes it: every W update of that shape 1e-2 wrong.  This tool lis
 
 whose destination is read or rewritten by a non-MFMA instruction inside the window (an instruction counts one wait state,
 s_nop N counts N + 1 -- the hazard recognizer's own arithmetic; a label or a branch ends the window as "nothing seen").
-MFMA readers are not listed: a chain's next link takes the register as SrcC, which the hardware forwards.
+An MFMA that takes the result as an operand (the next link of a chain) is listed when it follows inside four wait states.
 
     python tools/isa_mfma_valu_hazard.py flucoma-core_amd/lib/libflucoma_hip.so [more libraries or .co / .s files]
 
@@ -34,6 +34,7 @@ code_objects, vregs, OBJDUMP = _sh.code_objects, _sh.vregs, _sh.OBJDUMP
 DMFMA = re.compile(r"^v_mfma_f64_(4x4x4|16x16x4)")
 # (VALU read / write, memory-class read) wait states behind the write of the result
 NEED = {"4x4x4": (6, 9), "16x16x4": (19, 18)}
+NEED_MFMA = 4
 MEMCLASS = ("ds_", "global_", "flat_", "buffer_", "scratch_", "exp")
 
 
@@ -104,7 +105,16 @@ def audit_text(text, label):
             t = nxt[1]
             if t.startswith(("s_branch", "s_cbranch", "s_endpgm", "s_setpc")):
                 break
-            if not t.startswith(("v_mfma", "v_smfmac")):
+            if t.startswith(("v_mfma", "v_smfmac")):
+                # the next link of an accumulate chain (or any MFMA that takes the result as an operand): LLVM asks four wait
+                # states between a DMFMA 4x4 write and an overlapping MFMA read; the asm chains keep their links NG x PP >= 5
+                # instructions apart by construction -- held here
+                _, mops = operands(t)
+                srcs = set().union(*[vregs(o) for o in mops[1:]]) if len(mops) > 1 else set()
+                if (srcs & dst) and ws < NEED_MFMA:
+                    hits.append((label, item[2], ins, t, ws, NEED_MFMA))
+                    break
+            else:
                 rd, wr = reads_and_writes(t)
                 mem = t.startswith(MEMCLASS)
                 touched = rd if mem else (rd | wr)     # (a load's destination arrives long after the MFMA has retired)
