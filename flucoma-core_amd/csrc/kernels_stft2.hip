@@ -1253,7 +1253,9 @@ __global__ __launch_bounds__(64 * NW, SMALL ? 5 : 1) void stft_feat_kernel(StftB
     {
       cx pts[PPL];
 #ifdef FLUHIP_AB_SWITCHES
-      gather_points<R1, N>(a, b, t, lane, (SMALL || (a.prefetch & 1)) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
+      // FLUHIP_FEAT_SAMEFRAME=1 (bit 2; a TIMING experiment, wrong output): every frame gathers frame 2 of buffer 0 -- cache hits
+      // instead of the HBM's latency: the upper bound of what requesting the samples a frame ahead could buy
+      gather_points<R1, N>(a, (a.prefetch & 4) ? 0 : b, (a.prefetch & 4) ? 2 : t, lane, (SMALL || (a.prefetch & 1)) ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #else
       gather_points<R1, N>(a, b, t, lane, SMALL ? reinterpret_cast<const d2*>(a.window) : wl, pts, a.n);
 #endif
@@ -1661,7 +1663,8 @@ bool launch_stft_features(const StftArgs& a, const FeatArgs& f, const double* up
   {
     static const int wg = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_WINDOW_GLOBAL"); return e ? std::atoi(e) : 0; }();
     static const int pr = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_PRIO"); return e ? std::atoi(e) : 0; }();
-    k.prefetch = (wg ? 1 : 0) | (pr ? 2 : 0);
+    static const int sf = [] { const char* e = fluhip::ab_getenv("FLUHIP_FEAT_SAMEFRAME"); return e ? std::atoi(e) : 0; }();
+    k.prefetch = (wg ? 1 : 0) | (pr ? 2 : 0) | (sf ? 4 : 0);
   }
   FeatFusedArgs fa;
   fa.up = up; fa.dn = dn; fa.slot = slot; fa.dct = f.dct;
