@@ -917,6 +917,10 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
                       double (&vn)[NG], double (&man)[M], double (&mbn)[M], const double (&qc)[NG],
                       double (&qn)[NG]) {
         double ratio[NG];
+        constexpr int PP = (P <= M) ? P : M;
+        // LATE: the asm chains' sums wait until the second product has gone by (below)
+        constexpr bool LATE = QV && PP > 1;
+        double qp[NG][PP];
         const long long c0 = tick();
         // stages s+1, s+2 landed.  (Refills past the last step re-read the last step's rows -- L2 hits; skipping
         // them was measured slower both ways: a branch per DMA splits the MFMA stream into basic blocks, and
@@ -927,8 +931,6 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
         __builtin_amdgcn_sched_barrier(0);
         const long long c2 = tick();
         {
-          constexpr int PP = (P <= M) ? P : M;
-          double qp[NG][PP];
 #pragma unroll
           for (int g = 0; g < NG; g++)
 #pragma unroll
@@ -981,30 +983,16 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
                 __builtin_amdgcn_sched_barrier(0);
               }
             }
-          if constexpr (QV && PP > 1)
+          if constexpr (!LATE)
           {
-            // THE WAIT STATES BEHIND THE ASM CHAIN ARE LOAD-BEARING (round 6, session 2).  With more than one partial chain per
-            // group (NG <= 4) the VALU adds the chains up right here -- and a v_add_f64 that reads the destination of a
-            // double-precision MFMA still in flight reads the OLD register: the hazard recognizer pads the MFMAs it selects itself
-            // (DMFMA 4x4 write -> VALU read), not the inside of an asm statement, and it is free to hoist the adds above the last
-            // asm MFMA as well.  <10, 2> did both (`v_mfma v[126:127] ... ; s_nop 0 ; v_add_f64 .., v[126:127]`): every W update
-            // of a rank 33 .. 40 corpus with two column groups per strip came out 1e-2 wrong (tests/test_gpu_random_shapes.py
-            // r1_B20_K40).  The volatile statements keep their order: the MFMAs, the wait states (twice what the
-            // compiler pads its own double-precision 4x4 MFMAs with), then one empty statement per chain register that the adds
-            // depend on.  tools/isa_mfma_valu_hazard.py audits the shipped code objects for the pattern (CPU test).
-            asm volatile("s_nop 11" ::: "memory");   // 12 wait states (LLVM pads a DMFMA 4x4 write -> VALU read with 6)
 #pragma unroll
             for (int g = 0; g < NG; g++)
+            {
+              double t = qp[g][0];
 #pragma unroll
-              for (int p = 0; p < PP; p++) asm volatile("" : "+v"(qp[g][p]));
-          }
-#pragma unroll
-          for (int g = 0; g < NG; g++)
-          {
-            double t = qp[g][0];
-#pragma unroll
-            for (int p = 1; p < PP; p++) t += qp[g][p];
-            qn[g] = t;
+              for (int p = 1; p < PP; p++) t += qp[g][p];
+              qn[g] = t;
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1032,6 +1020,32 @@ __global__ __launch_bounds__(256 * WPS, WPS) void nmf_update5_kernel(Upd5Args a)
           for (int m = 0; m < M; m++) if constexpr (DS == 1) dsum[m] += mb[m];
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LATE)
+        {
+          // THE PLACE OF THESE SUMS IS LOAD-BEARING (round 6, session 2).  With more than one partial chain per group (NG <= 4) the
+          // VALU adds the chains up -- and a v_add_f64 that reads the destination of a double-precision MFMA still in flight reads
+          // the OLD register: the hazard recognizer pads the MFMAs it selects itself (DMFMA 4x4 write -> VALU read: 6 wait
+          // states), not the inside of an asm statement, and the scheduler may hoist the adds above the last asm MFMA as well.
+          // With the sums right behind the first product <10, 2> did both (`v_mfma v[126:127] ...; s_nop 0; v_add_f64 ..,
+          // v[126:127]`): every W update of a rank 33 .. 40 corpus with two column groups per strip came out 6e-2 wrong
+          // (tests/test_gpu_random_shapes.py r1_B20_K40).  Here the whole second product (NG M >= 8 MFMAs) lies between the chains and
+          // their sums: the scheduling barrier above keeps the adds below it, the empty statements (volatile, like the MFMAs:
+          // they keep their order) tie them to the chain registers -- no wait states to pay (behind the first product they
+          // cost the narrow-strip forms 4 %), and the next step's quotient block is where the sums are wanted.
+          // tools/isa_mfma_valu_hazard.py audits the shipped code objects for the pattern (CPU test).
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+#pragma unroll
+            for (int p = 0; p < PP; p++) asm volatile("" : "+v"(qp[g][p]));
+#pragma unroll
+          for (int g = 0; g < NG; g++)
+          {
+            double t = qp[g][0];
+#pragma unroll
+            for (int p = 1; p < PP; p++) t += qp[g][p];
+            qn[g] = t;
+          }
+        }
         const long long c4 = tick();
         if constexpr (INSTR) { tWait += c1 - c0; tRatio += c2 - c1; tQ += c3 - c2; tOut += c4 - c3; }
       };
