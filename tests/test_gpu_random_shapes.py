@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _cases():
-    # FLUHIP_SWEEP="seed,count" runs a different / larger sweep ad hoc (the committed default is 2024,36)
-    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP", "2024,36").split(","))
+    # FLUHIP_SWEEP="seed,count" runs a different / larger sweep ad hoc (the committed default is 2024,60 (36 until round 6; ragged 4711,24, was 14))
+    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP", "2024,60").split(","))
     rs = np.random.RandomState(seed)
     out = []
     ffts = [64, 128, 256, 512, 1024, 2048]
@@ -63,7 +63,7 @@ def test_random_shape(ctx, oracle, onp, case):
 
 
 def _ragged_cases():
-    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP_RAGGED", "4711,14").split(","))
+    seed, count = (int(v) for v in os.environ.get("FLUHIP_SWEEP_RAGGED", "4711,24").split(","))
     rs = np.random.RandomState(seed)
     out = []
     for i in range(count):
