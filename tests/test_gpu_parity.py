@@ -1592,3 +1592,37 @@ def test_small_corpora_with_narrow_strips_at_every_compute_rank(ctx, oracle, onp
             rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, uw, uh, 42)
             assert rel_err(W1[b], rW) < TOL_FACTORS_TIGHT and rel_err(H1[b], rH) < TOL_FACTORS_TIGHT, (K, frames, uw, uh, b, c.plan())
     c.close()
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1e38])
+@pytest.mark.parametrize("K", [8, 32, 40, 128])
+def test_factor_updates_over_the_magnitude_range_of_float_input(ctx, oracle, K, scale):
+    """The quotients' reciprocals come from product trees (csrc/recip_tree.h: one v_rcp_f64 per four operands, six in the
+    frame-strip kernel): the root of a tree is a product of up to six clamped Q values, which must stay inside the double range
+    for anything a float32 input can produce -- magnitudes up to ~3.4e38 x the window sum -- and for very quiet input, where
+    every Q sits far below 1 (alg/NMF.hpp:160, 168 divide element by element and have no such limit)."""
+    rs = np.random.RandomState(K)
+    T, F, iters = 300, 513, 6
+    X = (np.abs(rs.standard_normal((T, 5)) @ rs.standard_normal((5, F))) + 0.01 * rs.uniform(0, 1, (T, F))) * scale
+    W1, H1, V1, rc = ctx.nmf_process(X, K, iters, True, True, 42)
+    rW, rH, rV, _ = oracle.nmf_process(X, K, iters, True, True, 42)
+    assert rc == 0 and np.isfinite(W1).all() and np.isfinite(H1).all()
+    assert rel_err(W1, rW) < TOL_FACTORS_TIGHT and rel_err(H1, rH) < TOL_FACTORS_TIGHT and rel_err(V1, rV) < TOL_FACTORS_TIGHT, \
+        (K, scale, rel_err(W1, rW), rel_err(H1, rH))
+
+
+@pytest.mark.parametrize("K", [16, 32])
+def test_very_loud_float_audio_through_the_corpus_path(ctx, oracle, onp, K):
+    """float32 samples near the top of their range (1e30 x a normal signal): magnitudes ~1e33, the frame-strip kernel at
+    rank 16 (six quotients per reciprocal) and the batched kernel at rank 32 (four) against the oracle"""
+    import fluhip
+    n, win, fft, hop, iters = 30000, 2048, 2048, 512, 5
+    x = (onp.synth_audio(n, 4242).astype(np.float64) * 1e30).astype(np.float32)
+    assert np.isfinite(x).all()
+    c = fluhip.Corpus(ctx, 1, n, win, fft, hop, K)
+    c.set_audio(x[None, :]); c.stft(); c.nmf(iters, seed=42)
+    mag, W1, H1 = c.read_f64(); plan = c.plan(); c.close()
+    _, rmag = oracle.stft_f32(x, win, fft, hop)
+    rW, rH, _, _ = oracle.nmf_process(rmag, K, iters, True, True, 42)
+    assert rel_err(mag[0], rmag) < 1e-12 and np.isfinite(W1).all() and np.isfinite(H1).all()
+    assert rel_err(W1[0], rW) < TOL_FACTORS_TIGHT and rel_err(H1[0], rH) < TOL_FACTORS_TIGHT, (K, plan, rel_err(W1[0], rW), rel_err(H1[0], rH))
